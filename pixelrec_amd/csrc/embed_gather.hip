@@ -1,0 +1,53 @@
+// embed_gather.hip -- item-ID embedding row gather (K1 of SURVEY.md §2.1).
+//
+// Replaces `self.item_embedding(items)` (reference code/REC/model/IDNet/sasrec.py:68,101) and the
+// `item_feature[item_seq]` lookup of code/REC/model/PixelNet/mosasrec.py:102.
+//
+// HBM-bound: every output row is D*4 bytes read from a random table row + D*4 bytes written.
+// Layout: table [N, D] row-major fp32, idx int64 [n], out [n, D].  One lane moves one 16-byte chunk
+// (float4) so a wave moves 1 KiB per instruction; a block owns U*256 *consecutive* chunks and issues all
+// U loads before the first store so that U row fetches per lane are in flight (random rows miss L2 and the
+// 256 MiB Infinity Cache once the table is larger than it: 400 K x 512 x 4 B = 819 MB).
+#include "pxr_common.h"
+
+template <int U>
+__global__ void __launch_bounds__(256) embed_gather_kernel(const float4* __restrict__ table,
+                                                           const int64_t* __restrict__ idx,
+                                                           float4* __restrict__ out, int64_t total_chunks,
+                                                           int dv, int64_t n_rows_table) {
+  const int64_t base = ((int64_t)blockIdx.x * U) * 256 + threadIdx.x;
+  float4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t c = base + (int64_t)u * 256;
+    if (c < total_chunks) {
+      const int64_t row = c / dv;
+      const int col = (int)(c - row * dv);
+      int64_t r = idx[row];
+      // out-of-range ids would fault; clamp (the host wrapper validates ids when PXR_CHECK_INDICES=1)
+      r = r < 0 ? 0 : (r >= n_rows_table ? n_rows_table - 1 : r);
+      v[u] = table[r * dv + col];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t c = base + (int64_t)u * 256;
+    if (c < total_chunks) out[c] = v[u];
+  }
+}
+
+extern "C" int pxr_embed_gather_f32(const float* table, int64_t N, int D, const int64_t* idx, int64_t n,
+                                    float* out, void* stream) {
+  PXR_REQUIRE(table && idx && out, "pxr_embed_gather_f32: null pointer");
+  PXR_REQUIRE(N > 0 && D > 0 && (D % 4) == 0, "pxr_embed_gather_f32: need N>0 and D %% 4 == 0 (D=%d)", D);
+  PXR_REQUIRE(n >= 0, "pxr_embed_gather_f32: negative n");
+  if (n == 0) return PXR_OK;
+  const int dv = D / 4;
+  const int64_t total = n * dv;
+  constexpr int U = 4;
+  const int64_t blocks = (total + (int64_t)U * 256 - 1) / ((int64_t)U * 256);
+  PXR_REQUIRE(blocks < (1ll << 31), "pxr_embed_gather_f32: too many rows");
+  hipLaunchKernelGGL(embed_gather_kernel<U>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)table, idx, (float4*)out, total, dv, N);
+  return pxr_check_launch("pxr_embed_gather_f32");
+}

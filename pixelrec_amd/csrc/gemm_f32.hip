@@ -1,0 +1,273 @@
+// gemm_f32.hip -- fp32 MFMA GEMM entry points: nn.Linear forward / input-grad / weight-grad, plus the
+// deterministic column reductions used for bias / LayerNorm-affine / position-embedding gradients.
+//
+// Reference call sites replaced (all are ATen -> cuBLAS sgemm in the reference):
+//   layers.py:586-588 (query/key/value), :613 (dense), :666 (dense_1 + erf-GELU :651-660,667), :669 (dense_2),
+//   sasrec.py:112 (full-catalog scoring, un-fused form) and the autograd transposes of all of them.
+#include "gemm_f32.cuh"
+
+namespace pxr {
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3 };
+
+// erf-GELU exactly as the reference writes it: x * 0.5 * (1 + erf(x / sqrt(2)))  (layers.py:651-660)
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x / 1.41421356237309504880f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+            float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
+            float* __restrict__ aux, int64_t ldaux, int tiles_m, int tiles_n, int ksplit_len,
+            int64_t split_stride) {
+  using Cfg = GemmCfg<BM, BN, A_KC, B_KC>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
+
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = t % tiles_m, tn = t / tiles_m;  // m fastest: blocks sharing a B panel are neighbours on one XCD
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = blockIdx.y * ksplit_len;
+  const int kend = min(K, kbeg + ksplit_len);
+  C += (int64_t)blockIdx.y * split_stride;
+
+  typename Cfg::Acc accs;
+  gemm_mainloop<BM, BN, A_KC, B_KC>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
+
+  auto& acc = accs.v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + wn * Cfg::WN + j * 32 + r;
+    if (col >= N) continue;
+    float bv = 0.f;
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= M) continue;
+        float v = acc[i][j][e];
+        if constexpr (EPI == EPI_BIAS) {
+          v += bv;
+        } else if constexpr (EPI == EPI_BIAS_GELU) {
+          v += bv;
+          aux[(int64_t)row * ldaux + col] = v;  // pre-activation, kept for the backward pass
+          v = gelu_erf(v);
+        } else if constexpr (EPI == EPI_MUL_DGELU) {
+          v *= dgelu_erf(aux[(int64_t)row * ldaux + col]);
+        }
+        C[(int64_t)row * ldc + col] = v;
+      }
+    }
+  }
+}
+
+// out[i] = sum_z part[z * stride + i]   (fixed order => deterministic)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float4* __restrict__ part, float4* __restrict__ out,
+                                                            int64_t n4, int64_t stride4, int splits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = part[i];
+  for (int z = 1; z < splits; ++z) {
+    const float4 v = part[(int64_t)z * stride4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  out[i] = s;
+}
+
+// Column sums, stage 1: part[chunk][n] = sum over the rows of this chunk of x[row][n]
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
+                                                             int rows_per_chunk, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(M, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (col < N)
+    for (int row = r0 + ty; row < r1; row += 4) s += x[(int64_t)row * ldx + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+// stage 2: out[n] = sum_p part[p][n]
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int P, int N,
+                                                           float* __restrict__ out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(int64_t)p * N + col];
+  out[col] = s;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                       int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
+                       int64_t split_stride, hipStream_t st) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI>), dim3(tiles_m * tiles_n, splits), dim3(GEMM_THREADS), 0,
+                     st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m, tiles_n, ksplit_len,
+                     split_stride);
+  return pxr_check_launch("pxr_gemm_f32");
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int dispatch_tile(bool big, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                         int M, int N, int K, const float* bias, float* aux, int64_t ldaux, int splits,
+                         int ksplit_len, int64_t split_stride, hipStream_t st) {
+  if (big)
+    return launch_gemm<128, 128, A_KC, B_KC, EPI>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
+                                                  ksplit_len, split_stride, st);
+  return launch_gemm<64, 64, A_KC, B_KC, EPI>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
+                                              ksplit_len, split_stride, st);
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+// Bytes of workspace pxr_gemm_f32 may use for split-K partials (0 => never splits).
+extern "C" int64_t pxr_gemm_ws_bytes(int a_kc, int b_kc, int M, int N, int K) {
+  (void)a_kc; (void)b_kc; (void)K;
+  return (int64_t)16 * M * N * (int64_t)sizeof(float);  // at most 16 splits
+}
+
+// General entry: C[M,N] = A_op * B_op with the storage flavours of gemm_f32.cuh.
+//   tile_hint: 0 = heuristic, 64 / 128 = force that square tile.   split_hint: 0 = heuristic, >=1 = force.
+extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B,
+                            int64_t ldb, float* C, int64_t ldc, int epilogue, const float* bias, float* aux,
+                            int64_t ldaux, void* ws, int64_t ws_bytes, int tile_hint, int split_hint,
+                            void* stream) {
+  PXR_REQUIRE(A && B && C, "pxr_gemm_f32: null operand");
+  PXR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "pxr_gemm_f32: negative dim");
+  if (M == 0 || N == 0) return PXR_OK;
+  PXR_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, "pxr_gemm_f32: leading dims must be multiples of 4 floats");
+  PXR_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "pxr_gemm_f32: operands must be 16-byte aligned");
+  // the contiguous extent of each operand is read as float4
+  PXR_REQUIRE(a_kc ? (K % 4 == 0) : (M % 4 == 0), "pxr_gemm_f32: A contiguous extent must be a multiple of 4");
+  PXR_REQUIRE(b_kc ? (K % 4 == 0) : (N % 4 == 0), "pxr_gemm_f32: B contiguous extent must be a multiple of 4");
+  PXR_REQUIRE(epilogue >= 0 && epilogue <= 3, "pxr_gemm_f32: bad epilogue %d", epilogue);
+  PXR_REQUIRE(!(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU) || bias, "pxr_gemm_f32: epilogue needs bias");
+  PXR_REQUIRE(!(epilogue == EPI_BIAS_GELU || epilogue == EPI_MUL_DGELU) || aux, "pxr_gemm_f32: epilogue needs aux");
+  hipStream_t st = (hipStream_t)stream;
+
+  const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  bool big = (t128 >= 384);  // >= 1.5 waves of 128x128 tiles over 256 CUs; otherwise 64x64 tiles fill the chip better
+  if (tile_hint == 128) big = true;
+  if (tile_hint == 64) big = false;
+  const int bm = big ? 128 : 64;
+  const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bm - 1) / bm);
+  PXR_REQUIRE(tiles < (1ll << 31), "pxr_gemm_f32: too many tiles");
+
+  // split-K only for the plain epilogue (weight gradients: few output tiles, long token reduction)
+  int splits = 1;
+  const int nk = (K + GEMM_BK - 1) / GEMM_BK;
+  if (epilogue == EPI_NONE && ws) {
+    if (split_hint >= 1) splits = split_hint;
+    else if (tiles < 256 && nk >= 16) {
+      splits = (int)((512 + tiles - 1) / tiles);
+      if (splits > nk / 4) splits = nk / 4;
+    }
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+    while (splits > 1 && (int64_t)splits * M * N * 4 > ws_bytes) --splits;
+  }
+  int ktiles_per = (nk + splits - 1) / splits;
+  if (ktiles_per < 1) ktiles_per = 1;
+  splits = (nk + ktiles_per - 1) / ktiles_per;
+  if (splits < 1) splits = 1;
+  const int ksplit_len = (splits == 1) ? (K > 0 ? K : 1) : ktiles_per * GEMM_BK;
+
+  float* Cw = C;
+  int64_t ldcw = ldc, split_stride = 0;
+  if (splits > 1) {
+    Cw = (float*)ws;
+    ldcw = N;
+    split_stride = (int64_t)M * N;
+    PXR_REQUIRE((N % 4) == 0 && ldc == N, "pxr_gemm_f32: split-K needs a dense C with N %% 4 == 0");
+  }
+
+  int rc;
+#define PXR_GEMM_CASE(AK, BK_, E)                                                                            \
+  rc = dispatch_tile<AK, BK_, E>(big, A, lda, B, ldb, Cw, ldcw, M, N, K, bias, aux, ldaux, splits, ksplit_len, \
+                                 split_stride, st)
+  if (a_kc && b_kc) {
+    switch (epilogue) {
+      case EPI_NONE: PXR_GEMM_CASE(true, true, EPI_NONE); break;
+      case EPI_BIAS: PXR_GEMM_CASE(true, true, EPI_BIAS); break;
+      case EPI_BIAS_GELU: PXR_GEMM_CASE(true, true, EPI_BIAS_GELU); break;
+      default: pxr_set_error("pxr_gemm_f32: epilogue %d unsupported for (KC,KC)", epilogue); return PXR_ERR_BAD_ARG;
+    }
+  } else if (a_kc && !b_kc) {
+    switch (epilogue) {
+      case EPI_NONE: PXR_GEMM_CASE(true, false, EPI_NONE); break;
+      case EPI_MUL_DGELU: PXR_GEMM_CASE(true, false, EPI_MUL_DGELU); break;
+      default: pxr_set_error("pxr_gemm_f32: epilogue %d unsupported for (KC,XC)", epilogue); return PXR_ERR_BAD_ARG;
+    }
+  } else if (!a_kc && !b_kc) {
+    PXR_REQUIRE(epilogue == EPI_NONE, "pxr_gemm_f32: epilogue %d unsupported for (XC,XC)", epilogue);
+    PXR_GEMM_CASE(false, false, EPI_NONE);
+  } else {
+    pxr_set_error("pxr_gemm_f32: (XC,KC) operand combination is not instantiated");
+    return PXR_ERR_BAD_ARG;
+  }
+#undef PXR_GEMM_CASE
+  if (rc != PXR_OK) return rc;
+
+  if (splits > 1) {
+    const int64_t n4 = (int64_t)M * N / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       (const float4*)ws, (float4*)C, n4, n4, splits);
+    return pxr_check_launch("pxr_gemm_f32(split-K reduce)");
+  }
+  return PXR_OK;
+}
+
+// y[M,N] = x[M,K] W[N,K]^T + b   (act: 0 none, 1 erf-GELU with pre-activation saved to `pre`)
+extern "C" int pxr_linear_fwd_f32(const float* x, const float* W, const float* b, float* y, float* pre, int M,
+                                  int N, int K, int act, void* stream) {
+  const int epi = act ? EPI_BIAS_GELU : (b ? EPI_BIAS : EPI_NONE);
+  return pxr_gemm_f32(1, 1, M, N, K, x, K, W, K, y, N, epi, b, pre, N, nullptr, 0, 0, 0, stream);
+}
+// dx[M,K] = dy[M,N] W[N,K]     (dgelu_pre != NULL: dx *= gelu'(dgelu_pre), i.e. through the FFN activation)
+extern "C" int pxr_linear_bwd_input_f32(const float* dy, const float* W, float* dx, const float* dgelu_pre, int M,
+                                        int N, int K, void* stream) {
+  return pxr_gemm_f32(1, 0, M, K, N, dy, N, W, K, dx, K, dgelu_pre ? EPI_MUL_DGELU : EPI_NONE, nullptr,
+                      const_cast<float*>(dgelu_pre), K, nullptr, 0, 0, 0, stream);
+}
+// dW[N,K] = dy[M,N]^T x[M,K]   (reduction over the M tokens, split-K through ws)
+extern "C" int pxr_linear_bwd_weight_f32(const float* dy, const float* x, float* dW, int M, int N, int K, void* ws,
+                                         int64_t ws_bytes, void* stream) {
+  return pxr_gemm_f32(0, 0, N, K, M, dy, N, x, K, dW, K, EPI_NONE, nullptr, nullptr, 0, ws, ws_bytes, 0, 0, stream);
+}
+
+extern "C" int64_t pxr_colsum_ws_bytes(int M, int N) {
+  const int chunks = (M + 255) / 256;
+  return (int64_t)chunks * N * (int64_t)sizeof(float);
+}
+// out[n] = sum_m x[m][n]  -- bias gradients (autograd of nn.Linear bias) and the position-embedding
+// gradient (sum over the batch of dx0 viewed as [B, L*D]); two fixed-order stages => deterministic.
+extern "C" int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, void* ws, int64_t ws_bytes,
+                              void* stream) {
+  PXR_REQUIRE(x && out && ws, "pxr_colsum_f32: null pointer");
+  PXR_REQUIRE(M > 0 && N > 0, "pxr_colsum_f32: empty input");
+  const int rows_per_chunk = 256;
+  const int chunks = (M + rows_per_chunk - 1) / rows_per_chunk;
+  if ((int64_t)chunks * N * 4 > ws_bytes) {
+    pxr_set_error("pxr_colsum_f32: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)chunks * N * 4);
+    return PXR_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, x, ldx, M, N,
+                     rows_per_chunk, (float*)ws);
+  int rc = pxr_check_launch("pxr_colsum_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)ws, chunks, N, out);
+  return pxr_check_launch("pxr_colsum_f32(final)");
+}

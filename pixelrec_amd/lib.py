@@ -1,0 +1,90 @@
+"""ctypes binding of libpxr.so -- the C-ABI library of hand-written gfx950 HIP kernels.
+
+The product path has NO CPU fallback: if the library is missing or a symbol is absent this module raises,
+loudly, instead of routing around it (the CPU restatement under ``oracle/`` is test infrastructure only and is
+never imported from here).
+
+PyTorch is used for device memory and streams only: every wrapper hands raw ``data_ptr()`` addresses and the
+current HIP stream to the C entry points declared in ``include/pxr.h``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, c_uint64, c_double
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpxr.so")
+
+
+class PxrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes).  Must list every symbol include/pxr.h declares (tests/test_abi.py checks both
+# directions against the header).
+_P = c_void_p
+_SIGNATURES = {
+    "pxr_version": (c_int, []),
+    "pxr_last_error": (c_char_p, []),
+    "pxr_target_arch": (c_char_p, []),
+    "pxr_embed_gather_f32": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, _P]),
+    "pxr_gemm_ws_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "pxr_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P,
+                             _P, c_int64, _P, c_int64, c_int, c_int, _P]),
+    "pxr_linear_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pxr_linear_bwd_input_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "pxr_linear_bwd_weight_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P]),
+    "pxr_colsum_ws_bytes": (c_int64, [c_int, c_int]),
+    "pxr_colsum_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int64, _P]),
+}
+
+
+def load():
+    """Load libpxr.so (once) and bind every declared entry point.  Raises PxrError if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PxrError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C pixelrec_amd/csrc`). pixelrec_amd has no CPU fallback."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host's ROCm install
+        raise PxrError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PxrError(f"{LIB_PATH} does not export `{name}` (stale build?)") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().pxr_last_error()
+        raise PxrError(f"{what or 'pxr call'} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Raw device address of a (contiguous or deliberately strided) torch tensor, or None."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
