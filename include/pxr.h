@@ -1,0 +1,128 @@
+/* pxr.h -- C ABI of libpxr.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for the PixelRec
+ * sequential-recommender hot path (SASRec under IDNet).
+ *
+ * The reference (westlake-repl/PixelRec) is 100 % Python on stock PyTorch ops and has NO FFI of its own
+ * (SURVEY.md §8b): the seam is the Python model-class contract.  These entry points are what a binding for this
+ * path would bind -- plain pointers and sizes, no torch types -- and each one names the reference call site it
+ * replaces (paths relative to /root/reference/code/REC/).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - all tensors are dense row-major fp32 unless stated; indices are int64 (torch.long) like the reference's;
+ *   - every pointer is a DEVICE pointer; the library never allocates, frees or retains device memory;
+ *   - `stream` is a hipStream_t; calls are asynchronous, re-entrant, and hold no global mutable state
+ *     (usable from the autograd thread); all launches are hipGraph-capturable (no host syncs);
+ *   - return 0 on success, <0 on error (PXR_ERR_*); pxr_last_error() gives the thread-local message;
+ *   - `*_ws_bytes` functions return the scratch size the matching call needs.
+ *   - dropout: Bernoulli(1-p) keep-mask = counter hash of (seed, stream_id, element index); the backward call
+ *     must pass the same (p, seed, stream_id).  p = 0 disables it (eval).
+ */
+#ifndef PXR_H_
+#define PXR_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXR_OK 0
+#define PXR_ERR_BAD_ARG (-1)
+#define PXR_ERR_LAUNCH (-2)
+#define PXR_ERR_WORKSPACE (-3)
+
+int pxr_version(void);                 /* major*10000 + minor*100 + patch */
+const char* pxr_last_error(void);      /* message of the last failing call on this thread */
+const char* pxr_target_arch(void);     /* "gfx950" */
+
+/* ---- embedding table ---------------------------------------------------------------------------------------- */
+/* out[i,:] = table[idx[i],:]                       model/IDNet/sasrec.py:68,101; model/PixelNet/mosasrec.py:102 */
+int pxr_embed_gather_f32(const float* table, int64_t N, int D, const int64_t* idx, int64_t n, float* out,
+                         void* stream);
+
+/* Sparse embedding backward (replaces autograd's dense embedding_dense_backward of sasrec.py:31/68):
+ * (idx[n], rows[n,D]) -> ascending uniq_idx[<=n], uniq_rows[<=n,D] = scale * sum of the rows of each id,
+ * *n_uniq_dev = count.  Id 0 (padding_idx) and out-of-range ids are dropped.  Deterministic (stable sort). */
+int64_t pxr_embed_grad_ws_bytes(int64_t n_occ);
+int pxr_embed_grad_rows_f32(const int64_t* idx, int64_t n, const float* rows, int D, int64_t n_table, float scale,
+                            int64_t* uniq_idx, float* uniq_rows, int32_t* n_uniq_dev, void* ws, int64_t ws_bytes,
+                            void* stream);
+/* The same for the three uses of the table inside SASRec.forward (sasrec.py:68-74,88-89) without materialising the
+ * [B,2,L+1,D] gather: items[B,2,L+1]; dx0 = grad of (table row + pos) [B*L,D]; out = last-layer states [B*L,D];
+ * coef[B*L] from pxr_bpr_loss_bwd_f32.  n_occ = 3*B*L for the workspace size. */
+int pxr_sasrec_embed_grad_f32(const int64_t* items, int B, int L, const float* dx0, const float* out,
+                              const float* coef, int D, int64_t n_table, float scale, int64_t* uniq_idx,
+                              float* uniq_rows, int32_t* n_uniq_dev, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- LayerNorm sites ---------------------------------------------------------------------------------------- */
+/* y = dropout(LN(table[idx[b*idx_bstride+t]] + pos[t]))       sasrec.py:68,77-82 (train) / :99-104 (predict).
+ * xhat [B*L,D] / rstd [B*L] are saved for the backward and may be NULL for inference. */
+int pxr_input_ln_fwd_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
+                         const float* pos, const float* gamma, const float* beta, float eps, int B, int L, int D,
+                         float* y, float* xhat, float* rstd, float p_drop, uint64_t seed, uint32_t stream_id,
+                         void* stream);
+/* y = LN(dropout(x) + res)                                      layers.py:614-615 and :670-671 */
+int pxr_ln_residual_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                            int rows, int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
+                            uint32_t stream_id, void* stream);
+/* autograd of either site.  gather_mode=1: dy is w.r.t. the dropped output, dz = grad of (table row + pos).
+ * gather_mode=0: dz = grad w.r.t. res, dx (optional) = grad w.r.t. x.  dgamma/dbeta are overwritten. */
+int64_t pxr_ln_bwd_ws_bytes(int rows, int D);
+int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                   int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed,
+                   uint32_t stream_id, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32) --------------------------------------------------------------- */
+/* General: C[M,N] = A_op x B_op; a_kc/b_kc select k-contiguous ([M][K] / [N][K]) or x-contiguous ([K][M] / [K][N])
+ * storage.  epilogue: 0 none, 1 +bias[n], 2 +bias then erf-GELU (pre-activation -> aux), 3 *= gelu'(aux), 4 += aux. */
+int64_t pxr_gemm_ws_bytes(int a_kc, int b_kc, int M, int N, int K);
+int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, int epilogue, const float* bias, float* aux, int64_t ldaux, void* ws,
+                 int64_t ws_bytes, int tile_hint, int split_hint, void* stream);
+/* y = x W^T + b (act=1: erf-GELU, pre-activation saved)   layers.py:586-588,613,666-667,669; sasrec.py:112 */
+int pxr_linear_fwd_f32(const float* x, const float* W, const float* b, float* y, float* pre, int M, int N, int K,
+                       int act, void* stream);
+/* dx = dy W, optionally * gelu'(dgelu_pre) OR + add (residual gradient);  dW = dy^T x  -- autograd of nn.Linear */
+int pxr_linear_bwd_input_f32(const float* dy, const float* W, float* dx, const float* dgelu_pre, const float* add,
+                             int M, int N, int K, void* stream);
+int pxr_linear_bwd_weight_f32(const float* dy, const float* x, float* dW, int M, int N, int K, void* ws,
+                              int64_t ws_bytes, void* stream);
+/* out[n] = sum_m x[m,n]  (bias grads; position-embedding grad = colsum of dx0 viewed [B, L*D]); deterministic */
+int64_t pxr_colsum_ws_bytes(int M, int N);
+int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- masked multi-head self-attention core ------------------------------------------------------------------ */
+/* ctx = softmax(q k^T / sqrt(d) + mask) v with the reference's additive -1e9 causal+padding mask
+ * (layers.py:590-612, sasrec.py:119-126).  q/k/v element (b,t,h,c) at p[(b*L+t)*ld + h*d + c] (fused QKV output);
+ * key j of batch b is real iff keymask[b*km_bstride + j] != 0 (masked_index in training, item_seq in predict).
+ * ctx is written head-merged [B*L, ld_ctx]; probs [B,H,L,L] (pre-dropout) is saved for backward, may be NULL. */
+int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
+                     int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx, float* probs,
+                     float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
+                     const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d,
+                     float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* ---- training head ------------------------------------------------------------------------------------------ */
+/* loss = mean_b(-sum_t log(sigmoid(pos-neg)+1e-8) * mask)            sasrec.py:88-92; loss stays on the device */
+int pxr_bpr_loss_fwd_f32(const float* out, const float* table, int64_t n_table, const int64_t* items,
+                         const int64_t* masked_index, int B, int L, int D, float* pos_score, float* neg_score,
+                         float* lossrow, float* loss, void* stream);
+int pxr_bpr_loss_bwd_f32(const float* pos_score, const float* neg_score, const float* table, int64_t n_table,
+                         const int64_t* items, const int64_t* masked_index, int B, int L, int D, float grad_scale,
+                         const float* grad_scale_dev, float* dout, float* coef, void* stream);
+
+/* ---- optimizer ---------------------------------------------------------------------------------------------- */
+/* torch.optim.AdamW update (trainer.py:102,125), step is 1-based.  n must be a multiple of 4. */
+int pxr_adamw_flat_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, int64_t step, void* stream);
+/* Dense-semantics AdamW over the whole table with the gradient given sparsely; slot is an int32[N] map that must be
+ * all -1 on entry (pxr_slot_fill_i32 once) and is all -1 again on exit. */
+int pxr_slot_fill_i32(int32_t* slot, int64_t n, int32_t value, void* stream);
+int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_rows, int D, int32_t* slot,
+                        const int64_t* uniq_idx, const float* uniq_rows, const int32_t* n_uniq_dev, int64_t max_uniq,
+                        double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PXR_H_ */

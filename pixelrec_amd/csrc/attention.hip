@@ -1,0 +1,290 @@
+// attention.hip -- SASRec masked multi-head self-attention core, forward and backward, one workgroup per
+// (batch, head).  Replaces layers.py:590-612 (scores = QK^T / sqrt(d) + mask; softmax; dropout; PV; head merge)
+// together with the mask construction of sasrec.py:119-126, and their autograd.
+//
+// Shapes are tiny (L <= 64 keys, d = D/H per head): the work is latency/LDS-bound, not MFMA-shaped
+// (0.33 GFLOP per layer at B=64).  Design:
+//   * q/k/v are read in place from the fused QKV projection output [B, L, 3D] (row stride `ld`), the context
+//     is written head-merged into [B, L, D]: no permute/contiguous copies (layers.py:590-592,610-612);
+//   * Q/K (then V) tiles are staged through LDS in d-chunks of <= 128 columns, so any head size works
+//     (d = 32 for emb 128, 128 for emb 512, 1024 for emb 4096) with a fixed LDS footprint;
+//   * a wave owns query rows {w, w+4, ...}; lane j owns key j: one score per lane, so the row softmax is a pair
+//     of 64-lane shuffle reductions -- no LDS round trip;
+//   * mask semantics are the reference's ADDITIVE -1e9 in fp32 (not -inf): score + (-1e9) == -1e9 exactly, a
+//     fully masked (left-padded) query row therefore becomes a uniform 1/L distribution over ALL L keys
+//     (SURVEY.md §7 hard part 4) -- reproduced by doing the same arithmetic;
+//   * attention-prob dropout (layers.py:608) uses the counter-hash mask, regenerated in backward;
+//     the un-dropped probabilities are saved ([B,H,L,L]) for the backward pass.
+#include "pxr_common.h"
+
+namespace pxr {
+
+constexpr int ATT_MAXL = 64;   // keys per sequence handled by one wave-wide softmax
+constexpr int ATT_DC = 128;    // d-chunk staged through LDS
+constexpr int ATT_KLD = ATT_DC + 4;  // padded row stride of the "key-side" tile: conflict-free ds_read_b128 by lane=row
+
+struct AttnArgs {
+  const float* q; const float* k; const float* v;  // element (b,t,h,c) at p[(b*L+t)*ld + h*d + c]
+  int64_t ld;
+  const int64_t* keymask; int64_t km_bstride;      // key j of batch b is real iff keymask[b*km_bstride+j] != 0
+  float* ctx; int64_t ld_ctx;                      // [B*L, ld_ctx], head h at column h*d
+  float* probs;                                    // [B,H,L,L] (softmax output before dropout) or null
+  // backward only
+  const float* dctx; float* dq; float* dk; float* dv; int64_t ld_d;
+  int B, H, L, d;
+  float sqrt_d;
+  float p_drop; uint32_t drop_thr; uint32_t stream; uint64_t seed;
+};
+
+// stage tile[row][0..w) <- src[(row)*ld + 0..w) for row < L; 256 threads, float4 accesses
+__device__ __forceinline__ void stage_tile(float* tile, int tstride, const float* src, int64_t ld, int L, int w) {
+  const int q4 = w >> 2;
+  for (int f = threadIdx.x; f < L * q4; f += 256) {
+    const int row = f / q4, c = (f - row * q4) * 4;
+    *reinterpret_cast<float4*>(tile + row * tstride + c) = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
+  }
+}
+
+// acc[g] += sum_c A[i_g][c] * Bt[lane][c]  for the wave's rows i_g = wave + 4*g   (A stride ATT_DC, Bt stride ATT_KLD)
+__device__ __forceinline__ void score_accumulate(float (&acc)[16], const float* sA, const float* sB, int L, int w,
+                                                 int wave, int lane) {
+  const float* brow = sB + lane * ATT_KLD;
+#pragma unroll
+  for (int gg = 0; gg < 4; ++gg) {
+    const int i0 = wave + 16 * gg;
+    if (i0 >= L) break;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* r0 = sA + (i0)*ATT_DC;
+    const float* r1 = sA + (i0 + 4) * ATT_DC;
+    const float* r2 = sA + (i0 + 8) * ATT_DC;
+    const float* r3 = sA + (i0 + 12) * ATT_DC;
+    for (int c = 0; c < w; c += 4) {
+      const float4 kb = *reinterpret_cast<const float4*>(brow + c);
+      const float4 q0 = *reinterpret_cast<const float4*>(r0 + c);
+      const float4 q1 = *reinterpret_cast<const float4*>(r1 + c);
+      const float4 q2 = *reinterpret_cast<const float4*>(r2 + c);
+      const float4 q3 = *reinterpret_cast<const float4*>(r3 + c);
+      a0 += q0.x * kb.x + q0.y * kb.y + q0.z * kb.z + q0.w * kb.w;
+      a1 += q1.x * kb.x + q1.y * kb.y + q1.z * kb.z + q1.w * kb.w;
+      a2 += q2.x * kb.x + q2.y * kb.y + q2.z * kb.z + q2.w * kb.w;
+      a3 += q3.x * kb.x + q3.y * kb.y + q3.z * kb.z + q3.w * kb.w;
+    }
+    acc[gg * 4 + 0] += a0; acc[gg * 4 + 1] += a1; acc[gg * 4 + 2] += a2; acc[gg * 4 + 3] += a3;
+  }
+}
+
+// out[r][c] = sum_t W(r,t) * X[t][c]  for the wave's rows r = wave + 4*g, columns c = lane, lane+64 (< w).
+// TRANS=false: W(r,t) = sW[r*64 + t];  TRANS=true: W(r,t) = sW[t*64 + r].   X stride ATT_DC.
+template <bool TRANS>
+__device__ __forceinline__ void rowmix_store(const float* sW, const float* sX, int L, int w, int wave, int lane,
+                                             float* out, int64_t ld_out) {
+  for (int gg = 0; gg < 4; ++gg) {
+    const int i0 = wave + 16 * gg;
+    if (i0 >= L) break;
+    float o[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r][0] = o[r][1] = 0.f;
+    for (int t = 0; t < L; ++t) {
+      const float x0 = sX[t * ATT_DC + lane];
+      const float x1 = sX[t * ATT_DC + 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * r;  // rows >= L read in-bounds LDS garbage and are never stored
+        const float wv = TRANS ? sW[t * 64 + i] : sW[i * 64 + t];
+        o[r][0] += wv * x0;
+        o[r][1] += wv * x1;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * r;
+      if (i < L) {
+        if (lane < w) out[(int64_t)i * ld_out + lane] = o[r][0];
+        if (lane + 64 < w) out[(int64_t)i * ld_out + 64 + lane] = o[r][1];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sA[ATT_MAXL * ATT_DC];    // Q chunk, later V chunk
+  __shared__ __attribute__((aligned(16))) float sB[ATT_MAXL * ATT_KLD];   // K chunk
+  __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * 64];        // (dropped) probabilities
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int L = a.L, d = a.d;
+  const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
+
+  // LDS rows >= L are read (never used) by lanes/rows beyond L: zero them once so no NaN garbage circulates
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_DC; f += 256) sA[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_KLD; f += 256) sB[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * 64; f += 256) sP[f] = 0.f;
+  __syncthreads();
+
+  float acc[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+  for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
+    const int w = min(ATT_DC, d - dc0);
+    stage_tile(sA, ATT_DC, a.q + base + dc0, a.ld, L, w);
+    stage_tile(sB, ATT_KLD, a.k + base + dc0, a.ld, L, w);
+    __syncthreads();
+    score_accumulate(acc, sA, sB, L, w, wave, lane);
+    __syncthreads();
+  }
+
+  const bool key_real = (lane < L) && (a.keymask[(int64_t)b * a.km_bstride + lane] != 0);
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int i = wave + 4 * ((g >> 2) * 4 + (g & 3));  // acc[gg*4+r] holds row wave + 16*gg + 4*r
+    if (i < L) {
+      // reference arithmetic: scores / sqrt(d) + (-1e9 | 0)   (layers.py:597,601; sasrec.py:125)
+      float s = acc[g] / a.sqrt_d + ((key_real && lane <= i) ? 0.0f : -1e9f);
+      if (lane >= L) s = -INFINITY;
+      const float m = wave_max(s);
+      const float e = (lane < L) ? expf(s - m) : 0.f;
+      const float sum = wave_sum(e);
+      const float p = e / sum;
+      if (lane < L) {
+        const int64_t pi = (((int64_t)b * a.H + h) * L + i) * L + lane;
+        if (a.probs) a.probs[pi] = p;
+        float pd = p;
+        if (drop) pd = pxr_keep(a.seed, a.stream, (uint64_t)pi, a.drop_thr) ? p * inv_keep : 0.f;
+        sP[i * 64 + lane] = pd;
+      }
+    }
+  }
+  __syncthreads();
+
+  float* out = a.ctx + (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
+  for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
+    const int w = min(ATT_DC, d - dc0);
+    stage_tile(sA, ATT_DC, a.v + base + dc0, a.ld, L, w);
+    __syncthreads();
+    rowmix_store<false>(sP, sA, L, w, wave, lane, out + dc0, a.ld_ctx);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sA[ATT_MAXL * ATT_DC];
+  __shared__ __attribute__((aligned(16))) float sB[ATT_MAXL * ATT_KLD];
+  __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * 64];   // dropped probabilities Pd
+  __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * 64];   // dS / sqrt(d)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int L = a.L, d = a.d;
+  const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
+  const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
+  const int64_t dbase = (int64_t)b * L * a.ld_d + (int64_t)h * d;
+
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_DC; f += 256) sA[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_KLD; f += 256) sB[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * 64; f += 256) { sP[f] = 0.f; sS[f] = 0.f; }
+  __syncthreads();
+
+  // dPd[i][j] = sum_c dctx[i][c] * V[j][c]
+  float acc[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+  for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
+    const int w = min(ATT_DC, d - dc0);
+    stage_tile(sA, ATT_DC, a.dctx + cbase + dc0, a.ld_ctx, L, w);
+    stage_tile(sB, ATT_KLD, a.v + base + dc0, a.ld, L, w);
+    __syncthreads();
+    score_accumulate(acc, sA, sB, L, w, wave, lane);
+    __syncthreads();
+  }
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int i = wave + 4 * ((g >> 2) * 4 + (g & 3));
+    if (i < L) {
+      float p = 0.f, pd = 0.f, dp = 0.f;
+      if (lane < L) {
+        const int64_t pi = (((int64_t)b * a.H + h) * L + i) * L + lane;
+        p = a.probs[pi];
+        const bool keep = !drop || pxr_keep(a.seed, a.stream, (uint64_t)pi, a.drop_thr);
+        const float kf = drop ? (keep ? inv_keep : 0.f) : 1.f;
+        pd = p * kf;
+        dp = acc[g] * kf;
+      }
+      const float t = wave_sum(dp * p);
+      if (lane < L) {
+        sP[i * 64 + lane] = pd;
+        sS[i * 64 + lane] = p * (dp - t) / a.sqrt_d;   // softmax backward, then the 1/sqrt(d) of layers.py:597
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
+    const int w = min(ATT_DC, d - dc0);
+    // dV[j][c] = sum_i Pd[i][j] * dctx[i][c]
+    stage_tile(sA, ATT_DC, a.dctx + cbase + dc0, a.ld_ctx, L, w);
+    __syncthreads();
+    rowmix_store<true>(sP, sA, L, w, wave, lane, a.dv + dbase + dc0, a.ld_d);
+    __syncthreads();
+    // dQ[i][c] = sum_j dS[i][j] * K[j][c]
+    stage_tile(sA, ATT_DC, a.k + base + dc0, a.ld, L, w);
+    __syncthreads();
+    rowmix_store<false>(sS, sA, L, w, wave, lane, a.dq + dbase + dc0, a.ld_d);
+    __syncthreads();
+    // dK[j][c] = sum_i dS[i][j] * Q[i][c]
+    stage_tile(sA, ATT_DC, a.q + base + dc0, a.ld, L, w);
+    __syncthreads();
+    rowmix_store<true>(sS, sA, L, w, wave, lane, a.dk + dbase + dc0, a.ld_d);
+    __syncthreads();
+  }
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+static int attn_check(int B, int H, int L, int d, int64_t ld, const char* who) {
+  PXR_REQUIRE(B >= 0 && H > 0 && L > 0 && d > 0, "%s: bad shape", who);
+  PXR_REQUIRE(L <= ATT_MAXL, "%s: L=%d > %d keys is not supported by the wave-wide softmax", who, L, ATT_MAXL);
+  PXR_REQUIRE(d % 4 == 0 && ld % 4 == 0, "%s: d and ld must be multiples of 4", who);
+  return PXR_OK;
+}
+
+// ctx[b,t,h*d:(h+1)*d] = softmax(q k^T / sqrt(d) + mask) v       (eval: p_drop = 0)
+extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
+                                int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx,
+                                float* probs, float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+  PXR_REQUIRE(q && k && v && keymask && ctx, "pxr_attn_fwd_f32: null pointer");
+  int rc = attn_check(B, H, L, d, ld, "pxr_attn_fwd_f32");
+  if (rc) return rc;
+  PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_attn_fwd_f32: bad dropout p");
+  if (B == 0) return PXR_OK;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ld = ld; a.keymask = keymask; a.km_bstride = km_bstride;
+  a.ctx = ctx; a.ld_ctx = ld_ctx; a.probs = probs; a.B = B; a.H = H; a.L = L; a.d = d;
+  a.sqrt_d = sqrtf((float)d);
+  a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+  return pxr_check_launch("pxr_attn_fwd_f32");
+}
+
+// Gradients w.r.t. q, k, v (written with row stride ld_d, head h at column h*d) from dctx and the saved probs.
+extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v,
+                                int64_t ld, const float* probs, int B, int H, int L, int d, float* dq, float* dk,
+                                float* dv, int64_t ld_d, float p_drop, uint64_t seed, uint32_t stream_id,
+                                void* stream) {
+  PXR_REQUIRE(dctx && q && k && v && probs && dq && dk && dv, "pxr_attn_bwd_f32: null pointer");
+  int rc = attn_check(B, H, L, d, ld, "pxr_attn_bwd_f32");
+  if (rc) return rc;
+  PXR_REQUIRE(ld_d % 4 == 0 && ld_ctx % 4 == 0, "pxr_attn_bwd_f32: strides must be multiples of 4");
+  if (B == 0) return PXR_OK;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ld = ld; a.ld_ctx = ld_ctx; a.probs = const_cast<float*>(probs);
+  a.dctx = dctx; a.dq = dq; a.dk = dk; a.dv = dv; a.ld_d = ld_d; a.B = B; a.H = H; a.L = L; a.d = d;
+  a.sqrt_d = sqrtf((float)d);
+  a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+  return pxr_check_launch("pxr_attn_bwd_f32");
+}

@@ -1,0 +1,143 @@
+// bpr_loss.hip -- the SASRec training head (K13): pairwise loss against ONE sampled negative per position.
+//
+// Reference sasrec.py:88-92:
+//     pos = (out * E[items[:,0,1:]]).sum(-1);  neg = (out * E[items[:,1,1:]]).sum(-1)
+//     loss = mean_b( - sum_t log(sigmoid(pos - neg) + 1e-8) * masked_index[b,t] )
+// Fused with the target-row gathers: the [B,2,L+1,D] gathered tensor of sasrec.py:68 is never materialised,
+// each target row is read straight from the table by the wave that needs it (2 KB coalesced per row at D=512).
+// One 64-lane wave per (b,t) position; the scalar loss is produced by a fixed-order second stage (deterministic)
+// and STAYS ON THE DEVICE (the reference syncs the host every step with .item(), trainer.py:121).
+//
+// Backward: x = pos - neg, s = sigmoid(x);  dL/dx = -(mask/B) * s(1-s)/(s+1e-8) * grad_scale =: coef[b,t]
+//     d out[b,t,:]   = coef * (E[pos_id] - E[neg_id])
+//     d E[pos_id,:] += coef * out[b,t,:],  d E[neg_id,:] -= coef * out[b,t,:]   (done by embed_grad.hip from coef)
+#include "pxr_common.h"
+
+namespace pxr {
+
+struct BprArgs {
+  const float* out;       // [B*L, D]
+  const float* table;     // [N, D]
+  const int64_t* items;   // [B, 2, L+1]
+  const int64_t* mask;    // [B, L]
+  float* pos_score;       // [B*L]
+  float* neg_score;       // [B*L]
+  float* lossrow;         // [B*L]   fwd: per-position loss term
+  float* loss;            // [1]
+  float* dout;            // bwd: [B*L, D]
+  float* coef;            // bwd: [B*L]
+  int64_t n_table;
+  int B, L, D;
+  float grad_scale;
+  const float* grad_scale_dev;  // optional device scalar multiplied in (autograd's upstream gradient)
+};
+
+__device__ __forceinline__ int64_t clamp_id(int64_t r, int64_t n) { return r < 0 ? 0 : (r >= n ? n - 1 : r); }
+
+__global__ void __launch_bounds__(256) bpr_fwd_kernel(BprArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.B * a.L) return;
+  const int b = r / a.L, t = r - b * a.L;
+  const int64_t* it = a.items + (int64_t)b * 2 * (a.L + 1);
+  const float* ep = a.table + clamp_id(it[t + 1], a.n_table) * a.D;
+  const float* en = a.table + clamp_id(it[(a.L + 1) + t + 1], a.n_table) * a.D;
+  const float* o = a.out + (int64_t)r * a.D;
+  float sp = 0.f, sn = 0.f;
+  for (int c = lane * 4; c < a.D; c += 256) {
+    const float4 ov = *reinterpret_cast<const float4*>(o + c);
+    const float4 pv = *reinterpret_cast<const float4*>(ep + c);
+    const float4 nv = *reinterpret_cast<const float4*>(en + c);
+    sp += (ov.x * pv.x + ov.y * pv.y) + (ov.z * pv.z + ov.w * pv.w);
+    sn += (ov.x * nv.x + ov.y * nv.y) + (ov.z * nv.z + ov.w * nv.w);
+  }
+  sp = wave_sum(sp);
+  sn = wave_sum(sn);
+  if (lane == 0) {
+    a.pos_score[r] = sp;
+    a.neg_score[r] = sn;
+    const float x = sp - sn;
+    const float s = 1.0f / (1.0f + expf(-x));
+    a.lossrow[r] = -logf(s + 1e-8f) * (float)a.mask[r];
+  }
+}
+
+// loss = (1/B) * sum_b ( sum_t lossrow[b,t] )   single block, fixed order
+__global__ void __launch_bounds__(256) bpr_reduce_kernel(const float* __restrict__ lossrow, int B, int L,
+                                                         float* __restrict__ loss) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float sb = 0.f;
+    for (int t = 0; t < L; ++t) sb += lossrow[(int64_t)b * L + t];
+    s += sb;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
+}
+
+__global__ void __launch_bounds__(256) bpr_bwd_kernel(BprArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.B * a.L) return;
+  const int b = r / a.L, t = r - b * a.L;
+  const float x = a.pos_score[r] - a.neg_score[r];
+  const float s = 1.0f / (1.0f + expf(-x));
+  float cf = -((float)a.mask[r] / (float)a.B) * (s * (1.0f - s)) / (s + 1e-8f) * a.grad_scale;
+  if (a.grad_scale_dev) cf *= a.grad_scale_dev[0];
+  if (lane == 0) a.coef[r] = cf;
+  const int64_t* it = a.items + (int64_t)b * 2 * (a.L + 1);
+  const float* ep = a.table + clamp_id(it[t + 1], a.n_table) * a.D;
+  const float* en = a.table + clamp_id(it[(a.L + 1) + t + 1], a.n_table) * a.D;
+  float* d = a.dout + (int64_t)r * a.D;
+  for (int c = lane * 4; c < a.D; c += 256) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cf != 0.f) {
+      const float4 pv = *reinterpret_cast<const float4*>(ep + c);
+      const float4 nv = *reinterpret_cast<const float4*>(en + c);
+      o.x = cf * (pv.x - nv.x); o.y = cf * (pv.y - nv.y); o.z = cf * (pv.z - nv.z); o.w = cf * (pv.w - nv.w);
+    }
+    *reinterpret_cast<float4*>(d + c) = o;
+  }
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+// loss (device scalar), pos_score / neg_score [B*L].  lossrow is [B*L] scratch.
+extern "C" int pxr_bpr_loss_fwd_f32(const float* out, const float* table, int64_t n_table, const int64_t* items,
+                                    const int64_t* masked_index, int B, int L, int D, float* pos_score,
+                                    float* neg_score, float* lossrow, float* loss, void* stream) {
+  PXR_REQUIRE(out && table && items && masked_index && pos_score && neg_score && lossrow && loss,
+              "pxr_bpr_loss_fwd_f32: null pointer");
+  PXR_REQUIRE(B > 0 && L > 0 && D > 0 && D % 4 == 0, "pxr_bpr_loss_fwd_f32: bad shape");
+  BprArgs a{};
+  a.out = out; a.table = table; a.items = items; a.mask = masked_index; a.pos_score = pos_score;
+  a.neg_score = neg_score; a.lossrow = lossrow; a.loss = loss; a.n_table = n_table; a.B = B; a.L = L; a.D = D;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bpr_fwd_kernel, dim3((B * L + 3) / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)lossrow, B, L, loss);
+  return pxr_check_launch("pxr_bpr_loss_fwd_f32");
+}
+
+// dout [B*L, D] and coef [B*L] from the saved scores; upstream d(loss) = grad_scale * (*grad_scale_dev if given).
+extern "C" int pxr_bpr_loss_bwd_f32(const float* pos_score, const float* neg_score, const float* table,
+                                    int64_t n_table, const int64_t* items, const int64_t* masked_index, int B, int L,
+                                    int D, float grad_scale, const float* grad_scale_dev, float* dout, float* coef,
+                                    void* stream) {
+  PXR_REQUIRE(pos_score && neg_score && table && items && masked_index && dout && coef,
+              "pxr_bpr_loss_bwd_f32: null pointer");
+  PXR_REQUIRE(B > 0 && L > 0 && D > 0 && D % 4 == 0, "pxr_bpr_loss_bwd_f32: bad shape");
+  BprArgs a{};
+  a.table = table; a.items = items; a.mask = masked_index; a.pos_score = const_cast<float*>(pos_score);
+  a.neg_score = const_cast<float*>(neg_score); a.dout = dout; a.coef = coef; a.n_table = n_table;
+  a.B = B; a.L = L; a.D = D; a.grad_scale = grad_scale; a.grad_scale_dev = grad_scale_dev;
+  hipLaunchKernelGGL(bpr_bwd_kernel, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return pxr_check_launch("pxr_bpr_loss_bwd_f32");
+}

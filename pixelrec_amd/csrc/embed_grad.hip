@@ -1,0 +1,363 @@
+// embed_grad.hip -- gradient of the item-embedding table in SPARSE form (K1' of SURVEY.md §2.1).
+//
+// The reference's nn.Embedding (sasrec.py:31, no sparse=True) makes autograd materialise a dense [N, D] gradient
+// (819 MB at N=400K, D=512: zero-fill + scatter-add, `embedding_dense_backward`) that DDP then all-reduces.
+// Here the gradient is never dense: the (<= 3*B*L) row occurrences of a step are de-duplicated into
+//     uniq_idx[n_uniq] (ascending item ids, id 0 = padding_idx dropped)   and   uniq_rows[n_uniq, D]
+// by a stable LSD radix sort of the occurrence ids followed by a segmented sum in occurrence order, so the
+// result is bit-reproducible (no float atomics) and identical on every rank given identical inputs.
+//
+// Occurrences (what autograd would scatter-add):
+//   MODE_ROWS   : occurrence o adds  rows[o, :]                       to table row idx[o]   (plain embedding bwd)
+//   MODE_SASREC : the three uses of the table in SASRec.forward (sasrec.py:68-74,88-89), T = B*L, r = o % T:
+//        o in [0,T)    input  id items[b,0,t]     adds  dx0[r,:]                 (grad of the LN'd input)
+//        o in [T,2T)   target id items[b,0,t+1]   adds  +coef[r] * out[r,:]      (d pos_score)
+//        o in [2T,3T)  negative id items[b,1,t+1] adds  -coef[r] * out[r,:]      (d neg_score)
+//     which never materialises the [B,2,L+1,D] gather nor its gradient.
+//
+// Everything is launched with worst-case grids and reads the device-side counts, so the sequence is
+// hipGraph-capturable and needs no host synchronisation.
+#include "pxr_common.h"
+
+namespace pxr {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048 keys per block
+
+// ------------------------------------------------------------------------------------------------ keys
+__global__ void __launch_bounds__(256) occ_keys_rows_kernel(const int64_t* __restrict__ idx, int n,
+                                                            int* __restrict__ keys, int* __restrict__ vals,
+                                                            int64_t n_table) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  int64_t r = idx[o];
+  if (r < 0 || r >= n_table) r = 0;  // out-of-range ids are dropped like padding
+  keys[o] = (int)r;
+  vals[o] = o;
+}
+__global__ void __launch_bounds__(256) occ_keys_sasrec_kernel(const int64_t* __restrict__ items, int B, int L,
+                                                              int* __restrict__ keys, int* __restrict__ vals,
+                                                              int64_t n_table) {
+  const int T = B * L;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= 3 * T) return;
+  const int type = o / T, r = o - type * T;
+  const int b = r / L, t = r - b * L;
+  const int64_t* row = items + (int64_t)b * 2 * (L + 1);
+  int64_t id = (type == 0) ? row[t] : (type == 1 ? row[t + 1] : row[(L + 1) + t + 1]);
+  if (id < 0 || id >= n_table) id = 0;
+  keys[o] = (int)id;
+  vals[o] = o;
+}
+
+// ------------------------------------------------------------------------------------------------ radix sort
+__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const int* __restrict__ keys, int n, int shift, int nblk,
+                                                             int* __restrict__ hist) {
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int e = 0; e < RS_ITEMS; ++e) {
+    const int i = base + e * RS_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+  }
+  __syncthreads();
+  hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];  // digit-major so one exclusive scan gives global bases
+}
+
+// single-block exclusive scan of `len` ints (len <= 1024 * 256), in place; optionally writes the total
+__global__ void __launch_bounds__(1024) scan_excl_kernel(int* __restrict__ data, int len, int* __restrict__ total) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (len + 1023) / 1024;
+  const int b0 = min(len, tid * per), b1 = min(len, b0 + per);
+  int s = 0;
+  for (int i = b0; i < b1; ++i) s += data[i];
+  // exclusive scan of the 1024 per-thread sums
+  int incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    int c = 0;
+    for (int w = 0; w < 16; ++w) { const int t = wsum[w]; wsum[w] = c; c += t; }
+    carry = c;
+  }
+  __syncthreads();
+  int run = wsum[wave] + incl - s;
+  for (int i = b0; i < b1; ++i) { const int t = data[i]; data[i] = run; run += t; }
+  if (total && tid == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(RS_THREADS) rs_scatter_kernel(const int* __restrict__ keys_in,
+                                                                const int* __restrict__ vals_in, int n, int shift,
+                                                                int nblk, const int* __restrict__ hist_scanned,
+                                                                int* __restrict__ keys_out, int* __restrict__ vals_out) {
+  __shared__ int wcnt[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+  __syncthreads();
+  volatile int* mycnt = wcnt[wave];
+  const int base = blockIdx.x * RS_TILE + wave * (64 * RS_ITEMS);
+  int key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int e = 0; e < RS_ITEMS; ++e) {
+    const int i = base + e * 64 + lane;   // original order inside the block = (wave, e, lane): ranks keep it => stable
+    const bool valid = i < n;
+    key[e] = valid ? keys_in[i] : 0;
+    val[e] = valid ? vals_in[i] : 0;
+    const int dg = (key[e] >> shift) & 255;
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (dg >> bit) & 1;
+      const unsigned long long bm = __ballot(one);
+      m &= one ? bm : ~bm;
+    }
+    const int r = __popcll(m & lt);
+    int b0 = 0;
+    if (valid && r == 0) {  // lowest lane of each digit group bumps this wave's counter
+      b0 = mycnt[dg];
+      mycnt[dg] = b0 + __popcll(m);
+    }
+    const int leader = valid ? (__ffsll((long long)m) - 1) : lane;
+    b0 = __shfl(b0, leader, 64);
+    rank[e] = b0 + r;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // digit `tid`: exclusive prefix over the 4 waves + this block's global base
+  {
+    const int g = hist_scanned[tid * nblk + blockIdx.x];
+    int c = g;
+    for (int w = 0; w < 4; ++w) { const int t = wcnt[w][tid]; wcnt[w][tid] = c; c += t; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < RS_ITEMS; ++e) {
+    const int i = base + e * 64 + lane;
+    if (i < n) {
+      const int dg = (key[e] >> shift) & 255;
+      const int pos = wcnt[wave][dg] + rank[e];
+      keys_out[pos] = key[e];
+      vals_out[pos] = val[e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ segments
+// head(i) = key[i] != 0 && (i == 0 || key[i] != key[i-1]);  per-block head counts
+__global__ void __launch_bounds__(RS_THREADS) seg_count_kernel(const int* __restrict__ keys, int n,
+                                                               int* __restrict__ blk_count) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const int base = blockIdx.x * RS_TILE + threadIdx.x * RS_ITEMS;
+  int c = 0;
+#pragma unroll
+  for (int e = 0; e < RS_ITEMS; ++e) {
+    const int i = base + e;
+    if (i < n) {
+      const int k = keys[i];
+      c += (k != 0 && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+    }
+  }
+  c = (int)wave_sum((float)c);  // <= 512 per wave: exact in fp32
+  if ((threadIdx.x & 63) == 0) atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) blk_count[blockIdx.x] = cnt;
+}
+
+// assigns unique ids in key order; writes uniq_idx, seg_start (and the end sentinel seg_start[n_uniq] = n)
+__global__ void __launch_bounds__(RS_THREADS) seg_assign_kernel(const int* __restrict__ keys, int n,
+                                                                const int* __restrict__ blk_off,
+                                                                const int* __restrict__ n_uniq,
+                                                                int64_t* __restrict__ uniq_idx,
+                                                                int* __restrict__ seg_start) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base = blockIdx.x * RS_TILE + tid * RS_ITEMS;
+  int flag[RS_ITEMS], k[RS_ITEMS];
+  int c = 0;
+#pragma unroll
+  for (int e = 0; e < RS_ITEMS; ++e) {
+    const int i = base + e;
+    k[e] = (i < n) ? keys[i] : 0;
+    flag[e] = (i < n && k[e] != 0 && (i == 0 || keys[i - 1] != k[e])) ? 1 : 0;
+    c += flag[e];
+  }
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wsum[w];
+  int u = blk_off[blockIdx.x] + woff + incl - c;
+#pragma unroll
+  for (int e = 0; e < RS_ITEMS; ++e) {
+    if (flag[e]) {
+      uniq_idx[u] = k[e];
+      seg_start[u] = base + e;
+      ++u;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) seg_start[*n_uniq] = n;
+}
+
+// ------------------------------------------------------------------------------------------------ segmented sum
+enum { MODE_ROWS = 0, MODE_SASREC = 1 };
+
+struct SegSumArgs {
+  const int* vals;         // sorted occurrence ids
+  const int* seg_start;    // [n_uniq + 1]
+  const int* n_uniq;
+  const float* src0;       // MODE_ROWS: rows [n, D];  MODE_SASREC: dx0 [T, D]
+  const float* src1;       // MODE_SASREC: out [T, D]
+  const float* coef;       // MODE_SASREC: [T]
+  float* uniq_rows;        // [n_uniq, D]
+  float scale;             // applied to the summed row (1/world_size for gradient averaging; 1 otherwise)
+  int D, T;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(128) segsum_kernel(SegSumArgs a) {
+  const int nu = *a.n_uniq;
+  const int dv = a.D >> 2;
+  for (int u = blockIdx.x; u < nu; u += gridDim.x) {
+    const int s0 = a.seg_start[u], s1 = a.seg_start[u + 1];
+    for (int c4 = threadIdx.x; c4 < dv; c4 += 128) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = s0; s < s1; ++s) {
+        const int o = a.vals[s];
+        float cf = 1.f;
+        const float* row;
+        if constexpr (MODE == MODE_ROWS) {
+          row = a.src0 + (int64_t)o * a.D;
+        } else {
+          const int type = o / a.T, r = o - type * a.T;
+          row = (type == 0 ? a.src0 : a.src1) + (int64_t)r * a.D;
+          cf = (type == 0) ? 1.f : (type == 1 ? a.coef[r] : -a.coef[r]);
+        }
+        const float4 v = *reinterpret_cast<const float4*>(row + c4 * 4);
+        acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
+      }
+      acc.x *= a.scale; acc.y *= a.scale; acc.z *= a.scale; acc.w *= a.scale;
+      *reinterpret_cast<float4*>(a.uniq_rows + (int64_t)u * a.D + c4 * 4) = acc;
+    }
+  }
+}
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct SortWs {
+  int *keysA, *keysB, *valsA, *valsB, *hist, *blk, *seg_start;
+  int nblk;
+};
+static int64_t carve(void* ws, int n, SortWs* out) {
+  const int nblk = (n + RS_TILE - 1) / RS_TILE;
+  char* p = (char*)ws;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* r = p ? p + off : nullptr; off += align256(bytes); return r; };
+  int* kA = (int*)take((int64_t)n * 4); int* kB = (int*)take((int64_t)n * 4);
+  int* vA = (int*)take((int64_t)n * 4); int* vB = (int*)take((int64_t)n * 4);
+  int* hist = (int*)take((int64_t)256 * nblk * 4);
+  int* blk = (int*)take((int64_t)(nblk + 1) * 4);
+  int* seg = (int*)take((int64_t)(n + 1) * 4);
+  if (out) { out->keysA = kA; out->keysB = kB; out->valsA = vA; out->valsB = vB; out->hist = hist; out->blk = blk;
+             out->seg_start = seg; out->nblk = nblk; }
+  return off;
+}
+
+static int sort_and_segment(SortWs& w, int n, int64_t n_table, int64_t* uniq_idx, int* n_uniq, hipStream_t st,
+                            const int** sorted_vals) {
+  int bits = 1;
+  while (((int64_t)1 << bits) < n_table) ++bits;
+  const int npass = (bits + 7) / 8;
+  if (256 * w.nblk > 1024 * 256) { pxr_set_error("embed grad: too many occurrences (%d)", n); return PXR_ERR_BAD_ARG; }
+  int *kin = w.keysA, *kout = w.keysB, *vin = w.valsA, *vout = w.valsB;
+  for (int p = 0; p < npass; ++p) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(w.nblk), dim3(RS_THREADS), 0, st, kin, n, p * 8, w.nblk, w.hist);
+    hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(1024), 0, st, w.hist, 256 * w.nblk, (int*)nullptr);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(w.nblk), dim3(RS_THREADS), 0, st, kin, vin, n, p * 8, w.nblk, w.hist,
+                       kout, vout);
+    int* t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+  }
+  hipLaunchKernelGGL(seg_count_kernel, dim3(w.nblk), dim3(RS_THREADS), 0, st, kin, n, w.blk);
+  hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(1024), 0, st, w.blk, w.nblk, n_uniq);
+  hipLaunchKernelGGL(seg_assign_kernel, dim3(w.nblk), dim3(RS_THREADS), 0, st, kin, n, w.blk, n_uniq, uniq_idx,
+                     w.seg_start);
+  *sorted_vals = vin;
+  return pxr_check_launch("embed grad (sort/segment)");
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+extern "C" int64_t pxr_embed_grad_ws_bytes(int64_t n_occ) {
+  return carve(nullptr, (int)n_occ, nullptr);
+}
+
+// Plain embedding backward in sparse form: (idx[n], rows[n, D]) -> (uniq_idx[<=n] ascending, uniq_rows, *n_uniq).
+// idx == 0 (padding_idx) and out-of-range ids are dropped.  uniq_idx/uniq_rows must hold n entries / rows.
+extern "C" int pxr_embed_grad_rows_f32(const int64_t* idx, int64_t n, const float* rows, int D, int64_t n_table,
+                                       float scale, int64_t* uniq_idx, float* uniq_rows, int32_t* n_uniq_dev, void* ws,
+                                       int64_t ws_bytes, void* stream) {
+  PXR_REQUIRE(idx && rows && uniq_idx && uniq_rows && n_uniq_dev && ws, "pxr_embed_grad_rows_f32: null pointer");
+  PXR_REQUIRE(n > 0 && n < (1ll << 30) && D > 0 && D % 4 == 0 && n_table > 0 && n_table < (1ll << 31),
+              "pxr_embed_grad_rows_f32: bad shape");
+  SortWs w;
+  if (carve(ws, (int)n, &w) > ws_bytes) { pxr_set_error("pxr_embed_grad_rows_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(occ_keys_rows_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, st, idx, (int)n, w.keysA, w.valsA,
+                     n_table);
+  const int* sorted_vals = nullptr;
+  int rc = sort_and_segment(w, (int)n, n_table, uniq_idx, n_uniq_dev, st, &sorted_vals);
+  if (rc) return rc;
+  SegSumArgs a{};
+  a.vals = sorted_vals; a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = rows; a.uniq_rows = uniq_rows;
+  a.scale = scale; a.D = D; a.T = (int)n;
+  const int grid = (int)(n < 4096 ? n : 4096);
+  hipLaunchKernelGGL(segsum_kernel<MODE_ROWS>, dim3(grid), dim3(128), 0, st, a);
+  return pxr_check_launch("pxr_embed_grad_rows_f32");
+}
+
+// SASRec-specific form (see header comment): items int64 [B,2,L+1]; dx0, out [B*L, D]; coef [B*L].
+extern "C" int pxr_sasrec_embed_grad_f32(const int64_t* items, int B, int L, const float* dx0, const float* out,
+                                         const float* coef, int D, int64_t n_table, float scale, int64_t* uniq_idx,
+                                         float* uniq_rows, int32_t* n_uniq_dev, void* ws, int64_t ws_bytes,
+                                         void* stream) {
+  PXR_REQUIRE(items && dx0 && out && coef && uniq_idx && uniq_rows && n_uniq_dev && ws,
+              "pxr_sasrec_embed_grad_f32: null pointer");
+  const int64_t n64 = (int64_t)3 * B * L;
+  PXR_REQUIRE(B > 0 && L > 0 && n64 < (1ll << 30) && D > 0 && D % 4 == 0 && n_table > 0 && n_table < (1ll << 31),
+              "pxr_sasrec_embed_grad_f32: bad shape");
+  const int n = (int)n64;
+  SortWs w;
+  if (carve(ws, n, &w) > ws_bytes) { pxr_set_error("pxr_sasrec_embed_grad_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(occ_keys_sasrec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, items, B, L, w.keysA, w.valsA,
+                     n_table);
+  const int* sorted_vals = nullptr;
+  int rc = sort_and_segment(w, n, n_table, uniq_idx, n_uniq_dev, st, &sorted_vals);
+  if (rc) return rc;
+  SegSumArgs a{};
+  a.vals = sorted_vals; a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = dx0; a.src1 = out; a.coef = coef;
+  a.uniq_rows = uniq_rows; a.scale = scale; a.D = D; a.T = B * L;
+  const int grid = n < 4096 ? n : 4096;
+  hipLaunchKernelGGL(segsum_kernel<MODE_SASREC>, dim3(grid), dim3(128), 0, st, a);
+  return pxr_check_launch("pxr_sasrec_embed_grad_f32");
+}

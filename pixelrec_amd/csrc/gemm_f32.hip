@@ -8,7 +8,7 @@
 
 namespace pxr {
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD = 4 };
 
 // erf-GELU exactly as the reference writes it: x * 0.5 * (1 + erf(x / sqrt(2)))  (layers.py:651-660)
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
@@ -61,6 +61,8 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
           v = gelu_erf(v);
         } else if constexpr (EPI == EPI_MUL_DGELU) {
           v *= dgelu_erf(aux[(int64_t)row * ldaux + col]);
+        } else if constexpr (EPI == EPI_ADD) {
+          v += aux[(int64_t)row * ldaux + col];  // residual-branch gradient joins here
         }
         C[(int64_t)row * ldc + col] = v;
       }
@@ -152,9 +154,10 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   // the contiguous extent of each operand is read as float4
   PXR_REQUIRE(a_kc ? (K % 4 == 0) : (M % 4 == 0), "pxr_gemm_f32: A contiguous extent must be a multiple of 4");
   PXR_REQUIRE(b_kc ? (K % 4 == 0) : (N % 4 == 0), "pxr_gemm_f32: B contiguous extent must be a multiple of 4");
-  PXR_REQUIRE(epilogue >= 0 && epilogue <= 3, "pxr_gemm_f32: bad epilogue %d", epilogue);
+  PXR_REQUIRE(epilogue >= 0 && epilogue <= 4, "pxr_gemm_f32: bad epilogue %d", epilogue);
   PXR_REQUIRE(!(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU) || bias, "pxr_gemm_f32: epilogue needs bias");
-  PXR_REQUIRE(!(epilogue == EPI_BIAS_GELU || epilogue == EPI_MUL_DGELU) || aux, "pxr_gemm_f32: epilogue needs aux");
+  PXR_REQUIRE(!(epilogue == EPI_BIAS_GELU || epilogue == EPI_MUL_DGELU || epilogue == EPI_ADD) || aux,
+              "pxr_gemm_f32: epilogue needs aux");
   hipStream_t st = (hipStream_t)stream;
 
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
@@ -208,6 +211,7 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
     switch (epilogue) {
       case EPI_NONE: PXR_GEMM_CASE(true, false, EPI_NONE); break;
       case EPI_MUL_DGELU: PXR_GEMM_CASE(true, false, EPI_MUL_DGELU); break;
+      case EPI_ADD: PXR_GEMM_CASE(true, false, EPI_ADD); break;
       default: pxr_set_error("pxr_gemm_f32: epilogue %d unsupported for (KC,XC)", epilogue); return PXR_ERR_BAD_ARG;
     }
   } else if (!a_kc && !b_kc) {
@@ -235,11 +239,15 @@ extern "C" int pxr_linear_fwd_f32(const float* x, const float* W, const float* b
   const int epi = act ? EPI_BIAS_GELU : (b ? EPI_BIAS : EPI_NONE);
   return pxr_gemm_f32(1, 1, M, N, K, x, K, W, K, y, N, epi, b, pre, N, nullptr, 0, 0, 0, stream);
 }
-// dx[M,K] = dy[M,N] W[N,K]     (dgelu_pre != NULL: dx *= gelu'(dgelu_pre), i.e. through the FFN activation)
-extern "C" int pxr_linear_bwd_input_f32(const float* dy, const float* W, float* dx, const float* dgelu_pre, int M,
-                                        int N, int K, void* stream) {
-  return pxr_gemm_f32(1, 0, M, K, N, dy, N, W, K, dx, K, dgelu_pre ? EPI_MUL_DGELU : EPI_NONE, nullptr,
-                      const_cast<float*>(dgelu_pre), K, nullptr, 0, 0, 0, stream);
+// dx[M,K] = dy[M,N] W[N,K]     dgelu_pre != NULL: dx *= gelu'(dgelu_pre) (through the FFN activation);
+//                              add != NULL: dx += add (the residual branch's gradient).  At most one of the two.
+extern "C" int pxr_linear_bwd_input_f32(const float* dy, const float* W, float* dx, const float* dgelu_pre,
+                                        const float* add, int M, int N, int K, void* stream) {
+  PXR_REQUIRE(!(dgelu_pre && add), "pxr_linear_bwd_input_f32: dgelu_pre and add are mutually exclusive");
+  const float* aux = dgelu_pre ? dgelu_pre : add;
+  const int epi = dgelu_pre ? EPI_MUL_DGELU : (add ? EPI_ADD : EPI_NONE);
+  return pxr_gemm_f32(1, 0, M, K, N, dy, N, W, K, dx, K, epi, nullptr, const_cast<float*>(aux), K, nullptr, 0, 0, 0,
+                      stream);
 }
 // dW[N,K] = dy[M,N]^T x[M,K]   (reduction over the M tokens, split-K through ws)
 extern "C" int pxr_linear_bwd_weight_f32(const float* dy, const float* x, float* dW, int M, int N, int K, void* ws,

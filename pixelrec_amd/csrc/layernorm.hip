@@ -1,0 +1,363 @@
+// layernorm.hip -- the three LayerNorm sites of the SASRec block, fused with their neighbours.
+//
+//   mode GATHER   : z = table[idx[b,t]] + pos_emb[t];  y = dropout(LN(z))          (sasrec.py:68,77-82 / :99-104)
+//   mode RESIDUAL : z = dropout(x) + res;              y = LN(z)                   (layers.py:614-615, :670-671)
+//
+// LN is nn.LayerNorm: biased variance over the last dim, y = (z-mean)/sqrt(var+eps)*gamma + beta.
+// One 64-lane wave owns one row and keeps it in registers (VEC float4 per lane, D <= VEC*256), two-pass
+// mean / variance from registers (no E[x^2]-mean^2 cancellation), wave-shuffle reductions, 16-byte accesses.
+// The forward saves xhat (the normalised row) and rstd for the backward; dropout masks are regenerated from
+// the counter hash (pxr_common.h), never stored.
+//
+// Backward (autograd of the above):   a = dy*gamma;  dz = rstd*(a - mean(a) - xhat*mean(a*xhat))
+//   dgamma = sum_rows dy*xhat, dbeta = sum_rows dy  -> per-block partials, summed in fixed order by
+//   pxr_colsum-style stage 2 (deterministic, no float atomics).
+#include "pxr_common.h"
+
+namespace pxr {
+
+struct LnFwdArgs {
+  const float* x;          // RESIDUAL: [rows, D]
+  const float* res;        // RESIDUAL: [rows, D] (may be null => no residual)
+  const float* table;      // GATHER: [N, D]
+  const int64_t* idx;      // GATHER: ids, element (b, t) at idx[b * idx_bstride + t]
+  const float* pos;        // GATHER: [L, D]
+  const float* gamma;
+  const float* beta;
+  float* y;                // [rows, D]
+  float* xhat;             // [rows, D] or null (inference)
+  float* rstd;             // [rows] or null
+  int64_t idx_bstride;
+  int64_t n_table;
+  int rows, D, L;
+  float eps;
+  float p_drop;            // dropout probability (0 => off)
+  uint32_t drop_thr;
+  uint32_t stream;
+  uint64_t seed;
+};
+
+template <int VEC, bool GATHER>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
+  const int D = a.D;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  const bool drop = a.drop_thr != 0u;
+  float4 v[VEC];
+  const float* src;
+  const float* add;
+  if constexpr (GATHER) {
+    const int b = row / a.L, t = row - b * a.L;
+    int64_t r = a.idx[(int64_t)b * a.idx_bstride + t];
+    r = r < 0 ? 0 : (r >= a.n_table ? a.n_table - 1 : r);
+    src = a.table + r * D;
+    add = a.pos + (int64_t)t * D;
+  } else {
+    src = a.x + (int64_t)row * D;
+    add = a.res ? a.res + (int64_t)row * D : nullptr;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < D) {
+      float4 t4 = *reinterpret_cast<const float4*>(src + c);
+      if constexpr (!GATHER) {
+        if (drop) {  // dropout on the sub-layer output BEFORE the residual add (layers.py:614, :670)
+          const uint64_t e = (uint64_t)row * D + c;
+          t4.x = pxr_keep(a.seed, a.stream, e + 0, a.drop_thr) ? t4.x * inv_keep : 0.f;
+          t4.y = pxr_keep(a.seed, a.stream, e + 1, a.drop_thr) ? t4.y * inv_keep : 0.f;
+          t4.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? t4.z * inv_keep : 0.f;
+          t4.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? t4.w * inv_keep : 0.f;
+        }
+      }
+      if (add) {
+        const float4 r4 = *reinterpret_cast<const float4*>(add + c);
+        t4.x += r4.x; t4.y += r4.y; t4.z += r4.z; t4.w += r4.w;
+      }
+      v[k] = t4;
+      s += (t4.x + t4.y) + (t4.z + t4.w);
+    } else {
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < D) {
+      const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + a.eps);
+  if (a.rstd && lane == 0) a.rstd[row] = rstd;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < D) {
+      const float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
+      const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
+      float4 xh;
+      xh.x = (v[k].x - mean) * rstd; xh.y = (v[k].y - mean) * rstd;
+      xh.z = (v[k].z - mean) * rstd; xh.w = (v[k].w - mean) * rstd;
+      if (a.xhat) *reinterpret_cast<float4*>(a.xhat + (int64_t)row * D + c) = xh;
+      float4 y;
+      y.x = xh.x * g.x + be.x; y.y = xh.y * g.y + be.y; y.z = xh.z * g.z + be.z; y.w = xh.w * g.w + be.w;
+      if constexpr (GATHER) {
+        if (drop) {  // dropout AFTER the input LayerNorm (sasrec.py:82)
+          const uint64_t e = (uint64_t)row * D + c;
+          y.x = pxr_keep(a.seed, a.stream, e + 0, a.drop_thr) ? y.x * inv_keep : 0.f;
+          y.y = pxr_keep(a.seed, a.stream, e + 1, a.drop_thr) ? y.y * inv_keep : 0.f;
+          y.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? y.z * inv_keep : 0.f;
+          y.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? y.w * inv_keep : 0.f;
+        }
+      }
+      *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
+    }
+  }
+}
+
+struct LnBwdArgs {
+  const float* dy;      // [rows, D] gradient w.r.t. the LN site's output (for GATHER: w.r.t. dropout(LN(z)))
+  const float* xhat;    // [rows, D]
+  const float* rstd;    // [rows]
+  const float* gamma;
+  float* dz;            // [rows, D] gradient w.r.t. z (= d residual; = d(table row + pos) in GATHER mode)
+  float* dx;            // RESIDUAL with dropout: gradient w.r.t. x (= mask*dz/(1-p)); null => not needed
+  float* part;          // [nblk, 2*D] per-block partial (dgamma | dbeta)
+  int rows, D, rows_per_block;
+  float p_drop;
+  uint32_t drop_thr;
+  uint32_t stream;
+  uint64_t seed;
+};
+
+template <int VEC, bool GATHER>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
+  __shared__ float red[3][2 * VEC * 256];  // waves 1..3 park their partial (dgamma | dbeta) here
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = a.D;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  const bool drop = a.drop_thr != 0u;
+  float4 accg[VEC], accb[VEC], gam[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    accg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    accb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = (k * 64 + lane) * 4;
+    gam[k] = (c < D) ? *reinterpret_cast<const float4*>(a.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int r0 = blockIdx.x * a.rows_per_block;
+  const int r1 = min(a.rows, r0 + a.rows_per_block);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    float4 g4[VEC], xh[VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < D) {
+        float4 d = *reinterpret_cast<const float4*>(a.dy + (int64_t)row * D + c);
+        if constexpr (GATHER) {
+          if (drop) {
+            const uint64_t e = (uint64_t)row * D + c;
+            d.x = pxr_keep(a.seed, a.stream, e + 0, a.drop_thr) ? d.x * inv_keep : 0.f;
+            d.y = pxr_keep(a.seed, a.stream, e + 1, a.drop_thr) ? d.y * inv_keep : 0.f;
+            d.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? d.z * inv_keep : 0.f;
+            d.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? d.w * inv_keep : 0.f;
+          }
+        }
+        const float4 x = *reinterpret_cast<const float4*>(a.xhat + (int64_t)row * D + c);
+        xh[k] = x;
+        accg[k].x += d.x * x.x; accg[k].y += d.y * x.y; accg[k].z += d.z * x.z; accg[k].w += d.w * x.w;
+        accb[k].x += d.x; accb[k].y += d.y; accb[k].z += d.z; accb[k].w += d.w;
+        float4 t;
+        t.x = d.x * gam[k].x; t.y = d.y * gam[k].y; t.z = d.z * gam[k].z; t.w = d.w * gam[k].w;
+        g4[k] = t;
+        s1 += (t.x + t.y) + (t.z + t.w);
+        s2 += (t.x * x.x + t.y * x.y) + (t.z * x.z + t.w * x.w);
+      } else {
+        g4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[k] = g4[k];
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)D;
+    const float c2 = wave_sum(s2) / (float)D;
+    const float rs = a.rstd[row];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < D) {
+        float4 z;
+        z.x = rs * (g4[k].x - c1 - xh[k].x * c2); z.y = rs * (g4[k].y - c1 - xh[k].y * c2);
+        z.z = rs * (g4[k].z - c1 - xh[k].z * c2); z.w = rs * (g4[k].w - c1 - xh[k].w * c2);
+        *reinterpret_cast<float4*>(a.dz + (int64_t)row * D + c) = z;
+        if constexpr (!GATHER) {
+          if (a.dx) {
+            float4 o = z;
+            if (drop) {
+              const uint64_t e = (uint64_t)row * D + c;
+              o.x = pxr_keep(a.seed, a.stream, e + 0, a.drop_thr) ? z.x * inv_keep : 0.f;
+              o.y = pxr_keep(a.seed, a.stream, e + 1, a.drop_thr) ? z.y * inv_keep : 0.f;
+              o.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? z.z * inv_keep : 0.f;
+              o.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? z.w * inv_keep : 0.f;
+            }
+            *reinterpret_cast<float4*>(a.dx + (int64_t)row * D + c) = o;
+          }
+        }
+      }
+    }
+  }
+  // cross-wave reduction of the per-lane partials in a fixed order (wave0 + wave1 + wave2 + wave3)
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      *reinterpret_cast<float4*>(&red[wave - 1][c]) = accg[k];
+      *reinterpret_cast<float4*>(&red[wave - 1][VEC * 256 + c]) = accb[k];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < D) {
+        float4 g = accg[k], b = accb[k];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float4 og = *reinterpret_cast<const float4*>(&red[w][c]);
+          const float4 ob = *reinterpret_cast<const float4*>(&red[w][VEC * 256 + c]);
+          g.x += og.x; g.y += og.y; g.z += og.z; g.w += og.w;
+          b.x += ob.x; b.y += ob.y; b.z += ob.z; b.w += ob.w;
+        }
+        *reinterpret_cast<float4*>(a.part + (int64_t)blockIdx.x * 2 * D + c) = g;
+        *reinterpret_cast<float4*>(a.part + (int64_t)blockIdx.x * 2 * D + D + c) = b;
+      }
+    }
+  }
+}
+
+// out[n] = sum_p part[p][n]   (n < N)
+__global__ void __launch_bounds__(256) ln_part_reduce_kernel(const float* __restrict__ part, int P, int N,
+                                                             float* __restrict__ out_a, float* __restrict__ out_b,
+                                                             int D) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(int64_t)p * N + col];
+  if (col < D) out_a[col] = s;
+  else out_b[col - D] = s;
+}
+
+static inline int ln_vec_for(int D) {
+  int v = (D + 255) / 256;
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+template <bool GATHER>
+static int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
+  const int blocks = (a.rows + 3) / 4;
+  switch (ln_vec_for(a.D)) {
+    case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, GATHER>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, GATHER>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((ln_fwd_kernel<4, GATHER>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((ln_fwd_kernel<8, GATHER>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((ln_fwd_kernel<16, GATHER>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: pxr_set_error("layernorm: D=%d > 4096 unsupported", a.D); return PXR_ERR_BAD_ARG;
+  }
+  return pxr_check_launch("pxr_ln_fwd");
+}
+
+template <bool GATHER>
+static int launch_ln_bwd(const LnBwdArgs& a, int nblk, hipStream_t st) {
+  switch (ln_vec_for(a.D)) {
+    case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((ln_bwd_kernel<8, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
+    default: pxr_set_error("layernorm backward: D=%d > 2048 unsupported", a.D); return PXR_ERR_BAD_ARG;
+  }
+  return pxr_check_launch("pxr_ln_bwd");
+}
+
+static inline int ln_bwd_blocks(int rows, int* rows_per_block) {
+  int rpb = (rows + 511) / 512;  // aim at <= 512 blocks
+  if (rpb < 4) rpb = 4;
+  *rows_per_block = rpb;
+  return (rows + rpb - 1) / rpb;
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+// y = dropout(LN(table[idx] + pos))   rows = B*L; idx element (b,t) at idx[b*idx_bstride + t].
+// xhat / rstd may be null (inference).  (sasrec.py:68,77-82 train; :99-104 predict)
+extern "C" int pxr_input_ln_fwd_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
+                                    const float* pos, const float* gamma, const float* beta, float eps, int B, int L,
+                                    int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
+                                    uint32_t stream_id, void* stream) {
+  PXR_REQUIRE(table && idx && pos && gamma && beta && y, "pxr_input_ln_fwd_f32: null pointer");
+  PXR_REQUIRE(D > 0 && D % 4 == 0 && B >= 0 && L > 0, "pxr_input_ln_fwd_f32: bad shape");
+  PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_input_ln_fwd_f32: bad dropout p");
+  if (B == 0) return PXR_OK;
+  LnFwdArgs a{};
+  a.table = table; a.idx = idx; a.pos = pos; a.gamma = gamma; a.beta = beta; a.y = y; a.xhat = xhat; a.rstd = rstd;
+  a.idx_bstride = idx_bstride; a.n_table = n_table; a.rows = B * L; a.D = D; a.L = L; a.eps = eps;
+  a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  return launch_ln_fwd<true>(a, (hipStream_t)stream);
+}
+
+// y = LN(dropout(x) + res)   (layers.py:614-615, :670-671).  res may be null.
+extern "C" int pxr_ln_residual_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta,
+                                       float eps, int rows, int D, float* y, float* xhat, float* rstd, float p_drop,
+                                       uint64_t seed, uint32_t stream_id, void* stream) {
+  PXR_REQUIRE(x && gamma && beta && y, "pxr_ln_residual_fwd_f32: null pointer");
+  PXR_REQUIRE(D > 0 && D % 4 == 0 && rows >= 0, "pxr_ln_residual_fwd_f32: bad shape");
+  PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_ln_residual_fwd_f32: bad dropout p");
+  if (rows == 0) return PXR_OK;
+  LnFwdArgs a{};
+  a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xhat = xhat; a.rstd = rstd;
+  a.rows = rows; a.D = D; a.L = 1; a.eps = eps;
+  a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  return launch_ln_fwd<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int64_t pxr_ln_bwd_ws_bytes(int rows, int D) {
+  int rpb;
+  const int nblk = ln_bwd_blocks(rows, &rpb);
+  return (int64_t)nblk * 2 * D * (int64_t)sizeof(float);
+}
+
+// Backward of either LN site.  gather_mode=1: dy is w.r.t. dropout(LN(z)) and the mask is re-applied to dy;
+// gather_mode=0: dx (optional) = dropout-mask(dz)/(1-p) is the gradient w.r.t. the sub-layer output x and dz
+// the gradient w.r.t. the residual.  dgamma/dbeta are OVERWRITTEN (not accumulated).
+extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd,
+                              const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
+                              float p_drop, uint64_t seed, uint32_t stream_id, void* ws, int64_t ws_bytes,
+                              void* stream) {
+  PXR_REQUIRE(dy && xhat && rstd && gamma && dz && dgamma && dbeta && ws, "pxr_ln_bwd_f32: null pointer");
+  PXR_REQUIRE(D > 0 && D % 4 == 0 && rows > 0, "pxr_ln_bwd_f32: bad shape");
+  LnBwdArgs a{};
+  a.dy = dy; a.xhat = xhat; a.rstd = rstd; a.gamma = gamma; a.dz = dz; a.dx = dx; a.part = (float*)ws;
+  a.rows = rows; a.D = D;
+  const int nblk = ln_bwd_blocks(rows, &a.rows_per_block);
+  if ((int64_t)nblk * 2 * D * 4 > ws_bytes) {
+    pxr_set_error("pxr_ln_bwd_f32: workspace too small");
+    return PXR_ERR_WORKSPACE;
+  }
+  a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = gather_mode ? launch_ln_bwd<true>(a, nblk, st) : launch_ln_bwd<false>(a, nblk, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, (const float*)ws, nblk,
+                     2 * D, dgamma, dbeta, D);
+  return pxr_check_launch("pxr_ln_bwd_f32(reduce)");
+}

@@ -59,13 +59,16 @@ __device__ __forceinline__ float wave_max(float v) {
 // (oracle/dropout_rng.py) to feed identical masks to the CPU oracle.  The reference uses ATen's Philox
 // stream (nn.Dropout, sasrec.py:46, layers.py:575,579,641) which cannot be reproduced bit-for-bit;
 // training-mode parity is checked with this mask injected into the oracle.
+__device__ __host__ __forceinline__ uint32_t pxr_fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
 __device__ __host__ __forceinline__ uint32_t pxr_hash32(uint64_t seed, uint32_t stream, uint64_t idx) {
-  uint64_t x = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(stream + 1u);
-  x ^= seed;
-  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
-  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
-  x ^= x >> 33;
-  return (uint32_t)(x >> 16);
+  // 32-bit-only mixing (64-bit multiplies are multi-instruction on the VALU): two murmur3 finalizer rounds.
+  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = pxr_fmix32(lo ^ (uint32_t)seed);
+  h += hi * 0x9E3779B1u + stream * 0x85EBCA77u + (uint32_t)(seed >> 32);
+  return pxr_fmix32(h);
 }
 // threshold = floor(p * 2^32); keep when hash >= threshold  (p == 0 -> threshold 0 -> always keep)
 __device__ __host__ __forceinline__ uint32_t pxr_drop_threshold(float p) {

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, c_uint64, c_double
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpxr.so")
@@ -26,19 +26,33 @@ _lib = None
 # name -> (restype, argtypes).  Must list every symbol include/pxr.h declares (tests/test_abi.py checks both
 # directions against the header).
 _P = c_void_p
+_F, _D, _I, _I64, _U64, _U32 = c_float, c_double, c_int, c_int64, c_uint64, ctypes.c_uint32
 _SIGNATURES = {
     "pxr_version": (c_int, []),
     "pxr_last_error": (c_char_p, []),
     "pxr_target_arch": (c_char_p, []),
-    "pxr_embed_gather_f32": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, _P]),
-    "pxr_gemm_ws_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
-    "pxr_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P,
-                             _P, c_int64, _P, c_int64, c_int, c_int, _P]),
-    "pxr_linear_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "pxr_linear_bwd_input_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "pxr_linear_bwd_weight_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P]),
-    "pxr_colsum_ws_bytes": (c_int64, [c_int, c_int]),
-    "pxr_colsum_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int64, _P]),
+    "pxr_embed_gather_f32": (_I, [_P, _I64, _I, _P, _I64, _P, _P]),
+    "pxr_embed_grad_ws_bytes": (_I64, [_I64]),
+    "pxr_embed_grad_rows_f32": (_I, [_P, _I64, _P, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
+    "pxr_sasrec_embed_grad_f32": (_I, [_P, _I, _I, _P, _P, _P, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
+    "pxr_input_ln_fwd_f32": (_I, [_P, _I64, _P, _I64, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _F, _U64, _U32, _P]),
+    "pxr_ln_residual_fwd_f32": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _F, _U64, _U32, _P]),
+    "pxr_ln_bwd_ws_bytes": (_I64, [_I, _I]),
+    "pxr_ln_bwd_f32": (_I, [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U32, _P, _I64, _P]),
+    "pxr_gemm_ws_bytes": (_I64, [_I, _I, _I, _I, _I]),
+    "pxr_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _I64, _P, _I64, _I, _I, _P]),
+    "pxr_linear_fwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "pxr_linear_bwd_input_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "pxr_linear_bwd_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _I64, _P]),
+    "pxr_colsum_ws_bytes": (_I64, [_I, _I]),
+    "pxr_colsum_f32": (_I, [_P, _I64, _I, _I, _P, _P, _I64, _P]),
+    "pxr_attn_fwd_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _I, _I, _I, _I, _P, _I64, _P, _F, _U64, _U32, _P]),
+    "pxr_attn_bwd_f32": (_I, [_P, _I64, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _P, _I64, _F, _U64, _U32, _P]),
+    "pxr_bpr_loss_fwd_f32": (_I, [_P, _P, _I64, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "pxr_bpr_loss_bwd_f32": (_I, [_P, _P, _P, _I64, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "pxr_adamw_flat_f32": (_I, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),
+    "pxr_slot_fill_i32": (_I, [_P, _I64, ctypes.c_int32, _P]),
+    "pxr_adamw_table_f32": (_I, [_P, _P, _P, _I64, _I, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),
 }
 
 

@@ -1,0 +1,2 @@
+from .basemodel import BaseModel  # noqa: F401
+from .sasrec import SASRec  # noqa: F401

@@ -1,0 +1,319 @@
+"""SASRec (IDNet) on the MI355X-native kernels -- drop-in for the reference class
+`REC.model.IDNet.sasrec.SASRec` (code/REC/model/IDNet/sasrec.py:9-126).
+
+Contract kept: class attr `input_type`; `__init__(config, dataload)`; `forward(interaction) ->
+0-dim loss` usable with `loss.backward()`; `predict(item_seq, item_feature) -> [B, N]`; `compute_item_all()`;
+an nn.Module whose `state_dict()` keys are exactly the reference's, so checkpoints interchange.
+
+What differs underneath (nothing below runs stock ATen math on the hot path):
+  * the nn.Linear / nn.LayerNorm / nn.Embedding sub-modules are PARAMETER CONTAINERS only (they give the
+    reference's parameter names and `_init_weights` semantics); forward/backward are hand-written HIP kernels
+    called through the C ABI (pixelrec_amd/ops.py -> include/pxr.h);
+  * all non-table parameters live in ONE flat fp32 buffer (query|key|value weights adjacent => one fused QKV
+    GEMM; one flat gradient buffer => one fused AdamW launch and one RCCL all-reduce);
+  * the table gradient is never dense: backward leaves `(uniq_idx, uniq_rows, n)` in `self.sparse_table_grad`
+    for pixelrec_amd.optim.PxrAdamW (dense AdamW semantics, sparse gradient);
+  * gradients are OVERWRITTEN by each backward (the reference calls zero_grad() before every step,
+    trainer.py:117, so accumulation is never relied on).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib import PxrError
+from ..utils.enum_type import InputType
+from .basemodel import BaseModel
+
+
+# ---- parameter containers with the reference's module tree (names only; their forward is never called) -----
+class _MultiHeadAttentionParams(nn.Module):
+    def __init__(self, hidden, eps):
+        super().__init__()
+        self.query = nn.Linear(hidden, hidden)
+        self.key = nn.Linear(hidden, hidden)
+        self.value = nn.Linear(hidden, hidden)
+        self.dense = nn.Linear(hidden, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+
+
+class _FeedForwardParams(nn.Module):
+    def __init__(self, hidden, inner, eps):
+        super().__init__()
+        self.dense_1 = nn.Linear(hidden, inner)
+        self.dense_2 = nn.Linear(inner, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+
+
+class _TransformerLayerParams(nn.Module):
+    def __init__(self, hidden, inner, eps):
+        super().__init__()
+        self.multi_head_attention = _MultiHeadAttentionParams(hidden, eps)
+        self.feed_forward = _FeedForwardParams(hidden, inner, eps)
+
+
+class _TransformerEncoderParams(nn.Module):
+    def __init__(self, n_layers, hidden, inner, eps):
+        super().__init__()
+        self.layer = nn.ModuleList([_TransformerLayerParams(hidden, inner, eps) for _ in range(n_layers)])
+
+
+class _TrainStep(torch.autograd.Function):
+    """Bridges `loss.backward()` to the hand-written backward chain."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, items, masked_index):
+        ctx.model = model
+        return model._forward_train(items, masked_index).view(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._backward_train(grad_out)
+        return None, None, None, None
+
+
+class SASRec(BaseModel):
+    input_type = InputType.SEQ
+
+    def __init__(self, config, dataload):
+        super().__init__()
+        # hyper-parameters: same config keys as the reference (sasrec.py:16-29)
+        self.n_layers = config["n_layers"]
+        self.n_heads = config["n_heads"]
+        self.hidden_size = config["embedding_size"]
+        self.inner_size = config["inner_size"] * self.hidden_size  # sasrec.py:21 ("inner_size" is a multiplier)
+        self.hidden_dropout_prob = float(config["hidden_dropout_prob"])
+        self.attn_dropout_prob = float(config["attn_dropout_prob"])
+        self.hidden_act = config["hidden_act"]
+        self.layer_norm_eps = float(config["layer_norm_eps"])
+        self.initializer_range = config["initializer_range"]
+        self.max_seq_length = config["MAX_ITEM_LIST_LENGTH"]
+        self.item_num = dataload.item_num
+        if self.hidden_act != "gelu":
+            raise NotImplementedError("pixelrec_amd SASRec implements hidden_act='gelu' (the shipped config); "
+                                      f"got {self.hidden_act!r}")
+        if self.hidden_size % self.n_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (self.hidden_size, self.n_heads))
+        if self.hidden_size % 4 != 0:
+            raise ValueError("embedding_size must be a multiple of 4 (16-byte vector accesses)")
+
+        self.item_embedding = nn.Embedding(self.item_num, self.hidden_size, padding_idx=0)
+        self.position_embedding = nn.Embedding(self.max_seq_length, self.hidden_size)
+        self.trm_encoder = _TransformerEncoderParams(self.n_layers, self.hidden_size, self.inner_size,
+                                                     self.layer_norm_eps)
+        self.LayerNorm = nn.LayerNorm(self.hidden_size, eps=self.layer_norm_eps)
+        self.dropout = nn.Dropout(self.hidden_dropout_prob)
+        self.apply(self._init_weights)
+
+        self._flat = None            # packed non-table parameters
+        self._gflat = None           # packed gradients (same layout)
+        self._views = {}
+        self._anchor = None
+        self._saved = None
+        self.sparse_table_grad = None
+        self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
+        self._step_counter = 0
+
+    def _init_weights(self, module):
+        """N(0, initializer_range) for every Linear/Embedding weight incl. table row 0; LayerNorm (1, 0); biases 0
+        (sasrec.py:51-61)."""
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.initializer_range)
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    # ------------------------------------------------------------------------------------------ flat packing
+    def _flat_specs(self):
+        specs = [("pos", self.position_embedding.weight), ("ln0.w", self.LayerNorm.weight),
+                 ("ln0.b", self.LayerNorm.bias)]
+        for i, lay in enumerate(self.trm_encoder.layer):
+            a, f = lay.multi_head_attention, lay.feed_forward
+            specs += [(f"{i}.q.w", a.query.weight), (f"{i}.k.w", a.key.weight), (f"{i}.v.w", a.value.weight),
+                      (f"{i}.q.b", a.query.bias), (f"{i}.k.b", a.key.bias), (f"{i}.v.b", a.value.bias),
+                      (f"{i}.o.w", a.dense.weight), (f"{i}.o.b", a.dense.bias),
+                      (f"{i}.ln1.w", a.LayerNorm.weight), (f"{i}.ln1.b", a.LayerNorm.bias),
+                      (f"{i}.f1.w", f.dense_1.weight), (f"{i}.f1.b", f.dense_1.bias),
+                      (f"{i}.f2.w", f.dense_2.weight), (f"{i}.f2.b", f.dense_2.bias),
+                      (f"{i}.ln2.w", f.LayerNorm.weight), (f"{i}.ln2.b", f.LayerNorm.bias)]
+        return specs
+
+    def _ensure_packed(self):
+        """(Re)build the flat parameter / gradient buffers when the parameters moved (e.g. after .to(device))."""
+        w0 = self.position_embedding.weight
+        if self._flat is not None and self._flat.device == w0.device and w0.data_ptr() == self._flat.data_ptr():
+            return
+        dev = w0.device
+        if dev.type != "cuda":
+            raise PxrError("pixelrec_amd.SASRec runs on a HIP device only (no CPU fallback); move the model with "
+                           ".to('cuda') first")
+        specs = self._flat_specs()
+        total = sum(p.numel() for _, p in specs)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        views = {}
+        for name, p in specs:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = gflat[off:off + n].view(p.shape)
+            views[name] = (off, n, tuple(p.shape))
+            off += n
+        self._flat, self._gflat, self._views = flat, gflat, views
+        self._anchor = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
+        self.item_embedding.weight.data = self.item_embedding.weight.data.contiguous()
+
+    def _p(self, name, grad=False, span=1):
+        """View of parameter `name` (or of `span` adjacent ones fused along dim 0) in the flat (grad) buffer."""
+        off, n, shape = self._views[name]
+        buf = self._gflat if grad else self._flat
+        if span == 1:
+            return buf[off:off + n].view(shape)
+        return buf[off:off + span * n].view((span * shape[0],) + tuple(shape[1:]))
+
+    def flat_parameters(self):
+        self._ensure_packed()
+        return self._flat, self._gflat
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _encode(self, idx, idx_bstride, B, keymask, km_bstride, train: bool):
+        """ids -> last-layer states [B, L, D] (sasrec.py:68-86 / :97-109); saves activations when train."""
+        L, D, H = self.max_seq_length, self.hidden_size, self.n_heads
+        d = D // H
+        eps = self.layer_norm_eps
+        ph = self.hidden_dropout_prob if train else 0.0
+        pa = self.attn_dropout_prob if train else 0.0
+        seed = (self._drop_seed * 1000003 + self._step_counter) & 0xFFFFFFFFFFFFFFFF
+        table = self.item_embedding.weight.data
+        saved = {"seed": seed, "ph": ph, "pa": pa, "layers": []} if train else None
+        h, xhat0, rstd0 = ops.input_ln_fwd(table, idx, idx_bstride, B, L, self._p("pos"), self._p("ln0.w"),
+                                           self._p("ln0.b"), eps, ph, seed, 0, save=train)
+        if train:
+            saved["xhat0"], saved["rstd0"] = xhat0, rstd0
+        for i in range(self.n_layers):
+            qkv = ops.linear_fwd(h, self._p(f"{i}.q.w", span=3), self._p(f"{i}.q.b", span=3))
+            ctx, probs = ops.attn_fwd(qkv, keymask, km_bstride, B, H, L, d, pa, seed, 1 + 3 * i, save=train)
+            a = ops.linear_fwd(ctx, self._p(f"{i}.o.w"), self._p(f"{i}.o.b"))
+            h1, xhat1, rstd1 = ops.ln_residual_fwd(a, h, self._p(f"{i}.ln1.w"), self._p(f"{i}.ln1.b"), eps, ph, seed,
+                                                   2 + 3 * i, save=train)
+            f, u = ops.linear_fwd(h1, self._p(f"{i}.f1.w"), self._p(f"{i}.f1.b"), gelu=True)
+            f2 = ops.linear_fwd(f, self._p(f"{i}.f2.w"), self._p(f"{i}.f2.b"))
+            h2, xhat2, rstd2 = ops.ln_residual_fwd(f2, h1, self._p(f"{i}.ln2.w"), self._p(f"{i}.ln2.b"), eps, ph, seed,
+                                                   3 + 3 * i, save=train)
+            if train:
+                saved["layers"].append(dict(h_in=h, qkv=qkv, probs=probs, ctx=ctx, xhat1=xhat1, rstd1=rstd1, h1=h1,
+                                            u=u, f=f, xhat2=xhat2, rstd2=rstd2))
+            h = h2
+        return h, saved
+
+    def _forward_train(self, items, masked_index):
+        B = items.shape[0]
+        L = self.max_seq_length
+        out, saved = self._encode(items, 2 * (L + 1), B, masked_index, L, train=self.training)
+        table = self.item_embedding.weight.data
+        loss, pos, neg = ops.bpr_loss_fwd(out, table, items, masked_index)
+        if saved is None:  # eval-mode forward (dropout off): activations are not kept, backward is unavailable
+            self._saved = None
+        else:
+            saved.update(out=out, pos=pos, neg=neg, items=items, mask=masked_index, B=B)
+            self._saved = saved
+        self._last_scores = (pos, neg)
+        return loss
+
+    def forward(self, interaction):
+        """interaction = (items int64 [B,2,L+1], masked_index int64 [B,L]) -> 0-dim loss (sasrec.py:65-92)."""
+        items, masked_index = interaction
+        if items.dim() != 3 or items.shape[1] != 2 or items.shape[2] != self.max_seq_length + 1:
+            raise ValueError(f"items must be [B, 2, {self.max_seq_length + 1}], got {tuple(items.shape)}")
+        self._ensure_packed()
+        items = items.contiguous()
+        masked_index = masked_index.contiguous()
+        if torch.is_grad_enabled() and self.training:
+            return _TrainStep.apply(self._anchor, self, items, masked_index)
+        was = self.training
+        try:
+            self.training = False
+            return self._forward_train(items, masked_index).view(())
+        finally:
+            self.training = was
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _backward_train(self, grad_out):
+        s = self._saved
+        if s is None:
+            raise PxrError("backward() without a training-mode forward()")
+        B, L, D, H = s["B"], self.max_seq_length, self.hidden_size, self.n_heads
+        d = D // H
+        T = B * L
+        seed, ph, pa = s["seed"], s["ph"], s["pa"]
+        table = self.item_embedding.weight.data
+        g = lambda name, span=1: self._p(name, grad=True, span=span)
+        gsd = grad_out.reshape(1).to(torch.float32).contiguous()
+        dh, coef = ops.bpr_loss_bwd(s["pos"], s["neg"], table, s["items"], s["mask"], D, 1.0, gsd)
+        for i in reversed(range(self.n_layers)):
+            a = s["layers"][i]
+            # FFN: h2 = LN(dropout(f2) + h1)
+            dz2, dxf2 = ops.ln_bwd(0, dh, a["xhat2"], a["rstd2"], self._p(f"{i}.ln2.w"), g(f"{i}.ln2.w"),
+                                   g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0)
+            if dxf2 is None:
+                dxf2 = dz2
+            ops.linear_bwd_weight(dxf2.view(T, D), a["f"].view(T, -1), out=g(f"{i}.f2.w"))
+            ops.colsum(dxf2.view(T, D), out=g(f"{i}.f2.b"))
+            du = ops.linear_bwd_input(dxf2, self._p(f"{i}.f2.w"), dgelu_pre=a["u"])
+            ops.linear_bwd_weight(du.view(T, -1), a["h1"].view(T, D), out=g(f"{i}.f1.w"))
+            ops.colsum(du.view(T, -1), out=g(f"{i}.f1.b"))
+            dh1 = ops.linear_bwd_input(du, self._p(f"{i}.f1.w"), add=dz2)
+            # attention block: h1 = LN(dropout(a) + h)
+            dz1, dxa = ops.ln_bwd(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
+                                  g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0)
+            if dxa is None:
+                dxa = dz1
+            ops.linear_bwd_weight(dxa.view(T, D), a["ctx"].view(T, D), out=g(f"{i}.o.w"))
+            ops.colsum(dxa.view(T, D), out=g(f"{i}.o.b"))
+            dctx = ops.linear_bwd_input(dxa, self._p(f"{i}.o.w"))
+            dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i)
+            ops.linear_bwd_weight(dqkv.view(T, 3 * D), a["h_in"].view(T, D), out=g(f"{i}.q.w", 3))
+            ops.colsum(dqkv.view(T, 3 * D), out=g(f"{i}.q.b", 3))
+            dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1)
+        dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0)
+        ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1))
+        sp = self.sparse_table_grad
+        if sp is None or sp.cap != 3 * T or sp.rows.shape[1] != D or sp.rows.device != dx0.device:
+            sp = ops.SparseRows(3 * T, D, dx0.device)
+        self.sparse_table_grad = ops.sasrec_embed_grad(s["items"], dx0, s["out"], coef, self.item_num, 1.0, sp)
+        self._saved = None
+        self._step_counter += 1
+
+    # ------------------------------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def encode_last(self, item_seq):
+        """item_seq int64 [B, L] -> (states [B, L, D], view of the last position [B, D] with row stride L*D)."""
+        self._ensure_packed()
+        item_seq = item_seq.contiguous()
+        B, L = item_seq.shape
+        if L != self.max_seq_length:
+            raise ValueError(f"item_seq must have MAX_ITEM_LIST_LENGTH={self.max_seq_length} columns, got {L}")
+        out, _ = self._encode(item_seq, L, B, item_seq, L, train=False)
+        return out, out[:, -1]
+
+    @torch.no_grad()
+    def predict(self, item_seq, item_feature):
+        """scores [B, N] = last-position state x item_feature^T (sasrec.py:94-113)."""
+        out, last = self.encode_last(item_seq)
+        B, L, D = out.shape
+        feat = item_feature if item_feature.is_contiguous() else item_feature.contiguous()
+        N = feat.shape[0]
+        scores = torch.empty(B, N, dtype=torch.float32, device=out.device)
+        ops.gemm(True, True, B, N, D, last, L * D, feat, D, scores, N, ops.EPI_NONE, use_ws=False)
+        return scores
+
+    @torch.no_grad()
+    def compute_item_all(self):
+        return self.item_embedding.weight

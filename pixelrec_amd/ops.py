@@ -92,14 +92,15 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: b
     return (y, pre) if gelu else y
 
 
-def linear_bwd_input(dy: torch.Tensor, W: torch.Tensor, dgelu_pre: torch.Tensor | None = None):
-    """dx = dy W  (optionally times gelu'(pre) of the layer that produced this linear's input)."""
+def linear_bwd_input(dy: torch.Tensor, W: torch.Tensor, dgelu_pre: torch.Tensor | None = None,
+                     add: torch.Tensor | None = None):
+    """dx = dy W, optionally times gelu'(pre) (through the FFN activation) or plus `add` (residual gradient)."""
     L = _l.load()
     _req(dy, torch.float32, "dy"); _req(W, torch.float32, "W")
     N, K = W.shape
     M = dy.numel() // N
     dx = torch.empty(*dy.shape[:-1], K, dtype=torch.float32, device=dy.device)
-    _l.check(L.pxr_linear_bwd_input_f32(_l.ptr(dy), _l.ptr(W), _l.ptr(dx), _l.ptr(dgelu_pre), M, N, K,
+    _l.check(L.pxr_linear_bwd_input_f32(_l.ptr(dy), _l.ptr(W), _l.ptr(dx), _l.ptr(dgelu_pre), _l.ptr(add), M, N, K,
                                         _l.stream_ptr()), "pxr_linear_bwd_input_f32")
     return dx
 
@@ -128,3 +129,184 @@ def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None):
     ws = _ws.get(ws_bytes, x2d.device)
     _l.check(L.pxr_colsum_f32(_l.ptr(x2d), N, M, N, _l.ptr(o), _l.ptr(ws), ws_bytes, _l.stream_ptr()), "pxr_colsum_f32")
     return o
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm sites
+def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True):
+    """y = dropout(LN(table[idx[b,t]] + pos[t]))  (sasrec.py:68,77-82 / :99-104).  Returns (y, xhat, rstd)."""
+    Lb = _l.load()
+    _req(table, torch.float32, "table"); _req(idx, torch.int64, "idx", contiguous=False)
+    N, D = table.shape
+    y = torch.empty(B, L, D, dtype=torch.float32, device=table.device)
+    xhat = torch.empty_like(y) if save else None
+    rstd = torch.empty(B * L, dtype=torch.float32, device=table.device) if save else None
+    _l.check(Lb.pxr_input_ln_fwd_f32(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
+                                     _l.ptr(beta), eps, B, L, D, _l.ptr(y), _l.ptr(xhat), _l.ptr(rstd), p_drop, seed,
+                                     stream_id, _l.stream_ptr()), "pxr_input_ln_fwd_f32")
+    return y, xhat, rstd
+
+
+def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True):
+    """y = LN(dropout(x) + res)  (layers.py:614-615, :670-671).  Returns (y, xhat, rstd)."""
+    Lb = _l.load()
+    _req(x, torch.float32, "x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    xhat = torch.empty_like(x) if save else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    _l.check(Lb.pxr_ln_residual_fwd_f32(_l.ptr(x), _l.ptr(res), _l.ptr(gamma), _l.ptr(beta), eps, rows, D, _l.ptr(y),
+                                        _l.ptr(xhat), _l.ptr(rstd), p_drop, seed, stream_id, _l.stream_ptr()),
+             "pxr_ln_residual_fwd_f32")
+    return y, xhat, rstd
+
+
+def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0, stream_id=0, need_dx=False):
+    """Backward of either LN site; dgamma/dbeta ([D] tensors) are overwritten.  Returns (dz, dx|None)."""
+    Lb = _l.load()
+    _req(dy, torch.float32, "dy")
+    D = dy.shape[-1]
+    rows = dy.numel() // D
+    dz = torch.empty_like(dy)
+    dx = torch.empty_like(dy) if need_dx else None
+    ws_bytes = int(Lb.pxr_ln_bwd_ws_bytes(rows, D))
+    ws = _ws.get(ws_bytes, dy.device)
+    _l.check(Lb.pxr_ln_bwd_f32(int(gather_mode), _l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), rows, D,
+                               _l.ptr(dz), _l.ptr(dx), _l.ptr(dgamma), _l.ptr(dbeta), p_drop, seed, stream_id,
+                               _l.ptr(ws), ws_bytes, _l.stream_ptr()), "pxr_ln_bwd_f32")
+    return dz, dx
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, save=True):
+    """qkv [B,L,3*H*d] fused projection output -> (ctx [B,L,H*d], probs [B,H,L,L] | None)."""
+    Lb = _l.load()
+    _req(qkv, torch.float32, "qkv"); _req(keymask, torch.int64, "keymask", contiguous=False)
+    D = H * d
+    ctx = torch.empty(B, L, D, dtype=torch.float32, device=qkv.device)
+    probs = torch.empty(B, H, L, L, dtype=torch.float32, device=qkv.device) if save else None
+    base = qkv.data_ptr()
+    q, k, v = _l.c_void_p(base), _l.c_void_p(base + 4 * D), _l.c_void_p(base + 8 * D)
+    _l.check(Lb.pxr_attn_fwd_f32(q, k, v, 3 * D, _l.ptr(keymask), km_bstride, B, H, L, d, _l.ptr(ctx), D,
+                                 _l.ptr(probs), p_drop, seed, stream_id, _l.stream_ptr()), "pxr_attn_fwd_f32")
+    return ctx, probs
+
+
+def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0):
+    """-> dqkv [B,L,3*H*d] laid out like qkv."""
+    Lb = _l.load()
+    _req(dctx, torch.float32, "dctx"); _req(qkv, torch.float32, "qkv"); _req(probs, torch.float32, "probs")
+    D = H * d
+    dqkv = torch.empty_like(qkv)
+    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    cp = _l.c_void_p
+    _l.check(Lb.pxr_attn_bwd_f32(_l.ptr(dctx), D, cp(base), cp(base + 4 * D), cp(base + 8 * D), 3 * D, _l.ptr(probs),
+                                 B, H, L, d, cp(dbase), cp(dbase + 4 * D), cp(dbase + 8 * D), 3 * D, p_drop, seed,
+                                 stream_id, _l.stream_ptr()), "pxr_attn_bwd_f32")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------ loss head
+def bpr_loss_fwd(out, table, items, masked_index):
+    """-> (loss [1] on device, pos_score [B,L], neg_score [B,L])   (sasrec.py:88-92)."""
+    Lb = _l.load()
+    _req(out, torch.float32, "out"); _req(table, torch.float32, "table")
+    _req(items, torch.int64, "items"); _req(masked_index, torch.int64, "masked_index")
+    B, L, D = out.shape
+    dev = out.device
+    pos = torch.empty(B, L, dtype=torch.float32, device=dev)
+    neg = torch.empty(B, L, dtype=torch.float32, device=dev)
+    lossrow = torch.empty(B * L, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    _l.check(Lb.pxr_bpr_loss_fwd_f32(_l.ptr(out), _l.ptr(table), table.shape[0], _l.ptr(items), _l.ptr(masked_index),
+                                     B, L, D, _l.ptr(pos), _l.ptr(neg), _l.ptr(lossrow), _l.ptr(loss),
+                                     _l.stream_ptr()), "pxr_bpr_loss_fwd_f32")
+    return loss, pos, neg
+
+
+def bpr_loss_bwd(pos, neg, table, items, masked_index, D, grad_scale=1.0, grad_scale_dev=None):
+    """-> (dout [B,L,D], coef [B,L])."""
+    Lb = _l.load()
+    B, L = pos.shape
+    dout = torch.empty(B, L, D, dtype=torch.float32, device=pos.device)
+    coef = torch.empty(B, L, dtype=torch.float32, device=pos.device)
+    _l.check(Lb.pxr_bpr_loss_bwd_f32(_l.ptr(pos), _l.ptr(neg), _l.ptr(table), table.shape[0], _l.ptr(items),
+                                     _l.ptr(masked_index), B, L, D, float(grad_scale), _l.ptr(grad_scale_dev), _l.ptr(dout),
+                                     _l.ptr(coef),
+                                     _l.stream_ptr()), "pxr_bpr_loss_bwd_f32")
+    return dout, coef
+
+
+# ------------------------------------------------------------------------------------------------ sparse table grad
+class SparseRows:
+    """(uniq_idx [cap] int64 ascending, rows [cap, D], n [1] int32 on device): the table gradient of one step."""
+
+    def __init__(self, cap: int, D: int, device):
+        self.idx = torch.zeros(cap, dtype=torch.int64, device=device)
+        self.rows = torch.empty(cap, D, dtype=torch.float32, device=device)
+        self.n = torch.zeros(1, dtype=torch.int32, device=device)
+        self.cap = cap
+
+    def count(self) -> int:  # host sync; tests / logging only
+        return int(self.n.item())
+
+    def to_dense(self, n_table: int) -> torch.Tensor:  # tests only
+        n = self.count()
+        g = torch.zeros(n_table, self.rows.shape[1], dtype=torch.float32, device=self.rows.device)
+        g[self.idx[:n]] = self.rows[:n]
+        return g
+
+
+def embed_grad_rows(idx, rows, n_table, scale=1.0, out: SparseRows | None = None) -> SparseRows:
+    """Plain embedding backward in sparse form (see pxr.h)."""
+    Lb = _l.load()
+    _req(idx, torch.int64, "idx"); _req(rows, torch.float32, "rows")
+    n, D = idx.numel(), rows.shape[-1]
+    sp = out if out is not None else SparseRows(n, D, rows.device)
+    ws_bytes = int(Lb.pxr_embed_grad_ws_bytes(n))
+    ws = _ws.get(ws_bytes, rows.device)
+    _l.check(Lb.pxr_embed_grad_rows_f32(_l.ptr(idx), n, _l.ptr(rows), D, n_table, float(scale), _l.ptr(sp.idx),
+                                        _l.ptr(sp.rows), _l.ptr(sp.n), _l.ptr(ws), ws_bytes, _l.stream_ptr()),
+             "pxr_embed_grad_rows_f32")
+    return sp
+
+
+def sasrec_embed_grad(items, dx0, out, coef, n_table, scale=1.0, sp: SparseRows | None = None) -> SparseRows:
+    Lb = _l.load()
+    _req(items, torch.int64, "items"); _req(dx0, torch.float32, "dx0"); _req(out, torch.float32, "out")
+    _req(coef, torch.float32, "coef")
+    B, L, D = out.shape
+    n = 3 * B * L
+    sp = sp if sp is not None else SparseRows(n, D, out.device)
+    ws_bytes = int(Lb.pxr_embed_grad_ws_bytes(n))
+    ws = _ws.get(ws_bytes, out.device)
+    _l.check(Lb.pxr_sasrec_embed_grad_f32(_l.ptr(items), B, L, _l.ptr(dx0), _l.ptr(out), _l.ptr(coef), D, n_table,
+                                          float(scale), _l.ptr(sp.idx), _l.ptr(sp.rows), _l.ptr(sp.n), _l.ptr(ws),
+                                          ws_bytes, _l.stream_ptr()), "pxr_sasrec_embed_grad_f32")
+    return sp
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    Lb = _l.load()
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nm)
+    _l.check(Lb.pxr_adamw_flat_f32(_l.ptr(p), _l.ptr(g), _l.ptr(m), _l.ptr(v), p.numel(), lr, beta1, beta2, eps,
+                                   weight_decay, step, _l.stream_ptr()), "pxr_adamw_flat_f32")
+
+
+def slot_fill(slot, value=-1):
+    Lb = _l.load()
+    _req(slot, torch.int32, "slot")
+    _l.check(Lb.pxr_slot_fill_i32(_l.ptr(slot), slot.numel(), value, _l.stream_ptr()), "pxr_slot_fill_i32")
+
+
+def adamw_table(table, m, v, slot, sp: SparseRows | None, lr, beta1, beta2, eps, weight_decay, step):
+    Lb = _l.load()
+    _req(table, torch.float32, "table"); _req(m, torch.float32, "m"); _req(v, torch.float32, "v")
+    _req(slot, torch.int32, "slot")
+    N, D = table.shape
+    _l.check(Lb.pxr_adamw_table_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), N, D, _l.ptr(slot),
+                                    _l.ptr(sp.idx) if sp else None, _l.ptr(sp.rows) if sp else None,
+                                    _l.ptr(sp.n) if sp else None, sp.cap if sp else 0, lr, beta1, beta2, eps,
+                                    weight_decay, step, _l.stream_ptr()), "pxr_adamw_table_f32")

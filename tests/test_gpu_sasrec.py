@@ -1,0 +1,118 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden fixtures, on the golden cases' shapes.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sasrec_oracle as O
+from tests.golden_util import CASES, compare, load_case, oracle_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(meta, p_drop=0.0, dev="cuda"):
+    from pixelrec_amd.model import SASRec
+
+    cfg = {"n_layers": meta["n_layers"], "n_heads": meta["H"], "embedding_size": meta["D"], "inner_size": meta["inner"],
+           "hidden_dropout_prob": p_drop, "attn_dropout_prob": p_drop, "hidden_act": "gelu", "layer_norm_eps": 1e-12,
+           "initializer_range": 0.02, "MAX_ITEM_LIST_LENGTH": meta["L"], "seed": 2020}
+
+    class DL:
+        item_num = meta["n_items"]
+
+    m = SASRec(cfg, DL())
+    params = O.synth_params(meta["n_items"], meta["D"], meta["L"], meta["n_layers"], meta["inner"], seed=meta["seed"])
+    m.load_state_dict(params, strict=True)
+    return m.to(dev), params
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_loss_and_scores(case):
+    meta, z = load_case(case)
+    m, p = _model(meta)
+    m.train()
+    items = torch.from_numpy(z["items"]).cuda()
+    mask = torch.from_numpy(z["masked_index"]).cuda()
+    loss = m((items, mask))
+    ref_loss, _ = O.loss_and_grads(p, torch.from_numpy(z["items"]), torch.from_numpy(z["masked_index"]), oracle_cfg(meta))
+    assert abs(float(loss) - float(z["loss"])) <= 2e-5 * max(1.0, abs(float(z["loss"])))   # vs reference golden
+    assert abs(float(loss) - float(ref_loss)) <= 2e-5 * max(1.0, abs(float(ref_loss)))     # vs oracle
+    pos, neg = m._last_scores
+    compare(z, "pos_score", pos, 3e-5)
+    compare(z, "neg_score", neg, 3e-5)
+    compare(z, f"act.layer{meta['n_layers'] - 1}.ffn_out", m._saved["out"], 5e-5)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gradients(case):
+    meta, z = load_case(case)
+    m, p = _model(meta)
+    m.train()
+    items = torch.from_numpy(z["items"]).cuda()
+    mask = torch.from_numpy(z["masked_index"]).cuda()
+    loss = m((items, mask))
+    loss.backward()
+    _, g = O.loss_and_grads(p, torch.from_numpy(z["items"]), torch.from_numpy(z["masked_index"]), oracle_cfg(meta))
+    for k, v in m.named_parameters():
+        if k == "item_embedding.weight":
+            sp = m.sparse_table_grad
+            dense = sp.to_dense(meta["n_items"]).cpu()
+            n = sp.count()
+            idx = sp.idx[:n].cpu().numpy()
+            assert np.all(np.diff(idx) > 0) and (idx != 0).all()
+            ref = g[k]
+            err = (dense - ref).abs().max().item()
+            assert err <= 3e-6 + 1e-4 * ref.abs().max().item(), f"table grad err {err}"
+            rows = z["grad.item_embedding.rows"]
+            # every row the reference touched with a non-zero gradient is present
+            assert set(rows.tolist()) <= set(idx.tolist())
+            compare(z, "grad.item_embedding.vals", dense[torch.from_numpy(rows)], 3e-6, 1e-4)
+        else:
+            got = v.grad.detach().cpu()
+            ref = g[k]
+            err = (got - ref).abs().max().item()
+            assert err <= 5e-6 + 2e-4 * ref.abs().max().item(), f"{k}: err {err} (ref max {ref.abs().max().item()})"
+            compare(z, "grad." + k, got, 5e-6, 2e-4)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_adamw_four_steps(case):
+    from pixelrec_amd.optim import PxrAdamW
+
+    meta, z = load_case(case)
+    m, p = _model(meta)
+    m.train()
+    opt = PxrAdamW(m, lr=1e-4, weight_decay=0.1)
+    rows = torch.from_numpy(z["adamw.watch_rows"])
+    for s in range(4):
+        opt.zero_grad()
+        loss = m((torch.from_numpy(z["adamw.items"][s]).cuda(), torch.from_numpy(z["adamw.masks"][s]).cuda()))
+        loss.backward()
+        opt.step()
+        assert abs(float(loss) - float(z[f"adamw.loss{s}"])) <= 3e-5 * max(1.0, abs(float(loss)))
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        compare(z, f"adamw.step{s}.table_rows", sd["item_embedding.weight"][rows], 1e-5)
+        assert abs(float(sd["item_embedding.weight"].double().sum()) - float(z[f"adamw.step{s}.table_sum"])) < 1e-3
+        for k in ("position_embedding.weight", "LayerNorm.weight", "LayerNorm.bias",
+                  "trm_encoder.layer.0.multi_head_attention.query.weight",
+                  "trm_encoder.layer.1.feed_forward.dense_2.weight",
+                  "trm_encoder.layer.1.feed_forward.dense_1.bias",
+                  "trm_encoder.layer.0.feed_forward.LayerNorm.weight"):
+            compare(z, f"adamw.step{s}." + k, sd[k], 1e-5)
+    # the slot map is clean again
+    assert int((opt._slot != -1).sum()) == 0
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_predict_scores(case):
+    meta, z = load_case(case)
+    m, p = _model(meta)
+    m.eval()
+    seq = torch.from_numpy(z["eval.item_seq"]).cuda()
+    scores = m.predict(seq, m.compute_item_all()).cpu()
+    cs = int(z["eval.scores_colstride"])
+    err = np.abs(scores[:, ::cs].numpy() - z["eval.scores"]).max()
+    assert err <= 1e-4, err                                       # logits +-1e-4 (BASELINE.json)
+    masked = O.full_sort_scores(scores, torch.from_numpy(z["eval.history_u"]), torch.from_numpy(z["eval.history_i"]))
+    _, idx = torch.topk(masked, 10, dim=-1)
+    assert np.array_equal(idx.numpy(), z["eval.topk_idx"])
