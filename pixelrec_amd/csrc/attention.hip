@@ -8,13 +8,15 @@
 //     is written head-merged into [B, L, D]: no permute/contiguous copies (layers.py:590-592,610-612);
 //   * Q/K (then V) tiles are staged through LDS in d-chunks of <= 128 columns, so any head size works
 //     (d = 32 for emb 128, 128 for emb 512, 1024 for emb 4096) with a fixed LDS footprint;
-//   * a wave owns query rows {w, w+4, ...}; lane j owns key j: one score per lane, so the row softmax is a pair
+//   * NW (default 8) waves per workgroup; a wave owns query rows {w, w+NW, ...}; lane j owns key j: one score per lane, so the row softmax is a pair
 //     of 64-lane shuffle reductions -- no LDS round trip;
 //   * mask semantics are the reference's ADDITIVE -1e9 in fp32 (not -inf): score + (-1e9) == -1e9 exactly, a
 //     fully masked (left-padded) query row therefore becomes a uniform 1/L distribution over ALL L keys
 //     (SURVEY.md §7 hard part 4) -- reproduced by doing the same arithmetic;
 //   * attention-prob dropout (layers.py:608) uses the counter-hash mask, regenerated in backward;
 //     the un-dropped probabilities are saved ([B,H,L,L]) for the backward pass.
+#include <stdlib.h>
+
 #include "pxr_common.h"
 
 namespace pxr {
@@ -36,28 +38,29 @@ struct AttnArgs {
   float p_drop; uint32_t drop_thr; uint32_t stream; uint64_t seed;
 };
 
-// stage tile[row][0..w) <- src[(row)*ld + 0..w) for row < L; 256 threads, float4 accesses
+// stage tile[row][0..w) <- src[(row)*ld + 0..w) for row < L; all threads of the block, float4 accesses
 __device__ __forceinline__ void stage_tile(float* tile, int tstride, const float* src, int64_t ld, int L, int w) {
   const int q4 = w >> 2;
-  for (int f = threadIdx.x; f < L * q4; f += 256) {
+  for (int f = threadIdx.x; f < L * q4; f += blockDim.x) {
     const int row = f / q4, c = (f - row * q4) * 4;
     *reinterpret_cast<float4*>(tile + row * tstride + c) = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
   }
 }
 
-// acc[g] += sum_c A[i_g][c] * Bt[lane][c]  for the wave's rows i_g = wave + 4*g   (A stride ATT_DC, Bt stride ATT_KLD)
-__device__ __forceinline__ void score_accumulate(float (&acc)[16], const float* sA, const float* sB, int L, int w,
+// acc[g] += sum_c A[i_g][c] * Bt[lane][c]  for the wave's rows i_g = wave + NW*g   (A stride ATT_DC, Bt stride ATT_KLD)
+template <int NW>
+__device__ __forceinline__ void score_accumulate(float (&acc)[64 / NW], const float* sA, const float* sB, int L, int w,
                                                  int wave, int lane) {
   const float* brow = sB + lane * ATT_KLD;
 #pragma unroll
-  for (int gg = 0; gg < 4; ++gg) {
-    const int i0 = wave + 16 * gg;
+  for (int gg = 0; gg < 16 / NW; ++gg) {
+    const int i0 = wave + 4 * NW * gg;
     if (i0 >= L) break;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const float* r0 = sA + (i0)*ATT_DC;
-    const float* r1 = sA + (i0 + 4) * ATT_DC;
-    const float* r2 = sA + (i0 + 8) * ATT_DC;
-    const float* r3 = sA + (i0 + 12) * ATT_DC;
+    const float* r1 = sA + (i0 + NW) * ATT_DC;
+    const float* r2 = sA + (i0 + 2 * NW) * ATT_DC;
+    const float* r3 = sA + (i0 + 3 * NW) * ATT_DC;
     for (int c = 0; c < w; c += 4) {
       const float4 kb = *reinterpret_cast<const float4*>(brow + c);
       const float4 q0 = *reinterpret_cast<const float4*>(r0 + c);
@@ -73,13 +76,13 @@ __device__ __forceinline__ void score_accumulate(float (&acc)[16], const float* 
   }
 }
 
-// out[r][c] = sum_t W(r,t) * X[t][c]  for the wave's rows r = wave + 4*g, columns c = lane, lane+64 (< w).
+// out[r][c] = sum_t W(r,t) * X[t][c]  for the wave's rows r = wave + NW*g, columns c = lane, lane+64 (< w).
 // TRANS=false: W(r,t) = sW[r*64 + t];  TRANS=true: W(r,t) = sW[t*64 + r].   X stride ATT_DC.
-template <bool TRANS>
+template <int NW, bool TRANS>
 __device__ __forceinline__ void rowmix_store(const float* sW, const float* sX, int L, int w, int wave, int lane,
                                              float* out, int64_t ld_out) {
-  for (int gg = 0; gg < 4; ++gg) {
-    const int i0 = wave + 16 * gg;
+  for (int gg = 0; gg < 16 / NW; ++gg) {
+    const int i0 = wave + 4 * NW * gg;
     if (i0 >= L) break;
     float o[4][2];
 #pragma unroll
@@ -89,7 +92,7 @@ __device__ __forceinline__ void rowmix_store(const float* sW, const float* sX, i
       const float x1 = sX[t * ATT_DC + 64 + lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + 4 * r;  // rows >= L read in-bounds LDS garbage and are never stored
+        const int i = i0 + NW * r;  // rows >= L read zeroed LDS rows and are never stored
         const float wv = TRANS ? sW[t * 64 + i] : sW[i * 64 + t];
         o[r][0] += wv * x0;
         o[r][1] += wv * x1;
@@ -97,7 +100,7 @@ __device__ __forceinline__ void rowmix_store(const float* sW, const float* sX, i
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = i0 + 4 * r;
+      const int i = i0 + NW * r;
       if (i < L) {
         if (lane < w) out[(int64_t)i * ld_out + lane] = o[r][0];
         if (lane + 64 < w) out[(int64_t)i * ld_out + 64 + lane] = o[r][1];
@@ -106,7 +109,8 @@ __device__ __forceinline__ void rowmix_store(const float* sW, const float* sX, i
   }
 }
 
-__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sA[ATT_MAXL * ATT_DC];    // Q chunk, later V chunk
   __shared__ __attribute__((aligned(16))) float sB[ATT_MAXL * ATT_KLD];   // K chunk
   __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * 64];        // (dropped) probabilities
@@ -116,20 +120,20 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
 
   // LDS rows >= L are read (never used) by lanes/rows beyond L: zero them once so no NaN garbage circulates
-  for (int f = threadIdx.x; f < ATT_MAXL * ATT_DC; f += 256) sA[f] = 0.f;
-  for (int f = threadIdx.x; f < ATT_MAXL * ATT_KLD; f += 256) sB[f] = 0.f;
-  for (int f = threadIdx.x; f < ATT_MAXL * 64; f += 256) sP[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_DC; f += NW * 64) sA[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_KLD; f += NW * 64) sB[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * 64; f += NW * 64) sP[f] = 0.f;
   __syncthreads();
 
-  float acc[16];
+  float acc[64 / NW];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+  for (int g = 0; g < 64 / NW; ++g) acc[g] = 0.f;
   for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
     const int w = min(ATT_DC, d - dc0);
     stage_tile(sA, ATT_DC, a.q + base + dc0, a.ld, L, w);
     stage_tile(sB, ATT_KLD, a.k + base + dc0, a.ld, L, w);
     __syncthreads();
-    score_accumulate(acc, sA, sB, L, w, wave, lane);
+    score_accumulate<NW>(acc, sA, sB, L, w, wave, lane);
     __syncthreads();
   }
 
@@ -137,8 +141,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
   const bool drop = a.drop_thr != 0u;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int i = wave + 4 * ((g >> 2) * 4 + (g & 3));  // acc[gg*4+r] holds row wave + 16*gg + 4*r
+  for (int g = 0; g < 64 / NW; ++g) {
+    const int i = wave + NW * g;  // acc[gg*4+r] holds row wave + NW*(4*gg + r)
     if (i < L) {
       // reference arithmetic: scores / sqrt(d) + (-1e9 | 0)   (layers.py:597,601; sasrec.py:125)
       float s = acc[g] / a.sqrt_d + ((key_real && lane <= i) ? 0.0f : -1e9f);
@@ -163,12 +167,13 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
     const int w = min(ATT_DC, d - dc0);
     stage_tile(sA, ATT_DC, a.v + base + dc0, a.ld, L, w);
     __syncthreads();
-    rowmix_store<false>(sP, sA, L, w, wave, lane, out + dc0, a.ld_ctx);
+    rowmix_store<NW, false>(sP, sA, L, w, wave, lane, out + dc0, a.ld_ctx);
     __syncthreads();
   }
 }
 
-__global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sA[ATT_MAXL * ATT_DC];
   __shared__ __attribute__((aligned(16))) float sB[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * 64];   // dropped probabilities Pd
@@ -180,28 +185,28 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
   const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
   const int64_t dbase = (int64_t)b * L * a.ld_d + (int64_t)h * d;
 
-  for (int f = threadIdx.x; f < ATT_MAXL * ATT_DC; f += 256) sA[f] = 0.f;
-  for (int f = threadIdx.x; f < ATT_MAXL * ATT_KLD; f += 256) sB[f] = 0.f;
-  for (int f = threadIdx.x; f < ATT_MAXL * 64; f += 256) { sP[f] = 0.f; sS[f] = 0.f; }
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_DC; f += NW * 64) sA[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_KLD; f += NW * 64) sB[f] = 0.f;
+  for (int f = threadIdx.x; f < ATT_MAXL * 64; f += NW * 64) { sP[f] = 0.f; sS[f] = 0.f; }
   __syncthreads();
 
   // dPd[i][j] = sum_c dctx[i][c] * V[j][c]
-  float acc[16];
+  float acc[64 / NW];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+  for (int g = 0; g < 64 / NW; ++g) acc[g] = 0.f;
   for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
     const int w = min(ATT_DC, d - dc0);
     stage_tile(sA, ATT_DC, a.dctx + cbase + dc0, a.ld_ctx, L, w);
     stage_tile(sB, ATT_KLD, a.v + base + dc0, a.ld, L, w);
     __syncthreads();
-    score_accumulate(acc, sA, sB, L, w, wave, lane);
+    score_accumulate<NW>(acc, sA, sB, L, w, wave, lane);
     __syncthreads();
   }
   const bool drop = a.drop_thr != 0u;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int i = wave + 4 * ((g >> 2) * 4 + (g & 3));
+  for (int g = 0; g < 64 / NW; ++g) {
+    const int i = wave + NW * g;
     if (i < L) {
       float p = 0.f, pd = 0.f, dp = 0.f;
       if (lane < L) {
@@ -226,17 +231,17 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
     // dV[j][c] = sum_i Pd[i][j] * dctx[i][c]
     stage_tile(sA, ATT_DC, a.dctx + cbase + dc0, a.ld_ctx, L, w);
     __syncthreads();
-    rowmix_store<true>(sP, sA, L, w, wave, lane, a.dv + dbase + dc0, a.ld_d);
+    rowmix_store<NW, true>(sP, sA, L, w, wave, lane, a.dv + dbase + dc0, a.ld_d);
     __syncthreads();
     // dQ[i][c] = sum_j dS[i][j] * K[j][c]
     stage_tile(sA, ATT_DC, a.k + base + dc0, a.ld, L, w);
     __syncthreads();
-    rowmix_store<false>(sS, sA, L, w, wave, lane, a.dq + dbase + dc0, a.ld_d);
+    rowmix_store<NW, false>(sS, sA, L, w, wave, lane, a.dq + dbase + dc0, a.ld_d);
     __syncthreads();
     // dK[j][c] = sum_i dS[i][j] * Q[i][c]
     stage_tile(sA, ATT_DC, a.q + base + dc0, a.ld, L, w);
     __syncthreads();
-    rowmix_store<true>(sS, sA, L, w, wave, lane, a.dk + dbase + dc0, a.ld_d);
+    rowmix_store<NW, true>(sS, sA, L, w, wave, lane, a.dk + dbase + dc0, a.ld_d);
     __syncthreads();
   }
 }
@@ -244,6 +249,17 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
 }  // namespace pxr
 
 using namespace pxr;
+
+// waves per (batch, head) workgroup: 8 by default; PXR_ATTN_WAVES=4|8|16 overrides it (tuning knob)
+static int attn_waves() {
+  static int nw = 0;
+  if (nw == 0) {
+    const char* e = getenv("PXR_ATTN_WAVES");
+    const int v = e ? atoi(e) : 8;
+    nw = (v == 4 || v == 16) ? v : 8;
+  }
+  return nw;
+}
 
 static int attn_check(int B, int H, int L, int d, int64_t ld, const char* who) {
   PXR_REQUIRE(B >= 0 && H > 0 && L > 0 && d > 0, "%s: bad shape", who);
@@ -266,7 +282,11 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
   a.ctx = ctx; a.ld_ctx = ld_ctx; a.probs = probs; a.B = B; a.H = H; a.L = L; a.d = d;
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+  switch (attn_waves()) {
+    case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a); break;
+    case 16: hipLaunchKernelGGL(attn_fwd_kernel<16>, dim3(B * H), dim3(1024), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(B * H), dim3(512), 0, (hipStream_t)stream, a); break;
+  }
   return pxr_check_launch("pxr_attn_fwd_f32");
 }
 
@@ -285,6 +305,10 @@ extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* 
   a.dctx = dctx; a.dq = dq; a.dk = dk; a.dv = dv; a.ld_d = ld_d; a.B = B; a.H = H; a.L = L; a.d = d;
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+  switch (attn_waves()) {
+    case 4: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a); break;
+    case 16: hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(B * H), dim3(1024), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(attn_bwd_kernel<8>, dim3(B * H), dim3(512), 0, (hipStream_t)stream, a); break;
+  }
   return pxr_check_launch("pxr_attn_bwd_f32");
 }

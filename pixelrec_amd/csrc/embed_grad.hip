@@ -231,30 +231,55 @@ struct SegSumArgs {
   int D, T;
 };
 
+// One block per unique row.  The 256 threads form G = 256/dv groups (dv = D/4 float4 columns, G >= 1); group g
+// sums occurrences s0+g, s0+g+G, ... in order, then the G partial rows are added in group order through LDS:
+// a fixed summation tree => bit-reproducible, and popular items (hundreds of occurrences under the Zipf
+// popularity) no longer serialise on one chain of dependent 2 KB row reads.
 template <int MODE>
-__global__ void __launch_bounds__(128) segsum_kernel(SegSumArgs a) {
+__global__ void __launch_bounds__(256) segsum_kernel(SegSumArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float4 sred[];  // [G][dv]
   const int nu = *a.n_uniq;
   const int dv = a.D >> 2;
+  const int G = dv >= 256 ? 1 : 256 / dv;
+  const int g = (dv >= 256) ? 0 : threadIdx.x / dv;
+  const int c0 = (dv >= 256) ? threadIdx.x : threadIdx.x - g * dv;
+  const bool active = g < G;
   for (int u = blockIdx.x; u < nu; u += gridDim.x) {
     const int s0 = a.seg_start[u], s1 = a.seg_start[u + 1];
-    for (int c4 = threadIdx.x; c4 < dv; c4 += 128) {
+    for (int cb = 0; cb < dv; cb += 256) {  // dv > 256 (D > 1024): column blocks of 256 float4
+      const int c4 = cb + c0;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = s0; s < s1; ++s) {
-        const int o = a.vals[s];
-        float cf = 1.f;
-        const float* row;
-        if constexpr (MODE == MODE_ROWS) {
-          row = a.src0 + (int64_t)o * a.D;
-        } else {
-          const int type = o / a.T, r = o - type * a.T;
-          row = (type == 0 ? a.src0 : a.src1) + (int64_t)r * a.D;
-          cf = (type == 0) ? 1.f : (type == 1 ? a.coef[r] : -a.coef[r]);
+      if (active && c4 < dv) {
+        for (int s = s0 + g; s < s1; s += G) {
+          const int o = a.vals[s];
+          float cf = 1.f;
+          const float* row;
+          if constexpr (MODE == MODE_ROWS) {
+            row = a.src0 + (int64_t)o * a.D;
+          } else {
+            const int type = o / a.T, r = o - type * a.T;
+            row = (type == 0 ? a.src0 : a.src1) + (int64_t)r * a.D;
+            cf = (type == 0) ? 1.f : (type == 1 ? a.coef[r] : -a.coef[r]);
+          }
+          const float4 v = *reinterpret_cast<const float4*>(row + c4 * 4);
+          acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
         }
-        const float4 v = *reinterpret_cast<const float4*>(row + c4 * 4);
-        acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
       }
-      acc.x *= a.scale; acc.y *= a.scale; acc.z *= a.scale; acc.w *= a.scale;
-      *reinterpret_cast<float4*>(a.uniq_rows + (int64_t)u * a.D + c4 * 4) = acc;
+      if (G > 1) {
+        if (active) sred[g * dv + c0] = acc;
+        __syncthreads();
+        if (g == 0) {
+          for (int k = 1; k < G; ++k) {
+            const float4 t = sred[k * dv + c0];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+          }
+        }
+        __syncthreads();
+      }
+      if (g == 0 && c4 < dv) {
+        acc.x *= a.scale; acc.y *= a.scale; acc.z *= a.scale; acc.w *= a.scale;
+        *reinterpret_cast<float4*>(a.uniq_rows + (int64_t)u * a.D + c4 * 4) = acc;
+      }
     }
   }
 }
@@ -331,7 +356,7 @@ extern "C" int pxr_embed_grad_rows_f32(const int64_t* idx, int64_t n, const floa
   a.vals = sorted_vals; a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = rows; a.uniq_rows = uniq_rows;
   a.scale = scale; a.D = D; a.T = (int)n;
   const int grid = (int)(n < 4096 ? n : 4096);
-  hipLaunchKernelGGL(segsum_kernel<MODE_ROWS>, dim3(grid), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(segsum_kernel<MODE_ROWS>, dim3(grid), dim3(256), 256 * 16, st, a);
   return pxr_check_launch("pxr_embed_grad_rows_f32");
 }
 
@@ -358,6 +383,6 @@ extern "C" int pxr_sasrec_embed_grad_f32(const int64_t* items, int B, int L, con
   a.vals = sorted_vals; a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = dx0; a.src1 = out; a.coef = coef;
   a.uniq_rows = uniq_rows; a.scale = scale; a.D = D; a.T = B * L;
   const int grid = n < 4096 ? n : 4096;
-  hipLaunchKernelGGL(segsum_kernel<MODE_SASREC>, dim3(grid), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(segsum_kernel<MODE_SASREC>, dim3(grid), dim3(256), 256 * 16, st, a);
   return pxr_check_launch("pxr_sasrec_embed_grad_f32");
 }

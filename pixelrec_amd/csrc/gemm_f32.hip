@@ -98,16 +98,6 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
   __syncthreads();
   if (ty == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
-// stage 2: out[n] = sum_p part[p][n]
-__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int P, int N,
-                                                           float* __restrict__ out) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(int64_t)p * N + col];
-  out[col] = s;
-}
-
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                        int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
@@ -255,8 +245,13 @@ extern "C" int pxr_linear_bwd_weight_f32(const float* dy, const float* x, float*
   return pxr_gemm_f32(0, 0, N, K, M, dy, N, x, K, dW, K, EPI_NONE, nullptr, nullptr, 0, ws, ws_bytes, 0, 0, stream);
 }
 
+static inline int colsum_rows_per_chunk(int M) {
+  int rpc = (M + 127) / 128;  // <= 128 partial rows
+  return rpc < 32 ? 32 : rpc;
+}
 extern "C" int64_t pxr_colsum_ws_bytes(int M, int N) {
-  const int chunks = (M + 255) / 256;
+  const int rpc = colsum_rows_per_chunk(M);
+  const int chunks = (M + rpc - 1) / rpc;
   return (int64_t)chunks * N * (int64_t)sizeof(float);
 }
 // out[n] = sum_m x[m][n]  -- bias gradients (autograd of nn.Linear bias) and the position-embedding
@@ -265,7 +260,7 @@ extern "C" int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* 
                               void* stream) {
   PXR_REQUIRE(x && out && ws, "pxr_colsum_f32: null pointer");
   PXR_REQUIRE(M > 0 && N > 0, "pxr_colsum_f32: empty input");
-  const int rows_per_chunk = 256;
+  const int rows_per_chunk = colsum_rows_per_chunk(M);
   const int chunks = (M + rows_per_chunk - 1) / rows_per_chunk;
   if ((int64_t)chunks * N * 4 > ws_bytes) {
     pxr_set_error("pxr_colsum_f32: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)chunks * N * 4);
@@ -276,6 +271,7 @@ extern "C" int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* 
                      rows_per_chunk, (float*)ws);
   int rc = pxr_check_launch("pxr_colsum_f32(partial)");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)ws, chunks, N, out);
+  hipLaunchKernelGGL(pxr_reduce_partials_kernel, dim3((N + 31) / 32), dim3(256), 0, st, (const float*)ws, chunks, N,
+                     out, out, N);
   return pxr_check_launch("pxr_colsum_f32(final)");
 }

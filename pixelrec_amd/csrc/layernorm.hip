@@ -242,18 +242,6 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
   }
 }
 
-// out[n] = sum_p part[p][n]   (n < N)
-__global__ void __launch_bounds__(256) ln_part_reduce_kernel(const float* __restrict__ part, int P, int N,
-                                                             float* __restrict__ out_a, float* __restrict__ out_b,
-                                                             int D) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(int64_t)p * N + col];
-  if (col < D) out_a[col] = s;
-  else out_b[col - D] = s;
-}
-
 static inline int ln_vec_for(int D) {
   int v = (D + 255) / 256;
   int p = 1;
@@ -288,7 +276,7 @@ static int launch_ln_bwd(const LnBwdArgs& a, int nblk, hipStream_t st) {
 }
 
 static inline int ln_bwd_blocks(int rows, int* rows_per_block) {
-  int rpb = (rows + 511) / 512;  // aim at <= 512 blocks
+  int rpb = (rows + 255) / 256;  // <= 256 blocks (one per CU) => <= 256 partial rows for the stage-2 reduction
   if (rpb < 4) rpb = 4;
   *rows_per_block = rpb;
   return (rows + rpb - 1) / rpb;
@@ -357,7 +345,7 @@ extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xha
   hipStream_t st = (hipStream_t)stream;
   int rc = gather_mode ? launch_ln_bwd<true>(a, nblk, st) : launch_ln_bwd<false>(a, nblk, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_part_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, (const float*)ws, nblk,
+  hipLaunchKernelGGL(pxr_reduce_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, st, (const float*)ws, nblk,
                      2 * D, dgamma, dbeta, D);
   return pxr_check_launch("pxr_ln_bwd_f32(reduce)");
 }

@@ -53,6 +53,29 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------- fixed-order reduction of per-block partials
+// out[n] = sum_p part[p][n] for n < N.  Block = 32 columns x 8 row-lanes; lane r sums p = r, r+8, ... then the 8
+// lanes are combined in a fixed tree => deterministic.  Columns n < split go to out_a[n], the rest to
+// out_b[n - split] (LayerNorm dgamma | dbeta share one partial buffer); pass split = N for a single output.
+static __global__ void __launch_bounds__(256) pxr_reduce_partials_kernel(const float* __restrict__ part, int P, int N,
+                                                                  float* __restrict__ out_a,
+                                                                  float* __restrict__ out_b, int split) {
+  __shared__ float red[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;
+  float s = 0.f;
+  if (col < N)
+    for (int p = ty; p < P; p += 8) s += part[(int64_t)p * N + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < N) {
+    const float v = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) +
+                    ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    if (col < split) out_a[col] = v;
+    else out_b[col - split] = v;
+  }
+}
+
 // ---------------------------------------------------------------- stateless dropout RNG
 // keep(elem) for Bernoulli(1-p) dropout: a counter-based hash of (seed, stream, element index), so the
 // backward kernel regenerates the forward mask instead of storing it.  tests/ restates this in numpy

@@ -66,6 +66,10 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C pixelrec_amd/csrc`). pixelrec_amd has no CPU fallback."
         )
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime instance in this process (device memory and
+    # streams come from torch), so torch is imported BEFORE libpxr.so resolves the same soname.
+    import torch  # noqa: F401
+
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the host's ROCm install

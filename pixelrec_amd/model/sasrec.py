@@ -114,7 +114,9 @@ class SASRec(BaseModel):
         self._views = {}
         self._anchor = None
         self._saved = None
-        self.sparse_table_grad = None
+        self.sparse_table_grad = None   # the table gradient the optimizer will apply (local, or merged across ranks)
+        self._local_sparse = None       # reusable output buffer of this rank's backward
+        self.grad_scale = 1.0           # 1/world_size under data parallelism (sum-all-reduce == DDP's mean)
         self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
         self._step_counter = 0
 
@@ -256,7 +258,7 @@ class SASRec(BaseModel):
         table = self.item_embedding.weight.data
         g = lambda name, span=1: self._p(name, grad=True, span=span)
         gsd = grad_out.reshape(1).to(torch.float32).contiguous()
-        dh, coef = ops.bpr_loss_bwd(s["pos"], s["neg"], table, s["items"], s["mask"], D, 1.0, gsd)
+        dh, coef = ops.bpr_loss_bwd(s["pos"], s["neg"], table, s["items"], s["mask"], D, self.grad_scale, gsd)
         for i in reversed(range(self.n_layers)):
             a = s["layers"][i]
             # FFN: h2 = LN(dropout(f2) + h1)
@@ -284,9 +286,9 @@ class SASRec(BaseModel):
             dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1)
         dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0)
         ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1))
-        sp = self.sparse_table_grad
+        sp = self._local_sparse
         if sp is None or sp.cap != 3 * T or sp.rows.shape[1] != D or sp.rows.device != dx0.device:
-            sp = ops.SparseRows(3 * T, D, dx0.device)
+            sp = self._local_sparse = ops.SparseRows(3 * T, D, dx0.device)
         self.sparse_table_grad = ops.sasrec_embed_grad(s["items"], dx0, s["out"], coef, self.item_num, 1.0, sp)
         self._saved = None
         self._step_counter += 1

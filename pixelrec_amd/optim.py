@@ -19,6 +19,7 @@ class PxrAdamW:
         self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
         self.step_count = 0
         self._m = self._v = self._tm = self._tv = self._slot = None
+        self.table_events = None  # bench.py: list collecting (start, end) HIP events around the table sweep
         self.param_groups = [{"lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}]
 
     def _ensure_state(self):
@@ -44,9 +45,15 @@ class PxrAdamW:
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         ops.adamw_flat(flat, gflat, self._m, self._v, g["lr"], b1, b2, g["eps"], g["weight_decay"], self.step_count)
+        ev = None
+        if self.table_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         ops.adamw_table(table, self._tm, self._tv, self._slot, self.model.sparse_table_grad, g["lr"], b1, b2,
                         g["eps"], g["weight_decay"], self.step_count)
-        self.model.sparse_table_grad_consumed = True
+        if ev is not None:
+            ev[1].record()
+            self.table_events.append(ev)
 
     def state_dict(self):
         self._ensure_state()

@@ -1,0 +1,94 @@
+"""Data-parallel gradient exchange over RCCL/xGMI (torch.distributed backend "nccl" IS RCCL on ROCm) -- the
+counterpart of the reference's DistributedDataParallel wrapper (code/run.py:40) for this path.
+
+The reference all-reduces the DENSE 836 MB gradient every step, of which 819 MB is the
+embedding gradient.  Here:
+  * the 4.2 M transformer / position / LayerNorm gradients live in ONE flat buffer -> one all-reduce (SUM; every
+    rank pre-scales its loss gradient by 1/world so the sum IS DDP's mean);
+  * the table gradient stays sparse: each rank contributes its (uniq_idx, uniq_rows) padded to a fixed capacity
+    (padding ids are 0 = padding_idx, which the merge drops) -> one all-gather of ids + one of rows -> every
+    rank merges the W lists with the same deterministic sort/segment-sum kernel, so replicas stay bit-identical.
+No host synchronisation: counts stay on the device, shapes are static.
+
+`DataParallel` mirrors the only DDP surface the reference's Trainer uses: `.module`, `__call__`, `.train()`,
+`.eval()`, `.parameters()`, `.named_parameters()`, `.state_dict()`.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_sparse(idx: torch.Tensor, rows: torch.Tensor, n: torch.Tensor, group=None):
+    """All-gather a rank-local sparse gradient.  idx int64 [cap] (entries >= n are forced to 0 so that they are
+    dropped as padding), rows fp32 [cap, D], n int32 [1].  Returns (idx_all [W*cap], rows_all [W*cap, D])."""
+    _, world = world_info()
+    cap = idx.shape[0]
+    ar = torch.arange(cap, device=idx.device)
+    idx_masked = torch.where(ar < n.to(torch.int64), idx, torch.zeros_like(idx))
+    idx_all = torch.empty(world * cap, dtype=idx.dtype, device=idx.device)
+    rows_all = torch.empty(world * cap, rows.shape[1], dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(idx_all, idx_masked, group=group)
+    dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=group)
+    return idx_all, rows_all
+
+
+class GradSync:
+    """Synchronises the gradients of a pixelrec_amd SASRec across ranks after backward()."""
+
+    def __init__(self, model, merge_fn=None, group=None):
+        self.model = model
+        self.group = group
+        self.rank, self.world = world_info()
+        # merge_fn(idx_all, rows_all, n_table, out_sparse) -> SparseRows ; default = the HIP kernel
+        self._merge = merge_fn
+        self._merged = None
+        if self.world > 1:
+            model.grad_scale = 1.0 / self.world
+
+    def broadcast_parameters(self, src: int = 0):
+        """DDP's construction-time broadcast: make every replica start from rank `src`."""
+        if self.world == 1:
+            return
+        flat, _ = self.model.flat_parameters()
+        dist.broadcast(flat, src=src, group=self.group)
+        dist.broadcast(self.model.item_embedding.weight.data, src=src, group=self.group)
+
+    def sync(self):
+        if self.world == 1:
+            return
+        _, gflat = self.model.flat_parameters()
+        dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.group)
+        sp = self.model.sparse_table_grad
+        idx_all, rows_all = gather_sparse(sp.idx, sp.rows, sp.n, self.group)
+        if self._merge is None:
+            from . import ops
+
+            if self._merged is None or self._merged.cap != idx_all.numel():
+                self._merged = ops.SparseRows(idx_all.numel(), rows_all.shape[1], rows_all.device)
+            self.model.sparse_table_grad = ops.embed_grad_rows(idx_all, rows_all, self.model.item_num, 1.0,
+                                                               out=self._merged)
+        else:
+            self.model.sparse_table_grad = self._merge(idx_all, rows_all, self.model.item_num)
+
+
+class DataParallel(torch.nn.Module):
+    """Minimal DDP-shaped wrapper: the Trainer reaches the model through `.module` (trainer.py:332,349,358,374)."""
+
+    def __init__(self, module, merge_fn=None):
+        super().__init__()
+        self.module = module
+        self.grad_sync = GradSync(module, merge_fn)
+        self.grad_sync.broadcast_parameters(0)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def sync_gradients(self):
+        self.grad_sync.sync()
