@@ -33,6 +33,11 @@ int pxr_version(void);                 /* major*10000 + minor*100 + patch */
 const char* pxr_last_error(void);      /* message of the last failing call on this thread */
 const char* pxr_target_arch(void);     /* "gfx950" */
 
+/* HOST function: keep-mask bytes (1 = keep) of elements first_index .. first_index+n-1 for (seed, stream_id, p),
+ * computed with the same hash the kernels use.  For tests of the dropout restatement; no device work. */
+int pxr_dropout_keep_host(uint64_t seed, uint32_t stream_id, uint64_t first_index, int64_t n, float p,
+                          uint8_t* keep_out);
+
 /* ---- embedding table ---------------------------------------------------------------------------------------- */
 /* out[i,:] = table[idx[i],:]                       model/IDNet/sasrec.py:68,101; model/PixelNet/mosasrec.py:102 */
 int pxr_embed_gather_f32(const float* table, int64_t N, int D, const int64_t* idx, int64_t n, float* out,
@@ -109,6 +114,16 @@ int pxr_bpr_loss_fwd_f32(const float* out, const float* table, int64_t n_table, 
 int pxr_bpr_loss_bwd_f32(const float* pos_score, const float* neg_score, const float* table, int64_t n_table,
                          const int64_t* items, const int64_t* masked_index, int B, int L, int D, float grad_scale,
                          const float* grad_scale_dev, float* dout, float* coef, void* stream);
+
+/* ---- full-sort evaluation ------------------------------------------------------------------------------------ */
+/* Fused  scores = users x table^T (sasrec.py:112)  ->  scores[:,0] = -inf, scores[history] = -inf (trainer.py:333-336)
+ * ->  top-K (collector.py:133): the [B,N] score matrix never reaches HBM.  users [B,D] with row stride ld_users;
+ * hist_ptr int32 [B+1] + hist_items int64 = CSR of seq_eval_collate's (history_u, history_i) pairs (NULL = none);
+ * K <= 32.  Outputs topk_idx int64 [B,K] / topk_val [B,K], descending. */
+int64_t pxr_score_topk_ws_bytes(int B, int N, int K);
+int pxr_score_topk_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
+                       const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx, float* topk_val,
+                       void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- optimizer ---------------------------------------------------------------------------------------------- */
 /* torch.optim.AdamW update (trainer.py:102,125), step is 1-based.  n must be a multiple of 4. */

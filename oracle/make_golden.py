@@ -189,8 +189,108 @@ def run_case(name, c, REC):
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), loss={store['loss']:.6f}")
 
 
+def make_data_golden(REC):
+    """G5: tiny synthetic interaction CSV -> the REFERENCE's Data.build / SeqEvalDataset / seq_eval_collate outputs."""
+    import logging
+    from REC.data.dataload import Data
+    from REC.data.dataset import SeqEvalDataset, seq_eval_collate
+    from REC.utils.enum_type import InputType
+
+    rng = np.random.default_rng(99)
+    gdir = os.path.join(ROOT, "tests", "golden")
+    n_users, n_items, L = 60, 90, 6
+    rows = []
+    ts = rng.permutation(5000)[:2000]  # unique timestamps (pandas' default sort is not stable on ties)
+    k = 0
+    for u in range(n_users):
+        n = int(rng.integers(3, 30))  # 3 .. 29 interactions: shorter / equal / longer than L+1 after leave-2-out
+        for _ in range(n):
+            rows.append((f"i{int(rng.zipf(1.3)) % n_items}", f"u{u}", int(ts[k])))
+            k += 1
+    order = rng.permutation(len(rows))
+    csv_path = os.path.join(gdir, "TinyInter.csv")
+    with open(csv_path, "w") as f:
+        f.write("item_id,user_id,timestamp\n")
+        for j in order:
+            f.write("%s,%s,%d\n" % rows[j])
+    cfg = {"data_path": gdir, "dataset": "TinyInter", "MAX_ITEM_LIST_LENGTH": L, "MODEL_INPUT_TYPE": InputType.SEQ}
+    d = Data(cfg)
+    d.build()
+    store = {"L": np.array(L), "user_num": np.array(d.user_num), "item_num": np.array(d.item_num)}
+    useq = list(d.user_seq.values())
+    store["user_seq_keys"] = np.array(list(d.user_seq.keys()))
+    store["user_seq_flat"] = np.concatenate(useq)
+    store["user_seq_lens"] = np.array([len(x) for x in useq])
+    tw = d.train_feat["item_seq"]
+    store["train_flat"] = np.concatenate(tw)
+    store["train_lens"] = np.array([len(x) for x in tw])
+    store["train_uid"] = d.train_feat["user_id"]
+    for phase in ("valid", "test"):
+        ds = SeqEvalDataset(cfg, d, phase=phase)
+        batch = seq_eval_collate([ds[i] for i in range(len(ds))])
+        store[f"{phase}.item_seq"] = batch[0].numpy()
+        store[f"{phase}.history_u"] = batch[1][0].numpy()
+        store[f"{phase}.history_i"] = batch[1][1].numpy()
+        store[f"{phase}.positive_u"] = batch[2].numpy()
+        store[f"{phase}.item_target"] = batch[3].numpy()
+    np.savez_compressed(os.path.join(gdir, "data_tiny.npz"), **store)
+    print("data golden:", d.user_num, "users", d.item_num, "items", len(tw), "train windows")
+
+
+def make_harness_golden(REC):
+    """G5 harness level: the REFERENCE's own Config -> load_data -> bulid_dataloader -> SASRec -> DDP(gloo, CPU) ->
+    Trainer.evaluate(valid/test) on TinyInter.csv with seed-generated weights -> recall/ndcg @5/@10."""
+    import tempfile
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from REC.config import Config
+    from REC.data import load_data, bulid_dataloader
+    from REC.trainer import Trainer
+    from REC.utils import get_model
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    tmp = tempfile.mkdtemp()
+    model_yaml = os.path.join(tmp, "m.yaml"); over_yaml = os.path.join(tmp, "o.yaml")
+    D, L, H, inner, nl = 32, 6, 2, 2, 2
+    open(model_yaml, "w").write(f"model: SASRec\nn_layers: {nl}\nn_heads: {H}\nembedding_size: {D}\ninner_size: {inner}\n"
+                                "hidden_dropout_prob: 0.1\nattn_dropout_prob: 0.1\nhidden_act: 'gelu'\n"
+                                "layer_norm_eps: 1e-12\ninitializer_range: 0.02\n")
+    open(over_yaml, "w").write(f"seed: 2020\nstate: INFO\nuse_modality: False\nreproducibility: True\n"
+                               f"checkpoint_dir: '{tmp}/saved'\nshow_progress: False\nlog_wandb: False\n"
+                               f"MAX_ITEM_LIST_LENGTH: {L}\ndata_path: {gdir}/\ndataset: TinyInter\nepochs: 1\n"
+                               "train_batch_size: 8\noptim_args: {learning_rate: 0.0001, weight_decay: 0.1}\n"
+                               "eval_batch_size: 16\ntopk: [5,10]\nmetrics: ['Recall', 'NDCG']\nvalid_metric: NDCG@10\n"
+                               "metric_decimal_place: 7\neval_step: 1\nstopping_step: 30\n")
+    cwd = os.getcwd(); os.chdir(tmp)
+    try:
+        config = Config(config_file_list=[model_yaml, over_yaml])
+        config["device"] = torch.device("cpu")
+        dataload = load_data(config)
+        train_loader, valid_loader, test_loader = bulid_dataloader(config, dataload)
+        model = get_model(config["model"])(config, dataload)
+        params = synth_params(dataload.item_num, D, L, nl, inner, seed=77)
+        model.load_state_dict(params, strict=True)
+        ddp = DDP(model, find_unused_parameters=True)
+        trainer = Trainer(config, ddp)
+        store = {"meta": np.array([dataload.item_num, D, L, H, inner, nl, 77])}
+        for phase, loader in (("valid", valid_loader), ("test", test_loader)):
+            res = trainer.evaluate(loader, load_best_model=False)
+            store[f"{phase}.names"] = np.array(list(res.keys()))
+            store[f"{phase}.values"] = np.array([float(v) for v in res.values()])
+            print("harness golden", phase, dict(res))
+        np.savez_compressed(os.path.join(gdir, "harness_tiny.npz"), **store)
+    finally:
+        os.chdir(cwd)
+
+
 def main():
     REC = ref_shim.import_reference()
+    make_data_golden(REC)
+    make_harness_golden(REC)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     torch.set_num_threads(8)
     for name, c in CASES.items():

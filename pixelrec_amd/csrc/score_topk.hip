@@ -1,0 +1,216 @@
+// score_topk.hip -- full-catalog scoring fused with the full-sort evaluation epilogue (K19-K21).
+//
+// Reference: scores = seq_output @ item_feature^T   [B_e, N]  (sasrec.py:112)            1.64 GB at 1024 x 400K
+//            scores[:, 0] = -inf; scores[(history_u, history_i)] = -inf                   (trainer.py:333-336)
+//            torch.topk(scores, max(topk)) + [B_e, N] int positive matrix + gather         (collector.py:131-139)
+// Here the scores never leave the chip: every workgroup owns 128 users x one contiguous range of item tiles,
+// runs the fp32-MFMA main loop of gemm_f32.cuh per 128x128 tile, drops the tile into LDS (re-using the GEMM staging
+// buffers), applies the -inf masks there (column 0, the users' histories, the ragged last tile) and lets each
+// thread keep a private sorted top-K list in registers for (one user, half of the tile's columns).  A second
+// tiny kernel merges the 2 x n_split partial lists per user.  HBM traffic = the table once (819 MB) instead of
+// table + 2 x 1.64 GB of scores + the int matrix.
+//
+// Ties: scores are continuous fp32 dot products, so ties only occur among -inf entries, which can reach the
+// list only when fewer than K unmasked items exist.
+#include "gemm_f32.cuh"
+
+namespace pxr {
+
+constexpr int ST_BM = 128, ST_BN = 128;
+constexpr int ST_LD = ST_BN + 1;  // score-tile row stride in LDS: lane=row scans are conflict-free
+using StCfg = GemmCfg<ST_BM, ST_BN, true, true>;
+constexpr int ST_SMEM_FLOATS = (2 * StCfg::STAGE > ST_BM * ST_LD) ? 2 * StCfg::STAGE : ST_BM * ST_LD;
+
+template <int KT>
+struct TopList {
+  float v[KT];
+  int i[KT];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { v[k] = -INFINITY; i[k] = -1; }
+  }
+  // sorted descending; v[KT-1] is the admission threshold
+  __device__ __forceinline__ void insert(float x, int id) {
+    if (!(x > v[KT - 1])) return;
+    v[KT - 1] = x; i[KT - 1] = id;
+#pragma unroll
+    for (int k = KT - 1; k > 0; --k) {
+      if (v[k] > v[k - 1]) {
+        const float tv = v[k]; v[k] = v[k - 1]; v[k - 1] = tv;
+        const int ti = i[k]; i[k] = i[k - 1]; i[k - 1] = ti;
+      }
+    }
+  }
+};
+
+struct ScoreTopkArgs {
+  const float* users; int64_t ld_users;   // [B, D] rows at stride ld_users
+  const float* table;                     // [N, D]
+  const int* hist_ptr;                    // [B+1] CSR offsets into hist_items (may be null)
+  const int64_t* hist_items;              // item ids to mask per user
+  float* part_val; int* part_idx;         // [B, n_split*2, KT]
+  int B, N, D, tiles_n, n_split, row_blocks;
+};
+
+template <int KT>
+__global__ void __launch_bounds__(GEMM_THREADS) score_topk_kernel(ScoreTopkArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[ST_SMEM_FLOATS];
+  const int tid = threadIdx.x;
+  const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
+  const int rb = t % a.row_blocks, sp = t / a.row_blocks;   // row-block fastest: neighbours share the item tiles
+  const int m0 = rb * ST_BM;
+  const int per = (a.tiles_n + a.n_split - 1) / a.n_split;
+  const int tn0 = sp * per, tn1 = min(a.tiles_n, tn0 + per);
+
+  const int my_row = tid & 127, my_half = tid >> 7;
+  const int urow = m0 + my_row;
+  TopList<KT> top;
+  top.init();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  int hb = 0, he = 0;
+  if (a.hist_ptr) {
+    hb = a.hist_ptr[m0];
+    he = a.hist_ptr[min(a.B, m0 + ST_BM)];
+  }
+
+  for (int tn = tn0; tn < tn1; ++tn) {
+    const int n0 = tn * ST_BN;
+    typename StCfg::Acc accs;
+    gemm_mainloop<ST_BM, ST_BN, true, true>(accs, a.users, a.ld_users, a.table, (int64_t)a.D, a.B, a.N, 0, a.D, m0,
+                                             n0, smem);
+    // (the main loop ends with a barrier: the staging buffers are free) -> score tile in LDS, masks applied
+#pragma unroll
+    for (int j = 0; j < StCfg::TN; ++j) {
+      const int cl = wn * StCfg::WN + j * 32 + r;
+      const int col = n0 + cl;
+      const bool dead = (col >= a.N) || (col == 0);       // ragged edge; padding item 0 (trainer.py:334)
+#pragma unroll
+      for (int i = 0; i < StCfg::TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = wm * StCfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          smem[rl * ST_LD + cl] = dead ? -INFINITY : accs.v[i][j][e];
+        }
+    }
+    __syncthreads();
+    // history mask (trainer.py:335-336): every (user, item) pair of this row block that falls in this tile
+    for (int p = hb + tid; p < he; p += GEMM_THREADS) {
+      const int64_t it = a.hist_items[p];
+      if (it >= n0 && it < n0 + ST_BN) {
+        // owner row of pair p: the user u with hist_ptr[u] <= p < hist_ptr[u+1]; binary search inside the block
+        int lo = m0, hi = min(a.B, m0 + ST_BM) - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (a.hist_ptr[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        smem[(lo - m0) * ST_LD + (int)(it - n0)] = -INFINITY;
+      }
+    }
+    __syncthreads();
+    if (urow < a.B) {
+      const float* rowp = smem + my_row * ST_LD + my_half * 64;
+      const int cbase = n0 + my_half * 64;
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) top.insert(rowp[c], cbase + c);
+    }
+    __syncthreads();
+  }
+  if (urow < a.B) {
+    const int64_t o = ((int64_t)urow * (a.n_split * 2) + (sp * 2 + my_half)) * KT;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { a.part_val[o + k] = top.v[k]; a.part_idx[o + k] = top.i[k]; }
+  }
+}
+
+// one wave per user: pick the K best of its n_cand partial candidates, descending
+__global__ void __launch_bounds__(256) topk_merge_kernel(const float* __restrict__ part_val,
+                                                         const int* __restrict__ part_idx, int B, int n_cand, int K,
+                                                         int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + wave;
+  if (u >= B) return;
+  const float* pv = part_val + (int64_t)u * n_cand;
+  const int* pi = part_idx + (int64_t)u * n_cand;
+  float last_v = INFINITY;
+  int last_pos = -1;
+  for (int k = 0; k < K; ++k) {
+    // best remaining candidate = max over (value, -position) strictly "after" the previously emitted one
+    float bv = -INFINITY;
+    int bp = 0x7fffffff;
+    for (int c = lane; c < n_cand; c += 64) {
+      const float v = pv[c];
+      const bool remaining = (v < last_v) || (v == last_v && c > last_pos);
+      if (remaining && (v > bv || (v == bv && c < bp))) { bv = v; bp = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int op = __shfl_xor(bp, off, 64);
+      if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+    }
+    if (lane == 0) {
+      const bool ok = bp != 0x7fffffff;
+      out_val[(int64_t)u * K + k] = ok ? bv : -INFINITY;
+      out_idx[(int64_t)u * K + k] = ok ? (int64_t)pi[bp] : (int64_t)-1;
+    }
+    last_v = bv;
+    last_pos = bp;
+  }
+}
+
+static int pick_kt(int K) { return K <= 10 ? 10 : (K <= 16 ? 16 : (K <= 32 ? 32 : 0)); }
+static int pick_split(int B, int N) {
+  const int row_blocks = (B + ST_BM - 1) / ST_BM;
+  const int tiles_n = (N + ST_BN - 1) / ST_BN;
+  int s = (512 + row_blocks - 1) / row_blocks;  // ~2 resident workgroups per CU
+  if (s > tiles_n) s = tiles_n;
+  if (s < 1) s = 1;
+  return s;
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+extern "C" int64_t pxr_score_topk_ws_bytes(int B, int N, int K) {
+  const int kt = pick_kt(K);
+  if (kt == 0) return -1;
+  const int64_t cand = (int64_t)pick_split(B, N) * 2 * kt;
+  return (int64_t)B * cand * 8 + 256;
+}
+
+// Top-K item ids / scores per user of  users[B,D] x table[N,D]^T  with item 0 and each user's history masked.
+// hist_ptr int32 [B+1] / hist_items int64: CSR of the (history_u, history_i) pairs of seq_eval_collate (may be NULL).
+extern "C" int pxr_score_topk_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
+                                  const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx,
+                                  float* topk_val, void* ws, int64_t ws_bytes, void* stream) {
+  PXR_REQUIRE(users && table && topk_idx && topk_val && ws, "pxr_score_topk_f32: null pointer");
+  PXR_REQUIRE(B > 0 && N > 0 && D > 0 && D % 4 == 0 && ld_users % 4 == 0, "pxr_score_topk_f32: bad shape");
+  PXR_REQUIRE(!hist_ptr || hist_items, "pxr_score_topk_f32: hist_ptr without hist_items");
+  const int kt = pick_kt(K);
+  PXR_REQUIRE(K >= 1 && kt != 0, "pxr_score_topk_f32: K must be in [1, 32]");
+  ScoreTopkArgs a{};
+  a.users = users; a.ld_users = ld_users; a.table = table; a.hist_ptr = hist_ptr; a.hist_items = hist_items;
+  a.B = B; a.N = N; a.D = D;
+  a.row_blocks = (B + ST_BM - 1) / ST_BM;
+  a.tiles_n = (N + ST_BN - 1) / ST_BN;
+  a.n_split = pick_split(B, N);
+  const int64_t cand = (int64_t)a.n_split * 2 * kt;
+  if ((int64_t)B * cand * 8 + 256 > ws_bytes) { pxr_set_error("pxr_score_topk_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
+  a.part_val = (float*)ws;
+  a.part_idx = (int*)((char*)ws + (((int64_t)B * cand * 4 + 255) & ~(int64_t)255));
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(a.row_blocks * a.n_split);
+  switch (kt) {
+    case 10: hipLaunchKernelGGL(score_topk_kernel<10>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(score_topk_kernel<16>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL(score_topk_kernel<32>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+  }
+  int rc = pxr_check_launch("pxr_score_topk_f32");
+  if (rc) return rc;
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)a.part_val,
+                     (const int*)a.part_idx, B, (int)cand, K, topk_idx, topk_val);
+  return pxr_check_launch("pxr_score_topk_f32(merge)");
+}

@@ -1,0 +1,152 @@
+"""Train / eval batch construction for the SASRec family (reference REC/data/dataset/{trainset,evalset,
+collate_fn}.py) plus a vectorised whole-batch builder.
+
+Reference semantics kept:
+  * SEQTrainDataset item = (items [2, L+1], masked_index [L]): positives left-padded with 0; ONE negative per
+    target position, uniform over [1, N-1] rejecting the sequence's own items (trainset.py:40-44), right-aligned
+    (neg[0] is always 0); masked_index = 1 on the len-1 target positions (trainset.py:46-75);
+  * SeqEvalDataset item = (history tensor, last-L left-padded item_seq, target): valid = [:-2] / [-2],
+    test = [:-1] / [-1] (evalset.py:17-34); seq_eval_collate stacks them and emits the (history_u, history_i)
+    pairs used to mask the whole history at eval (collate_fn.py:6-32).
+What is new: `SeqTrainBatcher` builds whole batches with numpy (the per-sample Python `random` loop in 10 worker
+processes is the bottleneck once a step takes ~2 ms on the GPU).
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+class SEQTrainDataset(Dataset):
+    def __init__(self, config, dataload):
+        self.dataload = dataload
+        self.item_num = dataload.item_num
+        self.train_seq = dataload.train_feat["item_seq"]
+        self.length = len(self.train_seq)
+        self.max_seq_length = config["MAX_ITEM_LIST_LENGTH"] + 1
+
+    def __len__(self):
+        return self.length
+
+    def _neg_sample(self, item_set):
+        item = random.randint(1, self.item_num - 1)
+        while item in item_set:
+            item = random.randint(1, self.item_num - 1)
+        return item
+
+    @staticmethod
+    def _pad(sequence, max_length):
+        sequence = [0] * (max_length - len(sequence)) + list(sequence)
+        return torch.tensor(sequence[-max_length:], dtype=torch.long)
+
+    def __getitem__(self, index):
+        item_seq = self.train_seq[index]
+        n = len(item_seq)
+        neg = [self._neg_sample(item_seq) for _ in range(n - 1)]
+        mask = [1] * (n - 1)
+        return (torch.stack((self._pad(list(item_seq), self.max_seq_length), self._pad(neg, self.max_seq_length))),
+                self._pad(mask, self.max_seq_length - 1))
+
+
+class SeqTrainBatcher:
+    """Vectorised equivalent of DataLoader(SEQTrainDataset, sampler=DistributedSampler): yields whole
+    (items [B,2,L+1], masked_index [B,L]) int64 batches.  The sample ORDER reproduces torch's DistributedSampler
+    (shuffle with generator seed = seed + epoch, pad to a multiple of world by wrapping, rank-strided)."""
+
+    def __init__(self, config, dataload, rank=0, world=1, seed=0, drop_last=False):
+        self.item_num = dataload.item_num
+        self.W = config["MAX_ITEM_LIST_LENGTH"] + 1
+        self.batch_size = config["train_batch_size"]
+        seqs = dataload.train_feat["item_seq"]
+        self.n = len(seqs)
+        self.windows = np.zeros((self.n, self.W), dtype=np.int64)
+        self.lens = np.zeros(self.n, dtype=np.int64)
+        for i, s in enumerate(seqs):
+            k = len(s)
+            self.windows[i, self.W - k:] = s
+            self.lens[i] = k
+        self.rank, self.world, self.seed, self.epoch = rank, world, seed, 0
+        self.num_samples = -(-self.n // world)
+        self.drop_last = drop_last
+        self.neg_seed = int(config["seed"] or 0)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.num_samples // self.batch_size if self.drop_last else -(-self.num_samples // self.batch_size)
+
+    def _indices(self):
+        g = torch.Generator()
+        g.manual_seed(self.seed + self.epoch)
+        idx = torch.randperm(self.n, generator=g).tolist()
+        total = self.num_samples * self.world
+        pad = total - len(idx)
+        if pad > 0:
+            idx += (idx * ((pad + len(idx) - 1) // len(idx) + 1))[:pad]
+        return np.asarray(idx[self.rank:total:self.world], dtype=np.int64)
+
+    def make_batch(self, rows, rng):
+        pos = self.windows[rows]                                   # [B, W]
+        lens = self.lens[rows]
+        B, W = pos.shape
+        col = np.arange(W)[None, :]
+        tgt = col >= (W - lens[:, None] + 1)                       # target positions: the last len-1 columns
+        neg = rng.integers(1, self.item_num, size=(B, W))
+        if self.item_num > 2 * W:                                  # rejection of the sequence's own items
+            for _ in range(64):
+                clash = (neg[:, :, None] == pos[:, None, :]).any(-1) & tgt
+                if not clash.any():
+                    break
+                neg[clash] = rng.integers(1, self.item_num, size=int(clash.sum()))
+        neg = np.where(tgt, neg, 0)
+        items = np.stack((pos, neg), axis=1)
+        return items, tgt[:, 1:].astype(np.int64)
+
+    def __iter__(self):
+        idx = self._indices()
+        rng = np.random.default_rng([self.neg_seed, self.epoch, self.rank])
+        nb = len(self)
+        for b in range(nb):
+            rows = idx[b * self.batch_size:(b + 1) * self.batch_size]
+            items, mask = self.make_batch(rows, rng)
+            yield torch.from_numpy(items), torch.from_numpy(mask)
+
+
+class SeqEvalDataset(Dataset):
+    def __init__(self, config, dataload, phase="valid"):
+        self.dataload = dataload
+        self.max_item_list_length = config["MAX_ITEM_LIST_LENGTH"]
+        self.user_seq = list(dataload.user_seq.values())
+        self.phase = phase
+        self.length = len(self.user_seq)
+        self.item_num = dataload.item_num
+
+    def __len__(self):
+        return self.length
+
+    def _padding_sequence(self, sequence, max_length):
+        sequence = [0] * (max_length - len(sequence)) + list(sequence)
+        return sequence[-max_length:]
+
+    def __getitem__(self, index):
+        seq = self.user_seq[index]
+        if self.phase == "valid":
+            history_seq, item_target = seq[:-2], seq[-2]
+        else:
+            history_seq, item_target = seq[:-1], seq[-1]
+        item_seq = self._padding_sequence(history_seq, self.max_item_list_length)
+        return torch.tensor(np.asarray(history_seq, dtype=np.int64)), item_seq, int(item_target)
+
+
+def seq_eval_collate(batch):
+    history_i = [item[0] for item in batch]
+    item_seq = torch.tensor([item[1] for item in batch], dtype=torch.long)
+    item_target = torch.tensor([item[2] for item in batch], dtype=torch.long)
+    history_u = torch.cat([torch.full_like(h, i) for i, h in enumerate(history_i)])
+    history_i = torch.cat(history_i)
+    positive_u = torch.arange(item_seq.shape[0])
+    return item_seq, (history_u, history_i), positive_u, item_target

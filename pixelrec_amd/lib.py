@@ -31,6 +31,7 @@ _SIGNATURES = {
     "pxr_version": (c_int, []),
     "pxr_last_error": (c_char_p, []),
     "pxr_target_arch": (c_char_p, []),
+    "pxr_dropout_keep_host": (_I, [_U64, _U32, _U64, _I64, _F, _P]),
     "pxr_embed_gather_f32": (_I, [_P, _I64, _I, _P, _I64, _P, _P]),
     "pxr_embed_grad_ws_bytes": (_I64, [_I64]),
     "pxr_embed_grad_rows_f32": (_I, [_P, _I64, _P, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
@@ -50,6 +51,8 @@ _SIGNATURES = {
     "pxr_attn_bwd_f32": (_I, [_P, _I64, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _P, _I64, _F, _U64, _U32, _P]),
     "pxr_bpr_loss_fwd_f32": (_I, [_P, _P, _I64, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pxr_bpr_loss_bwd_f32": (_I, [_P, _P, _P, _I64, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "pxr_score_topk_ws_bytes": (_I64, [_I, _I, _I]),
+    "pxr_score_topk_f32": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I64, _P]),
     "pxr_adamw_flat_f32": (_I, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),
     "pxr_slot_fill_i32": (_I, [_P, _I64, ctypes.c_int32, _P]),
     "pxr_adamw_table_f32": (_I, [_P, _P, _P, _I64, _I, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),

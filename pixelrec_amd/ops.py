@@ -286,6 +286,35 @@ def sasrec_embed_grad(items, dx0, out, coef, n_table, scale=1.0, sp: SparseRows 
     return sp
 
 
+# ------------------------------------------------------------------------------------------------ full-sort eval
+def history_csr(history_u: torch.Tensor, history_i: torch.Tensor, B: int, device):
+    """(history_u, history_i) of seq_eval_collate (grouped by user, collate_fn.py:27-28) -> (hist_ptr int32 [B+1],
+    hist_items int64) on `device`.  Host-side index plumbing (a bincount), not arithmetic."""
+    counts = torch.bincount(history_u.cpu(), minlength=B)
+    ptr = torch.zeros(B + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return ptr.to(device), history_i.to(device=device, dtype=torch.int64).contiguous()
+
+
+def score_topk(users: torch.Tensor, ld_users: int, B: int, table: torch.Tensor, K: int, hist_ptr=None,
+               hist_items=None):
+    """Fused full-catalog scoring + masking + top-K (see pxr.h).  `users` may be a strided view (row stride
+    ld_users floats).  Returns (topk_idx int64 [B,K], topk_val fp32 [B,K])."""
+    Lb = _l.load()
+    _req(users, torch.float32, "users", contiguous=False); _req(table, torch.float32, "table")
+    N, D = table.shape
+    idx = torch.empty(B, K, dtype=torch.int64, device=table.device)
+    val = torch.empty(B, K, dtype=torch.float32, device=table.device)
+    ws_bytes = int(Lb.pxr_score_topk_ws_bytes(B, N, K))
+    if ws_bytes < 0:
+        raise _l.PxrError("score_topk: K must be in [1, 32]")
+    ws = _ws.get(ws_bytes, table.device)
+    _l.check(Lb.pxr_score_topk_f32(_l.ptr(users), ld_users, B, _l.ptr(table), N, D, _l.ptr(hist_ptr),
+                                   _l.ptr(hist_items), K, _l.ptr(idx), _l.ptr(val), _l.ptr(ws), ws_bytes,
+                                   _l.stream_ptr()), "pxr_score_topk_f32")
+    return idx, val
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     Lb = _l.load()

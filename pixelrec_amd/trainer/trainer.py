@@ -1,0 +1,277 @@
+"""Trainer -- the reference's epoch loop (code/REC/trainer/trainer.py:19-409) around the MI355X-native step.
+
+Same surface: `Trainer(config, model)` with `model` a DDP-shaped wrapper exposing `.module`; `fit(train, valid,
+saved, show_progress)`; `evaluate(loader, load_best_model, model_file)`; `resume_checkpoint(file)`; same
+checkpoint dict keys (`config, epoch, cur_step, best_valid_score, state_dict, optimizer, rng_state,
+cuda_rng_state`, trainer.py:146-155) so `.pth` files interchange; early stopping / eval_step / valid_metric logic
+as trainer.py:256-325; metric averaging = per-rank SUM -> all_gather -> / #users -> round (trainer.py:360-364,
+399-406).
+
+What changed for the hardware (SURVEY.md §7 hard part 6):
+  * the loss stays on the device: the per-step `.item()` + isnan host sync (trainer.py:120-121) becomes one sync
+    per epoch (NaN still raises ValueError('Training loss is nan'));
+  * zero_grad is a no-op (gradients are overwritten), backward leaves the table gradient sparse, gradients are
+    exchanged by parallel.GradSync, the optimizer is optim.PxrAdamW;
+  * full-sort evaluation uses the fused scoring+mask+top-K kernel; `eval_fused_topk: False` falls back to the
+    reference's literal sequence (predict -> mask -> torch.topk) for cross-checking.
+"""
+from __future__ import annotations
+
+import os
+import queue
+import threading
+from logging import getLogger
+from time import time
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..evaluator import Collector, Evaluator
+from ..optim import PxrAdamW
+from ..parallel import world_info
+from ..utils import calculate_valid_score, dict2str, early_stopping, ensure_dir, get_local_time
+
+
+class _Prefetcher:
+    """Builds host batches on a background thread (numpy releases the GIL) and stages them on the device."""
+
+    def __init__(self, loader, device, depth=4):
+        self.loader, self.device, self.q = loader, device, queue.Queue(maxsize=depth)
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        try:
+            for batch in self.loader:
+                self.q.put(batch)
+        except BaseException as e:  # surfaced in the consumer
+            self.q.put(e)
+        self.q.put(None)
+
+    def __iter__(self):
+        while True:
+            b = self.q.get()
+            if b is None:
+                return
+            if isinstance(b, BaseException):
+                raise b
+            yield tuple(x.to(self.device, non_blocking=True) for x in b)
+
+
+class Trainer:
+    def __init__(self, config, model):
+        self.config = config
+        self.model = model
+        self.logger = getLogger()
+        self.optim_args = config["optim_args"]
+        self.epochs = config["epochs"]
+        self.eval_step = min(config["eval_step"], self.epochs)
+        self.stopping_step = config["stopping_step"]
+        self.clip_grad_norm = config["clip_grad_norm"]
+        self.valid_metric = config["valid_metric"].lower()
+        self.valid_metric_bigger = config["valid_metric_bigger"]
+        self.test_batch_size = config["eval_batch_size"]
+        self.device = config["device"]
+        self.rank, self.world = world_info()
+        self.checkpoint_dir = config["checkpoint_dir"] or "saved"
+        if self.rank == 0:
+            ensure_dir(self.checkpoint_dir)
+        self.saved_model_file = os.path.join(self.checkpoint_dir, "{}-{}.pth".format(config["model"], get_local_time()))
+        self.use_modality = config["use_modality"]
+        self.start_epoch = 0
+        self.cur_step = 0
+        self.best_valid_score = -np.inf if self.valid_metric_bigger else np.inf
+        self.best_valid_result = None
+        self.train_loss_dict = {}
+        self.optimizer = self._build_optimizer()
+        self.eval_collector = Collector(config)
+        self.evaluator = Evaluator(config)
+        self.item_feature = None
+        self.tot_item_num = None
+        self.fused_topk = config["eval_fused_topk"] is None or bool(config["eval_fused_topk"])
+        if self.clip_grad_norm:
+            raise NotImplementedError("clip_grad_norm is not configured by any shipped YAML and is not built yet")
+
+    # ---------------------------------------------------------------------------------------------- optimizer
+    def _build_optimizer(self):
+        """trainer.py:66-103.  A 4-key optim_args selects separate modal/rec groups; for the ID model every
+        parameter is a 'rec' parameter, so both spellings resolve to one AdamW."""
+        a = self.optim_args
+        if len(a) == 4:
+            lr, wd = a["rec_lr"], a["rec_decay"]
+        else:
+            lr, wd = a["learning_rate"], a["weight_decay"]
+        return PxrAdamW(self.model.module, lr=lr, weight_decay=wd)
+
+    # ---------------------------------------------------------------------------------------------- training
+    def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
+        self.model.train()
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        for data in _Prefetcher(train_data, self.device):
+            self.optimizer.zero_grad()
+            losses = self.model(data)
+            losses.backward()
+            if hasattr(self.model, "sync_gradients"):
+                self.model.sync_gradients()
+            self.optimizer.step()
+            total = total + losses.detach()
+        total_loss = float(total.item())          # the only host sync of the epoch
+        self._check_nan(total_loss)
+        return total_loss
+
+    def _check_nan(self, loss):
+        if np.isnan(loss):
+            raise ValueError("Training loss is nan")
+
+    def _valid_epoch(self, valid_data, show_progress=False):
+        self._barrier()
+        valid_result = self.evaluate(valid_data, load_best_model=False, show_progress=show_progress)
+        valid_score = calculate_valid_score(valid_result, self.valid_metric)
+        self._barrier()
+        return valid_score, valid_result
+
+    def _barrier(self):
+        if self.world > 1:
+            torch.distributed.barrier()
+
+    def _save_checkpoint(self, epoch, verbose=True):
+        if self.rank == 0:
+            state = {
+                "config": dict(self.config.final_config_dict) if hasattr(self.config, "final_config_dict") else self.config,
+                "epoch": epoch,
+                "cur_step": self.cur_step,
+                "best_valid_score": self.best_valid_score,
+                "state_dict": {k: v.detach().cpu() for k, v in self.model.module.state_dict().items()},
+                "optimizer": {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v)
+                              for k, v in self.optimizer.state_dict().items()},
+                "rng_state": torch.get_rng_state(),
+                "cuda_rng_state": torch.cuda.get_rng_state() if torch.cuda.is_available() else None,
+            }
+            state["config"].pop("device", None)
+            torch.save(state, self.saved_model_file)
+            if verbose:
+                self.logger.info(f"Saving current: {self.saved_model_file}")
+        self._barrier()
+
+    def resume_checkpoint(self, resume_file):
+        """trainer.py:164-190: restores epoch / step / best score / optimizer / RNG (NOT the model weights,
+        exactly like the reference; load them with evaluate(load_best_model=True) or load_state_dict)."""
+        checkpoint = torch.load(str(resume_file), map_location="cpu", weights_only=False)
+        self.start_epoch = checkpoint["epoch"] + 1
+        self.cur_step = checkpoint["cur_step"]
+        self.best_valid_score = checkpoint["best_valid_score"]
+        if str(checkpoint["config"]["model"]).lower() != str(self.config["model"]).lower():
+            self.logger.warning("Architecture configuration given in config file is different from that of checkpoint.")
+        self.optimizer.load_state_dict(checkpoint["optimizer"])
+        torch.set_rng_state(checkpoint["rng_state"])
+        if checkpoint.get("cuda_rng_state") is not None and torch.cuda.is_available():
+            torch.cuda.set_rng_state(checkpoint["cuda_rng_state"])
+        self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))
+
+    def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
+        if saved and self.start_epoch >= self.epochs:
+            self._save_checkpoint(-1, verbose=verbose)
+        for epoch_idx in range(self.start_epoch, self.epochs):
+            if self.config["need_training"] is None or self.config["need_training"]:
+                train_data.sampler.set_epoch(epoch_idx)
+                t0 = time()
+                train_loss = self._train_epoch(train_data, epoch_idx, show_progress=show_progress)
+                self.train_loss_dict[epoch_idx] = train_loss
+                t1 = time()
+                if verbose:
+                    des = self.config["loss_decimal_place"] or 4
+                    self.logger.info(("epoch %d training [time: %.2fs, train loss: %." + str(des) + "f]")
+                                     % (epoch_idx, t1 - t0, train_loss))
+            if self.eval_step <= 0 or not valid_data:
+                if saved:
+                    self._save_checkpoint(epoch_idx, verbose=verbose)
+                continue
+            if (epoch_idx + 1) % self.eval_step == 0:
+                v0 = time()
+                valid_score, valid_result = self._valid_epoch(valid_data, show_progress=show_progress)
+                self.best_valid_score, self.cur_step, stop_flag, update_flag = early_stopping(
+                    valid_score, self.best_valid_score, self.cur_step, max_step=self.stopping_step,
+                    bigger=self.valid_metric_bigger)
+                if verbose:
+                    self.logger.info("epoch %d evaluating [time: %.2fs, valid_score: %f]" % (epoch_idx, time() - v0, valid_score))
+                    self.logger.info("valid result: \n" + dict2str(valid_result))
+                if update_flag:
+                    if saved:
+                        self._save_checkpoint(epoch_idx, verbose=verbose)
+                    self.best_valid_result = valid_result
+                if callback_fn:
+                    callback_fn(epoch_idx, valid_score)
+                if stop_flag:
+                    if verbose:
+                        self.logger.info("Finished training, best eval result in epoch %d"
+                                         % (epoch_idx - self.cur_step * self.eval_step))
+                    break
+        return self.best_valid_score, self.best_valid_result
+
+    # ---------------------------------------------------------------------------------------------- evaluation
+    @torch.no_grad()
+    def compute_item_feature(self, config, data):
+        if self.use_modality:
+            raise NotImplementedError("PixelNet item-feature extraction is not built yet (SURVEY.md §8 f3)")
+        self.item_feature = self.model.module.compute_item_all()
+
+    @torch.no_grad()
+    def _full_sort_batch_eval(self, batched_data):
+        """Reference-literal path (trainer.py:327-337): full scores, then the two -inf masks."""
+        user, history_index, positive_u, positive_i = batched_data
+        scores = self.model.module.predict(user.to(self.device), self.item_feature)
+        scores = scores.view(-1, self.tot_item_num)
+        scores[:, 0] = -np.inf
+        if history_index is not None:
+            hu, hi = history_index
+            scores[(hu.to(self.device), hi.to(self.device))] = -np.inf
+        return scores, positive_u, positive_i
+
+    @torch.no_grad()
+    def _full_sort_batch_topk(self, batched_data):
+        """Fused path: encoder -> pxr_score_topk_f32 (scores never reach HBM)."""
+        user, history_index, positive_u, positive_i = batched_data
+        m = self.model.module
+        out, last = m.encode_last(user.to(self.device))
+        B, L, D = out.shape
+        ptr = items = None
+        if history_index is not None:
+            ptr, items = ops.history_csr(history_index[0], history_index[1], B, self.device)
+        idx, _ = ops.score_topk(last, L * D, B, self.item_feature.data, max(self.config["topk"]), ptr, items)
+        return idx, positive_i
+
+    def distributed_concat(self, tensor, num_total_examples):
+        if self.world > 1:
+            outs = [tensor.clone() for _ in range(self.world)]
+            torch.distributed.all_gather(outs, tensor)
+            tensor = torch.cat(outs, dim=0)
+        return tensor.sum() / num_total_examples
+
+    @torch.no_grad()
+    def evaluate(self, eval_data, load_best_model=True, model_file=None, show_progress=False):
+        if not eval_data:
+            return
+        if load_best_model:
+            checkpoint_file = model_file or self.saved_model_file
+            checkpoint = torch.load(checkpoint_file, map_location="cpu", weights_only=False)
+            self.model.module.load_state_dict(checkpoint["state_dict"])
+            self.logger.info("Loading model structure and parameters from {}".format(checkpoint_file))
+        self.model.eval()
+        self.tot_item_num = eval_data.dataset.dataload.item_num
+        self.compute_item_feature(self.config, eval_data.dataset.dataload)
+        for batched_data in eval_data:
+            if self.fused_topk:
+                idx, positive_i = self._full_sort_batch_topk(batched_data)
+                self.eval_collector.eval_topk_collect(idx, positive_i)
+            else:
+                scores, positive_u, positive_i = self._full_sort_batch_eval(batched_data)
+                self.eval_collector.eval_batch_collect(scores, positive_u.to(self.device), positive_i.to(self.device))
+        num_total_examples = len(eval_data.sampler.dataset)
+        struct = self.eval_collector.get_data_struct()
+        result = self.evaluator.evaluate(struct)
+        places = 5 if self.config["metric_decimal_place"] is None else self.config["metric_decimal_place"]
+        for k, v in result.items():
+            r = self.distributed_concat(torch.tensor([v], dtype=torch.float64).to(self.device), num_total_examples).cpu()
+            result[k] = round(r.item(), places)
+        return result

@@ -1,0 +1,148 @@
+"""GPU tests of the evaluation path and the trainer harness (run with -m gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sasrec_oracle as O
+from tests.golden_util import CASES, GOLDEN_DIR, load_case, oracle_cfg
+from tests.test_gpu_sasrec import _model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fused_score_topk_matches_reference_topk(case):
+    from pixelrec_amd import ops
+
+    meta, z = load_case(case)
+    m, p = _model(meta)
+    m.eval()
+    seq = torch.from_numpy(z["eval.item_seq"]).cuda()
+    out, last = m.encode_last(seq)
+    B, L, D = out.shape
+    ptr, items = ops.history_csr(torch.from_numpy(z["eval.history_u"]), torch.from_numpy(z["eval.history_i"]), B, "cuda")
+    idx, val = ops.score_topk(last, L * D, B, m.compute_item_all().data, 10, ptr, items)
+    assert np.array_equal(idx.cpu().numpy(), z["eval.topk_idx"])            # identical top-10 as the reference
+    assert np.abs(val.cpu().numpy() - z["eval.topk_val"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("B,N,D,K", [(300, 50001, 64, 10), (130, 777, 128, 5), (64, 20000, 512, 20)])
+def test_fused_score_topk_random_ragged(B, N, D, K):
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(B + N)
+    users = torch.randn(B, D, generator=g)
+    table = torch.randn(N, D, generator=g) * 0.1
+    hist_len = torch.randint(0, 40, (B,), generator=g)
+    hu = torch.repeat_interleave(torch.arange(B), hist_len)
+    hi = torch.randint(1, N, (int(hist_len.sum()),), generator=g)
+    ref = users.double() @ table.double().t()
+    ref[:, 0] = -np.inf
+    ref[(hu, hi)] = -np.inf
+    rv, ri = torch.topk(ref, K, dim=-1)
+    ptr, items = ops.history_csr(hu, hi, B, "cuda")
+    idx, val = ops.score_topk(users.cuda(), D, B, table.cuda(), K, ptr, items)
+    idx, val = idx.cpu(), val.cpu()
+    assert (val.double() - rv).abs().max() < 1e-4
+    # ids may legitimately swap only where fp32 vs fp64 scores are closer than rounding; check by value
+    assert torch.equal(idx, ri) or (torch.gather(ref, 1, idx) - rv).abs().max() < 1e-5
+    # no masked item ever appears
+    assert (idx != 0).all()
+    bad = set(zip(hu.tolist(), hi.tolist()))
+    assert not any((u, int(i)) in bad for u in range(B) for i in idx[u])
+
+
+def _harness(tmp_path, D, L, H, inner, nl, epochs=1, fused=True, p_drop=0.1):
+    from pixelrec_amd.config import Config
+    from pixelrec_amd.data import bulid_dataloader, load_data
+    from pixelrec_amd.parallel import DataParallel
+    from pixelrec_amd.trainer import Trainer
+    from pixelrec_amd.utils import get_model
+
+    my = tmp_path / "m.yaml"
+    ov = tmp_path / "o.yaml"
+    my.write_text(f"model: SASRec\nn_layers: {nl}\nn_heads: {H}\nembedding_size: {D}\ninner_size: {inner}\n"
+                  f"hidden_dropout_prob: {p_drop}\nattn_dropout_prob: {p_drop}\nhidden_act: 'gelu'\n"
+                  "layer_norm_eps: 1e-12\ninitializer_range: 0.02\n")
+    ov.write_text(f"seed: 2020\nstate: INFO\nuse_modality: False\nreproducibility: True\n"
+                  f"checkpoint_dir: '{tmp_path}/saved'\nlog_path: '{tmp_path}/log'\nshow_progress: False\n"
+                  f"MAX_ITEM_LIST_LENGTH: {L}\ndata_path: {GOLDEN_DIR}/\ndataset: TinyInter\nepochs: {epochs}\n"
+                  "train_batch_size: 8\noptim_args: {learning_rate: 0.001, weight_decay: 0.1}\n"
+                  "eval_batch_size: 16\ntopk: [5,10]\nmetrics: ['Recall', 'NDCG']\nvalid_metric: NDCG@10\n"
+                  f"metric_decimal_place: 7\neval_step: 1\nstopping_step: 30\neval_fused_topk: {fused}\n")
+    config = Config([str(my), str(ov)])
+    config["device"] = torch.device("cuda", 0)
+    dataload = load_data(config)
+    loaders = bulid_dataloader(config, dataload)
+    model = get_model(config["model"])(config, dataload)
+    return config, dataload, loaders, model, DataParallel, Trainer
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_trainer_evaluate_matches_reference_trainer(tmp_path, fused):
+    """Recall@5/10 and NDCG@5/10 of the REFERENCE Trainer.evaluate on TinyInter (tests/golden/harness_tiny.npz)."""
+    z = np.load(os.path.join(GOLDEN_DIR, "harness_tiny.npz"))
+    n_items, D, L, H, inner, nl, seed = [int(x) for x in z["meta"]]
+    config, dataload, (train, valid, test), model, DataParallel, Trainer = _harness(tmp_path, D, L, H, inner, nl, fused=fused)
+    assert dataload.item_num == n_items
+    model.load_state_dict(O.synth_params(n_items, D, L, nl, inner, seed=seed), strict=True)
+    trainer = Trainer(config, DataParallel(model.to(config["device"])))
+    for phase, loader in (("valid", valid), ("test", test)):
+        res = trainer.evaluate(loader, load_best_model=False)
+        assert list(res.keys()) == [str(x) for x in z[f"{phase}.names"]]
+        assert np.allclose(list(res.values()), z[f"{phase}.values"], atol=1e-7), (phase, dict(res))
+
+
+def test_trainer_fit_checkpoint_roundtrip(tmp_path):
+    config, dataload, (train, valid, test), model, DataParallel, Trainer = _harness(tmp_path, 32, 6, 2, 2, 2, epochs=3)
+    trainer = Trainer(config, DataParallel(model.to(config["device"])))
+    best, best_res = trainer.fit(train, valid, saved=True)
+    losses = [trainer.train_loss_dict[e] for e in sorted(trainer.train_loss_dict)]
+    assert len(losses) == 3 and losses[-1] < losses[0]            # it learns
+    assert os.path.isfile(trainer.saved_model_file)
+    ck = torch.load(trainer.saved_model_file, map_location="cpu", weights_only=False)
+    assert set(ck) >= {"config", "epoch", "cur_step", "best_valid_score", "state_dict", "optimizer", "rng_state"}
+    ref_keys = set(O.param_shapes(dataload.item_num, 32, 6, 2, 2))
+    assert set(ck["state_dict"]) == ref_keys                       # reference state_dict key names
+    res = trainer.evaluate(test, load_best_model=True)
+    assert set(res) == {"recall@5", "recall@10", "ndcg@5", "ndcg@10"}
+    # a saved state_dict loads into the CPU oracle and gives the same scores as the HIP predict
+    params = {k: v.float() for k, v in ck["state_dict"].items()}
+    seq = next(iter(test))[0][:4]
+    ocfg = {"n_layers": 2, "n_heads": 2, "layer_norm_eps": 1e-12}
+    ref = O.predict(params, seq, params["item_embedding.weight"], ocfg)
+    trainer.model.eval()
+    got = trainer.model.module.predict(seq.cuda(), trainer.model.module.compute_item_all()).cpu()
+    assert (got - ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("case", ["tiny", "ns"])
+def test_training_mode_dropout_parity(case):
+    """Dropout ON: the kernels' counter-hash masks, restated in numpy, are injected into the oracle."""
+    from oracle import dropout_rng as R
+
+    meta, z = load_case(case)
+    m, p = _model(meta, p_drop=0.1)
+    m.train()
+    items = torch.from_numpy(z["items"]).cuda()
+    mask = torch.from_numpy(z["masked_index"]).cuda()
+    seed = (m._drop_seed * 1000003 + m._step_counter) & 0xFFFFFFFFFFFFFFFF
+    loss = m((items, mask))
+    loss.backward()
+    B = items.shape[0]
+    drop = R.sasrec_masks(seed, B, meta["L"], meta["D"], meta["H"], meta["n_layers"], 0.1, 0.1)
+    cfg = oracle_cfg(meta, train_dropout=True)
+    ref_loss, g = O.loss_and_grads(p, torch.from_numpy(z["items"]), torch.from_numpy(z["masked_index"]), cfg, drop)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 3e-5 * max(1.0, abs(float(ref_loss)))
+    for k, v in m.named_parameters():
+        if k == "item_embedding.weight":
+            got = m.sparse_table_grad.to_dense(meta["n_items"]).cpu()
+        else:
+            got = v.grad.detach().cpu()
+        err = (got - g[k]).abs().max().item()
+        assert err <= 5e-6 + 3e-4 * g[k].abs().max().item(), (k, err)
+    # and dropout really dropped something
+    loss_eval_mode = O.forward_loss(p, torch.from_numpy(z["items"]), torch.from_numpy(z["masked_index"]), oracle_cfg(meta))
+    assert abs(float(loss_eval_mode) - float(ref_loss)) > 1e-4
