@@ -34,8 +34,12 @@ def gather_sparse(idx: torch.Tensor, rows: torch.Tensor, n: torch.Tensor, group=
     idx_masked = torch.where(ar < n.to(torch.int64), idx, torch.zeros_like(idx))
     idx_all = torch.empty(world * cap, dtype=idx.dtype, device=idx.device)
     rows_all = torch.empty(world * cap, rows.shape[1], dtype=rows.dtype, device=rows.device)
-    dist.all_gather_into_tensor(idx_all, idx_masked, group=group)
-    dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=group)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(idx_all, idx_masked, group=group)
+        dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=group)
+    else:  # gloo (CPU tests): same result through the list form
+        dist.all_gather(list(idx_all.chunk(world)), idx_masked, group=group)
+        dist.all_gather(list(rows_all.chunk(world)), rows.contiguous(), group=group)
     return idx_all, rows_all
 
 
