@@ -110,14 +110,19 @@ static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb,
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-static int dispatch_tile(bool big, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                          int M, int N, int K, const float* bias, float* aux, int64_t ldaux, int splits,
                          int ksplit_len, int64_t split_stride, hipStream_t st) {
-  if (big)
-    return launch_gemm<128, 128, A_KC, B_KC, EPI>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
-                                                  ksplit_len, split_stride, st);
-  return launch_gemm<64, 64, A_KC, B_KC, EPI>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
-                                              ksplit_len, split_stride, st);
+#define PXR_TILE(BM_, BN_)                                                                                       \
+  return launch_gemm<BM_, BN_, A_KC, B_KC, EPI>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits, ksplit_len, \
+                                                split_stride, st)
+  switch (tile) {
+    case 128: PXR_TILE(128, 128);
+    case 12864: PXR_TILE(128, 64);
+    case 64128: PXR_TILE(64, 128);
+    default: PXR_TILE(64, 64);
+  }
+#undef PXR_TILE
 }
 
 }  // namespace pxr
@@ -152,10 +157,11 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
 
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   bool big = (t128 >= 384);  // >= 1.5 waves of 128x128 tiles over 256 CUs; otherwise 64x64 tiles fill the chip better
-  if (tile_hint == 128) big = true;
-  if (tile_hint == 64) big = false;
-  const int bm = big ? 128 : 64;
-  const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bm - 1) / bm);
+  int tile = big ? 128 : 64;
+  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128) tile = tile_hint;
+  const int bm = (tile == 128 || tile == 12864) ? 128 : 64;
+  const int bn = (tile == 128 || tile == 64128) ? 128 : 64;
+  const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   PXR_REQUIRE(tiles < (1ll << 31), "pxr_gemm_f32: too many tiles");
 
   // split-K only for the plain epilogue (weight gradients: few output tiles, long token reduction)
@@ -188,7 +194,7 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
 
   int rc;
 #define PXR_GEMM_CASE(AK, BK_, E)                                                                            \
-  rc = dispatch_tile<AK, BK_, E>(big, A, lda, B, ldb, Cw, ldcw, M, N, K, bias, aux, ldaux, splits, ksplit_len, \
+  rc = dispatch_tile<AK, BK_, E>(tile, A, lda, B, ldb, Cw, ldcw, M, N, K, bias, aux, ldaux, splits, ksplit_len, \
                                  split_stride, st)
   if (a_kc && b_kc) {
     switch (epilogue) {
