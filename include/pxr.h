@@ -57,6 +57,15 @@ int pxr_sasrec_embed_grad_f32(const int64_t* items, int B, int L, const float* d
                               const float* coef, int D, int64_t n_table, float scale, int64_t* uniq_idx,
                               float* uniq_rows, int32_t* n_uniq_dev, void* ws, int64_t ws_bytes, void* stream);
 
+/* The two phases separately: phase 1 depends on `items` only and may run before the forward pass (the lazy table
+ * optimizer brings exactly these unique rows up to date before they are read); `ws` carries the sorted occurrences to
+ * phase 2 and must not be touched in between. */
+int pxr_sasrec_occ_sort(const int64_t* items, int B, int L, int64_t n_table, int64_t* uniq_idx, int32_t* n_uniq_dev,
+                        void* ws, int64_t ws_bytes, void* stream);
+int pxr_sasrec_occ_segsum(const void* ws, int64_t ws_bytes, int B, int L, const float* dx0, const float* out,
+                          const float* coef, int D, int64_t n_table, float scale, const int32_t* n_uniq_dev,
+                          float* uniq_rows, void* stream);
+
 /* ---- LayerNorm sites ---------------------------------------------------------------------------------------- */
 /* y = dropout(LN(table[idx[b*idx_bstride+t]] + pos[t]))       sasrec.py:68,77-82 (train) / :99-104 (predict).
  * xhat [B*L,D] / rstd [B*L] are saved for the backward and may be NULL for inference. */
@@ -136,6 +145,19 @@ int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_rows, int D,
                         const int64_t* uniq_idx, const float* uniq_rows, const int32_t* n_uniq_dev, int64_t max_uniq,
                         double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                         void* stream);
+
+/* Lazy (exact catch-up) form of the same dense-semantics table update: no O(N*D) sweep per step.  last int32[N]
+ * holds, per row, the optimizer step through which the row is up to date; hyper (float4[capacity]) / cumlog
+ * (double[capacity]) hold each step's scalars, appended once per step.  pxr_adamw_rows_f32 replays a row's missed
+ * zero-gradient steps (bit-identical to the sweep for gaps <= 256 steps, closed-form weight decay beyond) through
+ * t_prev and, if t_apply = t_prev+1, applies that step with gradient rows grows[i,:].  rows == NULL: all N rows
+ * (flush before evaluation / checkpointing). */
+int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, double lr, double beta1,
+                           double beta2, double eps, double weight_decay, void* stream);
+int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D, const int64_t* rows,
+                       const int32_t* n_rows_dev, int64_t max_rows, const float* grows, const void* hyper,
+                       const void* cumlog, int64_t t_prev, int64_t t_apply, double beta1, double beta2, double eps,
+                       void* stream);
 
 #ifdef __cplusplus
 }

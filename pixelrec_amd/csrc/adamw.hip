@@ -43,12 +43,14 @@ static AdamHyper make_hyper(double lr, double b1, double b2, double eps, double 
   return h;
 }
 
+// The operation order is PINNED with explicit fmaf / __fmul_rn so that every kernel that updates a row (dense sweep,
+// lazy replay, lazy apply) produces bit-identical results regardless of how the compiler would contract a*b+c.
 __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamHyper& h) {
-  p *= h.decay;
-  m += (g - m) * h.one_m_b1;
-  v = v * h.b2 + h.one_m_b2 * g * g;
-  const float denom = sqrtf(v) * h.inv_sqrt_bc2 + h.eps;
-  p -= h.step_size * (m / denom);
+  p = __fmul_rn(p, h.decay);
+  m = fmaf(g - m, h.one_m_b1, m);
+  v = fmaf(v, h.b2, __fmul_rn(__fmul_rn(h.one_m_b2, g), g));
+  const float denom = fmaf(sqrtf(v), h.inv_sqrt_bc2, h.eps);
+  p = fmaf(-h.step_size, m / denom, p);
 }
 
 __global__ void __launch_bounds__(256) adamw_flat_kernel(float4* __restrict__ p, const float4* __restrict__ g,
@@ -115,6 +117,110 @@ __global__ void __launch_bounds__(256) adamw_table_kernel(float* __restrict__ p,
   }
 }
 
+// ------------------------------------------------------------------------------------------------ lazy table update
+// Dense AdamW semantics WITHOUT the dense sweep.  A row whose gradient is zero at step s evolves by a closed
+// recurrence that depends only on its own (p, m, v) and the step's scalars, so it can be replayed later: every row
+// carries last[r] = the step through which it is up to date; before a row is read (forward) or updated (apply) the
+// missed zero-gradient steps last[r]+1 .. t are replayed with the SAME per-element arithmetic as the dense kernel
+// (adam_elem with g = 0  =>  bit-identical to the sweep for gaps <= PXR_LAZY_EXACT).  Beyond PXR_LAZY_EXACT replayed
+// steps the Adam term is provably below fp32 resolution (|m|/sqrt(v) <= 31.6 * (beta1/sqrt(beta2))^j, so the skipped
+// updates sum to < 1e-13 for j > 256 at lr 1e-4) and only the weight decay acts: p *= prod(decay_s) in closed form
+// from a double-precision cumulative-log table, m *= beta1^j, v *= beta2^j.
+// hyper[s] = {decay_s, step_size_s, inv_sqrt_bc2_s, 0} and cumlog[s] = sum_{i<=s} log(decay_i) are appended by
+// pxr_adamw_hyper_append at every optimizer step (index 0 = identity), so a changing lr is replayed correctly.
+constexpr int PXR_LAZY_EXACT = 256;
+
+struct RowsArgs {
+  float* p; float* m; float* v; int* last;
+  const int64_t* rows; const int* n_rows; int64_t n_fixed;   // rows == null: all rows [0, n_fixed)
+  const float* grows;                                        // [n_rows, D] gradient rows (apply) or null
+  const float4* hyper; const double* cumlog;
+  int t_prev, t_apply, D;
+  float one_m_b1, b2, one_m_b2, eps, b1;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(256) adamw_rows_kernel(RowsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int64_t n = a.rows ? (int64_t)(*a.n_rows) : a.n_fixed;
+  for (int64_t i = wave_id; i < n; i += n_waves) {
+    const int64_t row = a.rows ? a.rows[i] : i;
+    const int k0 = a.last[row];
+    if (k0 >= a.t_prev && a.t_apply == 0) continue;
+    float4 pp[VEC], mm[VEC], vv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < a.D) {
+        const int64_t o = row * a.D + c;
+        pp[k] = *reinterpret_cast<const float4*>(a.p + o);
+        mm[k] = *reinterpret_cast<const float4*>(a.m + o);
+        vv[k] = *reinterpret_cast<const float4*>(a.v + o);
+      }
+    }
+    AdamHyper h;
+    h.one_m_b1 = a.one_m_b1; h.b2 = a.b2; h.one_m_b2 = a.one_m_b2; h.eps = a.eps;
+    int s = k0 + 1;
+    const int exact_end = min(a.t_prev, k0 + PXR_LAZY_EXACT);
+    for (; s <= exact_end; ++s) {
+      const float4 hs = a.hyper[s];
+      h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        adam_elem(pp[k].x, mm[k].x, vv[k].x, 0.f, h); adam_elem(pp[k].y, mm[k].y, vv[k].y, 0.f, h);
+        adam_elem(pp[k].z, mm[k].z, vv[k].z, 0.f, h); adam_elem(pp[k].w, mm[k].w, vv[k].w, 0.f, h);
+      }
+    }
+    if (s <= a.t_prev) {  // closed-form tail: only the weight decay still moves p
+      const int rem = a.t_prev - s + 1;
+      const float fp = (float)exp(a.cumlog[a.t_prev] - a.cumlog[s - 1]);
+      const float fm = (float)pow((double)a.b1, (double)rem);
+      const float fv = (float)pow((double)a.b2, (double)rem);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        pp[k].x *= fp; pp[k].y *= fp; pp[k].z *= fp; pp[k].w *= fp;
+        mm[k].x *= fm; mm[k].y *= fm; mm[k].z *= fm; mm[k].w *= fm;
+        vv[k].x *= fv; vv[k].y *= fv; vv[k].z *= fv; vv[k].w *= fv;
+      }
+    }
+    if (a.t_apply) {
+      const float4 hs = a.hyper[a.t_apply];
+      h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < a.D) {
+          const float4 g = a.grows ? *reinterpret_cast<const float4*>(a.grows + i * a.D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          adam_elem(pp[k].x, mm[k].x, vv[k].x, g.x, h); adam_elem(pp[k].y, mm[k].y, vv[k].y, g.y, h);
+          adam_elem(pp[k].z, mm[k].z, vv[k].z, g.z, h); adam_elem(pp[k].w, mm[k].w, vv[k].w, g.w, h);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < a.D) {
+        const int64_t o = row * a.D + c;
+        *reinterpret_cast<float4*>(a.p + o) = pp[k];
+        *reinterpret_cast<float4*>(a.m + o) = mm[k];
+        *reinterpret_cast<float4*>(a.v + o) = vv[k];
+      }
+    }
+    if (lane == 0) a.last[row] = a.t_apply ? a.t_apply : a.t_prev;
+  }
+}
+
+__global__ void hyper_append_kernel(float4* hyper, double* cumlog, int step, float decay, float step_size,
+                                    float inv_sqrt_bc2, double log_decay) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (step == 1) { hyper[0] = make_float4(1.f, 0.f, 1.f, 0.f); cumlog[0] = 0.0; }
+    hyper[step] = make_float4(decay, step_size, inv_sqrt_bc2, 0.f);
+    cumlog[step] = cumlog[step - 1] + log_decay;
+  }
+}
+
 __global__ void __launch_bounds__(256) fill_i32_kernel(int* __restrict__ x, int64_t n, int val) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = val;
 }
@@ -174,4 +280,46 @@ extern "C" int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_r
   else PXR_TABLE_CASE(16);
 #undef PXR_TABLE_CASE
   return pxr_check_launch("pxr_adamw_table_f32");
+}
+
+// ---- lazy (exact catch-up) table AdamW ----------------------------------------------------------------------
+// hyper: float4[capacity], cumlog: double[capacity]; appends the scalars of optimizer step `step` (1-based).
+extern "C" int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, double lr,
+                                      double beta1, double beta2, double eps, double weight_decay, void* stream) {
+  PXR_REQUIRE(hyper && cumlog && step >= 1 && step < capacity, "pxr_adamw_hyper_append: bad args (step %lld, capacity %lld)",
+              (long long)step, (long long)capacity);
+  const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, step);
+  hipLaunchKernelGGL(hyper_append_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (float4*)hyper, (double*)cumlog,
+                     (int)step, h.decay, h.step_size, h.inv_sqrt_bc2, log((double)h.decay));
+  return pxr_check_launch("pxr_adamw_hyper_append");
+}
+
+// Brings rows up to date through step t_prev (replaying their missed zero-gradient steps) and, if t_apply != 0,
+// applies step t_apply with gradient rows grows[i,:] (row i of the list).  rows == NULL: every row of the table
+// (flush; n_rows_dev ignored).  last: int32[N] "up to date through" step per row.
+extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D,
+                                  const int64_t* rows, const int32_t* n_rows_dev, int64_t max_rows, const float* grows,
+                                  const void* hyper, const void* cumlog, int64_t t_prev, int64_t t_apply, double beta1,
+                                  double beta2, double eps, void* stream) {
+  PXR_REQUIRE(table && m && v && last && hyper && cumlog, "pxr_adamw_rows_f32: null pointer");
+  PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 2048, "pxr_adamw_rows_f32: bad shape (D <= 2048)");
+  PXR_REQUIRE(!rows || n_rows_dev, "pxr_adamw_rows_f32: row list needs its device count");
+  PXR_REQUIRE(t_prev >= 0 && (t_apply == 0 || t_apply == t_prev + 1), "pxr_adamw_rows_f32: t_apply must be t_prev+1 or 0");
+  RowsArgs a{};
+  a.p = table; a.m = m; a.v = v; a.last = last; a.rows = rows; a.n_rows = n_rows_dev; a.n_fixed = n_table;
+  a.grows = grows; a.hyper = (const float4*)hyper; a.cumlog = (const double*)cumlog;
+  a.t_prev = (int)t_prev; a.t_apply = (int)t_apply; a.D = D;
+  a.one_m_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_m_b2 = (float)(1.0 - beta2); a.eps = (float)eps;
+  a.b1 = (float)beta1;
+  const int64_t work = rows ? max_rows : n_table;
+  if (work <= 0) return PXR_OK;
+  int64_t blocks = (work + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = (D + 255) / 256;
+  if (vec <= 1) hipLaunchKernelGGL((adamw_rows_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (vec <= 2) hipLaunchKernelGGL((adamw_rows_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (vec <= 4) hipLaunchKernelGGL((adamw_rows_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((adamw_rows_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  return pxr_check_launch("pxr_adamw_rows_f32");
 }

@@ -360,29 +360,58 @@ extern "C" int pxr_embed_grad_rows_f32(const int64_t* idx, int64_t n, const floa
   return pxr_check_launch("pxr_embed_grad_rows_f32");
 }
 
-// SASRec-specific form (see header comment): items int64 [B,2,L+1]; dx0, out [B*L, D]; coef [B*L].
-extern "C" int pxr_sasrec_embed_grad_f32(const int64_t* items, int B, int L, const float* dx0, const float* out,
-                                         const float* coef, int D, int64_t n_table, float scale, int64_t* uniq_idx,
-                                         float* uniq_rows, int32_t* n_uniq_dev, void* ws, int64_t ws_bytes,
-                                         void* stream) {
-  PXR_REQUIRE(items && dx0 && out && coef && uniq_idx && uniq_rows && n_uniq_dev && ws,
-              "pxr_sasrec_embed_grad_f32: null pointer");
+static const int* final_sorted_vals(const SortWs& w, int64_t n_table) {
+  int bits = 1;
+  while (((int64_t)1 << bits) < n_table) ++bits;
+  const int npass = (bits + 7) / 8;
+  return (npass & 1) ? w.valsB : w.valsA;   // the ping-pong buffers swap once per pass
+}
+
+// Phase 1 of the SASRec table gradient: occurrence keys -> stable sort -> unique ids + segments.  Depends on
+// `items` only, so it can run BEFORE the forward pass (the lazy table optimizer needs the unique rows of the batch
+// to bring them up to date before they are read).  The sorted state stays in `ws` for phase 2: the caller must keep
+// `ws` untouched in between.
+extern "C" int pxr_sasrec_occ_sort(const int64_t* items, int B, int L, int64_t n_table, int64_t* uniq_idx,
+                                   int32_t* n_uniq_dev, void* ws, int64_t ws_bytes, void* stream) {
+  PXR_REQUIRE(items && uniq_idx && n_uniq_dev && ws, "pxr_sasrec_occ_sort: null pointer");
   const int64_t n64 = (int64_t)3 * B * L;
-  PXR_REQUIRE(B > 0 && L > 0 && n64 < (1ll << 30) && D > 0 && D % 4 == 0 && n_table > 0 && n_table < (1ll << 31),
-              "pxr_sasrec_embed_grad_f32: bad shape");
+  PXR_REQUIRE(B > 0 && L > 0 && n64 < (1ll << 30) && n_table > 0 && n_table < (1ll << 31), "pxr_sasrec_occ_sort: bad shape");
   const int n = (int)n64;
   SortWs w;
-  if (carve(ws, n, &w) > ws_bytes) { pxr_set_error("pxr_sasrec_embed_grad_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
+  if (carve(ws, n, &w) > ws_bytes) { pxr_set_error("pxr_sasrec_occ_sort: workspace too small"); return PXR_ERR_WORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(occ_keys_sasrec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, items, B, L, w.keysA, w.valsA,
                      n_table);
   const int* sorted_vals = nullptr;
   int rc = sort_and_segment(w, n, n_table, uniq_idx, n_uniq_dev, st, &sorted_vals);
   if (rc) return rc;
+  if (sorted_vals != final_sorted_vals(w, n_table)) { pxr_set_error("pxr_sasrec_occ_sort: internal buffer parity"); return PXR_ERR_LAUNCH; }
+  return PXR_OK;
+}
+
+// Phase 2: uniq_rows[u,:] = scale * sum over the occurrences of unique id u (see the header comment for the terms).
+extern "C" int pxr_sasrec_occ_segsum(const void* ws, int64_t ws_bytes, int B, int L, const float* dx0, const float* out,
+                                     const float* coef, int D, int64_t n_table, float scale,
+                                     const int32_t* n_uniq_dev, float* uniq_rows, void* stream) {
+  PXR_REQUIRE(ws && dx0 && out && coef && n_uniq_dev && uniq_rows, "pxr_sasrec_occ_segsum: null pointer");
+  PXR_REQUIRE(B > 0 && L > 0 && D > 0 && D % 4 == 0, "pxr_sasrec_occ_segsum: bad shape");
+  const int n = 3 * B * L;
+  SortWs w;
+  if (carve(const_cast<void*>(ws), n, &w) > ws_bytes) { pxr_set_error("pxr_sasrec_occ_segsum: workspace too small"); return PXR_ERR_WORKSPACE; }
   SegSumArgs a{};
-  a.vals = sorted_vals; a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = dx0; a.src1 = out; a.coef = coef;
-  a.uniq_rows = uniq_rows; a.scale = scale; a.D = D; a.T = B * L;
+  a.vals = final_sorted_vals(w, n_table); a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = dx0; a.src1 = out;
+  a.coef = coef; a.uniq_rows = uniq_rows; a.scale = scale; a.D = D; a.T = B * L;
   const int grid = n < 4096 ? n : 4096;
-  hipLaunchKernelGGL(segsum_kernel<MODE_SASREC>, dim3(grid), dim3(256), 256 * 16, st, a);
-  return pxr_check_launch("pxr_sasrec_embed_grad_f32");
+  hipLaunchKernelGGL(segsum_kernel<MODE_SASREC>, dim3(grid), dim3(256), 256 * 16, (hipStream_t)stream, a);
+  return pxr_check_launch("pxr_sasrec_occ_segsum");
+}
+
+// Both phases back to back (gradient-only use).
+extern "C" int pxr_sasrec_embed_grad_f32(const int64_t* items, int B, int L, const float* dx0, const float* out,
+                                         const float* coef, int D, int64_t n_table, float scale, int64_t* uniq_idx,
+                                         float* uniq_rows, int32_t* n_uniq_dev, void* ws, int64_t ws_bytes,
+                                         void* stream) {
+  int rc = pxr_sasrec_occ_sort(items, B, L, n_table, uniq_idx, n_uniq_dev, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return pxr_sasrec_occ_segsum(ws, ws_bytes, B, L, dx0, out, coef, D, n_table, scale, n_uniq_dev, uniq_rows, stream);
 }

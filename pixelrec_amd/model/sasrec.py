@@ -117,6 +117,8 @@ class SASRec(BaseModel):
         self.sparse_table_grad = None   # the table gradient the optimizer will apply (local, or merged across ranks)
         self._local_sparse = None       # reusable output buffer of this rank's backward
         self.grad_scale = 1.0           # 1/world_size under data parallelism (sum-all-reduce == DDP's mean)
+        self._table_hooks = None        # the lazy optimizer (catch_up_rows / flush) when one is attached
+        self._occ_ws = None             # persistent workspace carrying the sorted occurrences fwd -> bwd
         self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
         self._step_counter = 0
 
@@ -180,6 +182,20 @@ class SASRec(BaseModel):
             return buf[off:off + n].view(shape)
         return buf[off:off + span * n].view((span * shape[0],) + tuple(shape[1:]))
 
+    def register_table_hooks(self, opt):
+        """Attach a lazy table optimizer: it is asked to bring rows up to date before they are read."""
+        self._table_hooks = opt
+
+    def sync_table(self):
+        """Make every table row current (no-op without a lazy optimizer).  Called before the table is read as a
+        whole: predict / compute_item_all / state_dict."""
+        if self._table_hooks is not None:
+            self._table_hooks.flush()
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_table()
+        return super().state_dict(*args, **kwargs)
+
     def flat_parameters(self):
         self._ensure_packed()
         return self._flat, self._gflat
@@ -218,6 +234,21 @@ class SASRec(BaseModel):
     def _forward_train(self, items, masked_index):
         B = items.shape[0]
         L = self.max_seq_length
+        D = self.hidden_size
+        if self.training:
+            # phase 1 of the table gradient runs first: the unique ids of the batch are what a lazy optimizer must
+            # bring up to date before the forward pass reads those rows
+            sp = self._local_sparse
+            if sp is None or sp.cap != 3 * B * L or sp.rows.shape[1] != D or sp.rows.device != items.device:
+                sp = self._local_sparse = ops.SparseRows(3 * B * L, D, items.device)
+            need = ops.occ_ws_bytes(B, L)
+            if self._occ_ws is None or self._occ_ws.numel() < need or self._occ_ws.device != items.device:
+                self._occ_ws = torch.empty(need, dtype=torch.uint8, device=items.device)
+            ops.sasrec_occ_sort(items, self.item_num, sp, self._occ_ws)
+            if self._table_hooks is not None:
+                self._table_hooks.catch_up_rows(sp.idx, sp.n, sp.cap)
+        elif self._table_hooks is not None:
+            self.sync_table()
         out, saved = self._encode(items, 2 * (L + 1), B, masked_index, L, train=self.training)
         table = self.item_embedding.weight.data
         loss, pos, neg = ops.bpr_loss_fwd(out, table, items, masked_index)
@@ -287,9 +318,8 @@ class SASRec(BaseModel):
         dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0)
         ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1))
         sp = self._local_sparse
-        if sp is None or sp.cap != 3 * T or sp.rows.shape[1] != D or sp.rows.device != dx0.device:
-            sp = self._local_sparse = ops.SparseRows(3 * T, D, dx0.device)
-        self.sparse_table_grad = ops.sasrec_embed_grad(s["items"], dx0, s["out"], coef, self.item_num, 1.0, sp)
+        ops.sasrec_occ_segsum(self._occ_ws, dx0, s["out"], coef, self.item_num, sp, 1.0)
+        self.sparse_table_grad = sp
         self._saved = None
         self._step_counter += 1
 
@@ -298,6 +328,7 @@ class SASRec(BaseModel):
     def encode_last(self, item_seq):
         """item_seq int64 [B, L] -> (states [B, L, D], view of the last position [B, D] with row stride L*D)."""
         self._ensure_packed()
+        self.sync_table()
         item_seq = item_seq.contiguous()
         B, L = item_seq.shape
         if L != self.max_seq_length:
@@ -318,4 +349,5 @@ class SASRec(BaseModel):
 
     @torch.no_grad()
     def compute_item_all(self):
+        self.sync_table()
         return self.item_embedding.weight

@@ -286,6 +286,28 @@ def sasrec_embed_grad(items, dx0, out, coef, n_table, scale=1.0, sp: SparseRows 
     return sp
 
 
+def occ_ws_bytes(B: int, L: int) -> int:
+    return int(_l.load().pxr_embed_grad_ws_bytes(3 * B * L))
+
+
+def sasrec_occ_sort(items, n_table, sp: SparseRows, ws: torch.Tensor):
+    """Phase 1 (ids only): fills sp.idx / sp.n, leaves the sorted occurrences in `ws` (caller-owned, persistent)."""
+    Lb = _l.load()
+    _req(items, torch.int64, "items")
+    B, _, W = items.shape
+    _l.check(Lb.pxr_sasrec_occ_sort(_l.ptr(items), B, W - 1, n_table, _l.ptr(sp.idx), _l.ptr(sp.n), _l.ptr(ws),
+                                    ws.numel(), _l.stream_ptr()), "pxr_sasrec_occ_sort")
+
+
+def sasrec_occ_segsum(ws: torch.Tensor, dx0, out, coef, n_table, sp: SparseRows, scale=1.0):
+    """Phase 2: sp.rows from the sorted occurrences in `ws`."""
+    Lb = _l.load()
+    B, L, D = out.shape
+    _l.check(Lb.pxr_sasrec_occ_segsum(_l.ptr(ws), ws.numel(), B, L, _l.ptr(dx0), _l.ptr(out), _l.ptr(coef), D,
+                                      n_table, float(scale), _l.ptr(sp.n), _l.ptr(sp.rows), _l.stream_ptr()),
+             "pxr_sasrec_occ_segsum")
+
+
 # ------------------------------------------------------------------------------------------------ full-sort eval
 def history_csr(history_u: torch.Tensor, history_i: torch.Tensor, B: int, device):
     """(history_u, history_i) of seq_eval_collate (grouped by user, collate_fn.py:27-28) -> (hist_ptr int32 [B+1],
@@ -339,3 +361,19 @@ def adamw_table(table, m, v, slot, sp: SparseRows | None, lr, beta1, beta2, eps,
                                     _l.ptr(sp.idx) if sp else None, _l.ptr(sp.rows) if sp else None,
                                     _l.ptr(sp.n) if sp else None, sp.cap if sp else 0, lr, beta1, beta2, eps,
                                     weight_decay, step, _l.stream_ptr()), "pxr_adamw_table_f32")
+
+
+def adamw_hyper_append(hyper, cumlog, step, lr, beta1, beta2, eps, weight_decay):
+    Lb = _l.load()
+    _l.check(Lb.pxr_adamw_hyper_append(_l.ptr(hyper), _l.ptr(cumlog), cumlog.numel(), step, lr, beta1, beta2, eps,
+                                       weight_decay, _l.stream_ptr()), "pxr_adamw_hyper_append")
+
+
+def adamw_rows(table, m, v, last, hyper, cumlog, t_prev, t_apply, beta1, beta2, eps, rows=None, n_rows=None,
+               max_rows=0, grows=None):
+    """Lazy table AdamW: catch rows up through t_prev (+ apply step t_apply with gradient rows).  rows=None: all."""
+    Lb = _l.load()
+    N, D = table.shape
+    _l.check(Lb.pxr_adamw_rows_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), _l.ptr(last), N, D, _l.ptr(rows),
+                                   _l.ptr(n_rows), max_rows, _l.ptr(grows), _l.ptr(hyper), _l.ptr(cumlog), t_prev,
+                                   t_apply, beta1, beta2, eps, _l.stream_ptr()), "pxr_adamw_rows_f32")

@@ -1,0 +1,105 @@
+"""The lazy (exact catch-up) table optimizer == the dense sweep: same dense-AdamW semantics, no O(N*D) pass."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_items, D=64, L=10, B=4, seed=3):
+    from oracle import sasrec_oracle as O
+    from pixelrec_amd import synth
+    from pixelrec_amd.model import SASRec
+
+    cfg = {"n_layers": 1, "n_heads": 2, "embedding_size": D, "inner_size": 2, "hidden_dropout_prob": 0.0,
+           "attn_dropout_prob": 0.0, "hidden_act": "gelu", "layer_norm_eps": 1e-12, "initializer_range": 0.02,
+           "MAX_ITEM_LIST_LENGTH": L, "seed": 2020}
+
+    class DL:
+        item_num = n_items
+
+    params = O.synth_params(n_items, D, L, 1, 2, seed=seed)
+
+    def make():
+        m = SASRec(cfg, DL())
+        m.load_state_dict(params, strict=True)
+        return m.cuda().train()
+
+    rng = np.random.default_rng(seed)
+    zipf = synth.ZipfItems(n_items, seed=seed)
+    return make, rng, zipf, synth
+
+
+def _run(make, batches, mode, flush_every=0):
+    from pixelrec_amd.optim import PxrAdamW
+
+    m = make()
+    opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1, table_update=mode)
+    for i, (it, mk) in enumerate(batches):
+        loss = m((it, mk))
+        loss.backward()
+        opt.step()
+        if flush_every and (i + 1) % flush_every == 0:
+            opt.flush()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}          # state_dict() flushes
+    return sd, opt
+
+
+def test_lazy_equals_dense_bitwise_short_gaps():
+    make, rng, zipf, synth = _setup(n_items=1500)
+    batches = [tuple(torch.from_numpy(x).cuda() for x in synth.train_batch(1500, 4, 10, rng, zipf)) for _ in range(60)]
+    dense, _ = _run(make, batches, "dense")
+    lazy, opt = _run(make, batches, "lazy")
+    for k in dense:
+        assert torch.equal(dense[k], lazy[k]), k                              # incl. rows never touched in 60 steps
+    assert torch.equal(opt._tm, _run(make, batches, "dense")[1]._tm)
+    assert int((opt._last != opt.step_count).sum()) == 0                     # flushed
+    lazy2, _ = _run(make, batches, "lazy", flush_every=7)                    # intermediate flushes change nothing
+    for k in dense:
+        assert torch.equal(dense[k], lazy2[k]), k
+
+
+def test_lazy_long_gaps_closed_form_tail():
+    """Optimizer kernels alone (no model feedback, which would chaotically amplify rounding through Adam's
+    sign-like update on noise-level gradients): identical sparse gradient sequences into the dense sweep and the
+    lazy replay, with gaps far beyond the 256 exactly-replayed steps.  There only weight decay acts and the closed
+    form p *= exp(sum log decay) replaces the sequential product: deviation is accumulated-rounding level."""
+    from pixelrec_amd import ops
+
+    N, D, T, lr, wd, b1, b2, eps = 4000, 64, 900, 1e-3, 0.1, 0.9, 0.999, 1e-8
+    g = torch.Generator().manual_seed(0)
+    p0 = (torch.randn(N, D, generator=g) * 0.02).cuda()
+    pd, md, vd = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pl, ml, vl = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    slot = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    last = torch.zeros(N, dtype=torch.int32, device="cuda")
+    hyper = torch.zeros(T + 8, 4, device="cuda")
+    cumlog = torch.zeros(T + 8, dtype=torch.float64, device="cuda")
+    cap = 16
+    max_gap = 0
+    seen = {}
+    for t in range(1, T + 1):
+        n = int(torch.randint(1, cap + 1, (1,), generator=g))
+        # rows 0..39 are hot (touched often), the rest are hit rarely => gaps of hundreds of steps
+        hot = torch.randint(1, 40, (n // 2 + 1,), generator=g)
+        cold = torch.randint(40, N, (n,), generator=g)
+        idx = torch.unique(torch.cat([hot, cold]))[:cap]
+        for r in idx.tolist():
+            max_gap = max(max_gap, t - seen.get(r, 0))
+            seen[r] = t
+        sp = ops.SparseRows(cap, D, "cuda")
+        sp.idx[:len(idx)] = idx.cuda()
+        sp.rows[:len(idx)] = (torch.randn(len(idx), D, generator=g) * 1e-3).cuda()
+        sp.n[0] = len(idx)
+        ops.adamw_table(pd, md, vd, slot, sp, lr, b1, b2, eps, wd, t)
+        ops.adamw_hyper_append(hyper, cumlog, t, lr, b1, b2, eps, wd)
+        ops.adamw_rows(pl, ml, vl, last, hyper, cumlog, t - 1, t, b1, b2, eps, rows=sp.idx, n_rows=sp.n, max_rows=cap,
+                       grows=sp.rows)
+    assert max_gap > 600
+    ops.adamw_rows(pl, ml, vl, last, hyper, cumlog, T, 0, b1, b2, eps)              # flush
+    assert int((last != T).sum()) == 0 and int((slot != -1).sum()) == 0
+    assert (pd - pl).abs().max().item() < 2e-7                                      # parity budget is 1e-5
+    assert (md - ml).abs().max().item() < 1e-9 and (vd - vl).abs().max().item() < 1e-10
+    # rows whose gaps never exceeded the exact window are bit-identical
+    hot_rows = torch.arange(1, 40).cuda()
+    assert torch.equal(pd[hot_rows], pl[hot_rows])
