@@ -15,6 +15,9 @@
  *   - `*_ws_bytes` functions return the scratch size the matching call needs.
  *   - dropout: Bernoulli(1-p) keep-mask = counter hash of (seed, stream_id, element index); the backward call
  *     must pass the same (p, seed, stream_id).  p = 0 disables it (eval).
+ *   - `step_dev` (const int64_t*, may be NULL): a device-resident step counter.  Dropout entry points add it to
+ *     `seed`; optimizer entry points take the step number from it.  With it a whole training step can be captured
+ *     in a hipGraph and replayed: pxr_counter_add_i64 advances the counter on the device, no host value is baked in.
  */
 #ifndef PXR_H_
 #define PXR_H_
@@ -72,17 +75,17 @@ int pxr_sasrec_occ_segsum(const void* ws, int64_t ws_bytes, int B, int L, const 
 int pxr_input_ln_fwd_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
                          const float* pos, const float* gamma, const float* beta, float eps, int B, int L, int D,
                          float* y, float* xhat, float* rstd, float p_drop, uint64_t seed, uint32_t stream_id,
-                         void* stream);
+                         const int64_t* step_dev, void* stream);
 /* y = LN(dropout(x) + res)                                      layers.py:614-615 and :670-671 */
 int pxr_ln_residual_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps,
                             int rows, int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
-                            uint32_t stream_id, void* stream);
+                            uint32_t stream_id, const int64_t* step_dev, void* stream);
 /* autograd of either site.  gather_mode=1: dy is w.r.t. the dropped output, dz = grad of (table row + pos).
  * gather_mode=0: dz = grad w.r.t. res, dx (optional) = grad w.r.t. x.  dgamma/dbeta are overwritten. */
 int64_t pxr_ln_bwd_ws_bytes(int rows, int D);
 int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd, const float* gamma,
                    int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed,
-                   uint32_t stream_id, void* ws, int64_t ws_bytes, void* stream);
+                   uint32_t stream_id, const int64_t* step_dev, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32) --------------------------------------------------------------- */
 /* General: C[M,N] = A_op x B_op; a_kc/b_kc select k-contiguous ([M][K] / [N][K]) or x-contiguous ([K][M] / [K][N])
@@ -110,10 +113,10 @@ int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, void* 
  * ctx is written head-merged [B*L, ld_ctx]; probs [B,H,L,L] (pre-dropout) is saved for backward, may be NULL. */
 int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
                      int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx, float* probs,
-                     float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+                     float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* stream);
 int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
                      const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d,
-                     float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+                     float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* stream);
 
 /* ---- training head ------------------------------------------------------------------------------------------ */
 /* loss = mean_b(-sum_t log(sigmoid(pos-neg)+1e-8) * mask)            sasrec.py:88-92; loss stays on the device */
@@ -152,12 +155,17 @@ int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_rows, int D,
  * zero-gradient steps (bit-identical to the sweep for gaps <= 256 steps, closed-form weight decay beyond) through
  * t_prev and, if t_apply = t_prev+1, applies that step with gradient rows grows[i,:].  rows == NULL: all N rows
  * (flush before evaluation / checkpointing). */
-int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, double lr, double beta1,
-                           double beta2, double eps, double weight_decay, void* stream);
+int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, const int64_t* step_dev,
+                           double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
 int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D, const int64_t* rows,
                        const int32_t* n_rows_dev, int64_t max_rows, const float* grows, const void* hyper,
-                       const void* cumlog, int64_t t_prev, int64_t t_apply, double beta1, double beta2, double eps,
-                       void* stream);
+                       const void* cumlog, int64_t t_prev, int64_t t_apply, const int64_t* step_dev, double beta1,
+                       double beta2, double eps, void* stream);
+/* pxr_adamw_flat_f32 with the step's scalars read from hyper[step] (or hyper[*step_dev + 1]). */
+int pxr_adamw_flat_tab_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper, int64_t step,
+                           const int64_t* step_dev, double beta1, double beta2, double eps, void* stream);
+/* *counter += delta on the device. */
+int pxr_counter_add_i64(int64_t* counter, int64_t delta, void* stream);
 
 #ifdef __cplusplus
 }

@@ -137,10 +137,15 @@ struct RowsArgs {
   const float4* hyper; const double* cumlog;
   int t_prev, t_apply, D;
   float one_m_b1, b2, one_m_b2, eps, b1;
+  const int64_t* step_dev;   // optional: t_prev = *step_dev (completed steps), t_apply = t_prev+1 if t_apply != 0
 };
 
 template <int VEC>
 __global__ void __launch_bounds__(256) adamw_rows_kernel(RowsArgs a) {
+  if (a.step_dev) {
+    a.t_prev = (int)a.step_dev[0];
+    if (a.t_apply) a.t_apply = a.t_prev + 1;
+  }
   const int lane = threadIdx.x & 63;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -212,13 +217,43 @@ __global__ void __launch_bounds__(256) adamw_rows_kernel(RowsArgs a) {
   }
 }
 
-__global__ void hyper_append_kernel(float4* hyper, double* cumlog, int step, float decay, float step_size,
-                                    float inv_sqrt_bc2, double log_decay) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    if (step == 1) { hyper[0] = make_float4(1.f, 0.f, 1.f, 0.f); cumlog[0] = 0.0; }
-    hyper[step] = make_float4(decay, step_size, inv_sqrt_bc2, 0.f);
-    cumlog[step] = cumlog[step - 1] + log_decay;
+// One thread computes the scalars of optimizer step `step` in double precision (same formulas as make_hyper) and
+// appends them.  step_dev != null: step = *step_dev + 1 (device counter => valid under hipGraph replay).
+__global__ void hyper_append_kernel(float4* hyper, double* cumlog, int64_t capacity, int64_t step,
+                                    const int64_t* step_dev, double lr, double b1, double b2, double wd) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (step_dev) step = step_dev[0] + 1;
+  if (step < 1 || step >= capacity) return;
+  if (step == 1) { hyper[0] = make_float4(1.f, 0.f, 1.f, 0.f); cumlog[0] = 0.0; }
+  const float decay = (float)(1.0 - lr * wd);
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2 = 1.0 - pow(b2, (double)step);
+  hyper[step] = make_float4(decay, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), 0.f);
+  cumlog[step] = cumlog[step - 1] + log((double)decay);
+}
+
+// flat AdamW reading the step's scalars from the hyper table (graph-replayable form of adamw_flat_kernel)
+__global__ void __launch_bounds__(256) adamw_flat_tab_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                             float4* __restrict__ m, float4* __restrict__ v,
+                                                             int64_t n4, const float4* __restrict__ hyper, int64_t step,
+                                                             const int64_t* step_dev, float one_m_b1, float b2,
+                                                             float one_m_b2, float eps) {
+  if (step_dev) step = step_dev[0] + 1;
+  const float4 hs = hyper[step];
+  AdamHyper h;
+  h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
+  h.one_m_b1 = one_m_b1; h.b2 = b2; h.one_m_b2 = one_m_b2; h.eps = eps;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 pp = p[i], mm = m[i], vv = v[i];
+    const float4 gg = g[i];
+    adam_elem(pp.x, mm.x, vv.x, gg.x, h); adam_elem(pp.y, mm.y, vv.y, gg.y, h);
+    adam_elem(pp.z, mm.z, vv.z, gg.z, h); adam_elem(pp.w, mm.w, vv.w, gg.w, h);
+    p[i] = pp; m[i] = mm; v[i] = vv;
   }
+}
+
+__global__ void counter_add_kernel(int64_t* c, int64_t delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += delta;
 }
 
 __global__ void __launch_bounds__(256) fill_i32_kernel(int* __restrict__ x, int64_t n, int val) {
@@ -283,24 +318,50 @@ extern "C" int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_r
 }
 
 // ---- lazy (exact catch-up) table AdamW ----------------------------------------------------------------------
-// hyper: float4[capacity], cumlog: double[capacity]; appends the scalars of optimizer step `step` (1-based).
-extern "C" int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, double lr,
-                                      double beta1, double beta2, double eps, double weight_decay, void* stream) {
-  PXR_REQUIRE(hyper && cumlog && step >= 1 && step < capacity, "pxr_adamw_hyper_append: bad args (step %lld, capacity %lld)",
-              (long long)step, (long long)capacity);
-  const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, step);
-  hipLaunchKernelGGL(hyper_append_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (float4*)hyper, (double*)cumlog,
-                     (int)step, h.decay, h.step_size, h.inv_sqrt_bc2, log((double)h.decay));
+// hyper: float4[capacity], cumlog: double[capacity]; appends the scalars of optimizer step `step` (1-based), or of
+// step *step_dev + 1 when a device counter is given (hipGraph-replayable).
+extern "C" int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, const int64_t* step_dev,
+                                      double lr, double beta1, double beta2, double eps, double weight_decay,
+                                      void* stream) {
+  (void)eps;
+  PXR_REQUIRE(hyper && cumlog && (step_dev || (step >= 1 && step < capacity)),
+              "pxr_adamw_hyper_append: bad args (step %lld, capacity %lld)", (long long)step, (long long)capacity);
+  hipLaunchKernelGGL(hyper_append_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (float4*)hyper, (double*)cumlog,
+                     capacity, step, step_dev, lr, beta1, beta2, weight_decay);
   return pxr_check_launch("pxr_adamw_hyper_append");
+}
+
+// Flat AdamW with the step's scalars taken from the hyper table entry `step` (or *step_dev + 1).
+extern "C" int pxr_adamw_flat_tab_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper,
+                                      int64_t step, const int64_t* step_dev, double beta1, double beta2, double eps,
+                                      void* stream) {
+  PXR_REQUIRE(p && g && m && v && hyper, "pxr_adamw_flat_tab_f32: null pointer");
+  PXR_REQUIRE(n >= 0 && n % 4 == 0 && (step_dev || step >= 1), "pxr_adamw_flat_tab_f32: bad n / step");
+  if (n == 0) return PXR_OK;
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adamw_flat_tab_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p,
+                     (const float4*)g, (float4*)m, (float4*)v, n4, (const float4*)hyper, step, step_dev,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
+  return pxr_check_launch("pxr_adamw_flat_tab_f32");
+}
+
+// *counter += delta on the device (step counters that hipGraph replays must advance without the host).
+extern "C" int pxr_counter_add_i64(int64_t* counter, int64_t delta, void* stream) {
+  PXR_REQUIRE(counter, "pxr_counter_add_i64: null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta);
+  return pxr_check_launch("pxr_counter_add_i64");
 }
 
 // Brings rows up to date through step t_prev (replaying their missed zero-gradient steps) and, if t_apply != 0,
 // applies step t_apply with gradient rows grows[i,:] (row i of the list).  rows == NULL: every row of the table
-// (flush; n_rows_dev ignored).  last: int32[N] "up to date through" step per row.
+// (flush; n_rows_dev ignored).  last: int32[N] "up to date through" step per row.  step_dev != NULL: t_prev is read
+// from the device counter (and t_apply = t_prev + 1 when t_apply != 0), which makes the call hipGraph-replayable.
 extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D,
                                   const int64_t* rows, const int32_t* n_rows_dev, int64_t max_rows, const float* grows,
-                                  const void* hyper, const void* cumlog, int64_t t_prev, int64_t t_apply, double beta1,
-                                  double beta2, double eps, void* stream) {
+                                  const void* hyper, const void* cumlog, int64_t t_prev, int64_t t_apply,
+                                  const int64_t* step_dev, double beta1, double beta2, double eps, void* stream) {
   PXR_REQUIRE(table && m && v && last && hyper && cumlog, "pxr_adamw_rows_f32: null pointer");
   PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 2048, "pxr_adamw_rows_f32: bad shape (D <= 2048)");
   PXR_REQUIRE(!rows || n_rows_dev, "pxr_adamw_rows_f32: row list needs its device count");
@@ -311,6 +372,7 @@ extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* las
   a.t_prev = (int)t_prev; a.t_apply = (int)t_apply; a.D = D;
   a.one_m_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_m_b2 = (float)(1.0 - beta2); a.eps = (float)eps;
   a.b1 = (float)beta1;
+  a.step_dev = step_dev;
   const int64_t work = rows ? max_rows : n_table;
   if (work <= 0) return PXR_OK;
   int64_t blocks = (work + 3) / 4;

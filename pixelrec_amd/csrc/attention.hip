@@ -36,6 +36,7 @@ struct AttnArgs {
   int B, H, L, d;
   float sqrt_d;
   float p_drop; uint32_t drop_thr; uint32_t stream; uint64_t seed;
+  const int64_t* step_dev;  // optional device counter added to the seed
 };
 
 // stage tile[row][0..w) <- src[(row)*ld + 0..w) for row < L; all threads of the block, float4 accesses
@@ -111,6 +112,7 @@ __device__ __forceinline__ void rowmix_store(const float* sW, const float* sX, i
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
   __shared__ __attribute__((aligned(16))) float sA[ATT_MAXL * ATT_DC];    // Q chunk, later V chunk
   __shared__ __attribute__((aligned(16))) float sB[ATT_MAXL * ATT_KLD];   // K chunk
   __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * 64];        // (dropped) probabilities
@@ -174,6 +176,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a) {
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
   __shared__ __attribute__((aligned(16))) float sA[ATT_MAXL * ATT_DC];
   __shared__ __attribute__((aligned(16))) float sB[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * 64];   // dropped probabilities Pd
@@ -271,7 +274,8 @@ static int attn_check(int B, int H, int L, int d, int64_t ld, const char* who) {
 // ctx[b,t,h*d:(h+1)*d] = softmax(q k^T / sqrt(d) + mask) v       (eval: p_drop = 0)
 extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
                                 int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx,
-                                float* probs, float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+                                float* probs, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                                void* stream) {
   PXR_REQUIRE(q && k && v && keymask && ctx, "pxr_attn_fwd_f32: null pointer");
   int rc = attn_check(B, H, L, d, ld, "pxr_attn_fwd_f32");
   if (rc) return rc;
@@ -282,6 +286,7 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
   a.ctx = ctx; a.ld_ctx = ld_ctx; a.probs = probs; a.B = B; a.H = H; a.L = L; a.d = d;
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  a.step_dev = step_dev;
   switch (attn_waves()) {
     case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a); break;
     case 16: hipLaunchKernelGGL(attn_fwd_kernel<16>, dim3(B * H), dim3(1024), 0, (hipStream_t)stream, a); break;
@@ -294,7 +299,7 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
 extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v,
                                 int64_t ld, const float* probs, int B, int H, int L, int d, float* dq, float* dk,
                                 float* dv, int64_t ld_d, float p_drop, uint64_t seed, uint32_t stream_id,
-                                void* stream) {
+                                const int64_t* step_dev, void* stream) {
   PXR_REQUIRE(dctx && q && k && v && probs && dq && dk && dv, "pxr_attn_bwd_f32: null pointer");
   int rc = attn_check(B, H, L, d, ld, "pxr_attn_bwd_f32");
   if (rc) return rc;
@@ -305,6 +310,7 @@ extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* 
   a.dctx = dctx; a.dq = dq; a.dk = dk; a.dv = dv; a.ld_d = ld_d; a.B = B; a.H = H; a.L = L; a.d = d;
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  a.step_dev = step_dev;
   switch (attn_waves()) {
     case 4: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a); break;
     case 16: hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(B * H), dim3(1024), 0, (hipStream_t)stream, a); break;

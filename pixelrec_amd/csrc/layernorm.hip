@@ -35,10 +35,12 @@ struct LnFwdArgs {
   uint32_t drop_thr;
   uint32_t stream;
   uint64_t seed;
+  const int64_t* step_dev;  // optional device counter added to the seed (hipGraph replays advance it on the device)
 };
 
 template <int VEC, bool GATHER>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.rows) return;
@@ -135,10 +137,12 @@ struct LnBwdArgs {
   uint32_t drop_thr;
   uint32_t stream;
   uint64_t seed;
+  const int64_t* step_dev;
 };
 
 template <int VEC, bool GATHER>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
   __shared__ float red[3][2 * VEC * 256];  // waves 1..3 park their partial (dgamma | dbeta) here
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = a.D;
@@ -291,7 +295,7 @@ using namespace pxr;
 extern "C" int pxr_input_ln_fwd_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
                                     const float* pos, const float* gamma, const float* beta, float eps, int B, int L,
                                     int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
-                                    uint32_t stream_id, void* stream) {
+                                    uint32_t stream_id, const int64_t* step_dev, void* stream) {
   PXR_REQUIRE(table && idx && pos && gamma && beta && y, "pxr_input_ln_fwd_f32: null pointer");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && B >= 0 && L > 0, "pxr_input_ln_fwd_f32: bad shape");
   PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_input_ln_fwd_f32: bad dropout p");
@@ -300,13 +304,14 @@ extern "C" int pxr_input_ln_fwd_f32(const float* table, int64_t n_table, const i
   a.table = table; a.idx = idx; a.pos = pos; a.gamma = gamma; a.beta = beta; a.y = y; a.xhat = xhat; a.rstd = rstd;
   a.idx_bstride = idx_bstride; a.n_table = n_table; a.rows = B * L; a.D = D; a.L = L; a.eps = eps;
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  a.step_dev = step_dev;
   return launch_ln_fwd<true>(a, (hipStream_t)stream);
 }
 
 // y = LN(dropout(x) + res)   (layers.py:614-615, :670-671).  res may be null.
 extern "C" int pxr_ln_residual_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta,
                                        float eps, int rows, int D, float* y, float* xhat, float* rstd, float p_drop,
-                                       uint64_t seed, uint32_t stream_id, void* stream) {
+                                       uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* stream) {
   PXR_REQUIRE(x && gamma && beta && y, "pxr_ln_residual_fwd_f32: null pointer");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && rows >= 0, "pxr_ln_residual_fwd_f32: bad shape");
   PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_ln_residual_fwd_f32: bad dropout p");
@@ -315,6 +320,7 @@ extern "C" int pxr_ln_residual_fwd_f32(const float* x, const float* res, const f
   a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xhat = xhat; a.rstd = rstd;
   a.rows = rows; a.D = D; a.L = 1; a.eps = eps;
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  a.step_dev = step_dev;
   return launch_ln_fwd<false>(a, (hipStream_t)stream);
 }
 
@@ -329,8 +335,8 @@ extern "C" int64_t pxr_ln_bwd_ws_bytes(int rows, int D) {
 // the gradient w.r.t. the residual.  dgamma/dbeta are OVERWRITTEN (not accumulated).
 extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd,
                               const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
-                              float p_drop, uint64_t seed, uint32_t stream_id, void* ws, int64_t ws_bytes,
-                              void* stream) {
+                              float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ws,
+                              int64_t ws_bytes, void* stream) {
   PXR_REQUIRE(dy && xhat && rstd && gamma && dz && dgamma && dbeta && ws, "pxr_ln_bwd_f32: null pointer");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && rows > 0, "pxr_ln_bwd_f32: bad shape");
   LnBwdArgs a{};
@@ -342,6 +348,7 @@ extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xha
     return PXR_ERR_WORKSPACE;
   }
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  a.step_dev = step_dev;
   hipStream_t st = (hipStream_t)stream;
   int rc = gather_mode ? launch_ln_bwd<true>(a, nblk, st) : launch_ln_bwd<false>(a, nblk, st);
   if (rc) return rc;

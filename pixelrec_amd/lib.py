@@ -38,10 +38,10 @@ _SIGNATURES = {
     "pxr_sasrec_embed_grad_f32": (_I, [_P, _I, _I, _P, _P, _P, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
     "pxr_sasrec_occ_sort": (_I, [_P, _I, _I, _I64, _P, _P, _P, _I64, _P]),
     "pxr_sasrec_occ_segsum": (_I, [_P, _I64, _I, _I, _P, _P, _P, _I, _I64, _F, _P, _P, _P]),
-    "pxr_input_ln_fwd_f32": (_I, [_P, _I64, _P, _I64, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _F, _U64, _U32, _P]),
-    "pxr_ln_residual_fwd_f32": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _F, _U64, _U32, _P]),
+    "pxr_input_ln_fwd_f32": (_I, [_P, _I64, _P, _I64, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _F, _U64, _U32, _P, _P]),
+    "pxr_ln_residual_fwd_f32": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _F, _U64, _U32, _P, _P]),
     "pxr_ln_bwd_ws_bytes": (_I64, [_I, _I]),
-    "pxr_ln_bwd_f32": (_I, [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U32, _P, _I64, _P]),
+    "pxr_ln_bwd_f32": (_I, [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64, _P]),
     "pxr_gemm_ws_bytes": (_I64, [_I, _I, _I, _I, _I]),
     "pxr_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _I64, _P, _I64, _I, _I, _P]),
     "pxr_linear_fwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -49,8 +49,8 @@ _SIGNATURES = {
     "pxr_linear_bwd_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _I64, _P]),
     "pxr_colsum_ws_bytes": (_I64, [_I, _I]),
     "pxr_colsum_f32": (_I, [_P, _I64, _I, _I, _P, _P, _I64, _P]),
-    "pxr_attn_fwd_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _I, _I, _I, _I, _P, _I64, _P, _F, _U64, _U32, _P]),
-    "pxr_attn_bwd_f32": (_I, [_P, _I64, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _P, _I64, _F, _U64, _U32, _P]),
+    "pxr_attn_fwd_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _I, _I, _I, _I, _P, _I64, _P, _F, _U64, _U32, _P, _P]),
+    "pxr_attn_bwd_f32": (_I, [_P, _I64, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _P, _I64, _F, _U64, _U32, _P, _P]),
     "pxr_bpr_loss_fwd_f32": (_I, [_P, _P, _I64, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pxr_bpr_loss_bwd_f32": (_I, [_P, _P, _P, _I64, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
     "pxr_score_topk_ws_bytes": (_I64, [_I, _I, _I]),
@@ -58,8 +58,10 @@ _SIGNATURES = {
     "pxr_adamw_flat_f32": (_I, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),
     "pxr_slot_fill_i32": (_I, [_P, _I64, ctypes.c_int32, _P]),
     "pxr_adamw_table_f32": (_I, [_P, _P, _P, _I64, _I, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),
-    "pxr_adamw_hyper_append": (_I, [_P, _P, _I64, _I64, _D, _D, _D, _D, _D, _P]),
-    "pxr_adamw_rows_f32": (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _I64, _P, _P, _P, _I64, _I64, _D, _D, _D, _P]),
+    "pxr_adamw_hyper_append": (_I, [_P, _P, _I64, _I64, _P, _D, _D, _D, _D, _D, _P]),
+    "pxr_adamw_rows_f32": (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _I64, _P, _P, _P, _I64, _I64, _P, _D, _D, _D, _P]),
+    "pxr_adamw_flat_tab_f32": (_I, [_P, _P, _P, _P, _I64, _P, _I64, _P, _D, _D, _D, _P]),
+    "pxr_counter_add_i64": (_I, [_P, _I64, _P]),
 }
 
 

@@ -117,6 +117,9 @@ class SASRec(BaseModel):
         self.sparse_table_grad = None   # the table gradient the optimizer will apply (local, or merged across ranks)
         self._local_sparse = None       # reusable output buffer of this rank's backward
         self.grad_scale = 1.0           # 1/world_size under data parallelism (sum-all-reduce == DDP's mean)
+        self._side_stream = None
+        self._drop_dev = None              # device counter of completed backward passes (dropout seed offset)
+        self.overlap_weight_grads = True   # weight/bias gradients on a side HIP stream (see _backward_train)
         self._table_hooks = None        # the lazy optimizer (catch_up_rows / flush) when one is attached
         self._occ_ws = None             # persistent workspace carrying the sorted occurrences fwd -> bwd
         self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
@@ -172,6 +175,7 @@ class SASRec(BaseModel):
             off += n
         self._flat, self._gflat, self._views = flat, gflat, views
         self._anchor = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
+        self._drop_dev = torch.full((1,), self._step_counter, dtype=torch.int64, device=dev)
         self.item_embedding.weight.data = self.item_embedding.weight.data.contiguous()
 
     def _p(self, name, grad=False, span=1):
@@ -208,23 +212,26 @@ class SASRec(BaseModel):
         eps = self.layer_norm_eps
         ph = self.hidden_dropout_prob if train else 0.0
         pa = self.attn_dropout_prob if train else 0.0
-        seed = (self._drop_seed * 1000003 + self._step_counter) & 0xFFFFFFFFFFFFFFFF
+        # dropout seed of this step = base + (device counter of completed backward passes): the counter lives on the
+        # device so that a captured hipGraph draws fresh masks on every replay
+        seed = (self._drop_seed * 1000003) & 0xFFFFFFFFFFFFFFFF
+        sdv = self._drop_dev if train else None
         table = self.item_embedding.weight.data
         saved = {"seed": seed, "ph": ph, "pa": pa, "layers": []} if train else None
         h, xhat0, rstd0 = ops.input_ln_fwd(table, idx, idx_bstride, B, L, self._p("pos"), self._p("ln0.w"),
-                                           self._p("ln0.b"), eps, ph, seed, 0, save=train)
+                                           self._p("ln0.b"), eps, ph, seed, 0, save=train, step_dev=sdv)
         if train:
             saved["xhat0"], saved["rstd0"] = xhat0, rstd0
         for i in range(self.n_layers):
             qkv = ops.linear_fwd(h, self._p(f"{i}.q.w", span=3), self._p(f"{i}.q.b", span=3))
-            ctx, probs = ops.attn_fwd(qkv, keymask, km_bstride, B, H, L, d, pa, seed, 1 + 3 * i, save=train)
+            ctx, probs = ops.attn_fwd(qkv, keymask, km_bstride, B, H, L, d, pa, seed, 1 + 3 * i, save=train, step_dev=sdv)
             a = ops.linear_fwd(ctx, self._p(f"{i}.o.w"), self._p(f"{i}.o.b"))
             h1, xhat1, rstd1 = ops.ln_residual_fwd(a, h, self._p(f"{i}.ln1.w"), self._p(f"{i}.ln1.b"), eps, ph, seed,
-                                                   2 + 3 * i, save=train)
+                                                   2 + 3 * i, save=train, step_dev=sdv)
             f, u = ops.linear_fwd(h1, self._p(f"{i}.f1.w"), self._p(f"{i}.f1.b"), gelu=True)
             f2 = ops.linear_fwd(f, self._p(f"{i}.f2.w"), self._p(f"{i}.f2.b"))
             h2, xhat2, rstd2 = ops.ln_residual_fwd(f2, h1, self._p(f"{i}.ln2.w"), self._p(f"{i}.ln2.b"), eps, ph, seed,
-                                                   3 + 3 * i, save=train)
+                                                   3 + 3 * i, save=train, step_dev=sdv)
             if train:
                 saved["layers"].append(dict(h_in=h, qkv=qkv, probs=probs, ctx=ctx, xhat1=xhat1, rstd1=rstd1, h1=h1,
                                             u=u, f=f, xhat2=xhat2, rstd2=rstd2))
@@ -286,41 +293,62 @@ class SASRec(BaseModel):
         d = D // H
         T = B * L
         seed, ph, pa = s["seed"], s["ph"], s["pa"]
+        sdv = self._drop_dev
         table = self.item_embedding.weight.data
         g = lambda name, span=1: self._p(name, grad=True, span=span)
         gsd = grad_out.reshape(1).to(torch.float32).contiguous()
+        # Weight / bias gradients are off the critical path (only the optimizer consumes them): they run on a side
+        # stream concurrently with the dX chain, filling the CUs the small M=B*L GEMMs leave idle.
+        main = torch.cuda.current_stream()
+        side = self._side_stream
+        if side is None or side.device != main.device:
+            side = self._side_stream = torch.cuda.Stream(device=main.device)
+        use_side = self.overlap_weight_grads
+
+        def weight_grads(dy2d, x2d, w_name, b_name, span=1):
+            if use_side:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.linear_bwd_weight(dy2d, x2d, out=g(w_name, span))
+                    ops.colsum(dy2d, out=g(b_name, span))
+                dy2d.record_stream(side)
+                x2d.record_stream(side)
+            else:
+                ops.linear_bwd_weight(dy2d, x2d, out=g(w_name, span))
+                ops.colsum(dy2d, out=g(b_name, span))
+
         dh, coef = ops.bpr_loss_bwd(s["pos"], s["neg"], table, s["items"], s["mask"], D, self.grad_scale, gsd)
         for i in reversed(range(self.n_layers)):
             a = s["layers"][i]
             # FFN: h2 = LN(dropout(f2) + h1)
             dz2, dxf2 = ops.ln_bwd(0, dh, a["xhat2"], a["rstd2"], self._p(f"{i}.ln2.w"), g(f"{i}.ln2.w"),
-                                   g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0)
+                                   g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0, step_dev=sdv)
             if dxf2 is None:
                 dxf2 = dz2
-            ops.linear_bwd_weight(dxf2.view(T, D), a["f"].view(T, -1), out=g(f"{i}.f2.w"))
-            ops.colsum(dxf2.view(T, D), out=g(f"{i}.f2.b"))
+            weight_grads(dxf2.view(T, D), a["f"].view(T, -1), f"{i}.f2.w", f"{i}.f2.b")
             du = ops.linear_bwd_input(dxf2, self._p(f"{i}.f2.w"), dgelu_pre=a["u"])
-            ops.linear_bwd_weight(du.view(T, -1), a["h1"].view(T, D), out=g(f"{i}.f1.w"))
-            ops.colsum(du.view(T, -1), out=g(f"{i}.f1.b"))
+            weight_grads(du.view(T, -1), a["h1"].view(T, D), f"{i}.f1.w", f"{i}.f1.b")
             dh1 = ops.linear_bwd_input(du, self._p(f"{i}.f1.w"), add=dz2)
             # attention block: h1 = LN(dropout(a) + h)
             dz1, dxa = ops.ln_bwd(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
-                                  g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0)
+                                  g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0, step_dev=sdv)
             if dxa is None:
                 dxa = dz1
-            ops.linear_bwd_weight(dxa.view(T, D), a["ctx"].view(T, D), out=g(f"{i}.o.w"))
-            ops.colsum(dxa.view(T, D), out=g(f"{i}.o.b"))
+            weight_grads(dxa.view(T, D), a["ctx"].view(T, D), f"{i}.o.w", f"{i}.o.b")
             dctx = ops.linear_bwd_input(dxa, self._p(f"{i}.o.w"))
-            dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i)
-            ops.linear_bwd_weight(dqkv.view(T, 3 * D), a["h_in"].view(T, D), out=g(f"{i}.q.w", 3))
-            ops.colsum(dqkv.view(T, 3 * D), out=g(f"{i}.q.b", 3))
+            dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv)
+            weight_grads(dqkv.view(T, 3 * D), a["h_in"].view(T, D), f"{i}.q.w", f"{i}.q.b", 3)
             dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1)
-        dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0)
+        dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,
+                            step_dev=sdv)
         ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1))
         sp = self._local_sparse
         ops.sasrec_occ_segsum(self._occ_ws, dx0, s["out"], coef, self.item_num, sp, 1.0)
         self.sparse_table_grad = sp
+        if use_side:
+            main.wait_stream(side)
         self._saved = None
+        ops.counter_add(self._drop_dev, 1)
         self._step_counter += 1
 
     # ------------------------------------------------------------------------------------------ inference

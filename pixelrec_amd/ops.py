@@ -25,21 +25,46 @@ def _req(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
 
 
 class Workspace:
-    """Grow-only scratch buffer (bytes) per device, reused by kernels that need temporary storage."""
+    """Grow-only scratch buffer (bytes) per (device, stream), reused by kernels that need temporary storage.
+    Keyed by the CURRENT stream so that work issued on a side stream never shares scratch with the main stream."""
 
     def __init__(self):
         self._buf = {}
+        self._retired = []
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        device = torch.device(device)
+        stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        key = (device.type, device.index, stream)
         b = self._buf.get(key)
         if b is None or b.numel() < nbytes:
+            if b is not None:
+                self._retired.append(b)   # a captured hipGraph may still hold this pointer: never free it
             b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self._buf[key] = b
         return b
 
 
 _ws = Workspace()
+
+# bench.py: set to a list to collect (start_event, end_event, flops) around every fp32-MFMA GEMM launch
+GEMM_TIMING = None
+
+
+class _gemm_timer:
+    def __init__(self, flops):
+        self.flops = flops
+        self.on = GEMM_TIMING is not None
+
+    def __enter__(self):
+        if self.on:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ev[1].record()
+            GEMM_TIMING.append((self.ev[0], self.ev[1], self.flops))
 
 
 # ------------------------------------------------------------------------------------------------ K1 gather
@@ -73,9 +98,10 @@ def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc,
         ws_bytes = int(L.pxr_gemm_ws_bytes(int(a_kc), int(b_kc), M, N, K))
         ws_bytes = min(ws_bytes, 1 << 30)
         ws = _ws.get(ws_bytes, C.device)
-    _l.check(L.pxr_gemm_f32(int(a_kc), int(b_kc), M, N, K, _l.ptr(A), lda, _l.ptr(B), ldb, _l.ptr(C), ldc, epilogue,
-                            _l.ptr(bias), _l.ptr(aux), ldaux, _l.ptr(ws), ws_bytes, tile_hint, split_hint,
-                            _l.stream_ptr()), "pxr_gemm_f32")
+    with _gemm_timer(2.0 * M * N * K):
+        _l.check(L.pxr_gemm_f32(int(a_kc), int(b_kc), M, N, K, _l.ptr(A), lda, _l.ptr(B), ldb, _l.ptr(C), ldc,
+                                epilogue, _l.ptr(bias), _l.ptr(aux), ldaux, _l.ptr(ws), ws_bytes, tile_hint,
+                                split_hint, _l.stream_ptr()), "pxr_gemm_f32")
     return C
 
 
@@ -87,8 +113,9 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: b
     M = x.numel() // K
     y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if gelu else None
-    _l.check(L.pxr_linear_fwd_f32(_l.ptr(x), _l.ptr(W), _l.ptr(b), _l.ptr(y), _l.ptr(pre), M, N, K, int(gelu),
-                                  _l.stream_ptr()), "pxr_linear_fwd_f32")
+    with _gemm_timer(2.0 * M * N * K):
+        _l.check(L.pxr_linear_fwd_f32(_l.ptr(x), _l.ptr(W), _l.ptr(b), _l.ptr(y), _l.ptr(pre), M, N, K, int(gelu),
+                                      _l.stream_ptr()), "pxr_linear_fwd_f32")
     return (y, pre) if gelu else y
 
 
@@ -100,8 +127,9 @@ def linear_bwd_input(dy: torch.Tensor, W: torch.Tensor, dgelu_pre: torch.Tensor 
     N, K = W.shape
     M = dy.numel() // N
     dx = torch.empty(*dy.shape[:-1], K, dtype=torch.float32, device=dy.device)
-    _l.check(L.pxr_linear_bwd_input_f32(_l.ptr(dy), _l.ptr(W), _l.ptr(dx), _l.ptr(dgelu_pre), _l.ptr(add), M, N, K,
-                                        _l.stream_ptr()), "pxr_linear_bwd_input_f32")
+    with _gemm_timer(2.0 * M * N * K):
+        _l.check(L.pxr_linear_bwd_input_f32(_l.ptr(dy), _l.ptr(W), _l.ptr(dx), _l.ptr(dgelu_pre), _l.ptr(add), M, N,
+                                            K, _l.stream_ptr()), "pxr_linear_bwd_input_f32")
     return dx
 
 
@@ -114,8 +142,9 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor | Non
     dW = out if out is not None else torch.empty(N, K, dtype=torch.float32, device=dy.device)
     ws_bytes = min(int(L.pxr_gemm_ws_bytes(0, 0, N, K, M)), 1 << 30)
     ws = _ws.get(ws_bytes, dy.device)
-    _l.check(L.pxr_linear_bwd_weight_f32(_l.ptr(dy), _l.ptr(x), _l.ptr(dW), M, N, K, _l.ptr(ws), ws_bytes,
-                                         _l.stream_ptr()), "pxr_linear_bwd_weight_f32")
+    with _gemm_timer(2.0 * M * N * K):
+        _l.check(L.pxr_linear_bwd_weight_f32(_l.ptr(dy), _l.ptr(x), _l.ptr(dW), M, N, K, _l.ptr(ws), ws_bytes,
+                                             _l.stream_ptr()), "pxr_linear_bwd_weight_f32")
     return dW
 
 
@@ -132,7 +161,8 @@ def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None):
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm sites
-def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True):
+def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True,
+                 step_dev=None):
     """y = dropout(LN(table[idx[b,t]] + pos[t]))  (sasrec.py:68,77-82 / :99-104).  Returns (y, xhat, rstd)."""
     Lb = _l.load()
     _req(table, torch.float32, "table"); _req(idx, torch.int64, "idx", contiguous=False)
@@ -142,11 +172,11 @@ def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.
     rstd = torch.empty(B * L, dtype=torch.float32, device=table.device) if save else None
     _l.check(Lb.pxr_input_ln_fwd_f32(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
                                      _l.ptr(beta), eps, B, L, D, _l.ptr(y), _l.ptr(xhat), _l.ptr(rstd), p_drop, seed,
-                                     stream_id, _l.stream_ptr()), "pxr_input_ln_fwd_f32")
+                                     stream_id, _l.ptr(step_dev), _l.stream_ptr()), "pxr_input_ln_fwd_f32")
     return y, xhat, rstd
 
 
-def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True):
+def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None):
     """y = LN(dropout(x) + res)  (layers.py:614-615, :670-671).  Returns (y, xhat, rstd)."""
     Lb = _l.load()
     _req(x, torch.float32, "x")
@@ -156,12 +186,13 @@ def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, s
     xhat = torch.empty_like(x) if save else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
     _l.check(Lb.pxr_ln_residual_fwd_f32(_l.ptr(x), _l.ptr(res), _l.ptr(gamma), _l.ptr(beta), eps, rows, D, _l.ptr(y),
-                                        _l.ptr(xhat), _l.ptr(rstd), p_drop, seed, stream_id, _l.stream_ptr()),
-             "pxr_ln_residual_fwd_f32")
+                                        _l.ptr(xhat), _l.ptr(rstd), p_drop, seed, stream_id, _l.ptr(step_dev),
+                                        _l.stream_ptr()), "pxr_ln_residual_fwd_f32")
     return y, xhat, rstd
 
 
-def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0, stream_id=0, need_dx=False):
+def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0, stream_id=0, need_dx=False,
+           step_dev=None):
     """Backward of either LN site; dgamma/dbeta ([D] tensors) are overwritten.  Returns (dz, dx|None)."""
     Lb = _l.load()
     _req(dy, torch.float32, "dy")
@@ -173,12 +204,12 @@ def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0
     ws = _ws.get(ws_bytes, dy.device)
     _l.check(Lb.pxr_ln_bwd_f32(int(gather_mode), _l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), rows, D,
                                _l.ptr(dz), _l.ptr(dx), _l.ptr(dgamma), _l.ptr(dbeta), p_drop, seed, stream_id,
-                               _l.ptr(ws), ws_bytes, _l.stream_ptr()), "pxr_ln_bwd_f32")
+                               _l.ptr(step_dev), _l.ptr(ws), ws_bytes, _l.stream_ptr()), "pxr_ln_bwd_f32")
     return dz, dx
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, save=True):
+def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None):
     """qkv [B,L,3*H*d] fused projection output -> (ctx [B,L,H*d], probs [B,H,L,L] | None)."""
     Lb = _l.load()
     _req(qkv, torch.float32, "qkv"); _req(keymask, torch.int64, "keymask", contiguous=False)
@@ -188,11 +219,12 @@ def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id
     base = qkv.data_ptr()
     q, k, v = _l.c_void_p(base), _l.c_void_p(base + 4 * D), _l.c_void_p(base + 8 * D)
     _l.check(Lb.pxr_attn_fwd_f32(q, k, v, 3 * D, _l.ptr(keymask), km_bstride, B, H, L, d, _l.ptr(ctx), D,
-                                 _l.ptr(probs), p_drop, seed, stream_id, _l.stream_ptr()), "pxr_attn_fwd_f32")
+                                 _l.ptr(probs), p_drop, seed, stream_id, _l.ptr(step_dev), _l.stream_ptr()),
+             "pxr_attn_fwd_f32")
     return ctx, probs
 
 
-def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0):
+def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, step_dev=None):
     """-> dqkv [B,L,3*H*d] laid out like qkv."""
     Lb = _l.load()
     _req(dctx, torch.float32, "dctx"); _req(qkv, torch.float32, "qkv"); _req(probs, torch.float32, "probs")
@@ -202,7 +234,7 @@ def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0):
     cp = _l.c_void_p
     _l.check(Lb.pxr_attn_bwd_f32(_l.ptr(dctx), D, cp(base), cp(base + 4 * D), cp(base + 8 * D), 3 * D, _l.ptr(probs),
                                  B, H, L, d, cp(dbase), cp(dbase + 4 * D), cp(dbase + 8 * D), 3 * D, p_drop, seed,
-                                 stream_id, _l.stream_ptr()), "pxr_attn_bwd_f32")
+                                 stream_id, _l.ptr(step_dev), _l.stream_ptr()), "pxr_attn_bwd_f32")
     return dqkv
 
 
@@ -363,17 +395,30 @@ def adamw_table(table, m, v, slot, sp: SparseRows | None, lr, beta1, beta2, eps,
                                     weight_decay, step, _l.stream_ptr()), "pxr_adamw_table_f32")
 
 
-def adamw_hyper_append(hyper, cumlog, step, lr, beta1, beta2, eps, weight_decay):
+def adamw_hyper_append(hyper, cumlog, step, lr, beta1, beta2, eps, weight_decay, step_dev=None):
     Lb = _l.load()
-    _l.check(Lb.pxr_adamw_hyper_append(_l.ptr(hyper), _l.ptr(cumlog), cumlog.numel(), step, lr, beta1, beta2, eps,
-                                       weight_decay, _l.stream_ptr()), "pxr_adamw_hyper_append")
+    _l.check(Lb.pxr_adamw_hyper_append(_l.ptr(hyper), _l.ptr(cumlog), cumlog.numel(), step, _l.ptr(step_dev), lr, beta1,
+                                       beta2, eps, weight_decay, _l.stream_ptr()), "pxr_adamw_hyper_append")
 
 
 def adamw_rows(table, m, v, last, hyper, cumlog, t_prev, t_apply, beta1, beta2, eps, rows=None, n_rows=None,
-               max_rows=0, grows=None):
-    """Lazy table AdamW: catch rows up through t_prev (+ apply step t_apply with gradient rows).  rows=None: all."""
+               max_rows=0, grows=None, step_dev=None):
+    """Lazy table AdamW: catch rows up through t_prev (+ apply step t_apply with gradient rows).  rows=None: all.
+    step_dev (device int64 counter of completed steps) overrides t_prev / t_apply (hipGraph-replayable)."""
     Lb = _l.load()
     N, D = table.shape
     _l.check(Lb.pxr_adamw_rows_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), _l.ptr(last), N, D, _l.ptr(rows),
                                    _l.ptr(n_rows), max_rows, _l.ptr(grows), _l.ptr(hyper), _l.ptr(cumlog), t_prev,
-                                   t_apply, beta1, beta2, eps, _l.stream_ptr()), "pxr_adamw_rows_f32")
+                                   t_apply, _l.ptr(step_dev), beta1, beta2, eps, _l.stream_ptr()), "pxr_adamw_rows_f32")
+
+
+def adamw_flat_tab(p, g, m, v, hyper, step, beta1, beta2, eps, step_dev=None):
+    Lb = _l.load()
+    _l.check(Lb.pxr_adamw_flat_tab_f32(_l.ptr(p), _l.ptr(g), _l.ptr(m), _l.ptr(v), p.numel(), _l.ptr(hyper), step,
+                                       _l.ptr(step_dev), beta1, beta2, eps, _l.stream_ptr()), "pxr_adamw_flat_tab_f32")
+
+
+def counter_add(counter, delta=1):
+    Lb = _l.load()
+    _req(counter, torch.int64, "counter")
+    _l.check(Lb.pxr_counter_add_i64(_l.ptr(counter), delta, _l.stream_ptr()), "pxr_counter_add_i64")

@@ -1,9 +1,16 @@
 """PxrAdamW -- torch.optim.AdamW semantics (reference trainer.py:66-103,125) on the fused HIP kernels.
 
-  * every non-table parameter is updated by ONE launch over the model's flat buffer (pxr_adamw_flat_f32);
+  * every non-table parameter is updated by ONE launch over the model's flat buffer;
   * the item-embedding table keeps DENSE AdamW semantics (weight decay and stale moments move every row each
-    step, overall/ID.yaml:20-23) but consumes the step's gradient in sparse form (pxr_adamw_table_f32), so the
-    819 MB dense gradient of the reference never exists.
+    step, overall/ID.yaml:20-23) while consuming the step's gradient in sparse form, so the 819 MB dense gradient of
+    the reference never exists.  Two equivalent schedules:
+      table_update="lazy"  (default): untouched rows are not swept; each row remembers the step it is current
+                           through and its missed zero-gradient steps are replayed exactly when the row is next read
+                           (before the forward) or updated; `flush()` brings every row up to date before
+                           evaluation / checkpointing (called automatically through the model's table hooks);
+      table_update="dense": sweep p, m, v of the whole table every step (HBM-bound, 4.9 GB/step at N=400K, D=512).
+  * the step number lives ON THE DEVICE (`_step_dev`): bias corrections are computed by a one-thread kernel into a
+    per-step scalar table, so a whole training step can be captured in a hipGraph and replayed.
 Defaults follow torch.optim.AdamW: betas (0.9, 0.999), eps 1e-8.
 """
 from __future__ import annotations
@@ -12,98 +19,87 @@ import torch
 
 from . import ops
 
+HYPER_CAPACITY = 1 << 22   # steps; 96 MB of per-step scalars, sized once so graph replays never see a reallocation
+
 
 class PxrAdamW:
     def __init__(self, model, lr=1e-4, weight_decay=0.1, betas=(0.9, 0.999), eps=1e-8, table_update="lazy"):
-        """table_update: "lazy" (default) = exact catch-up replay of untouched rows, no O(N*D) sweep per step;
-        "dense" = sweep the whole table every step.  Both implement the SAME dense-AdamW semantics."""
         if table_update not in ("lazy", "dense"):
             raise ValueError("table_update must be 'lazy' or 'dense'")
         self.table_update = table_update
-        self._last = self._hyper = self._cumlog = None
-        self._dirty = False   # lazy mode: some rows lag behind step_count (set by step, cleared by flush)
         self.model = model
+        self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.step_count = 0          # host mirror of the device counter
+        self._m = self._v = self._tm = self._tv = self._slot = None
+        self._last = self._hyper = self._cumlog = self._step_dev = None
+        self._dirty = False          # lazy mode: some rows lag behind step_count (set by step, cleared by flush)
+        self.param_groups = [{"lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}]
         if table_update == "lazy":
             model.register_table_hooks(self)
-        self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
-        self.step_count = 0
-        self._m = self._v = self._tm = self._tv = self._slot = None
-        self.table_events = None  # bench.py: list collecting (start, end) HIP events around the table sweep
-        self.param_groups = [{"lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}]
 
     def _ensure_state(self):
         flat, _ = self.model.flat_parameters()
         table = self.model.item_embedding.weight.data
+        dev = table.device
         if self._m is None or self._m.device != flat.device or self._m.numel() != flat.numel():
             self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
-        if self._tm is None or self._tm.device != table.device or self._tm.shape != table.shape:
+        if self._tm is None or self._tm.device != dev or self._tm.shape != table.shape:
             self._tm, self._tv = torch.zeros_like(table), torch.zeros_like(table)
-            self._slot = torch.empty(table.shape[0], dtype=torch.int32, device=table.device)
+            self._slot = torch.empty(table.shape[0], dtype=torch.int32, device=dev)
             ops.slot_fill(self._slot, -1)
-            self._last = torch.full((table.shape[0],), self.step_count, dtype=torch.int32, device=table.device)
-            self._grow_hyper(table.device, max(1 << 16, 2 * self.step_count + 2))
+            self._last = torch.full((table.shape[0],), self.step_count, dtype=torch.int32, device=dev)
+            self._hyper = torch.zeros(HYPER_CAPACITY, 4, dtype=torch.float32, device=dev)
+            self._cumlog = torch.zeros(HYPER_CAPACITY, dtype=torch.float64, device=dev)
+            self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=dev)
         return flat, table
-
-    def _grow_hyper(self, device, cap):
-        hyper = torch.zeros(cap, 4, dtype=torch.float32, device=device)
-        cumlog = torch.zeros(cap, dtype=torch.float64, device=device)
-        if self._hyper is not None:
-            n = self._hyper.shape[0]
-            hyper[:n].copy_(self._hyper)
-            cumlog[:n].copy_(self._cumlog)
-        self._hyper, self._cumlog = hyper, cumlog
-
-    # ---- hooks called by the model (lazy mode) ----------------------------------------------------------------
-    def catch_up_rows(self, idx, n_dev, cap):
-        """Bring the rows a forward pass is about to read up to date (through the last completed step)."""
-        if self.table_update != "lazy" or self.step_count == 0 or self._last is None:
-            return
-        g = self.param_groups[0]
-        ops.adamw_rows(self.model.item_embedding.weight.data, self._tm, self._tv, self._last, self._hyper, self._cumlog,
-                       self.step_count, 0, g["betas"][0], g["betas"][1], g["eps"], rows=idx, n_rows=n_dev, max_rows=cap)
-
-    def flush(self):
-        """Bring EVERY row up to date (before evaluation, checkpointing, or reading the table)."""
-        if self.table_update != "lazy" or not self._dirty or self._last is None:
-            return
-        g = self.param_groups[0]
-        ops.adamw_rows(self.model.item_embedding.weight.data, self._tm, self._tv, self._last, self._hyper, self._cumlog,
-                       self.step_count, 0, g["betas"][0], g["betas"][1], g["eps"])
-        self._dirty = False
 
     def zero_grad(self, set_to_none: bool = False):
         """No-op: every backward OVERWRITES the flat gradient buffer and the sparse table gradient."""
         return None
 
+    # ---- hooks called by the model (lazy mode) ----------------------------------------------------------------
+    def catch_up_rows(self, idx, n_dev, cap):
+        """Bring the rows a forward pass is about to read up to date (through the last completed step)."""
+        if self.table_update != "lazy" or self._last is None:
+            return
+        b1, b2 = self.param_groups[0]["betas"]
+        ops.adamw_rows(self.model.item_embedding.weight.data, self._tm, self._tv, self._last, self._hyper, self._cumlog,
+                       self.step_count, 0, b1, b2, self.param_groups[0]["eps"], rows=idx, n_rows=n_dev, max_rows=cap,
+                       step_dev=self._step_dev)
+
+    def flush(self):
+        """Bring EVERY row up to date (before evaluation, checkpointing, or reading the table as a whole)."""
+        if self.table_update != "lazy" or not self._dirty or self._last is None:
+            return
+        b1, b2 = self.param_groups[0]["betas"]
+        ops.adamw_rows(self.model.item_embedding.weight.data, self._tm, self._tv, self._last, self._hyper, self._cumlog,
+                       self.step_count, 0, b1, b2, self.param_groups[0]["eps"], step_dev=self._step_dev)
+        self._dirty = False
+
     @torch.no_grad()
     def step(self):
         flat, table = self._ensure_state()
         _, gflat = self.model.flat_parameters()
-        self.step_count += 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        ops.adamw_flat(flat, gflat, self._m, self._v, g["lr"], b1, b2, g["eps"], g["weight_decay"], self.step_count)
-        ev = None
-        if self.table_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
+        if self.step_count + 2 >= HYPER_CAPACITY:
+            raise RuntimeError("PxrAdamW: per-step scalar table exhausted (raise optim.HYPER_CAPACITY)")
+        sd = self._step_dev
+        ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 1, g["lr"], b1, b2, g["eps"],
+                               g["weight_decay"], step_dev=sd)
+        ops.adamw_flat_tab(flat, gflat, self._m, self._v, self._hyper, self.step_count + 1, b1, b2, g["eps"], step_dev=sd)
         sp = self.model.sparse_table_grad
         if self.table_update == "dense":
+            # host-computed scalars: this schedule is for eager execution / A-B measurements, not for graph capture
             ops.adamw_table(table, self._tm, self._tv, self._slot, sp, g["lr"], b1, b2, g["eps"], g["weight_decay"],
-                            self.step_count)
-        else:
-            if self.step_count + 1 >= self._cumlog.numel():
-                self._grow_hyper(table.device, 2 * self._cumlog.numel())
-            ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count, g["lr"], b1, b2, g["eps"],
-                                   g["weight_decay"])
-            if sp is not None:
-                ops.adamw_rows(table, self._tm, self._tv, self._last, self._hyper, self._cumlog, self.step_count - 1,
-                               self.step_count, b1, b2, g["eps"], rows=sp.idx, n_rows=sp.n, max_rows=sp.cap,
-                               grows=sp.rows)
+                            self.step_count + 1)
+        elif sp is not None:
+            ops.adamw_rows(table, self._tm, self._tv, self._last, self._hyper, self._cumlog, self.step_count,
+                           self.step_count + 1, b1, b2, g["eps"], rows=sp.idx, n_rows=sp.n, max_rows=sp.cap,
+                           grows=sp.rows, step_dev=sd)
             self._dirty = True
-        if ev is not None:
-            ev[1].record()
-            self.table_events.append(ev)
+        ops.counter_add(sd, 1)
+        self.step_count += 1
 
     def state_dict(self):
         self._ensure_state()
@@ -117,9 +113,9 @@ class PxrAdamW:
         self.param_groups = sd["param_groups"]
         for dst, key in ((self._m, "m"), (self._v, "v"), (self._tm, "table_m"), (self._tv, "table_v")):
             dst.copy_(sd[key])
-        # a checkpoint is always flushed: every row is up to date through `step`; the per-step scalars of earlier
-        # steps are never needed again, only the cumulative-log origin must be consistent (restart it at 0)
+        # a checkpoint is always flushed: every row is current through `step`; earlier per-step scalars are never
+        # needed again, only the cumulative-log origin must be consistent (restart it at 0)
         self._last.fill_(self.step_count)
-        if self.step_count + 2 >= self._cumlog.numel():
-            self._grow_hyper(self._tm.device, 2 * (self.step_count + 2))
+        self._step_dev.fill_(self.step_count)
         self._cumlog.zero_()
+        self._dirty = False
