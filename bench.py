@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the gather / scoring roofline micro-runs")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (A/B knob)")
+    ap.add_argument("--no-group", action="store_true", help="per-layer weight-gradient GEMMs instead of one grouped launch")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
@@ -123,7 +124,9 @@ def main():
     with torch.device(dev):
         model = SASRec(model_config(0.1), DL())  # random-init weights of the reference architecture
     model.train()
-    model.overlap_weight_grads = not args.no_overlap
+    if args.no_group:
+        model.group_weight_grads = False
+        model.overlap_weight_grads = not args.no_overlap
     dp = DataParallel(model)
     opt = PxrAdamW(model, lr=1e-4, weight_decay=0.1)
 

@@ -102,6 +102,11 @@ int pxr_linear_bwd_input_f32(const float* dy, const float* W, float* dx, const f
                              int M, int N, int K, void* stream);
 int pxr_linear_bwd_weight_f32(const float* dy, const float* x, float* dW, int M, int N, int K, void* ws,
                               int64_t ws_bytes, void* stream);
+/* Weight AND bias gradients of up to 16 nn.Linear layers in ONE launch (host arrays of n device pointers / sizes):
+ * dW[i][N_i,K_i] = dy[i][M_i,N_i]^T x[i][M_i,K_i], db[i][N_i] = column sums of dy[i] (db[i] may be NULL).
+ * No split-K, no partial buffers: all problems' 64x64 tiles share one grid.  Deterministic. */
+int pxr_grouped_linear_bwd_weight_f32(int n, const float* const* dy, const float* const* x, float* const* dW,
+                                      float* const* db, const int* M, const int* N, const int* K, void* stream);
 /* out[n] = sum_m x[m,n]  (bias grads; position-embedding grad = colsum of dx0 viewed [B, L*D]); deterministic */
 int64_t pxr_colsum_ws_bytes(int M, int N);
 int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, void* ws, int64_t ws_bytes, void* stream);

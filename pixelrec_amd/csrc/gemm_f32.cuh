@@ -103,11 +103,14 @@ __device__ __forceinline__ void stash_xc(const float4 (&r)[NLD], float* lds, int
 // ---- the main loop ---------------------------------------------------------------------------------------
 // acc[bi][bj] element `reg` of lane l is C[m0 + wm*WM + bi*32 + (reg&3) + 8*(reg>>2) + 4*(l>>5)]
 //                                         [n0 + wn*WN + bj*32 + (l&31)]          (gfx950 32x32 C/D map)
-template <int BM, int BN, bool A_KC, bool B_KC>
+// CS (only with an XC A operand): additionally accumulate, per thread, the sum over k of the A float4s it stages
+// (column sums of the stored [K][M] matrix = bias gradient when A = dY) into *cs; the caller reduces across threads.
+template <int BM, int BN, bool A_KC, bool B_KC, bool CS = false>
 __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_KC>::Acc& accs,
                                               const float* __restrict__ A, int64_t lda,
                                               const float* __restrict__ B, int64_t ldb, int M, int N,
-                                              int kbeg, int kend, int m0, int n0, float* smem) {
+                                              int kbeg, int kend, int m0, int n0, float* smem,
+                                              float4* cs = nullptr) {
   using Cfg = GemmCfg<BM, BN, A_KC, B_KC>;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -130,6 +133,11 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
     const int k0 = kbeg + kt * GEMM_BK;
     if constexpr (A_KC) fetch_kc<BM, Cfg::A_LD4>(ra, A, lda, m0, M, k0, kend, tid);
     else fetch_xc<BM, Cfg::A_LD4>(ra, A, lda, m0, M, k0, kend, tid);
+    if constexpr (CS) {
+      static_assert(!A_KC, "column sums are taken over an x-contiguous A operand");
+#pragma unroll
+      for (int p = 0; p < Cfg::A_LD4; ++p) { cs->x += ra[p].x; cs->y += ra[p].y; cs->z += ra[p].z; cs->w += ra[p].w; }
+    }
     if constexpr (B_KC) fetch_kc<BN, Cfg::B_LD4>(rb, B, ldb, n0, N, k0, kend, tid);
     else fetch_xc<BN, Cfg::B_LD4>(rb, B, ldb, n0, N, k0, kend, tid);
   };

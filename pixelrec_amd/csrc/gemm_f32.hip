@@ -98,6 +98,73 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
   __syncthreads();
   if (ty == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
+// ---- grouped weight-gradient GEMM ------------------------------------------------------------------------------
+// All dW[N,K] = dY[M,N]^T X[M,K] (+ db[N] = column sums of dY) of a backward pass in ONE launch.  Every problem has
+// the long token reduction (M = B*L) as its K loop, so with all problems' 64x64 output tiles in one grid (1024 tiles
+// for the two SASRec layers at D=512) the chip is full without split-K: no partial buffers, no reduce launches, no
+// separate bias-gradient reductions.  Deterministic: each output element is one fixed-order MFMA chain.
+constexpr int DW_MAX = 16;
+struct DwProblem {
+  const float* dy; const float* x; float* dW; float* db;
+  int M, N, K;        // tokens, out features, in features
+  int tile_begin, tiles_m;
+};
+struct DwGroup {
+  DwProblem p[DW_MAX];
+  int n, total_tiles;
+};
+
+__global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_kernel(DwGroup g) {
+  using Cfg = GemmCfg<64, 64, false, false>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
+  const int t = xcd_remap(blockIdx.x, g.total_tiles);
+  int pi = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.n; ++i)
+    if (t >= g.p[i].tile_begin) pi = i;
+  const DwProblem& P = g.p[pi];
+  const int local = t - P.tile_begin;
+  const int tm = local % P.tiles_m, tn = local / P.tiles_m;
+  const int m0 = tm * 64, n0 = tn * 64;
+  typename Cfg::Acc accs;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_bias = (P.db != nullptr) && (tn == 0);
+  if (do_bias)
+    gemm_mainloop<64, 64, false, false, true>(accs, P.dy, P.N, P.x, P.K, P.N, P.K, 0, P.M, m0, n0, smem, &cs);
+  else
+    gemm_mainloop<64, 64, false, false, false>(accs, P.dy, P.N, P.x, P.K, P.N, P.K, 0, P.M, m0, n0, smem);
+  auto& acc = accs.v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  const int col = n0 + wn * 32 + r;
+  if (col < P.K) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < P.N) P.dW[(int64_t)row * P.K + col] = acc[0][0][e];
+    }
+  }
+  if (do_bias) {
+    // thread tid staged columns 4*(tid%16) .. +3 of this 64-column block for its k rows: reduce the 16 threads of
+    // each column group in fixed order (the main loop ended with a barrier, smem is free)
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[threadIdx.x] = cs;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      float4 s = red[threadIdx.x];
+      for (int j = 1; j < 16; ++j) {
+        const float4 v = red[threadIdx.x + 16 * j];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int c = m0 + threadIdx.x * 4;
+      if (c + 0 < P.N) P.db[c + 0] = s.x;
+      if (c + 1 < P.N) P.db[c + 1] = s.y;
+      if (c + 2 < P.N) P.db[c + 2] = s.z;
+      if (c + 3 < P.N) P.db[c + 3] = s.w;
+    }
+  }
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                        int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
@@ -280,4 +347,29 @@ extern "C" int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* 
   hipLaunchKernelGGL(pxr_reduce_partials_kernel, dim3((N + 31) / 32), dim3(256), 0, st, (const float*)ws, chunks, N,
                      out, out, N);
   return pxr_check_launch("pxr_colsum_f32(final)");
+}
+
+// Weight AND bias gradients of up to 16 nn.Linear layers in one launch (see grouped_dw_kernel):
+//   dW[i] [N_i,K_i] = dy[i] [M_i,N_i]^T x[i] [M_i,K_i];   db[i] [N_i] = column sums of dy[i]   (db[i] may be NULL).
+extern "C" int pxr_grouped_linear_bwd_weight_f32(int n, const float* const* dy, const float* const* x,
+                                                 float* const* dW, float* const* db, const int* M, const int* N,
+                                                 const int* K, void* stream) {
+  PXR_REQUIRE(n >= 1 && n <= DW_MAX && dy && x && dW && db && M && N && K,
+              "pxr_grouped_linear_bwd_weight_f32: bad args (n=%d, max %d)", n, DW_MAX);
+  DwGroup g{};
+  g.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    PXR_REQUIRE(dy[i] && x[i] && dW[i] && M[i] > 0 && N[i] > 0 && K[i] > 0 && N[i] % 4 == 0 && K[i] % 4 == 0,
+                "pxr_grouped_linear_bwd_weight_f32: problem %d has a bad shape", i);
+    PXR_REQUIRE((((uintptr_t)dy[i] | (uintptr_t)x[i]) & 15) == 0, "pxr_grouped_linear_bwd_weight_f32: unaligned operand");
+    DwProblem& P = g.p[i];
+    P.dy = dy[i]; P.x = x[i]; P.dW = dW[i]; P.db = db[i]; P.M = M[i]; P.N = N[i]; P.K = K[i];
+    P.tile_begin = tiles;
+    P.tiles_m = (N[i] + 63) / 64;
+    tiles += P.tiles_m * ((K[i] + 63) / 64);
+  }
+  g.total_tiles = tiles;
+  hipLaunchKernelGGL(grouped_dw_kernel, dim3(tiles), dim3(GEMM_THREADS), 0, (hipStream_t)stream, g);
+  return pxr_check_launch("pxr_grouped_linear_bwd_weight_f32");
 }

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "pxr_linear_fwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "pxr_linear_bwd_input_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pxr_linear_bwd_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _I64, _P]),
+    "pxr_grouped_linear_bwd_weight_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pxr_colsum_ws_bytes": (_I64, [_I, _I]),
     "pxr_colsum_f32": (_I, [_P, _I64, _I, _I, _P, _P, _I64, _P]),
     "pxr_attn_fwd_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _I, _I, _I, _I, _P, _I64, _P, _F, _U64, _U32, _P, _P]),
@@ -111,7 +112,24 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+_raw_stream = None
+_dev_index = None
+
+
+def raw_stream() -> int:
+    """Raw hipStream_t of torch's CURRENT stream on this process' device (one process per GPU).  Uses the same
+    fast C accessor as torch's compiled-kernel launchers; `torch.cuda.current_stream()` costs ~10 us per call."""
+    global _raw_stream, _dev_index
     import torch
 
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or False
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()
+    if _raw_stream:
+        return _raw_stream(_dev_index)
+    return torch.cuda.current_stream().cuda_stream
+
+
+def stream_ptr():
+    return c_void_p(raw_stream())

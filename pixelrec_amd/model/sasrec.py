@@ -119,7 +119,8 @@ class SASRec(BaseModel):
         self.grad_scale = 1.0           # 1/world_size under data parallelism (sum-all-reduce == DDP's mean)
         self._side_stream = None
         self._drop_dev = None              # device counter of completed backward passes (dropout seed offset)
-        self.overlap_weight_grads = True   # weight/bias gradients on a side HIP stream (see _backward_train)
+        self.group_weight_grads = True     # all weight/bias gradients of a backward pass in one grouped GEMM launch
+        self.overlap_weight_grads = False  # alternative: per-layer launches on a side HIP stream (see _backward_train)
         self._table_hooks = None        # the lazy optimizer (catch_up_rows / flush) when one is attached
         self._occ_ws = None             # persistent workspace carrying the sorted occurrences fwd -> bwd
         self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
@@ -297,16 +298,22 @@ class SASRec(BaseModel):
         table = self.item_embedding.weight.data
         g = lambda name, span=1: self._p(name, grad=True, span=span)
         gsd = grad_out.reshape(1).to(torch.float32).contiguous()
-        # Weight / bias gradients are off the critical path (only the optimizer consumes them): they run on a side
-        # stream concurrently with the dX chain, filling the CUs the small M=B*L GEMMs leave idle.
+        # Weight / bias gradients are off the critical path (only the optimizer consumes them): they are collected
+        # and computed by ONE grouped launch at the end (all tiles of all layers in one grid: no split-K, no
+        # separate bias reductions), or -- overlap_weight_grads -- per layer on a side stream.
         main = torch.cuda.current_stream()
-        side = self._side_stream
-        if side is None or side.device != main.device:
-            side = self._side_stream = torch.cuda.Stream(device=main.device)
-        use_side = self.overlap_weight_grads
+        side = None
+        use_side = self.overlap_weight_grads and not self.group_weight_grads
+        if use_side:
+            side = self._side_stream
+            if side is None or side.device != main.device:
+                side = self._side_stream = torch.cuda.Stream(device=main.device)
+        pending = []
 
         def weight_grads(dy2d, x2d, w_name, b_name, span=1):
-            if use_side:
+            if self.group_weight_grads:
+                pending.append((dy2d, x2d, g(w_name, span), g(b_name, span)))
+            elif use_side:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     ops.linear_bwd_weight(dy2d, x2d, out=g(w_name, span))
@@ -345,6 +352,8 @@ class SASRec(BaseModel):
         sp = self._local_sparse
         ops.sasrec_occ_segsum(self._occ_ws, dx0, s["out"], coef, self.item_num, sp, 1.0)
         self.sparse_table_grad = sp
+        if pending:
+            ops.grouped_linear_bwd_weight(pending)
         if use_side:
             main.wait_stream(side)
         self._saved = None

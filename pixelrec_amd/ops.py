@@ -34,7 +34,7 @@ class Workspace:
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         device = torch.device(device)
-        stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        stream = _l.raw_stream() if device.type == "cuda" else 0
         key = (device.type, device.index, stream)
         b = self._buf.get(key)
         if b is None or b.numel() < nbytes:
@@ -146,6 +146,26 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor | Non
         _l.check(L.pxr_linear_bwd_weight_f32(_l.ptr(dy), _l.ptr(x), _l.ptr(dW), M, N, K, _l.ptr(ws), ws_bytes,
                                              _l.stream_ptr()), "pxr_linear_bwd_weight_f32")
     return dW
+
+
+def grouped_linear_bwd_weight(problems):
+    """problems: list of (dy2d [M,N], x2d [M,K], dW [N,K] out, db [N] out | None).  One launch for all of them."""
+    import ctypes
+
+    L = _l.load()
+    n = len(problems)
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    dy = P(*[p[0].data_ptr() for p in problems])
+    x = P(*[p[1].data_ptr() for p in problems])
+    dW = P(*[p[2].data_ptr() for p in problems])
+    db = P(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems])
+    M = I(*[p[0].shape[0] for p in problems])
+    N = I(*[p[0].shape[1] for p in problems])
+    K = I(*[p[1].shape[1] for p in problems])
+    flops = sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in problems)
+    with _gemm_timer(flops):
+        _l.check(L.pxr_grouped_linear_bwd_weight_f32(n, dy, x, dW, db, M, N, K, _l.stream_ptr()),
+                 "pxr_grouped_linear_bwd_weight_f32")
 
 
 def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None):
