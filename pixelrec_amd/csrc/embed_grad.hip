@@ -231,41 +231,77 @@ struct SegSumArgs {
   int D, T;
 };
 
-// One block per unique row.  The 256 threads form G = 256/dv groups (dv = D/4 float4 columns, G >= 1); group g
+// One block per unique row.  The 512 threads form G = 512/dv groups (dv = D/4 float4 columns, G >= 1); group g
 // sums occurrences s0+g, s0+g+G, ... in order, then the G partial rows are added in group order through LDS:
 // a fixed summation tree => bit-reproducible, and popular items (hundreds of occurrences under the Zipf
 // popularity) no longer serialise on one chain of dependent 2 KB row reads.
+constexpr int SEG_THREADS = 512;
+constexpr int SEG_CHUNK = 512;   // occurrences staged per pass
+
+// One block per unique row.  Per chunk of <= 512 occurrences the block first resolves every occurrence to
+// (source row offset, coefficient) cooperatively into LDS -- one coalesced read of the sorted ids instead of a
+// dependent load chain per occurrence -- then the 512 threads form G = 512/dv groups (dv = D/4 float4 columns);
+// group g adds occurrences g, g+G, ... in order with 8 independent row loads in flight, and the G partial rows are
+// combined in group order through LDS: a fixed summation tree => bit-reproducible, and a popular item (hundreds of
+// occurrences under the Zipf popularity) costs ~15 load round trips instead of hundreds.
 template <int MODE>
-__global__ void __launch_bounds__(256) segsum_kernel(SegSumArgs a) {
+__global__ void __launch_bounds__(SEG_THREADS) segsum_kernel(SegSumArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 sred[];  // [G][dv]
+  __shared__ int64_t s_off[SEG_CHUNK];
+  __shared__ float s_cf[SEG_CHUNK];
   const int nu = *a.n_uniq;
   const int dv = a.D >> 2;
-  const int G = dv >= 256 ? 1 : 256 / dv;
-  const int g = (dv >= 256) ? 0 : threadIdx.x / dv;
-  const int c0 = (dv >= 256) ? threadIdx.x : threadIdx.x - g * dv;
+  const int G = dv >= SEG_THREADS ? 1 : SEG_THREADS / dv;
+  const int g = (dv >= SEG_THREADS) ? 0 : threadIdx.x / dv;
+  const int c0 = (dv >= SEG_THREADS) ? threadIdx.x : threadIdx.x - g * dv;
   const bool active = g < G;
   for (int u = blockIdx.x; u < nu; u += gridDim.x) {
     const int s0 = a.seg_start[u], s1 = a.seg_start[u + 1];
-    for (int cb = 0; cb < dv; cb += 256) {  // dv > 256 (D > 1024): column blocks of 256 float4
+    for (int cb = 0; cb < dv; cb += SEG_THREADS) {  // dv > 512 (D > 2048): column blocks
       const int c4 = cb + c0;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (active && c4 < dv) {
-        for (int s = s0 + g; s < s1; s += G) {
-          const int o = a.vals[s];
-          float cf = 1.f;
-          const float* row;
+      for (int sb = s0; sb < s1; sb += SEG_CHUNK) {
+        const int cnt = min(SEG_CHUNK, s1 - sb);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += SEG_THREADS) {
+          const int o = a.vals[sb + j];
           if constexpr (MODE == MODE_ROWS) {
-            row = a.src0 + (int64_t)o * a.D;
+            s_off[j] = (int64_t)o * a.D;
+            s_cf[j] = 1.f;
           } else {
             const int type = o / a.T, r = o - type * a.T;
-            row = (type == 0 ? a.src0 : a.src1) + (int64_t)r * a.D;
-            cf = (type == 0) ? 1.f : (type == 1 ? a.coef[r] : -a.coef[r]);
+            // type 0 reads src0 (dx0); types 1/2 read src1 (out): encode the source in the sign bit of the offset
+            s_off[j] = (type == 0) ? (int64_t)r * a.D : ~((int64_t)r * a.D);
+            s_cf[j] = (type == 0) ? 1.f : (type == 1 ? a.coef[r] : -a.coef[r]);
           }
-          const float4 v = *reinterpret_cast<const float4*>(row + c4 * 4);
-          acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
+        }
+        __syncthreads();
+        if (active && c4 < dv) {
+          auto rowp = [&](int j) -> const float* {
+            const int64_t off = s_off[j];
+            if constexpr (MODE == MODE_ROWS) return a.src0 + off;
+            else return off >= 0 ? a.src0 + off : a.src1 + ~off;
+          };
+          int j = g;
+          for (; j + 7 * G < cnt; j += 8 * G) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(rowp(j + q * G) + c4 * 4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const float cf = s_cf[j + q * G];
+              acc.x += cf * v[q].x; acc.y += cf * v[q].y; acc.z += cf * v[q].z; acc.w += cf * v[q].w;
+            }
+          }
+          for (; j < cnt; j += G) {
+            const float cf = s_cf[j];
+            const float4 v = *reinterpret_cast<const float4*>(rowp(j) + c4 * 4);
+            acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
+          }
         }
       }
       if (G > 1) {
+        __syncthreads();
         if (active) sred[g * dv + c0] = acc;
         __syncthreads();
         if (g == 0) {
@@ -274,7 +310,6 @@ __global__ void __launch_bounds__(256) segsum_kernel(SegSumArgs a) {
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
           }
         }
-        __syncthreads();
       }
       if (g == 0 && c4 < dv) {
         acc.x *= a.scale; acc.y *= a.scale; acc.z *= a.scale; acc.w *= a.scale;
@@ -356,7 +391,7 @@ extern "C" int pxr_embed_grad_rows_f32(const int64_t* idx, int64_t n, const floa
   a.vals = sorted_vals; a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = rows; a.uniq_rows = uniq_rows;
   a.scale = scale; a.D = D; a.T = (int)n;
   const int grid = (int)(n < 4096 ? n : 4096);
-  hipLaunchKernelGGL(segsum_kernel<MODE_ROWS>, dim3(grid), dim3(256), 256 * 16, st, a);
+  hipLaunchKernelGGL(segsum_kernel<MODE_ROWS>, dim3(grid), dim3(SEG_THREADS), SEG_THREADS * 16, st, a);
   return pxr_check_launch("pxr_embed_grad_rows_f32");
 }
 
@@ -402,7 +437,7 @@ extern "C" int pxr_sasrec_occ_segsum(const void* ws, int64_t ws_bytes, int B, in
   a.vals = final_sorted_vals(w, n_table); a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = dx0; a.src1 = out;
   a.coef = coef; a.uniq_rows = uniq_rows; a.scale = scale; a.D = D; a.T = B * L;
   const int grid = n < 4096 ? n : 4096;
-  hipLaunchKernelGGL(segsum_kernel<MODE_SASREC>, dim3(grid), dim3(256), 256 * 16, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(segsum_kernel<MODE_SASREC>, dim3(grid), dim3(SEG_THREADS), SEG_THREADS * 16, (hipStream_t)stream, a);
   return pxr_check_launch("pxr_sasrec_occ_segsum");
 }
 

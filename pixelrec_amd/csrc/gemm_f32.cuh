@@ -29,9 +29,13 @@ namespace pxr {
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_THREADS = 256;
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+// KW = number of wave groups that split the k-steps of each K tile between them (intra-workgroup split-K): KW=2
+// doubles the waves per output tile, which is what hides the LDS/global latency bubbles when a GEMM has too few
+// output tiles to fill the chip (M = B*L = 3200 tokens); the KW partial accumulators are added through LDS.
+template <int BM, int BN, bool A_KC, bool B_KC, int KW = 1>
 struct GemmCfg {
   static constexpr int BK = GEMM_BK;
+  static constexpr int NT = GEMM_THREADS * KW;
   static constexpr int LDA = A_KC ? (BK + 4) : BM;
   static constexpr int LDB = B_KC ? (BK + 4) : BN;
   static constexpr int A_STAGE = (A_KC ? BM : BK) * LDA;  // floats
@@ -40,8 +44,9 @@ struct GemmCfg {
   static constexpr int LDS_BYTES = 2 * STAGE * 4;
   static constexpr int WM = BM / 2, WN = BN / 2;
   static constexpr int TM = WM / 32, TN = WN / 32;
-  static constexpr int A_LD4 = BM * BK / 4 / GEMM_THREADS;  // float4 loads per thread per tile
-  static constexpr int B_LD4 = BN * BK / 4 / GEMM_THREADS;
+  static constexpr int A_LD4 = BM * BK / 4 / NT;  // float4 loads per thread per tile
+  static constexpr int B_LD4 = BN * BK / 4 / NT;
+  static_assert(A_LD4 >= 1 && B_LD4 >= 1, "tile too small for this many threads");
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tile must be a multiple of 64");
   struct Acc {
     f32x16 v[TM][TN];
@@ -50,12 +55,12 @@ struct GemmCfg {
 
 // ---- global -> register tile fetch (zero-filled outside the matrix) ------------------------------------
 // KC operand: matrix [X][K] (row stride ld), tile rows x0.., k range k0..k0+31
-template <int BX, int NLD>
+template <int BX, int NLD, int NT>
 __device__ __forceinline__ void fetch_kc(float4 (&r)[NLD], const float* __restrict__ g, int64_t ld, int x0,
                                          int X, int k0, int kend, int tid) {
 #pragma unroll
   for (int p = 0; p < NLD; ++p) {
-    const int f = tid + p * GEMM_THREADS;  // float4 index in tile: row = f/8, q = f%8
+    const int f = tid + p * NT;  // float4 index in tile: row = f/8, q = f%8
     const int row = f >> 3, q = f & 7;
     const int gx = x0 + row, gk = k0 + q * 4;
     if (gx < X && gk < kend)
@@ -64,23 +69,23 @@ __device__ __forceinline__ void fetch_kc(float4 (&r)[NLD], const float* __restri
       r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
-template <int BX, int NLD>
+template <int BX, int NLD, int NT>
 __device__ __forceinline__ void stash_kc(const float4 (&r)[NLD], float* lds, int tid) {
 #pragma unroll
   for (int p = 0; p < NLD; ++p) {
-    const int f = tid + p * GEMM_THREADS;
+    const int f = tid + p * NT;
     const int row = f >> 3, q = f & 7;
     *reinterpret_cast<float4*>(lds + row * (GEMM_BK + 4) + q * 4) = r[p];
   }
 }
 // XC operand: matrix [K][X] (row stride ld), tile k rows k0..k0+31, x range x0..x0+BX-1
-template <int BX, int NLD>
+template <int BX, int NLD, int NT>
 __device__ __forceinline__ void fetch_xc(float4 (&r)[NLD], const float* __restrict__ g, int64_t ld, int x0,
                                          int X, int k0, int kend, int tid) {
   constexpr int Q = BX / 4;  // float4 per k row
 #pragma unroll
   for (int p = 0; p < NLD; ++p) {
-    const int f = tid + p * GEMM_THREADS;
+    const int f = tid + p * NT;
     const int kk = f / Q, q = f % Q;
     const int gk = k0 + kk, gx = x0 + q * 4;
     if (gk < kend && gx < X)
@@ -89,12 +94,12 @@ __device__ __forceinline__ void fetch_xc(float4 (&r)[NLD], const float* __restri
       r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
-template <int BX, int NLD>
+template <int BX, int NLD, int NT>
 __device__ __forceinline__ void stash_xc(const float4 (&r)[NLD], float* lds, int tid) {
   constexpr int Q = BX / 4;
 #pragma unroll
   for (int p = 0; p < NLD; ++p) {
-    const int f = tid + p * GEMM_THREADS;
+    const int f = tid + p * NT;
     const int kk = f / Q, q = f % Q;
     *reinterpret_cast<float4*>(lds + kk * BX + q * 4) = r[p];
   }
@@ -105,16 +110,18 @@ __device__ __forceinline__ void stash_xc(const float4 (&r)[NLD], float* lds, int
 //                                         [n0 + wn*WN + bj*32 + (l&31)]          (gfx950 32x32 C/D map)
 // CS (only with an XC A operand): additionally accumulate, per thread, the sum over k of the A float4s it stages
 // (column sums of the stored [K][M] matrix = bias gradient when A = dY) into *cs; the caller reduces across threads.
-template <int BM, int BN, bool A_KC, bool B_KC, bool CS = false>
-__device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_KC>::Acc& accs,
+template <int BM, int BN, bool A_KC, bool B_KC, bool CS = false, int KW = 1>
+__device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_KC, KW>::Acc& accs,
                                               const float* __restrict__ A, int64_t lda,
                                               const float* __restrict__ B, int64_t ldb, int M, int N,
                                               int kbeg, int kend, int m0, int n0, float* smem,
                                               float4* cs = nullptr) {
-  using Cfg = GemmCfg<BM, BN, A_KC, B_KC>;
+  using Cfg = GemmCfg<BM, BN, A_KC, B_KC, KW>;
+  constexpr int NT = Cfg::NT;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wk = wave >> 2, w4 = wave & 3;
+  const int wm = w4 >> 1, wn = w4 & 1;
   const int h = lane >> 5, r = lane & 31;
   auto& acc = accs.v;
 
@@ -131,23 +138,23 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
 
   auto fetch = [&](int kt) {
     const int k0 = kbeg + kt * GEMM_BK;
-    if constexpr (A_KC) fetch_kc<BM, Cfg::A_LD4>(ra, A, lda, m0, M, k0, kend, tid);
-    else fetch_xc<BM, Cfg::A_LD4>(ra, A, lda, m0, M, k0, kend, tid);
+    if constexpr (A_KC) fetch_kc<BM, Cfg::A_LD4, NT>(ra, A, lda, m0, M, k0, kend, tid);
+    else fetch_xc<BM, Cfg::A_LD4, NT>(ra, A, lda, m0, M, k0, kend, tid);
     if constexpr (CS) {
       static_assert(!A_KC, "column sums are taken over an x-contiguous A operand");
 #pragma unroll
       for (int p = 0; p < Cfg::A_LD4; ++p) { cs->x += ra[p].x; cs->y += ra[p].y; cs->z += ra[p].z; cs->w += ra[p].w; }
     }
-    if constexpr (B_KC) fetch_kc<BN, Cfg::B_LD4>(rb, B, ldb, n0, N, k0, kend, tid);
-    else fetch_xc<BN, Cfg::B_LD4>(rb, B, ldb, n0, N, k0, kend, tid);
+    if constexpr (B_KC) fetch_kc<BN, Cfg::B_LD4, NT>(rb, B, ldb, n0, N, k0, kend, tid);
+    else fetch_xc<BN, Cfg::B_LD4, NT>(rb, B, ldb, n0, N, k0, kend, tid);
   };
   auto stash = [&](int buf) {
     float* sa = smem + buf * Cfg::STAGE;
     float* sb = sa + Cfg::A_STAGE;
-    if constexpr (A_KC) stash_kc<BM, Cfg::A_LD4>(ra, sa, tid);
-    else stash_xc<BM, Cfg::A_LD4>(ra, sa, tid);
-    if constexpr (B_KC) stash_kc<BN, Cfg::B_LD4>(rb, sb, tid);
-    else stash_xc<BN, Cfg::B_LD4>(rb, sb, tid);
+    if constexpr (A_KC) stash_kc<BM, Cfg::A_LD4, NT>(ra, sa, tid);
+    else stash_xc<BM, Cfg::A_LD4, NT>(ra, sa, tid);
+    if constexpr (B_KC) stash_kc<BN, Cfg::B_LD4, NT>(rb, sb, tid);
+    else stash_xc<BN, Cfg::B_LD4, NT>(rb, sb, tid);
   };
 
   fetch(0);
@@ -160,7 +167,8 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
     const float* sa = smem + (kt & 1) * Cfg::STAGE;
     const float* sb = sa + Cfg::A_STAGE;
 #pragma unroll
-    for (int ks = 0; ks < GEMM_BK / 8; ++ks) {
+    for (int ks0 = 0; ks0 < GEMM_BK / 8; ks0 += KW) {
+      const int ks = ks0 + (KW > 1 ? wk : 0);
       float a[Cfg::TM][4], b[Cfg::TN][4];
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
@@ -194,6 +202,31 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
     }
     if (more) stash((kt + 1) & 1);
     __syncthreads();
+  }
+  if constexpr (KW > 1) {
+    // add the partial accumulators of wave group 1 into wave group 0 through LDS (the staging buffers are free:
+    // the loop ended with a barrier).  Layout [w4][element][lane] => conflict-free 4-byte accesses.
+    static_assert(KW == 2, "intra-workgroup split-K is built for 2 wave groups");
+    constexpr int NE = Cfg::TM * Cfg::TN * 16;
+    static_assert(4 * NE * 64 <= 2 * Cfg::STAGE, "accumulator exchange does not fit in the staging LDS");
+    float* ex = smem + (w4 * NE) * 64 + lane;
+    if (wk == 1) {
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) ex[((i * Cfg::TN + j) * 16 + e) * 64] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += ex[((i * Cfg::TN + j) * 16 + e) * 64];
+    }
   }
 }
 

@@ -18,13 +18,13 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-__global__ void __launch_bounds__(GEMM_THREADS)
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1>
+__global__ void __launch_bounds__(GEMM_THREADS * KW)
 gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
             float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
             float* __restrict__ aux, int64_t ldaux, int tiles_m, int tiles_n, int ksplit_len,
             int64_t split_stride) {
-  using Cfg = GemmCfg<BM, BN, A_KC, B_KC>;
+  using Cfg = GemmCfg<BM, BN, A_KC, B_KC, KW>;
   __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
 
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -35,10 +35,11 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
   C += (int64_t)blockIdx.y * split_stride;
 
   typename Cfg::Acc accs;
-  gemm_mainloop<BM, BN, A_KC, B_KC>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
+  gemm_mainloop<BM, BN, A_KC, B_KC, false, KW>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
 
   auto& acc = accs.v;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (KW > 1 && wave >= 4) return;  // the second wave group handed its partial sums over in the main loop
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
@@ -165,14 +166,14 @@ __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_kernel(DwGroup g) {
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1>
 static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                        int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
                        int64_t split_stride, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI>), dim3(tiles_m * tiles_n, splits), dim3(GEMM_THREADS), 0,
-                     st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m, tiles_n, ksplit_len,
-                     split_stride);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW>), dim3(tiles_m * tiles_n, splits),
+                     dim3(GEMM_THREADS * KW), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
+                     tiles_n, ksplit_len, split_stride);
   return pxr_check_launch("pxr_gemm_f32");
 }
 
@@ -187,6 +188,9 @@ static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, 
     case 128: PXR_TILE(128, 128);
     case 12864: PXR_TILE(128, 64);
     case 64128: PXR_TILE(64, 128);
+    case 642:  // 64x64 tile, 8 waves: two wave groups split the k-steps (see GemmCfg KW)
+      return launch_gemm<64, 64, A_KC, B_KC, EPI, 2>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
+                                                     ksplit_len, split_stride, st);
     default: PXR_TILE(64, 64);
   }
 #undef PXR_TILE
@@ -225,7 +229,7 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   bool big = (t128 >= 384);  // >= 1.5 waves of 128x128 tiles over 256 CUs; otherwise 64x64 tiles fill the chip better
   int tile = big ? 128 : 64;
-  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128) tile = tile_hint;
+  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642) tile = tile_hint;
   const int bm = (tile == 128 || tile == 12864) ? 128 : 64;
   const int bn = (tile == 128 || tile == 64128) ? 128 : 64;
   const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
