@@ -81,8 +81,10 @@ int pxr_ln_residual_fwd_f32(const float* x, const float* res, const float* gamma
                             int rows, int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
                             uint32_t stream_id, const int64_t* step_dev, void* stream);
 /* autograd of either site.  gather_mode=1: dy is w.r.t. the dropped output, dz = grad of (table row + pos).
- * gather_mode=0: dz = grad w.r.t. res, dx (optional) = grad w.r.t. x.  dgamma/dbeta are overwritten. */
+ * gather_mode=0: dz = grad w.r.t. res, dx (optional) = grad w.r.t. x.  dgamma/dbeta are overwritten; pass both NULL to
+ * defer the final reduction (partials stay in ws, reduce them with pxr_reduce_partials_multi_f32). */
 int64_t pxr_ln_bwd_ws_bytes(int rows, int D);
+int pxr_ln_bwd_partial_rows(int rows);   /* rows of the [P, 2*D] partial buffer left in ws when dgamma/dbeta are NULL */
 int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd, const float* gamma,
                    int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed,
                    uint32_t stream_id, const int64_t* step_dev, void* ws, int64_t ws_bytes, void* stream);
@@ -109,6 +111,11 @@ int pxr_grouped_linear_bwd_weight_f32(int n, const float* const* dy, const float
                                       float* const* db, const int* M, const int* N, const int* K, void* stream);
 /* out[n] = sum_m x[m,n]  (bias grads; position-embedding grad = colsum of dx0 viewed [B, L*D]); deterministic */
 int64_t pxr_colsum_ws_bytes(int M, int N);
+int pxr_colsum_partial_rows(int M);      /* rows of the [P, N] partial buffer left in ws when out is NULL */
+/* out_a[i][c] (c < split[i]) / out_b[i][c-split[i]] = sum_p part[i][p][c] for up to 16 partial buffers in one launch
+ * (host arrays of n entries; out_b[i] may be NULL => single output). */
+int pxr_reduce_partials_multi_f32(int n, const float* const* part, const int* P, const int* N, float* const* out_a,
+                                  float* const* out_b, const int* split, void* stream);
 int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- masked multi-head self-attention core ------------------------------------------------------------------ */

@@ -324,6 +324,11 @@ extern "C" int pxr_ln_residual_fwd_f32(const float* x, const float* res, const f
   return launch_ln_fwd<false>(a, (hipStream_t)stream);
 }
 
+extern "C" int pxr_ln_bwd_partial_rows(int rows) {
+  int rpb;
+  return ln_bwd_blocks(rows, &rpb);
+}
+
 extern "C" int64_t pxr_ln_bwd_ws_bytes(int rows, int D) {
   int rpb;
   const int nblk = ln_bwd_blocks(rows, &rpb);
@@ -337,7 +342,8 @@ extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xha
                               const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
                               float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ws,
                               int64_t ws_bytes, void* stream) {
-  PXR_REQUIRE(dy && xhat && rstd && gamma && dz && dgamma && dbeta && ws, "pxr_ln_bwd_f32: null pointer");
+  PXR_REQUIRE(dy && xhat && rstd && gamma && dz && ws, "pxr_ln_bwd_f32: null pointer");
+  PXR_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "pxr_ln_bwd_f32: dgamma and dbeta must both be given or both NULL");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && rows > 0, "pxr_ln_bwd_f32: bad shape");
   LnBwdArgs a{};
   a.dy = dy; a.xhat = xhat; a.rstd = rstd; a.gamma = gamma; a.dz = dz; a.dx = dx; a.part = (float*)ws;
@@ -352,7 +358,58 @@ extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xha
   hipStream_t st = (hipStream_t)stream;
   int rc = gather_mode ? launch_ln_bwd<true>(a, nblk, st) : launch_ln_bwd<false>(a, nblk, st);
   if (rc) return rc;
+  if (!dgamma) return PXR_OK;  // deferred: the caller reduces ws ([pxr_ln_bwd_partial_rows, 2*D]) later, e.g. with
+                               // pxr_reduce_partials_multi_f32 together with the other sites of the backward pass
   hipLaunchKernelGGL(pxr_reduce_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, st, (const float*)ws, nblk,
                      2 * D, dgamma, dbeta, D);
   return pxr_check_launch("pxr_ln_bwd_f32(reduce)");
+}
+
+// ---- several partial reductions in one launch ------------------------------------------------------------------
+struct MultiReduce {
+  const float* part[16]; float* out_a[16]; float* out_b[16];
+  int P[16], N[16], split[16], blk_begin[17];
+  int n;
+};
+__global__ void __launch_bounds__(256) reduce_partials_multi_kernel(MultiReduce m) {
+  __shared__ float red[8][33];
+  int pi = 0;
+  for (int i = 1; i < m.n; ++i)
+    if ((int)blockIdx.x >= m.blk_begin[i]) pi = i;
+  const float* part = m.part[pi];
+  const int P = m.P[pi], N = m.N[pi];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = ((int)blockIdx.x - m.blk_begin[pi]) * 32 + tx;
+  float s = 0.f;
+  if (col < N)
+    for (int p = ty; p < P; p += 8) s += part[(int64_t)p * N + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < N) {
+    const float v = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) +
+                    ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    if (col < m.split[pi]) m.out_a[pi][col] = v;
+    else m.out_b[pi][col - m.split[pi]] = v;
+  }
+}
+
+// out_a[i][c] (c < split[i]) / out_b[i][c - split[i]] = sum_p part[i][p][c], c < N[i], for up to 16 independent
+// partial buffers in ONE launch (same fixed-order tree as the single form => same bits).
+extern "C" int pxr_reduce_partials_multi_f32(int n, const float* const* part, const int* P, const int* N,
+                                             float* const* out_a, float* const* out_b, const int* split,
+                                             void* stream) {
+  PXR_REQUIRE(n >= 1 && n <= 16 && part && P && N && out_a && out_b && split, "pxr_reduce_partials_multi_f32: bad args");
+  MultiReduce m{};
+  m.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    PXR_REQUIRE(part[i] && out_a[i] && P[i] > 0 && N[i] > 0, "pxr_reduce_partials_multi_f32: problem %d is bad", i);
+    m.part[i] = part[i]; m.out_a[i] = out_a[i]; m.out_b[i] = out_b[i] ? out_b[i] : out_a[i];
+    m.P[i] = P[i]; m.N[i] = N[i]; m.split[i] = out_b[i] ? split[i] : N[i];
+    m.blk_begin[i] = blocks;
+    blocks += (N[i] + 31) / 32;
+  }
+  m.blk_begin[n] = blocks;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m);
+  return pxr_check_launch("pxr_reduce_partials_multi_f32");
 }

@@ -309,6 +309,7 @@ class SASRec(BaseModel):
             if side is None or side.device != main.device:
                 side = self._side_stream = torch.cuda.Stream(device=main.device)
         pending = []
+        defer = ops.DeferredReductions()   # second stage of every LayerNorm dgamma|dbeta / pos-emb reduction: one launch
 
         def weight_grads(dy2d, x2d, w_name, b_name, span=1):
             if self.group_weight_grads:
@@ -329,7 +330,7 @@ class SASRec(BaseModel):
             a = s["layers"][i]
             # FFN: h2 = LN(dropout(f2) + h1)
             dz2, dxf2 = ops.ln_bwd(0, dh, a["xhat2"], a["rstd2"], self._p(f"{i}.ln2.w"), g(f"{i}.ln2.w"),
-                                   g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0, step_dev=sdv)
+                                   g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer)
             if dxf2 is None:
                 dxf2 = dz2
             weight_grads(dxf2.view(T, D), a["f"].view(T, -1), f"{i}.f2.w", f"{i}.f2.b")
@@ -338,7 +339,7 @@ class SASRec(BaseModel):
             dh1 = ops.linear_bwd_input(du, self._p(f"{i}.f1.w"), add=dz2)
             # attention block: h1 = LN(dropout(a) + h)
             dz1, dxa = ops.ln_bwd(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
-                                  g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0, step_dev=sdv)
+                                  g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer)
             if dxa is None:
                 dxa = dz1
             weight_grads(dxa.view(T, D), a["ctx"].view(T, D), f"{i}.o.w", f"{i}.o.b")
@@ -347,8 +348,9 @@ class SASRec(BaseModel):
             weight_grads(dqkv.view(T, 3 * D), a["h_in"].view(T, D), f"{i}.q.w", f"{i}.q.b", 3)
             dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1)
         dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,
-                            step_dev=sdv)
-        ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1))
+                            step_dev=sdv, defer=defer)
+        ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1), defer=defer)
+        defer.flush()
         sp = self._local_sparse
         ops.sasrec_occ_segsum(self._occ_ws, dx0, s["out"], coef, self.item_num, sp, 1.0)
         self.sparse_table_grad = sp

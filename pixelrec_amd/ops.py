@@ -168,13 +168,18 @@ def grouped_linear_bwd_weight(problems):
                  "pxr_grouped_linear_bwd_weight_f32")
 
 
-def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None):
-    """out[n] = sum_m x[m, n] (deterministic two-stage reduction)."""
+def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None, defer=None):
+    """out[n] = sum_m x[m, n] (deterministic two-stage reduction; second stage deferred when `defer` is given)."""
     L = _l.load()
     _req(x2d, torch.float32, "x")
     M, N = x2d.shape
     o = out if out is not None else torch.empty(N, dtype=torch.float32, device=x2d.device)
     ws_bytes = int(L.pxr_colsum_ws_bytes(M, N))
+    if defer is not None:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2d.device)
+        defer.add(ws, int(L.pxr_colsum_partial_rows(M)), N, o)
+        _l.check(L.pxr_colsum_f32(_l.ptr(x2d), N, M, N, None, _l.ptr(ws), ws_bytes, _l.stream_ptr()), "pxr_colsum_f32")
+        return o
     ws = _ws.get(ws_bytes, x2d.device)
     _l.check(L.pxr_colsum_f32(_l.ptr(x2d), N, M, N, _l.ptr(o), _l.ptr(ws), ws_bytes, _l.stream_ptr()), "pxr_colsum_f32")
     return o
@@ -211,9 +216,37 @@ def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, s
     return y, xhat, rstd
 
 
+class DeferredReductions:
+    """Collects the second stage of several partial reductions (LayerNorm dgamma|dbeta, column sums) so that one
+    launch finishes all of them at the end of a backward pass."""
+
+    def __init__(self):
+        self.items = []      # (part tensor, P, N, out_a, out_b | None, split)
+
+    def add(self, part, P, N, out_a, out_b=None, split=0):
+        self.items.append((part, P, N, out_a, out_b, split))
+
+    def flush(self):
+        import ctypes
+
+        if not self.items:
+            return
+        Lb = _l.load()
+        for c0 in range(0, len(self.items), 16):
+            it = self.items[c0:c0 + 16]
+            n = len(it)
+            Pp, I = ctypes.c_void_p * n, ctypes.c_int * n
+            _l.check(Lb.pxr_reduce_partials_multi_f32(
+                n, Pp(*[x[0].data_ptr() for x in it]), I(*[x[1] for x in it]), I(*[x[2] for x in it]),
+                Pp(*[x[3].data_ptr() for x in it]), Pp(*[(x[4].data_ptr() if x[4] is not None else None) for x in it]),
+                I(*[x[5] for x in it]), _l.stream_ptr()), "pxr_reduce_partials_multi_f32")
+        self.items = []
+
+
 def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0, stream_id=0, need_dx=False,
-           step_dev=None):
-    """Backward of either LN site; dgamma/dbeta ([D] tensors) are overwritten.  Returns (dz, dx|None)."""
+           step_dev=None, defer: DeferredReductions | None = None):
+    """Backward of either LN site; dgamma/dbeta ([D] tensors) are overwritten (by `defer.flush()` when a
+    DeferredReductions collector is given).  Returns (dz, dx|None)."""
     Lb = _l.load()
     _req(dy, torch.float32, "dy")
     D = dy.shape[-1]
@@ -221,7 +254,12 @@ def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0
     dz = torch.empty_like(dy)
     dx = torch.empty_like(dy) if need_dx else None
     ws_bytes = int(Lb.pxr_ln_bwd_ws_bytes(rows, D))
-    ws = _ws.get(ws_bytes, dy.device)
+    if defer is not None:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)   # must outlive this call
+        defer.add(ws, int(Lb.pxr_ln_bwd_partial_rows(rows)), 2 * D, dgamma, dbeta, D)
+        dgamma = dbeta = None
+    else:
+        ws = _ws.get(ws_bytes, dy.device)
     _l.check(Lb.pxr_ln_bwd_f32(int(gather_mode), _l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), rows, D,
                                _l.ptr(dz), _l.ptr(dx), _l.ptr(dgamma), _l.ptr(dbeta), p_drop, seed, stream_id,
                                _l.ptr(step_dev), _l.ptr(ws), ws_bytes, _l.stream_ptr()), "pxr_ln_bwd_f32")
