@@ -139,6 +139,16 @@ int pxr_bpr_loss_bwd_f32(const float* pos_score, const float* neg_score, const f
                          const int64_t* items, const int64_t* masked_index, int B, int L, int D, float grad_scale,
                          const float* grad_scale_dev, float* dout, float* coef, void* stream);
 
+/* ---- PixelNet (MOSASRec) ------------------------------------------------------------------------------------- */
+/* Gradient w.r.t. the visual encoder's output viewed [B, L+1, 2, D] (pos_t | neg_t interleaved, PixelNet/
+ * mosasrec.py:69-74,88-89): d_emb[b,t,0] = [t<L] dx0[b,t] + [t>=1] coef[b,t-1] out[b,t-1];  d_emb[b,t,1] = -[t>=1] ... */
+int pxr_mosasrec_emb_grad_f32(const float* dx0, const float* out, const float* coef, int B, int L, int D, float* d_emb,
+                              void* stream);
+/* The reference's image transform on the GPU (data/dataset/trainset.py:85-96): uint8 HWC store [n_store,H,W,3] gathered
+ * by item id -> fp32 [n,3,H,W] = (x/255 - 0.5)/0.5; id 0 (padding) -> zeros. */
+int pxr_image_u8_to_f32(const uint8_t* store, int64_t n_store, int H, int W, const int64_t* ids, int n, float* out,
+                        void* stream);
+
 /* ---- full-sort evaluation ------------------------------------------------------------------------------------ */
 /* Fused  scores = users x table^T (sasrec.py:112)  ->  scores[:,0] = -inf, scores[history] = -inf (trainer.py:333-336)
  * ->  top-K (collector.py:133): the [B,N] score matrix never reaches HBM.  users [B,D] with row stride ld_users;

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "pxr_attn_bwd_f32": (_I, [_P, _I64, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _P, _I64, _F, _U64, _U32, _P, _P]),
     "pxr_bpr_loss_fwd_f32": (_I, [_P, _P, _I64, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pxr_bpr_loss_bwd_f32": (_I, [_P, _P, _P, _I64, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "pxr_mosasrec_emb_grad_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "pxr_image_u8_to_f32": (_I, [_P, _I64, _I, _I, _P, _I, _P, _P]),
     "pxr_score_topk_ws_bytes": (_I64, [_I, _I, _I]),
     "pxr_score_topk_f32": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I64, _P]),
     "pxr_adamw_flat_f32": (_I, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),

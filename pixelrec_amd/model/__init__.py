@@ -1,2 +1,3 @@
 from .basemodel import BaseModel  # noqa: F401
 from .sasrec import SASRec  # noqa: F401
+from .mosasrec import MOSASRec  # noqa: F401

@@ -5,20 +5,13 @@ Contract kept: class attr `input_type`; `__init__(config, datal
 0-dim loss` usable with `loss.backward()`; `predict(item_seq, item_feature) -> [B, N]`; `compute_item_all()`;
 an nn.Module whose `state_dict()` keys are exactly the reference's, so checkpoints interchange.
 
-What differs underneath (nothing below runs stock ATen math on the hot path):
-  * the nn.Linear / nn.LayerNorm / nn.Embedding sub-modules are PARAMETER CONTAINERS only (they give the
-    reference's parameter names and `_init_weights` semantics); forward/backward are hand-written HIP kernels
-    called through the C ABI (pixelrec_amd/ops.py -> include/pxr.h);
-  * all non-table parameters live in ONE flat fp32 buffer (query|key|value weights adjacent => one fused QKV
-    GEMM; one flat gradient buffer => one fused AdamW launch and one RCCL all-reduce);
-  * the table gradient is never dense: backward leaves `(uniq_idx, uniq_rows, n)` in `self.sparse_table_grad`
-    for pixelrec_amd.optim.PxrAdamW (dense AdamW semantics, sparse gradient);
-  * gradients are OVERWRITTEN by each backward (the reference calls zero_grad() before every step,
-    trainer.py:117, so accumulation is never relied on).
+The sequence block itself lives in seqcore.SeqRecCore; this class adds the item-embedding table:
+  * the table gradient is never dense: backward leaves `(uniq_idx, uniq_rows, n)` in `self.sparse_table_grad` for
+    pixelrec_amd.optim.PxrAdamW (dense AdamW semantics, sparse gradient);
+  * the occurrence sort that de-duplicates the batch's ids runs BEFORE the forward pass, so that a lazy optimizer can
+    bring exactly those rows up to date before they are read.
 """
 from __future__ import annotations
-
-import math
 
 import torch
 import torch.nn as nn
@@ -26,39 +19,7 @@ import torch.nn as nn
 from .. import ops
 from ..lib import PxrError
 from ..utils.enum_type import InputType
-from .basemodel import BaseModel
-
-
-# ---- parameter containers with the reference's module tree (names only; their forward is never called) -----
-class _MultiHeadAttentionParams(nn.Module):
-    def __init__(self, hidden, eps):
-        super().__init__()
-        self.query = nn.Linear(hidden, hidden)
-        self.key = nn.Linear(hidden, hidden)
-        self.value = nn.Linear(hidden, hidden)
-        self.dense = nn.Linear(hidden, hidden)
-        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
-
-
-class _FeedForwardParams(nn.Module):
-    def __init__(self, hidden, inner, eps):
-        super().__init__()
-        self.dense_1 = nn.Linear(hidden, inner)
-        self.dense_2 = nn.Linear(inner, hidden)
-        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
-
-
-class _TransformerLayerParams(nn.Module):
-    def __init__(self, hidden, inner, eps):
-        super().__init__()
-        self.multi_head_attention = _MultiHeadAttentionParams(hidden, eps)
-        self.feed_forward = _FeedForwardParams(hidden, inner, eps)
-
-
-class _TransformerEncoderParams(nn.Module):
-    def __init__(self, n_layers, hidden, inner, eps):
-        super().__init__()
-        self.layer = nn.ModuleList([_TransformerLayerParams(hidden, inner, eps) for _ in range(n_layers)])
+from .seqcore import SeqRecCore
 
 
 class _TrainStep(torch.autograd.Function):
@@ -75,117 +36,22 @@ class _TrainStep(torch.autograd.Function):
         return None, None, None, None
 
 
-class SASRec(BaseModel):
+class SASRec(SeqRecCore):
     input_type = InputType.SEQ
 
     def __init__(self, config, dataload):
         super().__init__()
-        # hyper-parameters: same config keys as the reference (sasrec.py:16-29)
-        self.n_layers = config["n_layers"]
-        self.n_heads = config["n_heads"]
-        self.hidden_size = config["embedding_size"]
-        self.inner_size = config["inner_size"] * self.hidden_size  # sasrec.py:21 ("inner_size" is a multiplier)
-        self.hidden_dropout_prob = float(config["hidden_dropout_prob"])
-        self.attn_dropout_prob = float(config["attn_dropout_prob"])
-        self.hidden_act = config["hidden_act"]
-        self.layer_norm_eps = float(config["layer_norm_eps"])
-        self.initializer_range = config["initializer_range"]
-        self.max_seq_length = config["MAX_ITEM_LIST_LENGTH"]
         self.item_num = dataload.item_num
-        if self.hidden_act != "gelu":
-            raise NotImplementedError("pixelrec_amd SASRec implements hidden_act='gelu' (the shipped config); "
-                                      f"got {self.hidden_act!r}")
-        if self.hidden_size % self.n_heads != 0:
-            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
-                             % (self.hidden_size, self.n_heads))
-        if self.hidden_size % 4 != 0:
-            raise ValueError("embedding_size must be a multiple of 4 (16-byte vector accesses)")
-
+        self._build_core(config)
         self.item_embedding = nn.Embedding(self.item_num, self.hidden_size, padding_idx=0)
-        self.position_embedding = nn.Embedding(self.max_seq_length, self.hidden_size)
-        self.trm_encoder = _TransformerEncoderParams(self.n_layers, self.hidden_size, self.inner_size,
-                                                     self.layer_norm_eps)
-        self.LayerNorm = nn.LayerNorm(self.hidden_size, eps=self.layer_norm_eps)
-        self.dropout = nn.Dropout(self.hidden_dropout_prob)
-        self.apply(self._init_weights)
-
-        self._flat = None            # packed non-table parameters
-        self._gflat = None           # packed gradients (same layout)
-        self._views = {}
-        self._anchor = None
-        self._saved = None
+        self.apply(self._init_weights)   # incl. table row 0 (sasrec.py:49,56)
         self.sparse_table_grad = None   # the table gradient the optimizer will apply (local, or merged across ranks)
         self._local_sparse = None       # reusable output buffer of this rank's backward
-        self.grad_scale = 1.0           # 1/world_size under data parallelism (sum-all-reduce == DDP's mean)
-        self._side_stream = None
-        self._drop_dev = None              # device counter of completed backward passes (dropout seed offset)
-        self.group_weight_grads = True     # all weight/bias gradients of a backward pass in one grouped GEMM launch
-        self.overlap_weight_grads = False  # alternative: per-layer launches on a side HIP stream (see _backward_train)
         self._table_hooks = None        # the lazy optimizer (catch_up_rows / flush) when one is attached
         self._occ_ws = None             # persistent workspace carrying the sorted occurrences fwd -> bwd
-        self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
-        self._step_counter = 0
 
-    def _init_weights(self, module):
-        """N(0, initializer_range) for every Linear/Embedding weight incl. table row 0; LayerNorm (1, 0); biases 0
-        (sasrec.py:51-61)."""
-        if isinstance(module, (nn.Linear, nn.Embedding)):
-            module.weight.data.normal_(mean=0.0, std=self.initializer_range)
-        elif isinstance(module, nn.LayerNorm):
-            module.bias.data.zero_()
-            module.weight.data.fill_(1.0)
-        if isinstance(module, nn.Linear) and module.bias is not None:
-            module.bias.data.zero_()
-
-    # ------------------------------------------------------------------------------------------ flat packing
-    def _flat_specs(self):
-        specs = [("pos", self.position_embedding.weight), ("ln0.w", self.LayerNorm.weight),
-                 ("ln0.b", self.LayerNorm.bias)]
-        for i, lay in enumerate(self.trm_encoder.layer):
-            a, f = lay.multi_head_attention, lay.feed_forward
-            specs += [(f"{i}.q.w", a.query.weight), (f"{i}.k.w", a.key.weight), (f"{i}.v.w", a.value.weight),
-                      (f"{i}.q.b", a.query.bias), (f"{i}.k.b", a.key.bias), (f"{i}.v.b", a.value.bias),
-                      (f"{i}.o.w", a.dense.weight), (f"{i}.o.b", a.dense.bias),
-                      (f"{i}.ln1.w", a.LayerNorm.weight), (f"{i}.ln1.b", a.LayerNorm.bias),
-                      (f"{i}.f1.w", f.dense_1.weight), (f"{i}.f1.b", f.dense_1.bias),
-                      (f"{i}.f2.w", f.dense_2.weight), (f"{i}.f2.b", f.dense_2.bias),
-                      (f"{i}.ln2.w", f.LayerNorm.weight), (f"{i}.ln2.b", f.LayerNorm.bias)]
-        return specs
-
-    def _ensure_packed(self):
-        """(Re)build the flat parameter / gradient buffers when the parameters moved (e.g. after .to(device))."""
-        w0 = self.position_embedding.weight
-        if self._flat is not None and self._flat.device == w0.device and w0.data_ptr() == self._flat.data_ptr():
-            return
-        dev = w0.device
-        if dev.type != "cuda":
-            raise PxrError("pixelrec_amd.SASRec runs on a HIP device only (no CPU fallback); move the model with "
-                           ".to('cuda') first")
-        specs = self._flat_specs()
-        total = sum(p.numel() for _, p in specs)
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
-        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        views = {}
-        for name, p in specs:
-            n = p.numel()
-            flat[off:off + n].copy_(p.data.reshape(-1))
-            p.data = flat[off:off + n].view(p.shape)
-            p.grad = gflat[off:off + n].view(p.shape)
-            views[name] = (off, n, tuple(p.shape))
-            off += n
-        self._flat, self._gflat, self._views = flat, gflat, views
-        self._anchor = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
-        self._drop_dev = torch.full((1,), self._step_counter, dtype=torch.int64, device=dev)
-        self.item_embedding.weight.data = self.item_embedding.weight.data.contiguous()
-
-    def _p(self, name, grad=False, span=1):
-        """View of parameter `name` (or of `span` adjacent ones fused along dim 0) in the flat (grad) buffer."""
-        off, n, shape = self._views[name]
-        buf = self._gflat if grad else self._flat
-        if span == 1:
-            return buf[off:off + n].view(shape)
-        return buf[off:off + span * n].view((span * shape[0],) + tuple(shape[1:]))
+    # state_dict key order of the reference: item_embedding first (sasrec.py:31-45); register order above differs only
+    # in position, which load_state_dict does not care about.
 
     def register_table_hooks(self, opt):
         """Attach a lazy table optimizer: it is asked to bring rows up to date before they are read."""
@@ -200,44 +66,6 @@ class SASRec(BaseModel):
     def state_dict(self, *args, **kwargs):
         self.sync_table()
         return super().state_dict(*args, **kwargs)
-
-    def flat_parameters(self):
-        self._ensure_packed()
-        return self._flat, self._gflat
-
-    # ------------------------------------------------------------------------------------------ forward
-    def _encode(self, idx, idx_bstride, B, keymask, km_bstride, train: bool):
-        """ids -> last-layer states [B, L, D] (sasrec.py:68-86 / :97-109); saves activations when train."""
-        L, D, H = self.max_seq_length, self.hidden_size, self.n_heads
-        d = D // H
-        eps = self.layer_norm_eps
-        ph = self.hidden_dropout_prob if train else 0.0
-        pa = self.attn_dropout_prob if train else 0.0
-        # dropout seed of this step = base + (device counter of completed backward passes): the counter lives on the
-        # device so that a captured hipGraph draws fresh masks on every replay
-        seed = (self._drop_seed * 1000003) & 0xFFFFFFFFFFFFFFFF
-        sdv = self._drop_dev if train else None
-        table = self.item_embedding.weight.data
-        saved = {"seed": seed, "ph": ph, "pa": pa, "layers": []} if train else None
-        h, xhat0, rstd0 = ops.input_ln_fwd(table, idx, idx_bstride, B, L, self._p("pos"), self._p("ln0.w"),
-                                           self._p("ln0.b"), eps, ph, seed, 0, save=train, step_dev=sdv)
-        if train:
-            saved["xhat0"], saved["rstd0"] = xhat0, rstd0
-        for i in range(self.n_layers):
-            qkv = ops.linear_fwd(h, self._p(f"{i}.q.w", span=3), self._p(f"{i}.q.b", span=3))
-            ctx, probs = ops.attn_fwd(qkv, keymask, km_bstride, B, H, L, d, pa, seed, 1 + 3 * i, save=train, step_dev=sdv)
-            a = ops.linear_fwd(ctx, self._p(f"{i}.o.w"), self._p(f"{i}.o.b"))
-            h1, xhat1, rstd1 = ops.ln_residual_fwd(a, h, self._p(f"{i}.ln1.w"), self._p(f"{i}.ln1.b"), eps, ph, seed,
-                                                   2 + 3 * i, save=train, step_dev=sdv)
-            f, u = ops.linear_fwd(h1, self._p(f"{i}.f1.w"), self._p(f"{i}.f1.b"), gelu=True)
-            f2 = ops.linear_fwd(f, self._p(f"{i}.f2.w"), self._p(f"{i}.f2.b"))
-            h2, xhat2, rstd2 = ops.ln_residual_fwd(f2, h1, self._p(f"{i}.ln2.w"), self._p(f"{i}.ln2.b"), eps, ph, seed,
-                                                   3 + 3 * i, save=train, step_dev=sdv)
-            if train:
-                saved["layers"].append(dict(h_in=h, qkv=qkv, probs=probs, ctx=ctx, xhat1=xhat1, rstd1=rstd1, h1=h1,
-                                            u=u, f=f, xhat2=xhat2, rstd2=rstd2))
-            h = h2
-        return h, saved
 
     def _forward_train(self, items, masked_index):
         B = items.shape[0]
@@ -257,16 +85,7 @@ class SASRec(BaseModel):
                 self._table_hooks.catch_up_rows(sp.idx, sp.n, sp.cap)
         elif self._table_hooks is not None:
             self.sync_table()
-        out, saved = self._encode(items, 2 * (L + 1), B, masked_index, L, train=self.training)
-        table = self.item_embedding.weight.data
-        loss, pos, neg = ops.bpr_loss_fwd(out, table, items, masked_index)
-        if saved is None:  # eval-mode forward (dropout off): activations are not kept, backward is unavailable
-            self._saved = None
-        else:
-            saved.update(out=out, pos=pos, neg=neg, items=items, mask=masked_index, B=B)
-            self._saved = saved
-        self._last_scores = (pos, neg)
-        return loss
+        return self._forward_core(self.item_embedding.weight.data, items, masked_index, self.training)
 
     def forward(self, interaction):
         """interaction = (items int64 [B,2,L+1], masked_index int64 [B,L]) -> 0-dim loss (sasrec.py:65-92)."""
@@ -285,82 +104,11 @@ class SASRec(BaseModel):
         finally:
             self.training = was
 
-    # ------------------------------------------------------------------------------------------ backward
     def _backward_train(self, grad_out):
-        s = self._saved
-        if s is None:
-            raise PxrError("backward() without a training-mode forward()")
-        B, L, D, H = s["B"], self.max_seq_length, self.hidden_size, self.n_heads
-        d = D // H
-        T = B * L
-        seed, ph, pa = s["seed"], s["ph"], s["pa"]
-        sdv = self._drop_dev
-        table = self.item_embedding.weight.data
-        g = lambda name, span=1: self._p(name, grad=True, span=span)
-        gsd = grad_out.reshape(1).to(torch.float32).contiguous()
-        # Weight / bias gradients are off the critical path (only the optimizer consumes them): they are collected
-        # and computed by ONE grouped launch at the end (all tiles of all layers in one grid: no split-K, no
-        # separate bias reductions), or -- overlap_weight_grads -- per layer on a side stream.
-        main = torch.cuda.current_stream()
-        side = None
-        use_side = self.overlap_weight_grads and not self.group_weight_grads
-        if use_side:
-            side = self._side_stream
-            if side is None or side.device != main.device:
-                side = self._side_stream = torch.cuda.Stream(device=main.device)
-        pending = []
-        defer = ops.DeferredReductions()   # second stage of every LayerNorm dgamma|dbeta / pos-emb reduction: one launch
-
-        def weight_grads(dy2d, x2d, w_name, b_name, span=1):
-            if self.group_weight_grads:
-                pending.append((dy2d, x2d, g(w_name, span), g(b_name, span)))
-            elif use_side:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    ops.linear_bwd_weight(dy2d, x2d, out=g(w_name, span))
-                    ops.colsum(dy2d, out=g(b_name, span))
-                dy2d.record_stream(side)
-                x2d.record_stream(side)
-            else:
-                ops.linear_bwd_weight(dy2d, x2d, out=g(w_name, span))
-                ops.colsum(dy2d, out=g(b_name, span))
-
-        dh, coef = ops.bpr_loss_bwd(s["pos"], s["neg"], table, s["items"], s["mask"], D, self.grad_scale, gsd)
-        for i in reversed(range(self.n_layers)):
-            a = s["layers"][i]
-            # FFN: h2 = LN(dropout(f2) + h1)
-            dz2, dxf2 = ops.ln_bwd(0, dh, a["xhat2"], a["rstd2"], self._p(f"{i}.ln2.w"), g(f"{i}.ln2.w"),
-                                   g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer)
-            if dxf2 is None:
-                dxf2 = dz2
-            weight_grads(dxf2.view(T, D), a["f"].view(T, -1), f"{i}.f2.w", f"{i}.f2.b")
-            du = ops.linear_bwd_input(dxf2, self._p(f"{i}.f2.w"), dgelu_pre=a["u"])
-            weight_grads(du.view(T, -1), a["h1"].view(T, D), f"{i}.f1.w", f"{i}.f1.b")
-            dh1 = ops.linear_bwd_input(du, self._p(f"{i}.f1.w"), add=dz2)
-            # attention block: h1 = LN(dropout(a) + h)
-            dz1, dxa = ops.ln_bwd(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
-                                  g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer)
-            if dxa is None:
-                dxa = dz1
-            weight_grads(dxa.view(T, D), a["ctx"].view(T, D), f"{i}.o.w", f"{i}.o.b")
-            dctx = ops.linear_bwd_input(dxa, self._p(f"{i}.o.w"))
-            dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv)
-            weight_grads(dqkv.view(T, 3 * D), a["h_in"].view(T, D), f"{i}.q.w", f"{i}.q.b", 3)
-            dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1)
-        dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,
-                            step_dev=sdv, defer=defer)
-        ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1), defer=defer)
-        defer.flush()
+        dx0, coef, s = self._backward_core(grad_out, self.item_embedding.weight.data)
         sp = self._local_sparse
         ops.sasrec_occ_segsum(self._occ_ws, dx0, s["out"], coef, self.item_num, sp, 1.0)
         self.sparse_table_grad = sp
-        if pending:
-            ops.grouped_linear_bwd_weight(pending)
-        if use_side:
-            main.wait_stream(side)
-        self._saved = None
-        ops.counter_add(self._drop_dev, 1)
-        self._step_counter += 1
 
     # ------------------------------------------------------------------------------------------ inference
     @torch.no_grad()
@@ -372,7 +120,7 @@ class SASRec(BaseModel):
         B, L = item_seq.shape
         if L != self.max_seq_length:
             raise ValueError(f"item_seq must have MAX_ITEM_LIST_LENGTH={self.max_seq_length} columns, got {L}")
-        out, _ = self._encode(item_seq, L, B, item_seq, L, train=False)
+        out, _ = self._encode(self.item_embedding.weight.data, item_seq, L, B, item_seq, L, train=False)
         return out, out[:, -1]
 
     @torch.no_grad()

@@ -1,0 +1,184 @@
+"""Visual item encoder for the PixelNet models -- the ViT branch of the reference's `load_model`
+(code/REC/model/load.py:90-120) plus the item-encoder heads of code/REC/model/layers.py:65-128.
+
+The reference builds HF `CLIPVisionModel.from_pretrained('openai/clip-vit-base-patch32')`, freezes the first
+`tune_scale` named parameters (165 => only encoder blocks 10 and 11 train), replaces `post_layernorm` by Identity and
+wraps it as `MeanItemEncoder`: out = mean over the 50 tokens of ReLU(rec_fc(last_hidden_state)).  Pretrained weights
+cannot be downloaded here (no network) and the installed transformers (5.x) no longer has the `.vision_model`
+attribute the reference pokes (SURVEY.md §7 hard part 8), so the encoder is restated as a small torch module with the
+SAME parameter names/order as transformers 4.16.2's `CLIPVisionModel` (`vision_model.embeddings.class_embedding`, ...,
+199 named parameters for B/32; index 165 = first parameter of block 10): reference checkpoints load by name.
+
+What runs where (round 1): the PATCH PROJECTION (conv 3->768, k=s=32 == GEMM
+[n*49, 3072] x [3072, 768]) runs on the fp32-MFMA GEMM kernel; the 12 transformer blocks ride PyTorch-ROCm ops; rec_fc
++ ReLU + token mean are torch ops on the trainable tail.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, hidden, image_size, patch_size):
+        super().__init__()
+        self.patch_size = patch_size
+        self.num_patches = (image_size // patch_size) ** 2
+        self.class_embedding = nn.Parameter(torch.randn(hidden))
+        self.patch_embedding = nn.Conv2d(3, hidden, kernel_size=patch_size, stride=patch_size, bias=False)
+        self.position_embedding = nn.Embedding(self.num_patches + 1, hidden)
+        self.use_hip_gemm = True
+
+    def forward(self, pixel_values):
+        n, c, H, W = pixel_values.shape
+        p = self.patch_size
+        w = self.patch_embedding.weight
+        if self.use_hip_gemm and pixel_values.is_cuda and not (torch.is_grad_enabled() and w.requires_grad):
+            # im2col is a pure layout change; the contraction runs on the fp32 MFMA GEMM (exact fp32)
+            patches = pixel_values.view(n, c, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(-1, c * p * p)
+            x = ops.linear_fwd(patches.contiguous(), w.detach().view(w.shape[0], -1).contiguous(), None)
+            x = x.view(n, self.num_patches, -1)
+        else:  # trainable patch projection (tune_scale < 2) or CPU construction-time checks
+            x = self.patch_embedding(pixel_values).flatten(2).transpose(1, 2)
+        cls = self.class_embedding.expand(n, 1, -1)
+        x = torch.cat([cls, x], dim=1)
+        return x + self.position_embedding.weight[None]
+
+
+class _Attention(nn.Module):
+    def __init__(self, hidden, heads):
+        super().__init__()
+        self.heads, self.d = heads, hidden // heads
+        self.k_proj = nn.Linear(hidden, hidden)
+        self.v_proj = nn.Linear(hidden, hidden)
+        self.q_proj = nn.Linear(hidden, hidden)
+        self.out_proj = nn.Linear(hidden, hidden)
+
+    def forward(self, x):
+        n, t, hdim = x.shape
+        q = self.q_proj(x) * (self.d ** -0.5)
+        k, v = self.k_proj(x), self.v_proj(x)
+        sh = lambda z: z.view(n, t, self.heads, self.d).transpose(1, 2)
+        att = torch.softmax(sh(q) @ sh(k).transpose(-1, -2), dim=-1)
+        return self.out_proj((att @ sh(v)).transpose(1, 2).reshape(n, t, hdim))
+
+
+class _MLP(nn.Module):
+    def __init__(self, hidden, inter):
+        super().__init__()
+        self.fc1 = nn.Linear(hidden, inter)
+        self.fc2 = nn.Linear(inter, hidden)
+
+    def forward(self, x):
+        x = self.fc1(x)
+        return self.fc2(x * torch.sigmoid(1.702 * x))   # quick_gelu
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, hidden, heads, inter, eps):
+        super().__init__()
+        self.self_attn = _Attention(hidden, heads)
+        self.layer_norm1 = nn.LayerNorm(hidden, eps=eps)
+        self.mlp = _MLP(hidden, inter)
+        self.layer_norm2 = nn.LayerNorm(hidden, eps=eps)
+
+    def forward(self, x):
+        x = x + self.self_attn(self.layer_norm1(x))
+        return x + self.mlp(self.layer_norm2(x))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n_layers, hidden, heads, inter, eps):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayer(hidden, heads, inter, eps) for _ in range(n_layers)])
+
+
+class _VisionTransformer(nn.Module):
+    def __init__(self, hidden, n_layers, heads, inter, image_size, patch_size, eps=1e-5):
+        super().__init__()
+        self.embeddings = _Embeddings(hidden, image_size, patch_size)
+        self.pre_layrnorm = nn.LayerNorm(hidden, eps=eps)      # (sic) the HF attribute name
+        self.encoder = _Encoder(n_layers, hidden, heads, inter, eps)
+        self.post_layernorm = nn.LayerNorm(hidden, eps=eps)    # kept for checkpoint keys; unused by 'mean'/'cls'
+                                                               # (the reference swaps it for Identity, load.py:112,116)
+
+    def forward(self, pixel_values):
+        x = self.pre_layrnorm(self.embeddings(pixel_values))
+        for layer in self.encoder.layers:
+            x = layer(x)
+        return x                                              # last_hidden_state
+
+
+class CLIPVisionEncoder(nn.Module):
+    """`CLIPVisionModel` look-alike: parameters are named `vision_model.*` like transformers 4.16.2."""
+
+    def __init__(self, hidden=768, n_layers=12, heads=12, inter=3072, image_size=224, patch_size=32):
+        super().__init__()
+        self.vision_model = _VisionTransformer(hidden, n_layers, heads, inter, image_size, patch_size)
+        self.hidden = hidden
+
+    def forward(self, pixel_values):
+        return (self.vision_model(pixel_values),)
+
+
+ENCODER_SHAPES = {
+    # name -> (hidden, layers, heads, mlp, image, patch)
+    "clip-vit-base-patch32": (768, 12, 12, 3072, 224, 32),
+    "clip-vit-tiny-test": (64, 3, 4, 128, 64, 32),     # unit tests only
+}
+
+
+class _ItemEncoderBase(nn.Module):
+    """PatchItemEncoder (layers.py:65-92): backbone + rec_fc = Linear(input_dim, output_dim) + activation,
+    xavier-normal weight / zero bias."""
+
+    def __init__(self, item_encoder, input_dim, output_dim, act_name="relu", dnn_layers=None):
+        super().__init__()
+        if dnn_layers:
+            raise NotImplementedError("dnn_layers != [] is not used by the shipped ViT config (overall/ViT.yaml:33)")
+        act = {"relu": nn.ReLU(), "sigmoid": nn.Sigmoid(), "tanh": nn.Tanh(), None: nn.Identity(), "none": nn.Identity()}
+        if (act_name.lower() if isinstance(act_name, str) else act_name) not in act:
+            raise NotImplementedError(f"activation {act_name!r}")
+        self.item_encoder = item_encoder
+        self.rec_fc = nn.Sequential(nn.Linear(input_dim, output_dim), act[act_name.lower() if isinstance(act_name, str) else act_name])
+        nn.init.xavier_normal_(self.rec_fc[0].weight.data)
+        nn.init.constant_(self.rec_fc[0].bias.data, 0)
+
+
+class MeanItemEncoder(_ItemEncoderBase):
+    def forward(self, x):                       # layers.py:125-128
+        x = self.item_encoder(x)[0]
+        return torch.mean(self.rec_fc(x), dim=1)
+
+
+class ClsItemEncoder(_ItemEncoderBase):
+    def forward(self, x):                       # layers.py:113-117
+        x = self.item_encoder(x)[0]
+        return self.rec_fc(x[:, 0, :])
+
+
+def load_model(config):
+    """ViT branch of the reference's load_model (load.py:90-120).  `pre_trained` cannot fetch weights offline: the
+    backbone is randomly initialised either way (load them afterwards with `pretrain_path` / load_state_dict)."""
+    name, source = config["encoder_name"], config["encoder_source"]
+    if source != "transformers" or name not in ENCODER_SHAPES:
+        raise NotImplementedError(f"visual encoder {source}/{name} is outside this build's scope "
+                                  f"(built: transformers/{sorted(ENCODER_SHAPES)})")
+    ft = config["fine_tune_arg"] or {}
+    tune_scale = ft.get("tune_scale", 0)
+    model = CLIPVisionEncoder(*ENCODER_SHAPES[name])
+    for index, (pname, param) in enumerate(model.named_parameters()):
+        if index < tune_scale:
+            param.requires_grad = False                                 # load.py:97-99
+        elif not ft.get("pre_trained", True):
+            param.data.normal_(mean=0.0, std=0.02)                      # load.py:104-108
+    method = ft.get("method", "mean")
+    cls = {"mean": MeanItemEncoder, "cls": ClsItemEncoder}.get(method)
+    if cls is None:
+        raise NotImplementedError(f"fine_tune_arg.method={method!r} (built: mean, cls)")
+    return cls(model, model.hidden, config["embedding_size"], ft.get("activation", "relu"), ft.get("dnn_layers"))

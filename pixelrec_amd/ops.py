@@ -398,6 +398,30 @@ def sasrec_occ_segsum(ws: torch.Tensor, dx0, out, coef, n_table, sp: SparseRows,
              "pxr_sasrec_occ_segsum")
 
 
+# ------------------------------------------------------------------------------------------------ PixelNet pieces
+def mosasrec_emb_grad(dx0, out, coef):
+    """-> d_emb [B, L+1, 2, D] (see pxr.h)."""
+    Lb = _l.load()
+    B, L, D = out.shape
+    d = torch.empty(B, L + 1, 2, D, dtype=torch.float32, device=out.device)
+    _l.check(Lb.pxr_mosasrec_emb_grad_f32(_l.ptr(dx0), _l.ptr(out), _l.ptr(coef), B, L, D, _l.ptr(d), _l.stream_ptr()),
+             "pxr_mosasrec_emb_grad_f32")
+    return d
+
+
+def image_u8_to_f32(store: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """store uint8 [n_store, H, W, 3] on device, ids int64 [...] -> fp32 [..., 3, H, W] normalised like the reference."""
+    Lb = _l.load()
+    _req(store, torch.uint8, "store"); _req(ids, torch.int64, "ids")
+    n_store, H, W, C = store.shape
+    if C != 3:
+        raise _l.PxrError("image store must be HWC with 3 channels")
+    out = torch.empty(*ids.shape, 3, H, W, dtype=torch.float32, device=store.device)
+    _l.check(Lb.pxr_image_u8_to_f32(_l.ptr(store), n_store, H, W, _l.ptr(ids), ids.numel(), _l.ptr(out),
+                                    _l.stream_ptr()), "pxr_image_u8_to_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ full-sort eval
 def history_csr(history_u: torch.Tensor, history_i: torch.Tensor, B: int, device):
     """(history_u, history_i) of seq_eval_collate (grouped by user, collate_fn.py:27-28) -> (hist_ptr int32 [B+1],
