@@ -57,6 +57,7 @@ class SeqTrainBatcher:
     (shuffle with generator seed = seed + epoch, pad to a multiple of world by wrapping, rank-strided)."""
 
     def __init__(self, config, dataload, rank=0, world=1, seed=0, drop_last=False):
+        self.dataload = dataload
         self.item_num = dataload.item_num
         self.W = config["MAX_ITEM_LIST_LENGTH"] + 1
         self.batch_size = config["train_batch_size"]

@@ -1,0 +1,95 @@
+"""Item images for the PixelNet models, kept RESIDENT IN HBM (reference: LMDB of pickled `LMDB_Image` objects read
+per sample by 10 DataLoader workers, code/generate_lmdb.py:20-71, data/dataset/trainset.py:79-167, batchset.py).
+
+An MI355X has 288 GB of HBM: the whole Pixel200K image set (96 K covers x 224x224x3 uint8 = 14.5 GB; PixelRec/8M:
+408 K covers = 61 GB) fits next to the model, so a training batch is assembled ON THE DEVICE from item ids by one
+kernel (pxr_image_u8_to_f32: gather + /255 + Normalize(0.5,0.5) + HWC->CHW; id 0 -> the all-zero pad image) instead of
+352 decoded float images (212 MB) crossing PCIe every step.
+
+Backends for filling the store (indexed by INTERNAL item id, row 0 = padding):
+  * `<path>.npy`  uint8 [n, H, W, 3] + `<path>.tokens.txt` (one item token per line, same order)   -- native format;
+  * LMDB in the reference's format (needs the `lmdb` module, absent in this image) -- key = ascii item token, value =
+    pickle of an object with `.image` bytes, `.size`, `.channels` (generate_lmdb.py / data/utils.py:192-201);
+  * `synthetic:<H>`  deterministic pseudo-random images (benchmarks / tests; no dataset is available offline).
+"""
+from __future__ import annotations
+
+import io
+import os
+import pickle
+
+import numpy as np
+import torch
+
+
+class _LmdbImage:  # stand-in for the reference's pickled LMDB_Image (any module path)
+    def get_image(self):
+        return np.frombuffer(self.image, dtype=np.uint8).reshape(*self.size, self.channels)
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if name == "LMDB_Image":
+            return _LmdbImage
+        return super().find_class(module, name)
+
+
+class ImageStore:
+    def __init__(self, images_u8: torch.Tensor):
+        assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+        self.images = images_u8
+        self.n, self.H, self.W = images_u8.shape[:3]
+
+    def to(self, device):
+        self.images = self.images.to(device)
+        return self
+
+    @staticmethod
+    def synthetic(item_num: int, size: int = 224, seed: int = 0, device="cpu"):
+        g = torch.Generator().manual_seed(seed)
+        img = torch.randint(0, 256, (item_num, size, size, 3), generator=g, dtype=torch.uint8)
+        img[0] = 0
+        return ImageStore(img.to(device))
+
+    @staticmethod
+    def from_config(config, dataload, device):
+        path = str(config["image_path"])
+        id2token = dataload.id2token["item_id"]
+        if path.startswith("synthetic:"):
+            return ImageStore.synthetic(dataload.item_num, int(path.split(":")[1]), int(config["seed"] or 0), device)
+        if path.endswith(".npy"):
+            arr = np.load(path, mmap_mode="r")
+            tokens = [t.strip() for t in open(path[:-4] + ".tokens.txt")]
+            pos = {t: i for i, t in enumerate(tokens)}
+            out = torch.zeros(dataload.item_num, *arr.shape[1:], dtype=torch.uint8)
+            for iid in range(1, dataload.item_num):
+                out[iid] = torch.from_numpy(np.ascontiguousarray(arr[pos[str(id2token[iid])]]))
+            return ImageStore(out.to(device))
+        try:
+            import lmdb
+        except ImportError as e:
+            raise RuntimeError(f"image_path {path!r} looks like an LMDB but the `lmdb` module is not installed; "
+                               "convert it to <name>.npy + <name>.tokens.txt") from e
+        env = lmdb.open(path, subdir=os.path.isdir(path), readonly=True, lock=False, readahead=False, meminit=False)
+        out = None
+        with env.begin() as txn:
+            for iid in range(1, dataload.item_num):
+                obj = _Unpickler(io.BytesIO(txn.get(str(id2token[iid]).encode("ascii")))).load()
+                img = obj.get_image()[..., :3]
+                if out is None:
+                    out = torch.zeros(dataload.item_num, *img.shape, dtype=torch.uint8)
+                out[iid] = torch.from_numpy(np.ascontiguousarray(img))
+        return ImageStore(out.to(device))
+
+    def batch(self, ids: torch.Tensor) -> torch.Tensor:
+        """ids int64 [...] on the store's device -> fp32 [..., 3, H, W], reference-normalised, on the device."""
+        from .. import ops
+
+        return ops.image_u8_to_f32(self.images, ids.contiguous())
+
+
+def interleave_pos_neg(items: torch.Tensor) -> torch.Tensor:
+    """items [B, 2, L+1] (positives | negatives) -> ids [B, 2(L+1)] ordered pos_0, neg_0, pos_1, neg_1, ... as
+    MOSEQTrainDataset stacks the images (trainset.py:145-165)."""
+    B = items.shape[0]
+    return items.permute(0, 2, 1).reshape(B, -1).contiguous()

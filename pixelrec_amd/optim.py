@@ -34,15 +34,22 @@ class PxrAdamW:
         self._last = self._hyper = self._cumlog = self._step_dev = None
         self._dirty = False          # lazy mode: some rows lag behind step_count (set by step, cleared by flush)
         self.param_groups = [{"lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}]
-        if table_update == "lazy":
+        self.has_table = hasattr(model, "item_embedding")
+        if table_update == "lazy" and self.has_table:
             model.register_table_hooks(self)
 
     def _ensure_state(self):
         flat, _ = self.model.flat_parameters()
-        table = self.model.item_embedding.weight.data
-        dev = table.device
+        dev = flat.device
         if self._m is None or self._m.device != flat.device or self._m.numel() != flat.numel():
             self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+        if not self.has_table:
+            if self._hyper is None or self._hyper.device != dev:
+                self._hyper = torch.zeros(HYPER_CAPACITY, 4, dtype=torch.float32, device=dev)
+                self._cumlog = torch.zeros(HYPER_CAPACITY, dtype=torch.float64, device=dev)
+                self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=dev)
+            return flat, None
+        table = self.model.item_embedding.weight.data
         if self._tm is None or self._tm.device != dev or self._tm.shape != table.shape:
             self._tm, self._tv = torch.zeros_like(table), torch.zeros_like(table)
             self._slot = torch.empty(table.shape[0], dtype=torch.int32, device=dev)
@@ -60,7 +67,7 @@ class PxrAdamW:
     # ---- hooks called by the model (lazy mode) ----------------------------------------------------------------
     def catch_up_rows(self, idx, n_dev, cap):
         """Bring the rows a forward pass is about to read up to date (through the last completed step)."""
-        if self.table_update != "lazy" or self._last is None:
+        if self.table_update != "lazy" or self._last is None or not self.has_table:
             return
         b1, b2 = self.param_groups[0]["betas"]
         ops.adamw_rows(self.model.item_embedding.weight.data, self._tm, self._tv, self._last, self._hyper, self._cumlog,
@@ -88,8 +95,10 @@ class PxrAdamW:
         ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 1, g["lr"], b1, b2, g["eps"],
                                g["weight_decay"], step_dev=sd)
         ops.adamw_flat_tab(flat, gflat, self._m, self._v, self._hyper, self.step_count + 1, b1, b2, g["eps"], step_dev=sd)
-        sp = self.model.sparse_table_grad
-        if self.table_update == "dense":
+        sp = self.model.sparse_table_grad if self.has_table else None
+        if not self.has_table:
+            pass
+        elif self.table_update == "dense":
             # host-computed scalars: this schedule is for eager execution / A-B measurements, not for graph capture
             ops.adamw_table(table, self._tm, self._tv, self._slot, sp, g["lr"], b1, b2, g["eps"], g["weight_decay"],
                             self.step_count + 1)
@@ -104,18 +113,54 @@ class PxrAdamW:
     def state_dict(self):
         self._ensure_state()
         self.flush()
-        return {"step": self.step_count, "param_groups": self.param_groups, "m": self._m, "v": self._v,
-                "table_m": self._tm, "table_v": self._tv}
+        sd = {"step": self.step_count, "param_groups": self.param_groups, "m": self._m, "v": self._v}
+        if self.has_table:
+            sd.update(table_m=self._tm, table_v=self._tv)
+        return sd
 
     def load_state_dict(self, sd):
         self._ensure_state()
         self.step_count = int(sd["step"])
         self.param_groups = sd["param_groups"]
-        for dst, key in ((self._m, "m"), (self._v, "v"), (self._tm, "table_m"), (self._tv, "table_v")):
+        pairs = [(self._m, "m"), (self._v, "v")] + ([(self._tm, "table_m"), (self._tv, "table_v")] if self.has_table else [])
+        for dst, key in pairs:
             dst.copy_(sd[key])
+        self._step_dev.fill_(self.step_count)
+        self._cumlog.zero_()
+        self._dirty = False
+        if not self.has_table:
+            return
         # a checkpoint is always flushed: every row is current through `step`; earlier per-step scalars are never
         # needed again, only the cumulative-log origin must be consistent (restart it at 0)
         self._last.fill_(self.step_count)
         self._step_dev.fill_(self.step_count)
         self._cumlog.zero_()
         self._dirty = False
+
+
+class OptimizerGroup:
+    """Several optimizers stepped together (reference trainer.py:86-96 builds ONE torch AdamW with a 'visual_encoder'
+    group and a rec group; here the rec group is PxrAdamW and the visual-encoder group a torch AdamW)."""
+
+    def __init__(self, *opts):
+        self.opts = [o for o in opts if o is not None]
+
+    def zero_grad(self, set_to_none: bool = True):
+        for o in self.opts:
+            o.zero_grad(set_to_none=set_to_none) if not isinstance(o, PxrAdamW) else o.zero_grad()
+
+    def step(self):
+        for o in self.opts:
+            o.step()
+
+    def flush(self):
+        for o in self.opts:
+            if hasattr(o, "flush"):
+                o.flush()
+
+    def state_dict(self):
+        return {"group": [o.state_dict() for o in self.opts]}
+
+    def load_state_dict(self, sd):
+        for o, s in zip(self.opts, sd["group"]):
+            o.load_state_dict(s)

@@ -62,13 +62,26 @@ class GradSync:
             return
         flat, _ = self.model.flat_parameters()
         dist.broadcast(flat, src=src, group=self.group)
-        dist.broadcast(self.model.item_embedding.weight.data, src=src, group=self.group)
+        if hasattr(self.model, "item_embedding"):
+            dist.broadcast(self.model.item_embedding.weight.data, src=src, group=self.group)
+        for p in self._extra_params():
+            dist.broadcast(p.data, src=src, group=self.group)
+
+    def _extra_params(self):
+        """Parameters outside the flat buffer and the table: the visual encoder of the PixelNet models."""
+        enc = getattr(self.model, "visual_encoder", None)
+        return list(enc.parameters()) if enc is not None else []
 
     def sync(self):
         if self.world == 1:
             return
         _, gflat = self.model.flat_parameters()
         dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.group)
+        for p in self._extra_params():      # trainable tail of the visual encoder (frozen parameters have no grads)
+            if p.grad is not None:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+        if not hasattr(self.model, "item_embedding"):
+            return
         sp = self.model.sparse_table_grad
         idx_all, rows_all = gather_sparse(sp.idx, sp.rows, sp.n, self.group)
         if self._merge is None:

@@ -28,7 +28,7 @@ import torch
 
 from .. import ops
 from ..evaluator import Collector, Evaluator
-from ..optim import PxrAdamW
+from ..optim import OptimizerGroup, PxrAdamW
 from ..parallel import world_info
 from ..utils import calculate_valid_score, dict2str, early_stopping, ensure_dir, get_local_time
 
@@ -98,11 +98,15 @@ class Trainer:
         """trainer.py:66-103.  A 4-key optim_args selects separate modal/rec groups; for the ID model every
         parameter is a 'rec' parameter, so both spellings resolve to one AdamW."""
         a = self.optim_args
+        m = self.model.module
         if len(a) == 4:
-            lr, wd = a["rec_lr"], a["rec_decay"]
-        else:
-            lr, wd = a["learning_rate"], a["weight_decay"]
-        return PxrAdamW(self.model.module, lr=lr, weight_decay=wd)
+            rec = PxrAdamW(m, lr=a["rec_lr"], weight_decay=a["rec_decay"])
+            modal = [p for n, p in m.named_parameters() if "visual_encoder" in n and p.requires_grad]
+            if not modal:
+                return rec
+            # the visual-encoder group (trainer.py:86-89): torch AdamW on the trainable tail of the backbone
+            return OptimizerGroup(torch.optim.AdamW(modal, lr=a["modal_lr"], weight_decay=a["modal_decay"]), rec)
+        return PxrAdamW(m, lr=a["learning_rate"], weight_decay=a["weight_decay"])
 
     # ---------------------------------------------------------------------------------------------- training
     def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
@@ -110,6 +114,10 @@ class Trainer:
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         for data in _Prefetcher(train_data, self.device):
             self.optimizer.zero_grad()
+            if self.use_modality:   # assemble the image batch on the device from the HBM-resident store
+                from ..data.images import interleave_pos_neg
+
+                data = (self._image_store(train_data).batch(interleave_pos_neg(data[0])), data[1])
             losses = self.model(data)
             losses.backward()
             if hasattr(self.model, "sync_gradients"):
@@ -210,11 +218,26 @@ class Trainer:
         return self.best_valid_score, self.best_valid_result
 
     # ---------------------------------------------------------------------------------------------- evaluation
+    def _image_store(self, loader=None):
+        if getattr(self, "_images", None) is None:
+            from ..data.images import ImageStore
+
+            dl = loader.dataset.dataload if hasattr(loader.dataset, "dataload") else loader.batcher.dataload
+            self._images = ImageStore.from_config(self.config, dl, self.device)
+        return self._images
+
     @torch.no_grad()
-    def compute_item_feature(self, config, data):
+    def compute_item_feature(self, config, data, loader=None):
+        """trainer.py:339-358: IDNet = the table itself; PixelNet = encode every item image in batches of 100."""
         if self.use_modality:
-            raise NotImplementedError("PixelNet item-feature extraction is not built yet (SURVEY.md §8 f3)")
-        self.item_feature = self.model.module.compute_item_all()
+            store = self._image_store(loader)
+            feats = []
+            for s in range(0, store.n, 100):
+                ids = torch.arange(s, min(store.n, s + 100), device=self.device)
+                feats.append(self.model.module.compute_item(store.batch(ids)))   # id 0 -> zero image (batchset.py:58-60)
+            self.item_feature = torch.cat(feats)
+        else:
+            self.item_feature = self.model.module.compute_item_all()
 
     @torch.no_grad()
     def _full_sort_batch_eval(self, batched_data):
@@ -233,7 +256,8 @@ class Trainer:
         """Fused path: encoder -> pxr_score_topk_f32 (scores never reach HBM)."""
         user, history_index, positive_u, positive_i = batched_data
         m = self.model.module
-        out, last = m.encode_last(user.to(self.device))
+        out, last = (m.encode_last(user.to(self.device), self.item_feature) if self.use_modality
+                     else m.encode_last(user.to(self.device)))
         B, L, D = out.shape
         ptr = items = None
         if history_index is not None:
@@ -259,7 +283,7 @@ class Trainer:
             self.logger.info("Loading model structure and parameters from {}".format(checkpoint_file))
         self.model.eval()
         self.tot_item_num = eval_data.dataset.dataload.item_num
-        self.compute_item_feature(self.config, eval_data.dataset.dataload)
+        self.compute_item_feature(self.config, eval_data.dataset.dataload, eval_data)
         for batched_data in eval_data:
             if self.fused_topk:
                 idx, positive_i = self._full_sort_batch_topk(batched_data)

@@ -124,3 +124,48 @@ def test_image_transform_kernel():
     ref = np.transpose(ref, (0, 1, 4, 2, 3))
     ref[ids == 0] = 0.0                                                 # pad image = zeros (trainset.py:96)
     assert out.shape == (2, 3, 3, 16, 12) and np.abs(out - ref).max() < 1e-6
+
+
+def test_pixelnet_trainer_end_to_end(tmp_path):
+    """main.py surface for the pixel model: YAML -> data -> MOSASRec -> Trainer.fit/evaluate with the HBM-resident
+    image store (synthetic covers), two optimizer groups, full-sort eval over encoder-produced item features."""
+    import os
+
+    from pixelrec_amd.config import Config
+    from pixelrec_amd.data import bulid_dataloader, load_data
+    from pixelrec_amd.data.images import interleave_pos_neg
+    from pixelrec_amd.optim import OptimizerGroup
+    from pixelrec_amd.parallel import DataParallel
+    from pixelrec_amd.trainer import Trainer
+    from pixelrec_amd.utils import get_model
+    from tests.golden_util import GOLDEN_DIR
+
+    my, ov = tmp_path / "m.yaml", tmp_path / "o.yaml"
+    my.write_text("model: MOSASRec\nn_layers: 2\nn_heads: 2\nembedding_size: 32\ninner_size: 2\nhidden_dropout_prob: 0.1\n"
+                  "attn_dropout_prob: 0.1\nhidden_act: 'gelu'\nlayer_norm_eps: 1e-12\ninitializer_range: 0.02\n")
+    ov.write_text(f"seed: 2020\nstate: INFO\nuse_modality: True\nreproducibility: True\ncheckpoint_dir: '{tmp_path}/saved'\n"
+                  f"log_path: '{tmp_path}/log'\nshow_progress: False\nMAX_ITEM_LIST_LENGTH: 6\ndata_path: {GOLDEN_DIR}/\n"
+                  "dataset: TinyInter\nimage_path: 'synthetic:64'\nencoder_name: 'clip-vit-tiny-test'\n"
+                  "encoder_source: 'transformers'\nepochs: 3\ntrain_batch_size: 8\n"
+                  "fine_tune_arg: {tune_scale: 37, pre_trained: True, activation: 'relu', dnn_layers: [], method: 'mean'}\n"
+                  "optim_args: {modal_lr: 0.001, rec_lr: 0.001, modal_decay: 0, rec_decay: 0.1}\n"
+                  "eval_batch_size: 16\ntopk: [5,10]\nmetrics: ['Recall', 'NDCG']\nvalid_metric: NDCG@10\n"
+                  "metric_decimal_place: 7\neval_step: 1\nstopping_step: 30\n")
+    config = Config([str(my), str(ov)])
+    config["device"] = torch.device("cuda", 0)
+    dataload = load_data(config)
+    train, valid, test = bulid_dataloader(config, dataload)
+    model = get_model(config["model"])(config, dataload).to(config["device"])
+    trainer = Trainer(config, DataParallel(model))
+    assert isinstance(trainer.optimizer, OptimizerGroup)
+    # the on-device batch assembly reproduces MOSEQTrainDataset's order pos_0, neg_0, pos_1, neg_1, ...
+    items = torch.tensor([[[0, 3, 5], [0, 0, 9]]])
+    assert interleave_pos_neg(items).tolist() == [[0, 0, 3, 0, 5, 9]]
+    best, res = trainer.fit(train, valid, saved=True)
+    losses = [trainer.train_loss_dict[e] for e in sorted(trainer.train_loss_dict)]
+    assert len(losses) == 3 and losses[-1] < losses[0]
+    out = trainer.evaluate(test, load_best_model=True)
+    assert set(out) == {"recall@5", "recall@10", "ndcg@5", "ndcg@10"}
+    assert trainer.item_feature.shape == (dataload.item_num, 32)
+    ck = torch.load(trainer.saved_model_file, map_location="cpu", weights_only=False)
+    assert any(k.startswith("visual_encoder.item_encoder.vision_model.encoder.layers.2.") for k in ck["state_dict"])
