@@ -249,6 +249,380 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a) {
   }
 }
 
+// =================================================================================================================
+// MFMA variant (default when d % 8 == 0): the four small matrix products of the attention core run on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, exact fp32) from LDS-resident operands; 4 waves per (batch, head), each owning one 32x32
+// block of the 64x64 score tile and a 32x64 slab of every 64x128 output chunk.  The softmax stays the wave-shuffle
+// row softmax above (lane = key) reading the score tile from LDS, so mask / dropout / saved-probability semantics are
+// byte-for-byte the same code.  Fragment reads follow gemm_f32.cuh: "KC" operands are [row][k] with a padded stride
+// (conflict-free ds_read_b128, k split 0-3 / 4-7 between half-waves), "XC" operands are [k][x] (ds_read_b32).
+constexpr int ATT_SLD = 64 + 4;        // score / probability tile stride (KC operand of P.V and dS.K)
+
+// acc[j] += A_op[32 rows @ m_base] x B_op[32 cols @ n_base + 32 j],  K multiple of 8
+template <bool A_KC, bool B_KC, int TN>
+__device__ __forceinline__ void lds_mma(f32x16 (&acc)[TN], const float* sA, int lda, const float* sB, int ldb, int m_base,
+                                        int n_base, int K, int lane) {
+  const int h = lane >> 5, r = lane & 31;
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    float a[4], b[TN][4];
+    if constexpr (A_KC) {
+      const float4 v = *reinterpret_cast<const float4*>(sA + (m_base + r) * lda + k0 + h * 4);
+      a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = sA[(k0 + h * 4 + t) * lda + m_base + r];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (B_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(sB + (n_base + j * 32 + r) * ldb + k0 + h * 4);
+        b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[j][t] = sB[(k0 + h * 4 + t) * ldb + n_base + j * 32 + r];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[j][t], acc[j], 0, 0, 0);
+  }
+}
+
+template <int TN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TN]) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+}
+
+// global out[row][col] = acc  for row < L, col < w   (block at m_base, n_base + 32 j)
+template <int TN>
+__device__ __forceinline__ void store_acc(const f32x16 (&acc)[TN], float* out, int64_t ld, int m_base, int n_base, int L,
+                                          int w, int lane) {
+  const int h = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n_base + j * 32 + r;
+    if (col >= w) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m_base + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < L) out[(int64_t)row * ld + col] = acc[j][e];
+    }
+  }
+}
+
+// stage rows < L of a [L][w] global tile into LDS with the given stride; rows L..63 are zero-filled.
+// All of a thread's global loads are issued BEFORE its first LDS store: with one workgroup per CU a
+// load -> wait -> ds_write loop would serialise ~8 HBM round trips per tile (measured: 20 of the kernel's 25 us).
+__device__ __forceinline__ void stage_tile_z(float* tile, int tstride, const float* src, int64_t ld, int L, int w) {
+  const int q4 = w >> 2;
+  const int total = ATT_MAXL * q4;            // <= 64 * 32 = 2048 float4 => <= 8 per thread at 256 threads
+  float4 v[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int f = threadIdx.x + p * 256;
+    v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < total) {
+      const int row = f / q4, c = (f - row * q4) * 4;
+      if (row < L) v[p] = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int f = threadIdx.x + p * 256;
+    if (f < total) {
+      const int row = f / q4, c = (f - row * q4) * 4;
+      *reinterpret_cast<float4*>(tile + row * tstride + c) = v[p];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(AttnArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  __shared__ __attribute__((aligned(16))) float sQ[ATT_MAXL * ATT_KLD];   // Q chunk (KC); later V chunk (XC, stride 128)
+  __shared__ __attribute__((aligned(16))) float sK[ATT_MAXL * ATT_KLD];   // K chunk (KC)
+  __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];   // scores -> dropped probabilities
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int L = a.L, d = a.d;
+  const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
+
+  f32x16 accS[1];
+  zero_acc<1>(accS);
+  for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
+    const int w = min(ATT_DC, d - dc0);
+    stage_tile_z(sQ, ATT_KLD, a.q + base + dc0, a.ld, L, w);
+    stage_tile_z(sK, ATT_KLD, a.k + base + dc0, a.ld, L, w);
+    __syncthreads();
+    lds_mma<true, true, 1>(accS, sQ, ATT_KLD, sK, ATT_KLD, wm * 32, wn * 32, w, lane);
+    __syncthreads();
+  }
+  {
+    const int hh = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      sS[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ATT_SLD + wn * 32 + r] = accS[0][e];
+  }
+  __syncthreads();
+
+  const bool key_real = (lane < L) && (a.keymask[(int64_t)b * a.km_bstride + lane] != 0);
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  for (int i = wave; i < L; i += 4) {
+    // reference arithmetic: scores / sqrt(d) + (-1e9 | 0)   (layers.py:597,601; sasrec.py:125)
+    float s = sS[i * ATT_SLD + lane] / a.sqrt_d + ((key_real && lane <= i) ? 0.0f : -1e9f);
+    if (lane >= L) s = -INFINITY;
+    const float m = wave_max(s);
+    const float e = (lane < L) ? expf(s - m) : 0.f;
+    const float sum = wave_sum(e);
+    const float p = e / sum;
+    float pd = 0.f;
+    if (lane < L) {
+      const int64_t pi = (((int64_t)b * a.H + h) * L + i) * L + lane;
+      if (a.probs) a.probs[pi] = p;
+      pd = p;
+      if (drop) pd = pxr_keep(a.seed, a.stream, (uint64_t)pi, a.drop_thr) ? p * inv_keep : 0.f;
+    }
+    sS[i * ATT_SLD + lane] = pd;   // lanes >= L: exact zeros, so the padded V rows never contribute
+  }
+  __syncthreads();
+
+  float* out = a.ctx + (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
+  for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
+    const int w = min(ATT_DC, d - dc0);
+    stage_tile_z(sQ, ATT_DC, a.v + base + dc0, a.ld, L, w);
+    __syncthreads();
+    f32x16 accO[2];
+    zero_acc<2>(accO);
+    if (wn * 64 < w) lds_mma<true, false, 2>(accO, sS, ATT_SLD, sQ, ATT_DC, wm * 32, wn * 64, 64, lane);
+    store_acc<2>(accO, out + dc0, a.ld_ctx, wm * 32, wn * 64, L, w, lane);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(AttnArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  __shared__ __attribute__((aligned(16))) float sQ[ATT_MAXL * ATT_KLD];   // dO chunk (KC) / generic XC tile (stride 128)
+  __shared__ __attribute__((aligned(16))) float sK[ATT_MAXL * ATT_KLD];   // V chunk (KC)
+  __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * ATT_SLD];   // dropped probabilities Pd
+  __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];   // dP, then dS / sqrt(d)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int L = a.L, d = a.d;
+  const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
+  const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
+  const int64_t dbase = (int64_t)b * L * a.ld_d + (int64_t)h * d;
+
+  for (int f = threadIdx.x; f < ATT_MAXL * ATT_SLD; f += 256) sP[f] = 0.f;
+
+  // dPd[i][j] = sum_c dctx[i][c] * V[j][c]
+  f32x16 accP[1];
+  zero_acc<1>(accP);
+  for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
+    const int w = min(ATT_DC, d - dc0);
+    stage_tile_z(sQ, ATT_KLD, a.dctx + cbase + dc0, a.ld_ctx, L, w);
+    stage_tile_z(sK, ATT_KLD, a.v + base + dc0, a.ld, L, w);
+    __syncthreads();
+    lds_mma<true, true, 1>(accP, sQ, ATT_KLD, sK, ATT_KLD, wm * 32, wn * 32, w, lane);
+    __syncthreads();
+  }
+  {
+    const int hh = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      sS[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ATT_SLD + wn * 32 + r] = accP[0][e];
+  }
+  __syncthreads();
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  for (int i = wave; i < L; i += 4) {
+    float p = 0.f, pd = 0.f, dp = 0.f;
+    if (lane < L) {
+      const int64_t pi = (((int64_t)b * a.H + h) * L + i) * L + lane;
+      p = a.probs[pi];
+      const bool keep = !drop || pxr_keep(a.seed, a.stream, (uint64_t)pi, a.drop_thr);
+      const float kf = drop ? (keep ? inv_keep : 0.f) : 1.f;
+      pd = p * kf;
+      dp = sS[i * ATT_SLD + lane] * kf;
+    }
+    const float t = wave_sum(dp * p);
+    sP[i * ATT_SLD + lane] = pd;
+    sS[i * ATT_SLD + lane] = (lane < L) ? p * (dp - t) / a.sqrt_d : 0.f;   // softmax backward, then 1/sqrt(d)
+  }
+  __syncthreads();
+
+  for (int dc0 = 0; dc0 < d; dc0 += ATT_DC) {
+    const int w = min(ATT_DC, d - dc0);
+    const bool mine = wn * 64 < w;
+    f32x16 acc[2];
+    // dV[j][c] = sum_i Pd[i][j] * dctx[i][c]
+    stage_tile_z(sQ, ATT_DC, a.dctx + cbase + dc0, a.ld_ctx, L, w);
+    __syncthreads();
+    zero_acc<2>(acc);
+    if (mine) lds_mma<false, false, 2>(acc, sP, ATT_SLD, sQ, ATT_DC, wm * 32, wn * 64, 64, lane);
+    store_acc<2>(acc, a.dv + dbase + dc0, a.ld_d, wm * 32, wn * 64, L, w, lane);
+    __syncthreads();
+    // dQ[i][c] = sum_j dS[i][j] * K[j][c]
+    stage_tile_z(sQ, ATT_DC, a.k + base + dc0, a.ld, L, w);
+    __syncthreads();
+    zero_acc<2>(acc);
+    if (mine) lds_mma<true, false, 2>(acc, sS, ATT_SLD, sQ, ATT_DC, wm * 32, wn * 64, 64, lane);
+    store_acc<2>(acc, a.dq + dbase + dc0, a.ld_d, wm * 32, wn * 64, L, w, lane);
+    __syncthreads();
+    // dK[j][c] = sum_i dS[i][j] * Q[i][c]
+    stage_tile_z(sQ, ATT_DC, a.q + base + dc0, a.ld, L, w);
+    __syncthreads();
+    zero_acc<2>(acc);
+    if (mine) lds_mma<false, false, 2>(acc, sS, ATT_SLD, sQ, ATT_DC, wm * 32, wn * 64, 64, lane);
+    store_acc<2>(acc, a.dk + dbase + dc0, a.ld_d, wm * 32, wn * 64, L, w, lane);
+    __syncthreads();
+  }
+}
+
+// ---- single-phase MFMA kernels for d <= 128 (every shipped config: d = 32 .. 128) ---------------------------------
+// With ONE workgroup per CU nothing hides a global->LDS staging round trip, and the chunked kernels above pay one per
+// operand (3 forward, 5 backward).  Here every operand of the (batch, head) problem is fetched ONCE, up front, into
+// its own [64][132] LDS tile -- a padded stride serves both fragment flavours (ds_read_b128 along k for "KC" uses,
+// ds_read_b32 along x for "XC" uses) -- so the kernel is one load phase followed by back-to-back MFMA phases.
+// Backward keeps dS in registers while the probability tile is used for dV, so one 64x68 tile suffices:
+// 4 x 33 KB + 17 KB = 152 KB of the CU's 160 KB.
+__global__ void __launch_bounds__(256) attn_fwd_mfma1_kernel(AttnArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  __shared__ __attribute__((aligned(16))) float sQ[ATT_MAXL * ATT_KLD];
+  __shared__ __attribute__((aligned(16))) float sK[ATT_MAXL * ATT_KLD];
+  __shared__ __attribute__((aligned(16))) float sV[ATT_MAXL * ATT_KLD];
+  __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int L = a.L, d = a.d;
+  const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
+  stage_tile_z(sQ, ATT_KLD, a.q + base, a.ld, L, d);
+  stage_tile_z(sK, ATT_KLD, a.k + base, a.ld, L, d);
+  stage_tile_z(sV, ATT_KLD, a.v + base, a.ld, L, d);
+  const bool key_real = (lane < L) && (a.keymask[(int64_t)b * a.km_bstride + lane] != 0);
+  __syncthreads();
+
+  f32x16 accS[1];
+  zero_acc<1>(accS);
+  lds_mma<true, true, 1>(accS, sQ, ATT_KLD, sK, ATT_KLD, wm * 32, wn * 32, d, lane);
+  {
+    const int hh = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      sS[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ATT_SLD + wn * 32 + r] = accS[0][e];
+  }
+  __syncthreads();
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  for (int i = wave; i < L; i += 4) {
+    float s = sS[i * ATT_SLD + lane] / a.sqrt_d + ((key_real && lane <= i) ? 0.0f : -1e9f);
+    if (lane >= L) s = -INFINITY;
+    const float m = wave_max(s);
+    const float e = (lane < L) ? expf(s - m) : 0.f;
+    const float sum = wave_sum(e);
+    const float p = e / sum;
+    float pd = 0.f;
+    if (lane < L) {
+      const int64_t pi = (((int64_t)b * a.H + h) * L + i) * L + lane;
+      if (a.probs) a.probs[pi] = p;
+      pd = p;
+      if (drop) pd = pxr_keep(a.seed, a.stream, (uint64_t)pi, a.drop_thr) ? p * inv_keep : 0.f;
+    }
+    sS[i * ATT_SLD + lane] = pd;
+  }
+  __syncthreads();
+  f32x16 accO[2];
+  zero_acc<2>(accO);
+  if (wn * 64 < d) lds_mma<true, false, 2>(accO, sS, ATT_SLD, sV, ATT_KLD, wm * 32, wn * 64, 64, lane);
+  store_acc<2>(accO, a.ctx + (int64_t)b * L * a.ld_ctx + (int64_t)h * d, a.ld_ctx, wm * 32, wn * 64, L, d, lane);
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_mfma1_kernel(AttnArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  __shared__ __attribute__((aligned(16))) float sQ[ATT_MAXL * ATT_KLD];
+  __shared__ __attribute__((aligned(16))) float sK[ATT_MAXL * ATT_KLD];
+  __shared__ __attribute__((aligned(16))) float sV[ATT_MAXL * ATT_KLD];
+  __shared__ __attribute__((aligned(16))) float sO[ATT_MAXL * ATT_KLD];   // dctx
+  __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];   // dP -> Pd -> dS/sqrt(d)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int L = a.L, d = a.d;
+  const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
+  const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
+  const int64_t dbase = (int64_t)b * L * a.ld_d + (int64_t)h * d;
+  stage_tile_z(sO, ATT_KLD, a.dctx + cbase, a.ld_ctx, L, d);
+  stage_tile_z(sV, ATT_KLD, a.v + base, a.ld, L, d);
+  stage_tile_z(sK, ATT_KLD, a.k + base, a.ld, L, d);
+  stage_tile_z(sQ, ATT_KLD, a.q + base, a.ld, L, d);
+  // this wave's probability rows (saved by the forward pass) -- issued before the barrier so they overlap the staging
+  float prow[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int i = wave + 4 * g;
+    prow[g] = (i < L && lane < L) ? a.probs[(((int64_t)b * a.H + h) * L + i) * L + lane] : 0.f;
+  }
+  __syncthreads();
+
+  f32x16 accP[1];
+  zero_acc<1>(accP);
+  lds_mma<true, true, 1>(accP, sO, ATT_KLD, sV, ATT_KLD, wm * 32, wn * 32, d, lane);   // dPd = dctx V^T
+  {
+    const int hh = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      sS[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ATT_SLD + wn * 32 + r] = accP[0][e];
+  }
+  __syncthreads();
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  float dsrow[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int i = wave + 4 * g;
+    dsrow[g] = 0.f;
+    if (i < L) {   // wave-uniform
+      const float p = prow[g];
+      float pd = 0.f, dp = 0.f;
+      if (lane < L) {
+        const int64_t pi = (((int64_t)b * a.H + h) * L + i) * L + lane;
+        const bool keep = !drop || pxr_keep(a.seed, a.stream, (uint64_t)pi, a.drop_thr);
+        const float kf = drop ? (keep ? inv_keep : 0.f) : 1.f;
+        pd = p * kf;
+        dp = sS[i * ATT_SLD + lane] * kf;
+      }
+      const float t = wave_sum(dp * p);
+      dsrow[g] = (lane < L) ? p * (dp - t) / a.sqrt_d : 0.f;   // softmax backward, then the 1/sqrt(d) of layers.py:597
+      sS[i * ATT_SLD + lane] = pd;                              // tile now holds Pd (rows >= L stay 0: dctx rows are 0)
+    }
+  }
+  __syncthreads();
+  const bool mine = wn * 64 < d;
+  f32x16 acc[2];
+  zero_acc<2>(acc);
+  if (mine) lds_mma<false, false, 2>(acc, sS, ATT_SLD, sO, ATT_KLD, wm * 32, wn * 64, 64, lane);   // dV = Pd^T dctx
+  store_acc<2>(acc, a.dv + dbase, a.ld_d, wm * 32, wn * 64, L, d, lane);
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int i = wave + 4 * g;
+    if (i < L) sS[i * ATT_SLD + lane] = dsrow[g];
+  }
+  __syncthreads();
+  zero_acc<2>(acc);
+  if (mine) lds_mma<true, false, 2>(acc, sS, ATT_SLD, sK, ATT_KLD, wm * 32, wn * 64, 64, lane);    // dQ = dS K
+  store_acc<2>(acc, a.dq + dbase, a.ld_d, wm * 32, wn * 64, L, d, lane);
+  zero_acc<2>(acc);
+  if (mine) lds_mma<false, false, 2>(acc, sS, ATT_SLD, sQ, ATT_KLD, wm * 32, wn * 64, 64, lane);   // dK = dS^T Q
+  store_acc<2>(acc, a.dk + dbase, a.ld_d, wm * 32, wn * 64, L, d, lane);
+}
+
 }  // namespace pxr
 
 using namespace pxr;
@@ -262,6 +636,16 @@ static int attn_waves() {
     nw = (v == 4 || v == 16) ? v : 8;
   }
   return nw;
+}
+
+// MFMA attention is the default whenever the head size allows it; PXR_ATTN_MFMA=0 selects the VALU kernels
+static bool attn_use_mfma(int d) {
+  static int flag = -1;
+  if (flag < 0) {
+    const char* e = getenv("PXR_ATTN_MFMA");
+    flag = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return flag == 1 && (d % 8) == 0;
 }
 
 static int attn_check(int B, int H, int L, int d, int64_t ld, const char* who) {
@@ -287,6 +671,11 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
+  if (attn_use_mfma(d)) {
+    if (d <= ATT_DC) hipLaunchKernelGGL(attn_fwd_mfma1_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    return pxr_check_launch("pxr_attn_fwd_f32(mfma)");
+  }
   switch (attn_waves()) {
     case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a); break;
     case 16: hipLaunchKernelGGL(attn_fwd_kernel<16>, dim3(B * H), dim3(1024), 0, (hipStream_t)stream, a); break;
@@ -311,6 +700,11 @@ extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* 
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
+  if (attn_use_mfma(d)) {
+    if (d <= ATT_DC) hipLaunchKernelGGL(attn_bwd_mfma1_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    return pxr_check_launch("pxr_attn_bwd_f32(mfma)");
+  }
   switch (attn_waves()) {
     case 4: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a); break;
     case 16: hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(B * H), dim3(1024), 0, (hipStream_t)stream, a); break;
