@@ -25,6 +25,10 @@ class GraphedTrainStep:
         with torch.cuda.stream(s):          # eager warm-up: sizes every persistent buffer / workspace
             for _ in range(warmup):
                 self._eager()
+            if warmup == 0:
+                # size the buffers WITHOUT consuming a training step: run one eager step on a snapshot of all state and
+                # restore it (a trainer that captures in the middle of an epoch must not train on a batch twice)
+                self._dry_run()
         cur.wait_stream(s)
         torch.cuda.synchronize()
         host_state = (self.opt.step_count, self.model._step_counter, self.opt._dirty)
@@ -34,6 +38,26 @@ class GraphedTrainStep:
         # stream capture RECORDS the kernels without running them: the device counters did not advance, so the host
         # mirrors that the Python code bumped during capture are rolled back
         self.opt.step_count, self.model._step_counter, self.opt._dirty = host_state
+
+    def _dry_run(self):
+        m, o = self.model, self.opt
+        flat, _ = m.flat_parameters()
+        o._ensure_state()
+        keep = [t.clone() for t in (flat, o._m, o._v)]
+        table_state = None
+        if getattr(o, "has_table", False):
+            o.flush()
+            table_state = [t.clone() for t in (m.item_embedding.weight.data, o._tm, o._tv, o._last)]
+        counters = (o.step_count, m._step_counter, o._dirty, o._step_dev.clone(), m._drop_dev.clone())
+        self._eager()
+        for dst, src in zip((flat, o._m, o._v), keep):
+            dst.copy_(src)
+        if table_state is not None:
+            for dst, src in zip((m.item_embedding.weight.data, o._tm, o._tv, o._last), table_state):
+                dst.copy_(src)
+        o.step_count, m._step_counter, o._dirty = counters[:3]
+        o._step_dev.copy_(counters[3])
+        m._drop_dev.copy_(counters[4])
 
     def _eager(self):
         self.opt.zero_grad()

@@ -103,3 +103,36 @@ def test_lazy_long_gaps_closed_form_tail():
     # rows whose gaps never exceeded the exact window are bit-identical
     hot_rows = torch.arange(1, 40).cuda()
     assert torch.equal(pd[hot_rows], pl[hot_rows])
+
+
+def test_graph_replay_equals_eager_steps():
+    """hipGraph replay of the whole step == the eager sequence, step for step (dropout on: the seed offset and the
+    optimizer step number live on the device), including a capture that starts without consuming a batch."""
+    from pixelrec_amd.graph import GraphedTrainStep
+    from pixelrec_amd.optim import PxrAdamW
+
+    make, rng, zipf, synth = _setup(n_items=3000)
+    batches = [tuple(torch.from_numpy(x).cuda() for x in synth.train_batch(3000, 4, 10, rng, zipf)) for _ in range(12)]
+
+    def run(graph):
+        m = make()
+        m.hidden_dropout_prob = m.attn_dropout_prob = 0.1
+        opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1)
+        losses = []
+        g = None
+        for i, (it, mk) in enumerate(batches):
+            if graph and i >= 2:
+                if g is None:
+                    g = GraphedTrainStep(m, opt, it, mk, warmup=0)
+                losses.append(float(g(it, mk)))
+            else:
+                loss = m((it, mk)); loss.backward(); opt.step()
+                losses.append(float(loss.detach()))
+        return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, opt.step_count
+
+    le, se, ne = run(False)
+    lg, sg, ng = run(True)
+    assert ne == ng == len(batches)
+    assert le == lg                                   # identical losses, step by step (same kernels, same seeds)
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
