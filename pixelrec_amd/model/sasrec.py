@@ -74,9 +74,12 @@ class SASRec(SeqRecCore):
         if self.training:
             # phase 1 of the table gradient runs first: the unique ids of the batch are what a lazy optimizer must
             # bring up to date before the forward pass reads those rows
+            # a batch touches at most B*(L+1) positive + B*L negative distinct ids: that bounds the unique rows (and the
+            # per-rank payload of the data-parallel row exchange), not the 3*B*L occurrences
+            cap = B * (2 * L + 1)
             sp = self._local_sparse
-            if sp is None or sp.cap != 3 * B * L or sp.rows.shape[1] != D or sp.rows.device != items.device:
-                sp = self._local_sparse = ops.SparseRows(3 * B * L, D, items.device)
+            if sp is None or sp.cap != cap or sp.rows.shape[1] != D or sp.rows.device != items.device:
+                sp = self._local_sparse = ops.SparseRows(cap, D, items.device)
             need = ops.occ_ws_bytes(B, L)
             if self._occ_ws is None or self._occ_ws.numel() < need or self._occ_ws.device != items.device:
                 self._occ_ws = torch.empty(need, dtype=torch.uint8, device=items.device)
