@@ -1,0 +1,130 @@
+"""BASELINE.json's full sizes on the GPU: configs[1] (N=400 001, D=512, L=50, B=64) and configs[0]'s shape
+(D=128, L=20, Pixel200K-sized catalogue) -- direct oracle comparison of one training step where the CPU oracle still
+finishes in seconds, plus size-independent properties (run-to-run bit reproducibility, lazy == dense schedule,
+eval-mode loss == training loss with dropout off, ragged/empty edge cases)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sasrec_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(D, L, H, p=0.0):
+    return {"n_layers": 2, "n_heads": H, "embedding_size": D, "inner_size": 2, "hidden_dropout_prob": p,
+            "attn_dropout_prob": p, "hidden_act": "gelu", "layer_norm_eps": 1e-12, "initializer_range": 0.02,
+            "MAX_ITEM_LIST_LENGTH": L, "seed": 2020}
+
+
+def _batch(N, B, L, seed):
+    from pixelrec_amd import synth
+
+    rng = np.random.default_rng(seed)
+    it, mk = synth.train_batch(N, B, L, rng, synth.ZipfItems(N, seed=seed))
+    return torch.from_numpy(it), torch.from_numpy(mk)
+
+
+def _model(N, D, L, H, params=None, p=0.0):
+    from pixelrec_amd.model import SASRec
+
+    class DL:
+        item_num = N
+
+    m = SASRec(_cfg(D, L, H, p), DL())
+    if params is not None:
+        m.load_state_dict(params, strict=True)
+    return m.cuda().train()
+
+
+@pytest.mark.parametrize("N,D,L,H,B", [(400_001, 512, 50, 4, 64), (96_001, 128, 20, 4, 64)])
+def test_one_step_at_full_size_matches_oracle(N, D, L, H, B):
+    from pixelrec_amd.optim import PxrAdamW
+
+    params = O.synth_params(N, D, L, 2, 2, seed=21, perturb=True)
+    m = _model(N, D, L, H, params)
+    opt = PxrAdamW(m, lr=1e-4, weight_decay=0.1)
+    items, mask = _batch(N, B, L, 5)
+    loss = m((items.cuda(), mask.cuda()))
+    loss.backward()
+    tr = O.OracleTrainer(params, {"n_layers": 2, "n_heads": H, "layer_norm_eps": 1e-12}, lr=1e-4, weight_decay=0.1)
+    ref_loss, g = O.loss_and_grads(tr.p, items, mask, tr.cfg)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 3e-5 * max(1.0, abs(float(ref_loss)))
+    sp = m.sparse_table_grad
+    n = sp.count()
+    idx = sp.idx[:n].cpu()
+    ref_rows = g["item_embedding.weight"][idx]
+    assert (sp.rows[:n].cpu() - ref_rows).abs().max().item() <= 3e-6 + 2e-4 * ref_rows.abs().max().item()
+    touched = torch.zeros(N, dtype=torch.bool); touched[idx] = True
+    assert float(g["item_embedding.weight"][~touched].abs().max()) == 0.0          # nothing missed
+    for k in ("position_embedding.weight", "trm_encoder.layer.0.multi_head_attention.query.weight",
+              "trm_encoder.layer.1.feed_forward.dense_2.weight", "LayerNorm.weight"):
+        got = dict(m.named_parameters())[k].grad.cpu()
+        assert (got - g[k]).abs().max().item() <= 5e-6 + 3e-4 * g[k].abs().max().item(), k
+    opt.step()
+    tr.step(items, mask)
+    sd = m.state_dict()                                                            # flushes the lazy table
+    rows = torch.cat([idx[:200], torch.tensor([0, 1, 2, N - 1])])
+    assert (sd["item_embedding.weight"][rows.cuda()].cpu() - tr.p["item_embedding.weight"][rows]).abs().max().item() < 1e-5
+    assert abs(float(sd["item_embedding.weight"].double().sum()) - float(tr.p["item_embedding.weight"].double().sum())) < 0.05
+    for k in ("position_embedding.weight", "trm_encoder.layer.1.feed_forward.dense_2.weight"):
+        assert (sd[k].cpu() - tr.p[k]).abs().max().item() < 1e-5, k
+
+
+def test_bit_reproducible_and_schedule_independent():
+    """Same inputs -> same bits, run to run (no float atomics anywhere) and across lazy / dense table schedules and
+    grouped / per-layer weight-gradient launches."""
+    from pixelrec_amd.optim import PxrAdamW
+
+    N, D, L, H, B = 50_001, 256, 50, 4, 32
+    params = O.synth_params(N, D, L, 2, 2, seed=8)
+    batches = [_batch(N, B, L, s) for s in range(6)]
+
+    def run(schedule, grouped, p):
+        m = _model(N, D, L, H, params, p)
+        m.group_weight_grads = grouped
+        opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1, table_update=schedule)
+        for it, mk in batches:
+            loss = m((it.cuda(), mk.cuda())); loss.backward(); opt.step()
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    a = run("lazy", True, 0.1)
+    b = run("lazy", True, 0.1)
+    c = run("dense", True, 0.1)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], c[k]), k
+    # grouped vs per-layer weight-gradient launches use different GEMM kernels (no split-K vs split-K): same math,
+    # rounding-level differences in ONE backward (trained weights would amplify them through Adam's sign-like step)
+    grads = []
+    for grouped in (True, False):
+        m = _model(N, D, L, H, params, 0.0)
+        m.group_weight_grads = grouped
+        it, mk = batches[0]
+        m((it.cuda(), mk.cuda())).backward()
+        grads.append({k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None})
+    for k in grads[0]:
+        ref = grads[0][k].abs().max().item()
+        assert (grads[0][k] - grads[1][k]).abs().max().item() <= 1e-7 + 2e-5 * ref, k
+
+
+def test_edge_cases_all_padding_and_min_length():
+    """A batch holding an all-padding row, a 2-item row (one target) and L = 64 (the widest sequence one wave-wide
+    softmax handles)."""
+    N, D, L, H = 300, 64, 64, 2
+    params = O.synth_params(N, D, L, 2, 2, seed=2)
+    m = _model(N, D, L, H, params)
+    items = torch.zeros(3, 2, L + 1, dtype=torch.int64)
+    mask = torch.zeros(3, L, dtype=torch.int64)
+    items[1, 0, -2:] = torch.tensor([4, 9]); items[1, 1, -1] = 17; mask[1, -1] = 1
+    g = torch.Generator().manual_seed(0)
+    items[2, 0] = torch.randint(1, N, (L + 1,), generator=g); items[2, 1, 1:] = torch.randint(1, N, (L,), generator=g)
+    mask[2] = 1
+    loss = m((items.cuda(), mask.cuda()))
+    loss.backward()
+    ref, gr = O.loss_and_grads(params, items, mask, {"n_layers": 2, "n_heads": H, "layer_norm_eps": 1e-12})
+    assert torch.isfinite(loss) and abs(float(loss.detach()) - float(ref)) < 3e-5 * max(1.0, abs(float(ref)))
+    dense = m.sparse_table_grad.to_dense(N).cpu()
+    assert (dense - gr["item_embedding.weight"]).abs().max().item() < 5e-6 + 2e-4 * gr["item_embedding.weight"].abs().max().item()
+    with pytest.raises(Exception):
+        _model(N, D, 65, H)((torch.zeros(1, 2, 66, dtype=torch.int64).cuda(), torch.zeros(1, 65, dtype=torch.int64).cuda()))
