@@ -107,11 +107,16 @@ class SASRec(SeqRecCore):
         finally:
             self.training = was
 
-    def _backward_train(self, grad_out):
-        dx0, coef, s = self._backward_core(grad_out, self.item_embedding.weight.data)
+    def _after_input_grads(self, dx0, coef, s):
         sp = self._local_sparse
         ops.sasrec_occ_segsum(self._occ_ws, dx0, s["out"], coef, self.item_num, sp, 1.0)
         self.sparse_table_grad = sp
+        hook = getattr(self, "_sparse_ready_hook", None)
+        if hook is not None:
+            hook()
+
+    def _backward_train(self, grad_out):
+        self._backward_core(grad_out, self.item_embedding.weight.data)
 
     # ------------------------------------------------------------------------------------------ inference
     @torch.no_grad()

@@ -163,6 +163,11 @@ class SeqRecCore(BaseModel):
         self._ensure_packed()
         return self._flat, self._gflat
 
+    def _after_input_grads(self, dx0, coef, saved):
+        """Hook: runs inside the backward right after the gradient w.r.t. the gathered rows is known and BEFORE the
+        grouped weight-gradient GEMM (so whatever it launches -- e.g. a data-parallel row exchange -- overlaps it)."""
+        return None
+
     # ------------------------------------------------------------------------------------------ forward
     def _encode(self, table, idx, idx_bstride, B, keymask, km_bstride, train: bool):
         """row ids into `table` -> last-layer states [B, L, D] (sasrec.py:68-86 / :97-109); saves activations when
@@ -279,6 +284,7 @@ class SeqRecCore(BaseModel):
                             step_dev=sdv, defer=defer)
         ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1), defer=defer)
         defer.flush()
+        self._after_input_grads(dx0, coef, s)   # model-specific tail that only needs dx0/coef (table rows, exchange)
         if pending:
             ops.grouped_linear_bwd_weight(pending)
         if use_side:

@@ -76,6 +76,8 @@ def _worker(rank, port, results):
         assert m.grad_scale == 1.0 / WORLD                     # sum-all-reduce of pre-scaled grads == DDP mean
         gs.broadcast_parameters(0)
         assert torch.all(m.flat == 0.0) and torch.all(m.item_embedding.weight.data == 0.5)
+        assert m._sparse_ready_hook == gs.start_sparse_exchange
+        m._sparse_ready_hook()                                   # what the backward does right after segsum
         gs.sync()
         exp_flat = sum(_rank_data(r)[0] for r in range(WORLD))
         assert torch.allclose(m.gflat, exp_flat)
