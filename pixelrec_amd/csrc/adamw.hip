@@ -363,7 +363,7 @@ extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* las
                                   const void* hyper, const void* cumlog, int64_t t_prev, int64_t t_apply,
                                   const int64_t* step_dev, double beta1, double beta2, double eps, void* stream) {
   PXR_REQUIRE(table && m && v && last && hyper && cumlog, "pxr_adamw_rows_f32: null pointer");
-  PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 2048, "pxr_adamw_rows_f32: bad shape (D <= 2048)");
+  PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 4096, "pxr_adamw_rows_f32: bad shape (D <= 4096)");
   PXR_REQUIRE(!rows || n_rows_dev, "pxr_adamw_rows_f32: row list needs its device count");
   PXR_REQUIRE(t_prev >= 0 && (t_apply == 0 || t_apply == t_prev + 1), "pxr_adamw_rows_f32: t_apply must be t_prev+1 or 0");
   RowsArgs a{};
@@ -382,6 +382,7 @@ extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* las
   if (vec <= 1) hipLaunchKernelGGL((adamw_rows_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else if (vec <= 2) hipLaunchKernelGGL((adamw_rows_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else if (vec <= 4) hipLaunchKernelGGL((adamw_rows_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((adamw_rows_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (vec <= 8) hipLaunchKernelGGL((adamw_rows_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((adamw_rows_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   return pxr_check_launch("pxr_adamw_rows_f32");
 }

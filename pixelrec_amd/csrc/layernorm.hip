@@ -274,7 +274,8 @@ static int launch_ln_bwd(const LnBwdArgs& a, int nblk, hipStream_t st) {
     case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
     case 8: hipLaunchKernelGGL((ln_bwd_kernel<8, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
-    default: pxr_set_error("layernorm backward: D=%d > 2048 unsupported", a.D); return PXR_ERR_BAD_ARG;
+    case 16: hipLaunchKernelGGL((ln_bwd_kernel<16, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
+    default: pxr_set_error("layernorm backward: D=%d > 4096 unsupported", a.D); return PXR_ERR_BAD_ARG;
   }
   return pxr_check_launch("pxr_ln_bwd");
 }
