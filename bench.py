@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--no-group", action="store_true", help="per-layer weight-gradient GEMMs instead of one grouped launch")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="1-GPU validation knob: create a 1-rank RCCL group and run every gradient collective anyway")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="capture the RCCL collectives inside the step hipGraph too (opt-in for world > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,9 +110,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from pixelrec_amd import ops, synth
     from pixelrec_amd.model import SASRec
@@ -127,7 +132,7 @@ def main():
     if args.no_group:
         model.group_weight_grads = False
         model.overlap_weight_grads = not args.no_overlap
-    dp = DataParallel(model)
+    dp = DataParallel(model, force_collectives=args.force_collectives)
     opt = PxrAdamW(model, lr=1e-4, weight_decay=0.1)
 
     # synthetic batches, rank-distinct, resident in HBM before the timed region
@@ -139,7 +144,8 @@ def main():
         pool.append((torch.from_numpy(it).to(dev), torch.from_numpy(mk).to(dev)))
 
     gemm_events = []
-    use_graph = (not args.no_graph) and world == 1   # multi-rank capture of RCCL collectives is not validated yet
+    # replaying RCCL collectives from a hipGraph is opt-in: it cannot be validated on the 1-GPU development box
+    use_graph = (not args.no_graph) and ((world == 1 and not args.force_collectives) or args.graph_collectives)
     gstep = None
     if use_graph:
         from pixelrec_amd.graph import GraphedTrainStep
@@ -195,7 +201,7 @@ def main():
         torch.cuda.synchronize()
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -266,8 +272,12 @@ def main():
     elif world == 1:
         out["cpu_baseline"] = None
 
-    print(json.dumps(out))
-    if world > 1:
+    # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION is exported on the GPU boxes) and that buffer
+    # is only flushed at exit: flush it now so the JSON line is the LAST line on stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -53,6 +53,15 @@ int64_t pxr_embed_grad_ws_bytes(int64_t n_occ);
 int pxr_embed_grad_rows_f32(const int64_t* idx, int64_t n, const float* rows, int D, int64_t n_table, float scale,
                             int64_t* uniq_idx, float* uniq_rows, int32_t* n_uniq_dev, void* ws, int64_t ws_bytes,
                             void* stream);
+/* Data-parallel merge of the W rank-local sparse gradients after the all-gather (the build's replacement of DDP's
+ * dense all-reduce, run.py:40): idx_all[W,cap] / rows_all[W,cap,D], every list ascending and unique over its whole
+ * cap (unused tail slots hold ids >= n_table).  No re-sort: the lowest rank holding an id owns it and adds the other
+ * ranks' rows in rank order (same fixed order on every replica).  Output is not compacted: out_idx[e] = id or 0
+ * (empty slot, skipped by pxr_adamw_rows_f32 / pxr_adamw_table_f32), out_rows[e,:] = scale * sum, *n_out = W*cap. */
+int64_t pxr_merge_rows_ws_bytes(int W, int64_t cap);
+int pxr_merge_sorted_rows_f32(const int64_t* idx_all, const float* rows_all, int W, int64_t cap, int D,
+                              int64_t n_table, float scale, int64_t* out_idx, float* out_rows, int32_t* n_out_dev,
+                              void* ws, int64_t ws_bytes, void* stream);
 /* The same for the three uses of the table inside SASRec.forward (sasrec.py:68-74,88-89) without materialising the
  * [B,2,L+1,D] gather: items[B,2,L+1]; dx0 = grad of (table row + pos) [B*L,D]; out = last-layer states [B*L,D];
  * coef[B*L] from pxr_bpr_loss_bwd_f32.  n_occ = 3*B*L for the workspace size. */

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) slot_set_kernel(const int64_t* __restrict
   const int nu = *n_uniq;
   for (int u = blockIdx.x * 256 + threadIdx.x; u < nu; u += gridDim.x * 256) {
     const int64_t r = uniq_idx[u];
-    if (r >= 0 && r < n_table) slot[r] = u;
+    if (r > 0 && r < n_table) slot[r] = u;   // id 0 marks an empty slot of a merged (non-compacted) list
   }
 }
 
@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(256) adamw_rows_kernel(RowsArgs a) {
   const int64_t n = a.rows ? (int64_t)(*a.n_rows) : a.n_fixed;
   for (int64_t i = wave_id; i < n; i += n_waves) {
     const int64_t row = a.rows ? a.rows[i] : i;
+    if (a.rows && row <= 0) continue;   // id 0 = empty slot of a merged (non-compacted) row list
     const int k0 = a.last[row];
     if (k0 >= a.t_prev && a.t_apply == 0) continue;
     float4 pp[VEC], mm[VEC], vv[VEC];

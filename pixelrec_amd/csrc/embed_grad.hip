@@ -363,6 +363,76 @@ static int sort_and_segment(SortWs& w, int n, int64_t n_table, int64_t* uniq_idx
   return pxr_check_launch("embed grad (sort/segment)");
 }
 
+// ------------------------------------------------------------------------------------------------ rank merge
+// Data-parallel merge of W rank-local sparse gradients that are each ALREADY sorted and unique (the output of the
+// kernels above), concatenated as idx_all [W, cap] / rows_all [W, cap, D]; every list is ascending over its whole
+// `cap` (unused tail slots hold ids >= n_table).  No second sort: a lower-bound search finds where an id sits in
+// the other W-1 lists, the lowest rank holding an id owns its output slot and adds the other ranks' rows in rank
+// order -- a fixed order that is the same on every replica, so replicas stay bit-identical.  The output is NOT
+// compacted: slot e = (rank, i) carries (id, summed row) if that rank owns the id, else id 0 (= padding_idx, which
+// every consumer skips); *n_out = W * cap.
+__global__ void __launch_bounds__(256) merge_locate_kernel(const int64_t* __restrict__ idx_all, int W, int cap,
+                                                           int64_t n_table, int* __restrict__ pos) {
+  const int64_t total = (int64_t)W * cap * W;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t e = t / W;
+    const int q = (int)(t - e * W);
+    const int r = (int)(e / cap);
+    const int64_t key = idx_all[e];
+    int p = -1;
+    if (key > 0 && key < n_table) {
+      if (q == r) {
+        p = (int)(e - (int64_t)r * cap);
+      } else {
+        const int64_t* list = idx_all + (int64_t)q * cap;
+        int lo = 0, hi = cap;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (list[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < cap && list[lo] == key) p = lo;
+      }
+    }
+    pos[t] = p;
+  }
+}
+
+// one wave per output slot
+__global__ void __launch_bounds__(256) merge_sum_kernel(const int64_t* __restrict__ idx_all,
+                                                        const float* __restrict__ rows_all,
+                                                        const int* __restrict__ pos, int W, int cap, int D, float scale,
+                                                        int64_t* __restrict__ out_idx, float* __restrict__ out_rows,
+                                                        int32_t* __restrict__ n_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t E = (int64_t)W * cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = (int32_t)E;
+  const int dv = D >> 2;
+  for (int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += (int64_t)gridDim.x * 4) {
+    const int r = (int)(e / cap);
+    const int p = lane < W ? pos[e * W + lane] : -1;
+    const unsigned long long have = __ballot(p >= 0);
+    const bool owner = have != 0ull && (__ffsll((long long)have) - 1) == r;   // wave-uniform
+    if (!owner) {
+      if (lane == 0) out_idx[e] = 0;
+      continue;
+    }
+    for (int c = lane; c < dv; c += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned long long m = have;
+      while (m) {
+        const int q = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int pq = __shfl(p, q, 64);
+        const float4 v = *reinterpret_cast<const float4*>(rows_all + ((int64_t)q * cap + pq) * D + c * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+      *reinterpret_cast<float4*>(out_rows + e * D + c * 4) = acc;
+    }
+    if (lane == 0) out_idx[e] = idx_all[e];
+  }
+}
+
 }  // namespace pxr
 
 using namespace pxr;
@@ -449,4 +519,26 @@ extern "C" int pxr_sasrec_embed_grad_f32(const int64_t* items, int B, int L, con
   int rc = pxr_sasrec_occ_sort(items, B, L, n_table, uniq_idx, n_uniq_dev, ws, ws_bytes, stream);
   if (rc) return rc;
   return pxr_sasrec_occ_segsum(ws, ws_bytes, B, L, dx0, out, coef, D, n_table, scale, n_uniq_dev, uniq_rows, stream);
+}
+
+extern "C" int64_t pxr_merge_rows_ws_bytes(int W, int64_t cap) {
+  return align256((int64_t)W * cap * W * 4);
+}
+
+// See merge_locate_kernel: merges W sorted-unique sparse gradients without re-sorting.
+extern "C" int pxr_merge_sorted_rows_f32(const int64_t* idx_all, const float* rows_all, int W, int64_t cap, int D,
+                                         int64_t n_table, float scale, int64_t* out_idx, float* out_rows,
+                                         int32_t* n_out_dev, void* ws, int64_t ws_bytes, void* stream) {
+  PXR_REQUIRE(idx_all && rows_all && out_idx && out_rows && n_out_dev && ws, "pxr_merge_sorted_rows_f32: null pointer");
+  PXR_REQUIRE(W >= 1 && W <= 64 && cap > 0 && (int64_t)W * cap * W < (1ll << 31) && D > 0 && D % 4 == 0 &&
+              n_table > 0, "pxr_merge_sorted_rows_f32: bad shape");
+  if (pxr_merge_rows_ws_bytes(W, cap) > ws_bytes) { pxr_set_error("pxr_merge_sorted_rows_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)W * cap * W, E = (int64_t)W * cap;
+  int64_t b1 = (total + 255) / 256; if (b1 > 8192) b1 = 8192;
+  hipLaunchKernelGGL(merge_locate_kernel, dim3((unsigned)b1), dim3(256), 0, st, idx_all, W, (int)cap, n_table, (int*)ws);
+  int64_t b2 = (E + 3) / 4; if (b2 > 8192) b2 = 8192;
+  hipLaunchKernelGGL(merge_sum_kernel, dim3((unsigned)b2), dim3(256), 0, st, idx_all, rows_all, (const int*)ws, W,
+                     (int)cap, D, scale, out_idx, out_rows, n_out_dev);
+  return pxr_check_launch("pxr_merge_sorted_rows_f32");
 }

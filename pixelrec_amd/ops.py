@@ -343,7 +343,8 @@ class SparseRows:
     def to_dense(self, n_table: int) -> torch.Tensor:  # tests only
         n = self.count()
         g = torch.zeros(n_table, self.rows.shape[1], dtype=torch.float32, device=self.rows.device)
-        g[self.idx[:n]] = self.rows[:n]
+        keep = self.idx[:n] > 0          # a merged (non-compacted) list marks its empty slots with id 0
+        g[self.idx[:n][keep]] = self.rows[:n][keep]
         return g
 
 
@@ -358,6 +359,22 @@ def embed_grad_rows(idx, rows, n_table, scale=1.0, out: SparseRows | None = None
     _l.check(Lb.pxr_embed_grad_rows_f32(_l.ptr(idx), n, _l.ptr(rows), D, n_table, float(scale), _l.ptr(sp.idx),
                                         _l.ptr(sp.rows), _l.ptr(sp.n), _l.ptr(ws), ws_bytes, _l.stream_ptr()),
              "pxr_embed_grad_rows_f32")
+    return sp
+
+
+def merge_sorted_rows(idx_all, rows_all, world, n_table, scale=1.0, out: SparseRows | None = None) -> SparseRows:
+    """Merge `world` sorted-unique sparse gradients (idx_all [world*cap] padded with ids >= n_table, rows_all
+    [world*cap, D]) without re-sorting; the result keeps world*cap slots, empty ones carry id 0 (see pxr.h)."""
+    Lb = _l.load()
+    _req(idx_all, torch.int64, "idx_all"); _req(rows_all, torch.float32, "rows_all")
+    E, D = idx_all.numel(), rows_all.shape[-1]
+    cap = E // world
+    sp = out if out is not None else SparseRows(E, D, rows_all.device)
+    ws_bytes = int(Lb.pxr_merge_rows_ws_bytes(world, cap))
+    ws = _ws.get(ws_bytes, rows_all.device)
+    _l.check(Lb.pxr_merge_sorted_rows_f32(_l.ptr(idx_all), _l.ptr(rows_all), world, cap, D, n_table, float(scale),
+                                          _l.ptr(sp.idx), _l.ptr(sp.rows), _l.ptr(sp.n), _l.ptr(ws), ws_bytes,
+                                          _l.stream_ptr()), "pxr_merge_sorted_rows_f32")
     return sp
 
 

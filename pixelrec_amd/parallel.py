@@ -7,7 +7,8 @@ embedding gradient.  Here:
     rank pre-scales its loss gradient by 1/world so the sum IS DDP's mean);
   * the table gradient stays sparse: each rank contributes its (uniq_idx, uniq_rows) padded to a fixed capacity
     (padding ids are 0 = padding_idx, which the merge drops) -> one all-gather of ids + one of rows -> every
-    rank merges the W lists with the same deterministic sort/segment-sum kernel, so replicas stay bit-identical.
+    rank merges the W (already sorted, unique) lists with the same rank-ordered merge kernel -- no second sort --
+    so replicas stay bit-identical.
 No host synchronisation: counts stay on the device, shapes are static.
 
 `DataParallel` mirrors the only DDP surface the reference's Trainer uses: `.module`, `__call__`, `.train()`,
@@ -25,14 +26,18 @@ def world_info():
     return 0, 1
 
 
+PAD_ID = torch.iinfo(torch.int64).max   # tail filler of an exchanged id list: keeps the list ascending, never a row
+
+
 def gather_sparse(idx: torch.Tensor, rows: torch.Tensor, n: torch.Tensor, group=None, async_op: bool = False):
-    """All-gather a rank-local sparse gradient.  idx int64 [cap] (entries >= n are forced to 0 so that they are
-    dropped as padding), rows fp32 [cap, D], n int32 [1].  Returns (idx_all [W*cap], rows_all [W*cap, D], handles);
-    with async_op the collectives run on the backend's own stream and `handles` must be waited before use."""
+    """All-gather a rank-local sparse gradient.  idx int64 [cap] ascending over its first n entries (entries >= n
+    are forced to PAD_ID: the merge drops ids outside the table, and every list stays ascending over its whole cap),
+    rows fp32 [cap, D], n int32 [1].  Returns (idx_all [W*cap], rows_all [W*cap, D], handles); with async_op the
+    collectives run on the backend's own stream and `handles` must be waited before use."""
     _, world = world_info()
     cap = idx.shape[0]
-    ar = torch.arange(cap, device=idx.device)
-    idx_masked = torch.where(ar < n.to(torch.int64), idx, torch.zeros_like(idx))
+    ar = _arange(cap, idx.device)
+    idx_masked = torch.where(ar < n, idx, PAD_ID)
     idx_all = torch.empty(world * cap, dtype=idx.dtype, device=idx.device)
     rows_all = torch.empty(world * cap, rows.shape[1], dtype=rows.dtype, device=rows.device)
     rows = rows.contiguous()
@@ -45,18 +50,31 @@ def gather_sparse(idx: torch.Tensor, rows: torch.Tensor, n: torch.Tensor, group=
     return idx_all, rows_all, ([x for x in h if x is not None], idx_masked, rows)
 
 
+_ARANGE = {}
+
+
+def _arange(cap, device):
+    key = (cap, str(device))
+    if key not in _ARANGE:
+        _ARANGE[key] = torch.arange(cap, device=device, dtype=torch.int32)
+    return _ARANGE[key]
+
+
 class GradSync:
     """Synchronises the gradients of a pixelrec_amd SASRec across ranks after backward()."""
 
-    def __init__(self, model, merge_fn=None, group=None):
+    def __init__(self, model, merge_fn=None, group=None, force: bool = False):
         self.model = model
         self.group = group
         self.rank, self.world = world_info()
+        # force=True runs every collective even in a world of one (a 1-rank RCCL group on a single-GPU box
+        # still goes through the same torch.distributed/RCCL entry points, streams and async handles)
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         # merge_fn(idx_all, rows_all, n_table, out_sparse) -> SparseRows ; default = the HIP kernel
         self._merge = merge_fn
         self._merged = None
         self._pending = None
-        if self.world > 1:
+        if self.active:
             model.grad_scale = 1.0 / self.world
             # start the row exchange as soon as the sparse rows exist, i.e. BEFORE the grouped weight-gradient GEMM of
             # the same backward pass: the all-gather (xGMI) then runs under 0.25 ms of MFMA work
@@ -68,7 +86,7 @@ class GradSync:
 
     def broadcast_parameters(self, src: int = 0):
         """DDP's construction-time broadcast: make every replica start from rank `src`."""
-        if self.world == 1:
+        if not self.active:
             return
         flat, _ = self.model.flat_parameters()
         dist.broadcast(flat, src=src, group=self.group)
@@ -83,39 +101,43 @@ class GradSync:
         return list(enc.parameters()) if enc is not None else []
 
     def sync(self):
-        if self.world == 1:
+        """Order matters for overlap: the flat all-reduce is only ENQUEUED (async, on RCCL's stream) and runs under
+        the merge of the gathered sparse rows (radix sort + segmented sum); the compute stream waits for it last."""
+        if not self.active:
             return
         _, gflat = self.model.flat_parameters()
-        dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.group)
+        waits = [dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
         for p in self._extra_params():      # trainable tail of the visual encoder (frozen parameters have no grads)
             if p.grad is not None:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
-        if not hasattr(self.model, "item_embedding"):
-            return
-        if self._pending is None:
-            self.start_sparse_exchange()
-        idx_all, rows_all, (handles, *_keepalive) = self._pending
-        for h in handles:
-            h.wait()
-        self._pending = None
-        if self._merge is None:
-            from . import ops
+                waits.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if hasattr(self.model, "item_embedding"):
+            if self._pending is None:
+                self.start_sparse_exchange()
+            idx_all, rows_all, (handles, *_keepalive) = self._pending
+            for h in handles:
+                h.wait()
+            self._pending = None
+            if self._merge is None:
+                from . import ops
 
-            if self._merged is None or self._merged.cap != idx_all.numel():
-                self._merged = ops.SparseRows(idx_all.numel(), rows_all.shape[1], rows_all.device)
-            self.model.sparse_table_grad = ops.embed_grad_rows(idx_all, rows_all, self.model.item_num, 1.0,
-                                                               out=self._merged)
-        else:
-            self.model.sparse_table_grad = self._merge(idx_all, rows_all, self.model.item_num)
+                if self._merged is None or self._merged.cap != idx_all.numel():
+                    self._merged = ops.SparseRows(idx_all.numel(), rows_all.shape[1], rows_all.device)
+                self.model.sparse_table_grad = ops.merge_sorted_rows(idx_all, rows_all, self.world,
+                                                                     self.model.item_num, 1.0, out=self._merged)
+            else:
+                self.model.sparse_table_grad = self._merge(idx_all, rows_all, self.model.item_num)
+        for h in waits:
+            if h is not None:
+                h.wait()
 
 
 class DataParallel(torch.nn.Module):
     """Minimal DDP-shaped wrapper: the Trainer reaches the model through `.module` (trainer.py:332,349,358,374)."""
 
-    def __init__(self, module, merge_fn=None):
+    def __init__(self, module, merge_fn=None, force_collectives: bool = False):
         super().__init__()
         self.module = module
-        self.grad_sync = GradSync(module, merge_fn)
+        self.grad_sync = GradSync(module, merge_fn, force=force_collectives)
         self.grad_sync.broadcast_parameters(0)
 
     def forward(self, *args, **kwargs):

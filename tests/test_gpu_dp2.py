@@ -79,3 +79,30 @@ def test_two_ranks_equal_one_big_batch():
     assert r["err_vs_oracle"] < 2e-5, r["err_vs_oracle"]
     assert r["tab0"] == r["tab1"]                      # replicas stay bit-identical
     assert r["sum0"] == r["sum1"]
+
+
+@pytest.mark.parametrize("W,cap,D,n_table", [(1, 37, 64, 50), (2, 100, 128, 300), (8, 257, 512, 900), (5, 64, 4096, 40)])
+def test_merge_sorted_rows_kernel(W, cap, D, n_table):
+    """pxr_merge_sorted_rows_f32 against a dense index_add; ids overlap heavily between ranks (n_table < W*cap)."""
+    from pixelrec_amd import ops
+    from pixelrec_amd.parallel import PAD_ID
+
+    g = torch.Generator().manual_seed(W * 1000 + cap)
+    idx_all = torch.full((W, cap), PAD_ID, dtype=torch.int64)
+    rows_all = torch.randn(W, cap, D, generator=g)
+    dense = torch.zeros(n_table, D, dtype=torch.float64)
+    for r in range(W):
+        n = int(torch.randint(0, min(cap, n_table - 1) + 1, (1,), generator=g))
+        ids = torch.sort(torch.randperm(n_table - 1, generator=g)[:n] + 1).values
+        idx_all[r, :n] = ids
+        dense.index_add_(0, ids, rows_all[r, :n].double())
+    sp = ops.merge_sorted_rows(idx_all.reshape(-1).cuda(), rows_all.reshape(W * cap, D).cuda(), W, n_table, 0.5)
+    assert sp.count() == W * cap
+    idx = sp.idx.cpu()
+    live = idx[idx > 0]
+    assert live.numel() == live.unique().numel()                       # every id owned by exactly one slot
+    assert set(live.tolist()) == set(idx_all[idx_all < n_table].tolist())
+    got = sp.to_dense(n_table).cpu().double()
+    assert torch.allclose(got, 0.5 * dense, atol=1e-5)
+    sp2 = ops.merge_sorted_rows(idx_all.reshape(-1).cuda(), rows_all.reshape(W * cap, D).cuda(), W, n_table, 0.5)
+    assert torch.equal(sp2.idx, sp.idx) and torch.equal(sp2.to_dense(n_table), sp.to_dense(n_table))

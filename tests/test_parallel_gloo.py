@@ -58,6 +58,7 @@ class _FakeModel:
 
 def _cpu_merge(idx_all, rows_all, n_table):
     dense = torch.zeros(n_table, rows_all.shape[1])
+    idx_all = torch.where(idx_all < n_table, idx_all, 0)       # tail slots carry parallel.PAD_ID
     dense.index_add_(0, idx_all, rows_all)
     dense[0] = 0                                   # id 0 = padding / masked-out slots
     return dense
