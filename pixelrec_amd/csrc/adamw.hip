@@ -17,6 +17,8 @@
 //     The kernel clears the slots it consumes, so the map is all -1 again afterwards.
 #include "pxr_common.h"
 
+#include <cstdlib>
+
 namespace pxr {
 
 struct AdamHyper {
@@ -78,7 +80,7 @@ __global__ void __launch_bounds__(256) slot_set_kernel(const int64_t* __restrict
 
 // One wave sweeps whole rows (grid-stride): coalesced float4 streams of p, m, v; gradient rows come from the
 // compact buffer when slot >= 0.  ROWS_PER_ITER rows are in flight per wave to keep enough loads outstanding.
-template <int VEC>
+template <int VEC, int NT>
 __global__ void __launch_bounds__(256) adamw_table_kernel(float* __restrict__ p, float* __restrict__ m,
                                                           float* __restrict__ v, int64_t n_rows, int D,
                                                           int* __restrict__ slot, const float* __restrict__ grows,
@@ -96,9 +98,13 @@ __global__ void __launch_bounds__(256) adamw_table_kernel(float* __restrict__ p,
       const int c = (k * 64 + lane) * 4;
       if (c < D) {
         const int64_t o = row * D + c;
-        pp[k] = *reinterpret_cast<const float4*>(p + o);
-        mm[k] = *reinterpret_cast<const float4*>(m + o);
-        vv[k] = *reinterpret_cast<const float4*>(v + o);
+        if constexpr (NT & 1) {
+          pp[k] = pxr_ld_stream(p + o); mm[k] = pxr_ld_stream(m + o); vv[k] = pxr_ld_stream(v + o);
+        } else {
+          pp[k] = *reinterpret_cast<const float4*>(p + o);
+          mm[k] = *reinterpret_cast<const float4*>(m + o);
+          vv[k] = *reinterpret_cast<const float4*>(v + o);
+        }
         gg[k] = gr ? *reinterpret_cast<const float4*>(gr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -109,9 +115,13 @@ __global__ void __launch_bounds__(256) adamw_table_kernel(float* __restrict__ p,
         const int64_t o = row * D + c;
         adam_elem(pp[k].x, mm[k].x, vv[k].x, gg[k].x, h); adam_elem(pp[k].y, mm[k].y, vv[k].y, gg[k].y, h);
         adam_elem(pp[k].z, mm[k].z, vv[k].z, gg[k].z, h); adam_elem(pp[k].w, mm[k].w, vv[k].w, gg[k].w, h);
-        *reinterpret_cast<float4*>(p + o) = pp[k];
-        *reinterpret_cast<float4*>(m + o) = mm[k];
-        *reinterpret_cast<float4*>(v + o) = vv[k];
+        if constexpr (NT & 2) {
+          pxr_st_stream(p + o, pp[k]); pxr_st_stream(m + o, mm[k]); pxr_st_stream(v + o, vv[k]);
+        } else {
+          *reinterpret_cast<float4*>(p + o) = pp[k];
+          *reinterpret_cast<float4*>(m + o) = mm[k];
+          *reinterpret_cast<float4*>(v + o) = vv[k];
+        }
       }
     }
   }
@@ -307,14 +317,23 @@ extern "C" int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_r
   int64_t blocks = (n_rows + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   const int vec = (D + 255) / 256;
-#define PXR_TABLE_CASE(V) \
-  hipLaunchKernelGGL((adamw_table_kernel<V>), dim3((unsigned)blocks), dim3(256), 0, st, table, m, v, n_rows, D, slot, uniq_rows, h)
+  static const int nt = getenv("PXR_ADAMW_NT") ? atoi(getenv("PXR_ADAMW_NT")) : 3;   // A/B knob: 0 none, 1 loads, 2 stores, 3 both
+#define PXR_TABLE_LAUNCH(V, T) \
+  hipLaunchKernelGGL((adamw_table_kernel<V, T>), dim3((unsigned)blocks), dim3(256), 0, st, table, m, v, n_rows, D, slot, uniq_rows, h)
+#define PXR_TABLE_CASE(V)                                  \
+  do {                                                     \
+    if (nt == 0) PXR_TABLE_LAUNCH(V, 0);                   \
+    else if (nt == 1) PXR_TABLE_LAUNCH(V, 1);              \
+    else if (nt == 2) PXR_TABLE_LAUNCH(V, 2);              \
+    else PXR_TABLE_LAUNCH(V, 3);                           \
+  } while (0)
   if (vec <= 1) PXR_TABLE_CASE(1);
   else if (vec <= 2) PXR_TABLE_CASE(2);
   else if (vec <= 4) PXR_TABLE_CASE(4);
   else if (vec <= 8) PXR_TABLE_CASE(8);
   else PXR_TABLE_CASE(16);
 #undef PXR_TABLE_CASE
+#undef PXR_TABLE_LAUNCH
   return pxr_check_launch("pxr_adamw_table_f32");
 }
 
