@@ -54,19 +54,32 @@ struct GemmCfg {
 };
 
 // ---- global -> register tile fetch (zero-filled outside the matrix) ------------------------------------
-// KC operand: matrix [X][K] (row stride ld), tile rows x0.., k range k0..k0+31
+// Through buffer loads: the hardware bounds check returns 0 for lanes whose offset lies outside the descriptor, so
+// ragged edges need no branch (a divergent branch around a load makes the compiler drain ALL outstanding loads --
+// s_waitcnt vmcnt(0) -- at the top of every K tile, which defeats any prefetching).  Descriptors are built from
+// block-uniform values only (kernel arguments, blockIdx-derived tile origins, the K-tile counter).
+typedef __amdgpu_buffer_rsrc_t bufrsrc;
+__device__ __forceinline__ bufrsrc make_rsrc(const float* base, int64_t bytes) {
+  const int nb = bytes > 0x7FFFFFF0ll ? 0x7FFFFFF0 : (bytes < 0 ? 0 : (int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nb, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld16(bufrsrc rs, unsigned byte_off) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+constexpr unsigned BUF_OOB = 0xFFFFFFFFu;
+
+// KC operand: matrix [X][K] (row stride ld); `rs` starts at the tile's first row, rows_left = X - x0
 template <int BX, int NLD, int NT>
-__device__ __forceinline__ void fetch_kc(float4 (&r)[NLD], const float* __restrict__ g, int64_t ld, int x0,
-                                         int X, int k0, int kend, int tid) {
+__device__ __forceinline__ void fetch_kc(float4 (&r)[NLD], bufrsrc rs, int ld, int rows_left, int k0, int kend,
+                                         int tid) {
 #pragma unroll
   for (int p = 0; p < NLD; ++p) {
     const int f = tid + p * NT;  // float4 index in tile: row = f/8, q = f%8
     const int row = f >> 3, q = f & 7;
-    const int gx = x0 + row, gk = k0 + q * 4;
-    if (gx < X && gk < kend)
-      r[p] = *reinterpret_cast<const float4*>(g + (int64_t)gx * ld + gk);
-    else
-      r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gk = k0 + q * 4;
+    const bool ok = row < rows_left && gk < kend;
+    r[p] = buf_ld16(rs, ok ? (unsigned)(row * ld + gk) * 4u : BUF_OOB);
   }
 }
 template <int BX, int NLD, int NT>
@@ -78,20 +91,18 @@ __device__ __forceinline__ void stash_kc(const float4 (&r)[NLD], float* lds, int
     *reinterpret_cast<float4*>(lds + row * (GEMM_BK + 4) + q * 4) = r[p];
   }
 }
-// XC operand: matrix [K][X] (row stride ld), tile k rows k0..k0+31, x range x0..x0+BX-1
+// XC operand: matrix [K][X] (row stride ld); `rs` starts at element [k0][x0], krows_left = kend - k0,
+// cols_left = X - x0
 template <int BX, int NLD, int NT>
-__device__ __forceinline__ void fetch_xc(float4 (&r)[NLD], const float* __restrict__ g, int64_t ld, int x0,
-                                         int X, int k0, int kend, int tid) {
+__device__ __forceinline__ void fetch_xc(float4 (&r)[NLD], bufrsrc rs, int ld, int krows_left, int cols_left,
+                                         int tid) {
   constexpr int Q = BX / 4;  // float4 per k row
 #pragma unroll
   for (int p = 0; p < NLD; ++p) {
     const int f = tid + p * NT;
     const int kk = f / Q, q = f % Q;
-    const int gk = k0 + kk, gx = x0 + q * 4;
-    if (gk < kend && gx < X)
-      r[p] = *reinterpret_cast<const float4*>(g + (int64_t)gk * ld + gx);
-    else
-      r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ok = kk < krows_left && q * 4 < cols_left;
+    r[p] = buf_ld16(rs, ok ? (unsigned)(kk * ld + q * 4) * 4u : BUF_OOB);
   }
 }
 template <int BX, int NLD, int NT>
@@ -110,7 +121,12 @@ __device__ __forceinline__ void stash_xc(const float4 (&r)[NLD], float* lds, int
 //                                         [n0 + wn*WN + bj*32 + (l&31)]          (gfx950 32x32 C/D map)
 // CS (only with an XC A operand): additionally accumulate, per thread, the sum over k of the A float4s it stages
 // (column sums of the stored [K][M] matrix = bias gradient when A = dY) into *cs; the caller reduces across threads.
-template <int BM, int BN, bool A_KC, bool B_KC, bool CS = false, int KW = 1>
+// PD = prefetch depth: tiles kt+1 .. kt+PD are in flight (global -> registers) while tile kt is multiplied.  A 64x64
+// tile spends only ~0.43 us of MFMA time per K tile, far less than a global round trip, so with PD = 1 a workgroup
+// that is alone on its CU (M = B*L = 3200 tokens => ~1.5 workgroups per CU) stalls on every K tile; PD = 3..4 keeps
+// enough loads in flight (16 VGPRs per slot at 64x64).  LDS stays double-buffered: slot (kt+1) % PD is written to
+// the other buffer while tile kt is read.
+template <int BM, int BN, bool A_KC, bool B_KC, bool CS = false, int KW = 1, int PD = 2>
 __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_KC, KW>::Acc& accs,
                                               const float* __restrict__ A, int64_t lda,
                                               const float* __restrict__ B, int64_t ldb, int M, int N,
@@ -132,77 +148,129 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[Cfg::A_LD4], rb[Cfg::B_LD4];
+  float4 ra[PD][Cfg::A_LD4], rb[PD][Cfg::B_LD4];
   const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
   if (nk <= 0) return;
 
-  auto fetch = [&](int kt) {
+  // descriptors of the k-contiguous operands cover the tile's rows for the whole K range; the x-contiguous ones are
+  // re-based per K tile (32-bit offsets stay small however long the token reduction is)
+  bufrsrc rsA = make_rsrc(A, 0), rsB = make_rsrc(B, 0);
+  if constexpr (A_KC) rsA = make_rsrc(A + (int64_t)m0 * lda, (int64_t)(M - m0) * lda * 4);
+  if constexpr (B_KC) rsB = make_rsrc(B + (int64_t)n0 * ldb, (int64_t)(N - n0) * ldb * 4);
+  auto fetch = [&](int kt, float4 (&fa)[Cfg::A_LD4], float4 (&fb)[Cfg::B_LD4]) {
     const int k0 = kbeg + kt * GEMM_BK;
-    if constexpr (A_KC) fetch_kc<BM, Cfg::A_LD4, NT>(ra, A, lda, m0, M, k0, kend, tid);
-    else fetch_xc<BM, Cfg::A_LD4, NT>(ra, A, lda, m0, M, k0, kend, tid);
+    if constexpr (A_KC) {
+      fetch_kc<BM, Cfg::A_LD4, NT>(fa, rsA, (int)lda, M - m0, k0, kend, tid);
+    } else {
+      const bufrsrc rs = make_rsrc(A + (int64_t)k0 * lda + m0, ((int64_t)(kend - k0) * lda - m0) * 4);
+      fetch_xc<BM, Cfg::A_LD4, NT>(fa, rs, (int)lda, kend - k0, M - m0, tid);
+    }
     if constexpr (CS) {
       static_assert(!A_KC, "column sums are taken over an x-contiguous A operand");
 #pragma unroll
-      for (int p = 0; p < Cfg::A_LD4; ++p) { cs->x += ra[p].x; cs->y += ra[p].y; cs->z += ra[p].z; cs->w += ra[p].w; }
+      for (int p = 0; p < Cfg::A_LD4; ++p) { cs->x += fa[p].x; cs->y += fa[p].y; cs->z += fa[p].z; cs->w += fa[p].w; }
     }
-    if constexpr (B_KC) fetch_kc<BN, Cfg::B_LD4, NT>(rb, B, ldb, n0, N, k0, kend, tid);
-    else fetch_xc<BN, Cfg::B_LD4, NT>(rb, B, ldb, n0, N, k0, kend, tid);
+    if constexpr (B_KC) {
+      fetch_kc<BN, Cfg::B_LD4, NT>(fb, rsB, (int)ldb, N - n0, k0, kend, tid);
+    } else {
+      const bufrsrc rs = make_rsrc(B + (int64_t)k0 * ldb + n0, ((int64_t)(kend - k0) * ldb - n0) * 4);
+      fetch_xc<BN, Cfg::B_LD4, NT>(fb, rs, (int)ldb, kend - k0, N - n0, tid);
+    }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const float4 (&fa)[Cfg::A_LD4], const float4 (&fb)[Cfg::B_LD4]) {
     float* sa = smem + buf * Cfg::STAGE;
     float* sb = sa + Cfg::A_STAGE;
-    if constexpr (A_KC) stash_kc<BM, Cfg::A_LD4, NT>(ra, sa, tid);
-    else stash_xc<BM, Cfg::A_LD4, NT>(ra, sa, tid);
-    if constexpr (B_KC) stash_kc<BN, Cfg::B_LD4, NT>(rb, sb, tid);
-    else stash_xc<BN, Cfg::B_LD4, NT>(rb, sb, tid);
+    if constexpr (A_KC) stash_kc<BM, Cfg::A_LD4, NT>(fa, sa, tid);
+    else stash_xc<BM, Cfg::A_LD4, NT>(fa, sa, tid);
+    if constexpr (B_KC) stash_kc<BN, Cfg::B_LD4, NT>(fb, sb, tid);
+    else stash_xc<BN, Cfg::B_LD4, NT>(fb, sb, tid);
+  };
+  // fragments of one 8-wide k sub-step: a[i][t] / b[j][t] feed MFMA t (see the layout notes at the top)
+  struct Frag {
+    float a[Cfg::TM][4], b[Cfg::TN][4];
+  };
+  constexpr int NS = GEMM_BK / 8 / KW;   // sub-steps per K tile for this wave group
+  static_assert(NS % 2 == 0, "fragment double-buffering needs an even number of sub-steps");
+  auto read_frag = [&](Frag& f, int buf, int ks0) {
+    const float* sa = smem + buf * Cfg::STAGE;
+    const float* sb = sa + Cfg::A_STAGE;
+    const int ks = ks0 * KW + (KW > 1 ? wk : 0);
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      const int row = wm * Cfg::WM + i * 32 + r;
+      if constexpr (A_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(sa + row * Cfg::LDA + ks * 8 + h * 4);
+        f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f.a[i][t] = sa[(ks * 8 + h * 4 + t) * Cfg::LDA + row];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = wn * Cfg::WN + j * 32 + r;
+      if constexpr (B_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(sb + col * Cfg::LDB + ks * 8 + h * 4);
+        f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f.b[j][t] = sb[(ks * 8 + h * 4 + t) * Cfg::LDB + col];
+      }
+    }
+  };
+  auto mfma = [&](const Frag& f, int t0, int t1) {
+#pragma unroll
+    for (int t = t0; t < t1; ++t)
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][t], f.b[j][t], acc[i][j], 0, 0, 0);
   };
 
-  fetch(0);
-  stash(0);
+  // tile j lives in register slot j % PD.  Fetches past the last K tile are issued unconditionally: every lane is
+  // out of range, so they move no data and return zeros -- and a straight-line loop body lets the compiler count
+  // outstanding loads exactly (s_waitcnt vmcnt(n) for the slot being written instead of draining everything).
+#pragma unroll
+  for (int s = 0; s < PD; ++s) fetch(s, ra[s], rb[s]);
+  stash(0, ra[0], rb[0]);
   __syncthreads();
+  Frag fr[2];
+  read_frag(fr[0], 0, 0);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
-    if (more) fetch(kt + 1);
-    const float* sa = smem + (kt & 1) * Cfg::STAGE;
-    const float* sb = sa + Cfg::A_STAGE;
+  // Software pipeline inside the wave.  Instructions issue in order and a wave can run at most one MFMA ahead of the
+  // matrix pipe, so whatever should overlap with MFMA execution has to be ISSUED before those MFMAs; the
+  // sched_barriers pin that order (left alone, the scheduler moves the LDS reads behind the MFMAs they should
+  // overlap with):  fragments of sub-step q+1 are read before sub-step q multiplies; the next tile is written to the
+  // other LDS buffer before the last sub-step; the barrier sits in the MIDDLE of the last sub-step and the first
+  // fragment read of the next tile follows it immediately, so both run under the remaining MFMAs.
+  for (int kt0 = 0; kt0 < nk; kt0 += PD) {
 #pragma unroll
-    for (int ks0 = 0; ks0 < GEMM_BK / 8; ks0 += KW) {
-      const int ks = ks0 + (KW > 1 ? wk : 0);
-      float a[Cfg::TM][4], b[Cfg::TN][4];
+    for (int s = 0; s < PD; ++s) {
+      const int kt = kt0 + s;
+      if (kt < nk) {   // block-uniform
+        const int buf = kt & 1;
+        fetch(kt + PD, ra[s], rb[s]);   // slot s held tile kt, which already sits in LDS
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) {
-        const int row = wm * Cfg::WM + i * 32 + r;
-        if constexpr (A_KC) {
-          const float4 v = *reinterpret_cast<const float4*>(sa + row * Cfg::LDA + ks * 8 + h * 4);
-          a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) a[i][t] = sa[(ks * 8 + h * 4 + t) * Cfg::LDA + row];
+        for (int q = 0; q + 1 < NS; ++q) {
+          read_frag(fr[(q + 1) & 1], buf, q + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma(fr[q & 1], 0, 4);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        stash(buf ^ 1, ra[(s + 1) % PD], rb[(s + 1) % PD]);   // (zeros after the last tile)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(fr[(NS - 1) & 1], 0, 2);
+        __syncthreads();
+        read_frag(fr[0], buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(fr[(NS - 1) & 1], 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {
-        const int col = wn * Cfg::WN + j * 32 + r;
-        if constexpr (B_KC) {
-          const float4 v = *reinterpret_cast<const float4*>(sb + col * Cfg::LDB + ks * 8 + h * 4);
-          b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) b[j][t] = sb[(ks * 8 + h * 4 + t) * Cfg::LDB + col];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-          for (int j = 0; j < Cfg::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
     }
-    if (more) stash((kt + 1) & 1);
-    __syncthreads();
   }
+  __syncthreads();   // the staging LDS is reused by the callers' epilogues
   if constexpr (KW > 1) {
     // add the partial accumulators of wave group 1 into wave group 0 through LDS (the staging buffers are free:
     // the loop ended with a barrier).  Layout [w4][element][lane] => conflict-free 4-byte accesses.

@@ -6,6 +6,8 @@
 //   sasrec.py:112 (full-catalog scoring, un-fused form) and the autograd transposes of all of them.
 #include "gemm_f32.cuh"
 
+#include <cstdlib>
+
 namespace pxr {
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD = 4 };
@@ -18,7 +20,7 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1>
 __global__ void __launch_bounds__(GEMM_THREADS * KW)
 gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
             float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
@@ -35,7 +37,7 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
   C += (int64_t)blockIdx.y * split_stride;
 
   typename Cfg::Acc accs;
-  gemm_mainloop<BM, BN, A_KC, B_KC, false, KW>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
+  gemm_mainloop<BM, BN, A_KC, B_KC, false, KW, PD>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
 
   auto& acc = accs.v;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -166,12 +168,12 @@ __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_kernel(DwGroup g) {
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1>
 static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                        int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
                        int64_t split_stride, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW>), dim3(tiles_m * tiles_n, splits),
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD>), dim3(tiles_m * tiles_n, splits),
                      dim3(GEMM_THREADS * KW), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
                      tiles_n, ksplit_len, split_stride);
   return pxr_check_launch("pxr_gemm_f32");
@@ -181,18 +183,26 @@ template <bool A_KC, bool B_KC, int EPI>
 static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                          int M, int N, int K, const float* bias, float* aux, int64_t ldaux, int splits,
                          int ksplit_len, int64_t split_stride, hipStream_t st) {
-#define PXR_TILE(BM_, BN_)                                                                                       \
-  return launch_gemm<BM_, BN_, A_KC, B_KC, EPI>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits, ksplit_len, \
-                                                split_stride, st)
+  static const int pd = getenv("PXR_GEMM_PD") ? atoi(getenv("PXR_GEMM_PD")) : 2;   // prefetch depth (tuning knob)
+#define PXR_TILE_PD(BM_, BN_, KW_, PD_)                                                                          \
+  return launch_gemm<BM_, BN_, A_KC, B_KC, EPI, KW_, PD_>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits, \
+                                                          ksplit_len, split_stride, st)
+#define PXR_TILE(BM_, BN_, KW_)                  \
+  do {                                           \
+    if (pd >= 4) PXR_TILE_PD(BM_, BN_, KW_, 4);  \
+    if (pd == 3) PXR_TILE_PD(BM_, BN_, KW_, 3);  \
+    if (pd == 2) PXR_TILE_PD(BM_, BN_, KW_, 2);  \
+    PXR_TILE_PD(BM_, BN_, KW_, 1);               \
+  } while (0)
   switch (tile) {
-    case 128: PXR_TILE(128, 128);
-    case 12864: PXR_TILE(128, 64);
-    case 64128: PXR_TILE(64, 128);
+    case 128: PXR_TILE_PD(128, 128, 1, 1);   // 1.7 us of MFMA work per K tile: one tile of prefetch is enough
+    case 12864: PXR_TILE(128, 64, 1);
+    case 64128: PXR_TILE(64, 128, 1);
     case 642:  // 64x64 tile, 8 waves: two wave groups split the k-steps (see GemmCfg KW)
-      return launch_gemm<64, 64, A_KC, B_KC, EPI, 2>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
-                                                     ksplit_len, split_stride, st);
-    default: PXR_TILE(64, 64);
+      PXR_TILE(64, 64, 2);
+    default: PXR_TILE(64, 64, 1);
   }
+#undef PXR_TILE_PD
 #undef PXR_TILE
 }
 

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) score_topk_kernel(ScoreTopkArgs 
   for (int tn = tn0; tn < tn1; ++tn) {
     const int n0 = tn * ST_BN;
     typename StCfg::Acc accs;
-    gemm_mainloop<ST_BM, ST_BN, true, true>(accs, a.users, a.ld_users, a.table, (int64_t)a.D, a.B, a.N, 0, a.D, m0,
+    gemm_mainloop<ST_BM, ST_BN, true, true, false, 1, 1>(accs, a.users, a.ld_users, a.table, (int64_t)a.D, a.B, a.N, 0, a.D, m0,
                                              n0, smem);
     // (the main loop ends with a barrier: the staging buffers are free) -> score tile in LDS, masks applied
 #pragma unroll
