@@ -19,6 +19,8 @@
 // hipGraph-capturable and needs no host synchronisation.
 #include "pxr_common.h"
 
+#include <cstdlib>
+
 namespace pxr {
 
 constexpr int RS_THREADS = 256;
@@ -214,6 +216,206 @@ __global__ void __launch_bounds__(RS_THREADS) seg_assign_kernel(const int* __res
     }
   }
   if (blockIdx.x == 0 && tid == 0) seg_start[*n_uniq] = n;
+}
+
+// ------------------------------------------------------------------------------------------------ fused passes
+// For the batch sizes of the training step (n = 3*B*L = 9600 occurrences at B=64) the multi-launch sort above is
+// pure launch latency: 13 kernels of ~5 us.  Below, ONE launch per radix pass and ONE for the segments: instead of
+// exchanging per-block histograms through global memory (hist -> scan -> scatter), every block redundantly
+// histograms ALL n keys in LDS (n is small; the keys sit in L2), which gives it the global digit bases AND the
+// counts of the blocks before it without any inter-block communication.  Digits widen to up to 10 bits, so 19-bit
+// ids (N = 400 K) need 2 passes.  Same stable order as the multi-launch path => identical results.
+constexpr int FP_MAXBITS = 10;
+constexpr int FP_BINS = 1 << FP_MAXBITS;
+constexpr int FP_THREADS = 1024;         // 16 waves: the redundant histogram is one global round trip for n <= 16 K
+constexpr int FP_WAVES = FP_THREADS / 64;
+constexpr int FP_ITEMS = 2;              // keys ranked per thread => the same 2048-key tile as the multi-launch path
+constexpr int FP_HB = 16;                // keys per thread per histogram batch
+constexpr int FP_MAX_N = 32 * RS_TILE;   // beyond this the redundant histogram stops paying
+static_assert(FP_THREADS * FP_ITEMS == RS_TILE, "fused passes share the tile size (and workspace) of the radix sort");
+
+struct FusedPassArgs {
+  const int64_t* src;          // pass 0: idx[n] (MODE_ROWS) or items [B,2,L+1] (MODE_SASREC); later passes: unused
+  const int* keys_in; const int* vals_in;
+  int* keys_out; int* vals_out;
+  int n, B, L, shift, bits, first;
+  int64_t n_table;
+};
+
+template <int MODE>
+__device__ __forceinline__ int occ_key(const FusedPassArgs& a, int o) {
+  int64_t id;
+  if constexpr (MODE == 0) {
+    id = a.src[o];
+  } else {
+    const int T = a.B * a.L;
+    const int type = o / T, r = o - type * T;
+    const int b = r / a.L, t = r - b * a.L;
+    const int64_t* row = a.src + (int64_t)b * 2 * (a.L + 1);
+    id = (type == 0) ? row[t] : (type == 1 ? row[t + 1] : row[(a.L + 1) + t + 1]);
+  }
+  return (id < 0 || id >= a.n_table) ? 0 : (int)id;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(FP_THREADS) fused_pass_kernel(FusedPassArgs a) {
+  __shared__ int h_all[FP_BINS];       // histogram of all keys -> exclusive digit bases (+ blocks before this one)
+  __shared__ int h_prev[FP_BINS];      // histogram of the keys that belong to earlier blocks
+  __shared__ int wcnt[FP_WAVES][FP_BINS];
+  __shared__ int wsum[FP_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = 1 << a.bits, mask = nb - 1;
+  for (int i = tid; i < nb; i += FP_THREADS) { h_all[i] = 0; h_prev[i] = 0; }
+  for (int i = tid; i < FP_WAVES * FP_BINS; i += FP_THREADS) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  const int my0 = blockIdx.x * RS_TILE;
+  // FP_HB keys per thread are loaded before the first LDS atomic (one global round trip per 16 K keys); a wave
+  // whose 64 keys share one digit (runs of padding zeros, a popular item) adds once instead of 64 times
+  for (int i0 = 0; i0 < a.n; i0 += FP_HB * FP_THREADS) {
+    int k[FP_HB];
+#pragma unroll
+    for (int e = 0; e < FP_HB; ++e) {
+      const int i = i0 + e * FP_THREADS + tid;
+      k[e] = (i < a.n) ? (a.first ? occ_key<MODE>(a, i) : a.keys_in[i]) : -1;
+    }
+#pragma unroll
+    for (int e = 0; e < FP_HB; ++e) {
+      const int i = i0 + e * FP_THREADS + tid;          // a wave covers 64 consecutive i: `i < my0` is wave-uniform
+      const bool valid = k[e] >= 0;
+      const int dg = (k[e] >> a.shift) & mask;
+      const int dg0 = __shfl(dg, 0, 64);
+      if (__ballot(valid && dg == dg0) == ~0ull) {
+        if (lane == 0) { atomicAdd(&h_all[dg], 64); if (i < my0) atomicAdd(&h_prev[dg], 64); }
+      } else if (valid) {
+        atomicAdd(&h_all[dg], 1);
+        if (i < my0) atomicAdd(&h_prev[dg], 1);
+      }
+    }
+  }
+  __syncthreads();
+  // exclusive scan of h_all over the digits (one bin per thread)
+  {
+    const int own = (tid < nb) ? h_all[tid] : 0;
+    int incl = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - own;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (tid < nb) h_all[tid] = run + h_prev[tid];
+  }
+  // rank this block's keys: order inside the block = (wave, e, lane) = ascending index => stable
+  volatile int* mycnt = wcnt[wave];
+  const int base = my0 + wave * (64 * FP_ITEMS);
+  int key[FP_ITEMS], val[FP_ITEMS], rank[FP_ITEMS];
+#pragma unroll
+  for (int e = 0; e < FP_ITEMS; ++e) {
+    const int i = base + e * 64 + lane;
+    const bool valid = i < a.n;
+    key[e] = valid ? (a.first ? occ_key<MODE>(a, i) : a.keys_in[i]) : 0;
+    val[e] = valid ? (a.first ? i : a.vals_in[i]) : 0;
+    const int dg = (key[e] >> a.shift) & mask;
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < FP_MAXBITS; ++bit) {   // bits above the digit width are 0 in every lane: no-ops
+      const bool one = (dg >> bit) & 1;
+      const unsigned long long bm = __ballot(one);
+      m &= one ? bm : ~bm;
+    }
+    const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    int b0 = 0;
+    if (valid && r == 0) {  // lowest lane of each digit group bumps this wave's counter
+      b0 = mycnt[dg];
+      mycnt[dg] = b0 + __popcll(m);
+    }
+    const int leader = valid ? (__ffsll((long long)m) - 1) : lane;
+    b0 = __shfl(b0, leader, 64);
+    rank[e] = b0 + r;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  if (tid < nb) {   // digit tid: exclusive prefix over the waves + global base of this block
+    int c = h_all[tid];
+    for (int w = 0; w < FP_WAVES; ++w) { const int t = wcnt[w][tid]; wcnt[w][tid] = c; c += t; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < FP_ITEMS; ++e) {
+    const int i = base + e * 64 + lane;
+    if (i < a.n) {
+      const int pos = wcnt[wave][(key[e] >> a.shift) & mask] + rank[e];
+      a.keys_out[pos] = key[e];
+      a.vals_out[pos] = val[e];
+    }
+  }
+}
+
+// seg_count + scan + seg_assign in one launch: block b also counts the heads of the tiles before it
+__global__ void __launch_bounds__(RS_THREADS) fused_segments_kernel(const int* __restrict__ keys, int n,
+                                                                    int64_t* __restrict__ uniq_idx,
+                                                                    int* __restrict__ seg_start,
+                                                                    int* __restrict__ n_uniq) {
+  __shared__ int wsum[4];
+  __shared__ int s_prev;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto head = [&](int i) { const int k = keys[i]; return (k != 0 && (i == 0 || keys[i - 1] != k)) ? 1 : 0; };
+  const int my0 = blockIdx.x * RS_TILE;
+  int cprev = 0;
+  for (int i0 = 0; i0 < my0; i0 += 8 * RS_THREADS) {   // my0 is a multiple of 2048 = 8 * 256: no tail
+    int k0[8], k1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                       // all 16 loads in flight before the first compare
+      const int i = i0 + e * RS_THREADS + tid;
+      k0[e] = keys[i];
+      k1[e] = i > 0 ? keys[i - 1] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e * RS_THREADS + tid;
+      cprev += (k0[e] != 0 && (i == 0 || k1[e] != k0[e])) ? 1 : 0;
+    }
+  }
+  cprev = (int)wave_sum((float)cprev);   // < 2^24: exact in fp32
+  if (lane == 0) wsum[wave] = cprev;
+  __syncthreads();
+  if (tid == 0) s_prev = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  const int base = my0 + tid * RS_ITEMS;
+  int flag[RS_ITEMS], c = 0;
+#pragma unroll
+  for (int e = 0; e < RS_ITEMS; ++e) {
+    const int i = base + e;
+    flag[e] = (i < n) ? head(i) : 0;
+    c += flag[e];
+  }
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+  for (int w = 0; w < 4; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+  int u = s_prev + woff + incl - c;
+#pragma unroll
+  for (int e = 0; e < RS_ITEMS; ++e) {
+    if (flag[e]) {
+      uniq_idx[u] = keys[base + e];
+      seg_start[u] = base + e;
+      ++u;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    *n_uniq = s_prev + tot;
+    seg_start[s_prev + tot] = n;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ segmented sum
@@ -437,6 +639,49 @@ __global__ void __launch_bounds__(256) merge_sum_kernel(const int64_t* __restric
 
 using namespace pxr;
 
+static int radix_passes(int64_t n_table) {
+  int bits = 1;
+  while (((int64_t)1 << bits) < n_table) ++bits;
+  return (bits + 7) / 8;
+}
+// n <= FP_MAX_N: one launch per (wide) radix pass + one for the segments (PXR_FUSED_SORT=0 forces the multi-launch
+// path, for A/B tests).  Returns the buffer the sorted occurrence ids end up in through *sorted_vals.
+static bool use_fused_sort(int n) {
+  static const int enabled = getenv("PXR_FUSED_SORT") ? atoi(getenv("PXR_FUSED_SORT")) : 1;
+  return enabled && n <= FP_MAX_N;
+}
+static int fused_passes(int64_t n_table) {
+  int bits = 1;
+  while (((int64_t)1 << bits) < n_table) ++bits;
+  return (bits + FP_MAXBITS - 1) / FP_MAXBITS;
+}
+template <int MODE>
+static int fused_sort(const int64_t* src, int n, int B, int L, int64_t n_table, const SortWs& w, int64_t* uniq_idx,
+                      int* n_uniq, hipStream_t st, const int** sorted_vals) {
+  int bits = 1;
+  while (((int64_t)1 << bits) < n_table) ++bits;
+  const int npass = fused_passes(n_table);
+  const int width = (bits + npass - 1) / npass;
+  int *kin = w.keysA, *kout = w.keysB, *vin = w.valsA, *vout = w.valsB;
+  for (int p = 0; p < npass; ++p) {
+    FusedPassArgs a{};
+    a.src = src; a.keys_in = kin; a.vals_in = vin; a.keys_out = kout; a.vals_out = vout;
+    a.n = n; a.B = B; a.L = L; a.shift = p * width; a.bits = width; a.first = (p == 0); a.n_table = n_table;
+    hipLaunchKernelGGL(fused_pass_kernel<MODE>, dim3(w.nblk), dim3(FP_THREADS), 0, st, a);
+    int* t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+  }
+  hipLaunchKernelGGL(fused_segments_kernel, dim3(w.nblk), dim3(RS_THREADS), 0, st, kin, n, uniq_idx, w.seg_start,
+                     n_uniq);
+  *sorted_vals = vin;
+  return pxr_check_launch("embed grad (fused sort/segment)");
+}
+// where pxr_sasrec_occ_sort leaves the sorted occurrence ids for pxr_sasrec_occ_segsum
+static const int* sasrec_sorted_vals(const SortWs& w, int n, int64_t n_table) {
+  const int npass = use_fused_sort(n) ? fused_passes(n_table) : radix_passes(n_table);
+  return (npass & 1) ? w.valsB : w.valsA;   // the ping-pong buffers swap once per pass
+}
+
 extern "C" int64_t pxr_embed_grad_ws_bytes(int64_t n_occ) {
   return carve(nullptr, (int)n_occ, nullptr);
 }
@@ -452,10 +697,15 @@ extern "C" int pxr_embed_grad_rows_f32(const int64_t* idx, int64_t n, const floa
   SortWs w;
   if (carve(ws, (int)n, &w) > ws_bytes) { pxr_set_error("pxr_embed_grad_rows_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(occ_keys_rows_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, st, idx, (int)n, w.keysA, w.valsA,
-                     n_table);
   const int* sorted_vals = nullptr;
-  int rc = sort_and_segment(w, (int)n, n_table, uniq_idx, n_uniq_dev, st, &sorted_vals);
+  int rc;
+  if (use_fused_sort((int)n)) {
+    rc = fused_sort<MODE_ROWS>(idx, (int)n, 0, 0, n_table, w, uniq_idx, n_uniq_dev, st, &sorted_vals);
+  } else {
+    hipLaunchKernelGGL(occ_keys_rows_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, st, idx, (int)n, w.keysA,
+                       w.valsA, n_table);
+    rc = sort_and_segment(w, (int)n, n_table, uniq_idx, n_uniq_dev, st, &sorted_vals);
+  }
   if (rc) return rc;
   SegSumArgs a{};
   a.vals = sorted_vals; a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = rows; a.uniq_rows = uniq_rows;
@@ -465,12 +715,6 @@ extern "C" int pxr_embed_grad_rows_f32(const int64_t* idx, int64_t n, const floa
   return pxr_check_launch("pxr_embed_grad_rows_f32");
 }
 
-static const int* final_sorted_vals(const SortWs& w, int64_t n_table) {
-  int bits = 1;
-  while (((int64_t)1 << bits) < n_table) ++bits;
-  const int npass = (bits + 7) / 8;
-  return (npass & 1) ? w.valsB : w.valsA;   // the ping-pong buffers swap once per pass
-}
 
 // Phase 1 of the SASRec table gradient: occurrence keys -> stable sort -> unique ids + segments.  Depends on
 // `items` only, so it can run BEFORE the forward pass (the lazy table optimizer needs the unique rows of the batch
@@ -485,12 +729,18 @@ extern "C" int pxr_sasrec_occ_sort(const int64_t* items, int B, int L, int64_t n
   SortWs w;
   if (carve(ws, n, &w) > ws_bytes) { pxr_set_error("pxr_sasrec_occ_sort: workspace too small"); return PXR_ERR_WORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
+  const int* sorted_vals = nullptr;
+  if (use_fused_sort(n)) {
+    int rc = fused_sort<MODE_SASREC>(items, n, B, L, n_table, w, uniq_idx, n_uniq_dev, st, &sorted_vals);
+    if (rc) return rc;
+    if (sorted_vals != sasrec_sorted_vals(w, n, n_table)) { pxr_set_error("pxr_sasrec_occ_sort: internal buffer parity"); return PXR_ERR_LAUNCH; }
+    return PXR_OK;
+  }
   hipLaunchKernelGGL(occ_keys_sasrec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, items, B, L, w.keysA, w.valsA,
                      n_table);
-  const int* sorted_vals = nullptr;
   int rc = sort_and_segment(w, n, n_table, uniq_idx, n_uniq_dev, st, &sorted_vals);
   if (rc) return rc;
-  if (sorted_vals != final_sorted_vals(w, n_table)) { pxr_set_error("pxr_sasrec_occ_sort: internal buffer parity"); return PXR_ERR_LAUNCH; }
+  if (sorted_vals != sasrec_sorted_vals(w, n, n_table)) { pxr_set_error("pxr_sasrec_occ_sort: internal buffer parity"); return PXR_ERR_LAUNCH; }
   return PXR_OK;
 }
 
@@ -504,7 +754,7 @@ extern "C" int pxr_sasrec_occ_segsum(const void* ws, int64_t ws_bytes, int B, in
   SortWs w;
   if (carve(const_cast<void*>(ws), n, &w) > ws_bytes) { pxr_set_error("pxr_sasrec_occ_segsum: workspace too small"); return PXR_ERR_WORKSPACE; }
   SegSumArgs a{};
-  a.vals = final_sorted_vals(w, n_table); a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = dx0; a.src1 = out;
+  a.vals = sasrec_sorted_vals(w, n, n_table); a.seg_start = w.seg_start; a.n_uniq = n_uniq_dev; a.src0 = dx0; a.src1 = out;
   a.coef = coef; a.uniq_rows = uniq_rows; a.scale = scale; a.D = D; a.T = B * L;
   const int grid = n < 4096 ? n : 4096;
   hipLaunchKernelGGL(segsum_kernel<MODE_SASREC>, dim3(grid), dim3(SEG_THREADS), SEG_THREADS * 16, (hipStream_t)stream, a);

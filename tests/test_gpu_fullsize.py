@@ -37,7 +37,8 @@ def _model(N, D, L, H, params=None, p=0.0):
     return m.cuda().train()
 
 
-@pytest.mark.parametrize("N,D,L,H,B", [(400_001, 512, 50, 4, 64), (96_001, 128, 20, 4, 64)])
+# B=64 takes the fused sort (n = 3*B*L <= 65536 occurrences: one launch per pass), B=1200 the multi-launch radix sort
+@pytest.mark.parametrize("N,D,L,H,B", [(400_001, 512, 50, 4, 64), (96_001, 128, 20, 4, 64), (96_001, 128, 20, 4, 1200)])
 def test_one_step_at_full_size_matches_oracle(N, D, L, H, B):
     from pixelrec_amd.optim import PxrAdamW
 

@@ -116,3 +116,27 @@ def test_predict_scores(case):
     masked = O.full_sort_scores(scores, torch.from_numpy(z["eval.history_u"]), torch.from_numpy(z["eval.history_i"]))
     _, idx = torch.topk(masked, 10, dim=-1)
     assert np.array_equal(idx.numpy(), z["eval.topk_idx"])
+
+
+@pytest.mark.parametrize("n,n_table", [(1, 10), (700, 50), (5000, 400_001), (2048, 3000), (2049, 5_000_000), (65536, 70_000),
+                                        (65537, 70_000), (150_000, 3000)])
+def test_embed_grad_rows_sort_paths(n, n_table):
+    """Sparse embedding backward vs a dense index_add: n <= 65536 runs the fused passes (one launch per wide radix
+    pass), larger n the multi-launch radix sort; ids include padding (0) and out-of-range values, which are dropped."""
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(n)
+    idx = torch.randint(0, n_table, (n,), generator=g)
+    if n > 10:
+        idx[::7] = 0
+        idx[3] = n_table + 5
+        idx[5] = -2
+    rows = torch.randn(n, 16, generator=g)
+    sp = ops.embed_grad_rows(idx.cuda(), rows.cuda(), n_table, 0.5)
+    cnt = sp.count()
+    got_idx = sp.idx[:cnt].cpu()
+    ok = (idx > 0) & (idx < n_table)
+    assert torch.equal(got_idx, torch.unique(idx[ok]))               # ascending, unique, padding / OOR dropped
+    dense = torch.zeros(n_table, 16, dtype=torch.float64)
+    dense.index_add_(0, idx[ok], rows[ok].double())
+    assert torch.allclose(sp.to_dense(n_table).cpu().double(), 0.5 * dense, atol=1e-5)
