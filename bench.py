@@ -231,6 +231,36 @@ def main():
         "roofline": roof,
     }
 
+    if not args.no_extras and world == 1 and B == 64:
+        # (0) the same step at throughput-oriented batch sizes (SURVEY.md §8d asks for B=64 AND 512 / 2048 per GPU)
+        from pixelrec_amd.graph import GraphedTrainStep as _G
+
+        out["throughput_batches"] = []
+        for Bt in (512, 2048):
+            bt = [tuple(torch.from_numpy(a).to(dev) for a in synth.train_batch(N, Bt, L, rng, zipf)) for _ in range(4)]
+            g2 = _G(dp, opt, *bt[0]) if use_graph else None
+
+            def step_b(i):
+                if g2 is not None:
+                    return g2(*bt[i % 4])
+                opt.zero_grad()
+                dp(bt[i % 4]).backward()
+                dp.sync_gradients()
+                opt.step()
+
+            for i in range(3):
+                step_b(i)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            n_b = 20 if Bt == 512 else 8
+            for i in range(n_b):
+                step_b(i)
+            torch.cuda.synchronize()
+            tb = (time.perf_counter() - tb) / n_b
+            out["throughput_batches"].append({"batch_per_gpu": Bt, "value": Bt / tb, "unit": "sequences/s",
+                                              "ms_per_step": tb * 1e3, "steps": n_b})
+            del g2, bt
+
     if not args.no_extras and world == 1:
         # (1) embedding gather, north-star HBM target: uniform ids (worst case for caches), B=2048-equivalent rows
         n_rows = 2048 * 2 * (L + 1)

@@ -1,10 +1,14 @@
 """CPU ORACLE for the PixelNet path -- TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED for the visual encoder: the reference's ViT branch cannot be imported here (it downloads
-`openai/clip-vit-base-patch32` and pokes `model.vision_model`, which transformers 5.x no longer has -- SURVEY.md §7
-hard part 8), so there are no reference-generated goldens for it.  As SURVEY.md §8c prescribes, the oracle is a hand
-restatement of code/REC/model/load.py:91-120 + layers.py:121-128 ON TOP OF the installed HF `CLIPVisionModel` (random
-init), and the sequence part re-uses oracle.sasrec_oracle, which IS pinned against the reference.
+Pinned against the reference's own classes: tests/golden/mosasrec_tiny.npz is produced by oracle/make_golden_pixel.py
+from the REFERENCE's `MOSASRec` (code/REC/model/PixelNet/mosasrec.py:66-119) and `MeanItemEncoder`
+(code/REC/model/layers.py:121-128), imported unmodified, over a random tiny HF `CLIPVisionModel`;
+tests/test_mosasrec_golden.py checks this restatement (and the HIP path) against it: loss, all 53 gradients,
+`compute_item`, `predict`.  What stays UNPINNED: the reference's `load_model` ViT branch itself cannot run offline
+(load.py:94 downloads `openai/clip-vit-base-patch32`; load.py:112,116 poke `model.vision_model`, which transformers
+5.x no longer has -- SURVEY.md §7 hard part 8), so the goldens use the installed transformers 5.x tower, not the
+reference's pinned 4.16.2, and random rather than pre-trained weights.  The sequence part re-uses
+oracle.sasrec_oracle, which is pinned against the reference's SASRec.
 """
 from __future__ import annotations
 

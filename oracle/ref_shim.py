@@ -74,6 +74,8 @@ def install_stubs():
         tv.transforms = _mod("torchvision.transforms", Compose=_unavailable, Resize=_unavailable,
                              ToTensor=_unavailable, Normalize=_unavailable)
         tv.models = _mod("torchvision.models")
+    if "clip" not in sys.modules:          # OpenAI CLIP package: imported by REC/model/load.py:2, unused by the ViT branch
+        _mod("clip", load=_unavailable)
     for name in ("wandb", "hyperopt"):
         if name not in sys.modules:
             try:

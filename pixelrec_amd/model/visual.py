@@ -128,7 +128,9 @@ class CLIPVisionEncoder(nn.Module):
 
 ENCODER_SHAPES = {
     # name -> (hidden, layers, heads, mlp, image, patch)
-    "clip-vit-base-patch32": (768, 12, 12, 3072, 224, 32),
+    "clip-vit-base-patch32": (768, 12, 12, 3072, 224, 32),     # the encoder the reference ships (overall/ViT.yaml)
+    "clip-vit-base-patch16": (768, 12, 12, 3072, 224, 16),     # BASELINE configs[2]
+    "clip-vit-large-patch14": (1024, 24, 16, 4096, 224, 14),   # BASELINE configs[4]
     "clip-vit-tiny-test": (64, 3, 4, 128, 64, 32),     # unit tests only
 }
 

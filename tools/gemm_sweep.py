@@ -19,7 +19,7 @@ shapes = [("fwd", M, 1536, 512), ("fwd", M, 512, 512), ("fwd", M, 1024, 512), ("
 tot = {}
 for kind, m, n, k in shapes:
     line = f"{kind:3s} M={m:6d} N={n:5d} K={k:6d} ideal={2*m*n*k/157.3e12*1e6:6.1f}us |"
-    for tile in (64, 642, 128):
+    for tile in [int(t) for t in os.environ.get("TILES", "64,642,128").split(",")]:
         if kind == "fwd":
             x = torch.randn(m, k, device=dev); W = torch.randn(n, k, device=dev); b = torch.randn(n, device=dev); y = torch.empty(m, n, device=dev)
             f = lambda: ops.gemm(True, True, m, n, k, x, k, W, k, y, n, ops.EPI_BIAS, bias=b, use_ws=False, tile_hint=tile)
