@@ -14,8 +14,9 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, dp_model, optimizer, items, masked_index, warmup=3):
+    def __init__(self, dp_model, optimizer, items, masked_index, warmup=3, clip_grad_norm=None):
         self.dp, self.opt = dp_model, optimizer
+        self.clip = clip_grad_norm        # dict(max_norm=..., norm_type=2) as in the reference YAML, or None
         self.model = dp_model.module if hasattr(dp_model, "module") else dp_model
         self.items = items.clone()
         self.mask = masked_index.clone()
@@ -65,6 +66,10 @@ class GraphedTrainStep:
         loss.backward()
         if hasattr(self.dp, "sync_gradients"):
             self.dp.sync_gradients()
+        if self.clip:
+            from .optim import clip_grad_norm_
+
+            clip_grad_norm_(self.model, **self.clip)
         self.opt.step()
         return loss
 

@@ -138,6 +138,35 @@ class PxrAdamW:
         self._dirty = False
 
 
+def clip_grad_norm_(model, max_norm, norm_type=2.0, **_ignored):
+    """torch.nn.utils.clip_grad_norm_ for this build's gradient layout (reference trainer.py:123-124, K18): the flat
+    gradient buffer + the sparse table rows (absent rows are zeros of the dense gradient the reference clips) + the
+    visual-encoder gradients.  Everything stays on the device (no .item()), so it is hipGraph-capturable.  Call it
+    after `sync_gradients()`.  Returns the total norm as a 0-dim device tensor."""
+    if float(norm_type) != 2.0:
+        raise NotImplementedError("clip_grad_norm_: only the 2-norm is built (torch's default)")
+    model = model.module if hasattr(model, "module") else model
+    _, gflat = model.flat_parameters()
+    sq = gflat.pow(2).sum()
+    sp = getattr(model, "sparse_table_grad", None) if hasattr(model, "item_embedding") else None
+    live = None
+    if sp is not None:
+        ar = torch.arange(sp.rows.shape[0], device=sp.rows.device, dtype=torch.int32)
+        live = ((ar < sp.n) & (sp.idx > 0)).unsqueeze(1)          # slots beyond n / empty slots of a merged list
+        sq = sq + torch.where(live, sp.rows, 0.0).pow(2).sum()
+    extra = [p.grad for n, p in model.named_parameters() if "visual_encoder" in n and p.grad is not None]
+    for g in extra:
+        sq = sq + g.pow(2).sum()
+    total = sq.sqrt()
+    coef = torch.clamp(float(max_norm) / (total + 1e-6), max=1.0)
+    gflat.mul_(coef)
+    if sp is not None:
+        sp.rows.mul_(coef)
+    for g in extra:
+        g.mul_(coef)
+    return total
+
+
 class OptimizerGroup:
     """Several optimizers stepped together (reference trainer.py:86-96 builds ONE torch AdamW with a 'visual_encoder'
     group and a rec group; here the rec group is PxrAdamW and the visual-encoder group a torch AdamW)."""

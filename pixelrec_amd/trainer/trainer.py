@@ -28,7 +28,7 @@ import torch
 
 from .. import ops
 from ..evaluator import Collector, Evaluator
-from ..optim import OptimizerGroup, PxrAdamW
+from ..optim import OptimizerGroup, PxrAdamW, clip_grad_norm_
 from ..parallel import world_info
 from ..utils import calculate_valid_score, dict2str, early_stopping, ensure_dir, get_local_time
 
@@ -95,8 +95,6 @@ class Trainer:
         g = config["use_hip_graph"]
         self.use_graph = (g is None or bool(g)) and self.world == 1 and not self.use_modality
         self._gstep = None
-        if self.clip_grad_norm:
-            raise NotImplementedError("clip_grad_norm is not configured by any shipped YAML and is not built yet")
 
     # ---------------------------------------------------------------------------------------------- optimizer
     def _build_optimizer(self):
@@ -122,7 +120,8 @@ class Trainer:
                 if self._gstep is None and data[0].shape[0] == self.config["train_batch_size"]:
                     from ..graph import GraphedTrainStep
 
-                    self._gstep = GraphedTrainStep(self.model, self.optimizer, data[0], data[1], warmup=0)
+                    self._gstep = GraphedTrainStep(self.model, self.optimizer, data[0], data[1], warmup=0,
+                                                   clip_grad_norm=self.clip_grad_norm)
                 if self._gstep is not None and self._gstep.matches(data[0], data[1]):
                     total = total + self._gstep(data[0], data[1])
                     continue
@@ -135,6 +134,8 @@ class Trainer:
             losses.backward()
             if hasattr(self.model, "sync_gradients"):
                 self.model.sync_gradients()
+            if self.clip_grad_norm:                                   # trainer.py:123-124
+                clip_grad_norm_(self.model, **self.clip_grad_norm)
             self.optimizer.step()
             total = total + losses.detach()
         total_loss = float(total.item())          # the only host sync of the epoch

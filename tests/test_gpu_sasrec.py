@@ -140,3 +140,30 @@ def test_embed_grad_rows_sort_paths(n, n_table):
     dense = torch.zeros(n_table, 16, dtype=torch.float64)
     dense.index_add_(0, idx[ok], rows[ok].double())
     assert torch.allclose(sp.to_dense(n_table).cpu().double(), 0.5 * dense, atol=1e-5)
+
+
+@pytest.mark.parametrize("max_norm", [0.05, 1e6])
+def test_clip_grad_norm_matches_torch(max_norm):
+    """clip_grad_norm_ over the flat buffer + sparse table rows == torch.nn.utils.clip_grad_norm_ over the oracle's
+    dense gradients (reference trainer.py:123-124); the second value leaves the gradients untouched."""
+    from pixelrec_amd.optim import clip_grad_norm_
+
+    meta, z = load_case("tiny")
+    m, p = _model(meta)
+    m.train()
+    items, mask = torch.from_numpy(z["items"]), torch.from_numpy(z["masked_index"])
+    m((items.cuda(), mask.cuda())).backward()
+    _, g = O.loss_and_grads(p, items, mask, oracle_cfg(meta))
+    ref = [v.clone() for v in g.values()]
+    holders = [torch.nn.Parameter(torch.zeros_like(v)) for v in ref]
+    for h, v in zip(holders, ref):
+        h.grad = v
+    ref_total = torch.nn.utils.clip_grad_norm_(holders, max_norm=max_norm, norm_type=2)
+    total = clip_grad_norm_(m, max_norm=max_norm, norm_type=2)
+    assert abs(float(total) - float(ref_total)) <= 1e-5 * float(ref_total)
+    clipped = dict(zip(g.keys(), (h.grad for h in holders)))
+    got_table = m.sparse_table_grad.to_dense(meta["n_items"]).cpu()
+    assert (got_table - clipped["item_embedding.weight"]).abs().max().item() <= 1e-7 + 2e-4 * clipped["item_embedding.weight"].abs().max().item()
+    for k in ("position_embedding.weight", "trm_encoder.layer.0.multi_head_attention.query.weight", "LayerNorm.bias"):
+        got = dict(m.named_parameters())[k].grad.cpu()
+        assert (got - clipped[k]).abs().max().item() <= 1e-7 + 2e-4 * clipped[k].abs().max().item(), k
