@@ -35,19 +35,25 @@ constexpr int GEMM_THREADS = 256;
 template <int BM, int BN, bool A_KC, bool B_KC, int KW = 1>
 struct GemmCfg {
   static constexpr int BK = GEMM_BK;
-  static constexpr int NT = GEMM_THREADS * KW;
+  // wave grid of one k-group: WGM x 2.  BM = 32 tiles use one wave row; with KW = 2 that is still a 256-thread
+  // workgroup, but each output tile is half as large: twice as many, independently synchronised workgroups per CU --
+  // what overlaps one workgroup's barrier / LDS bubbles when a GEMM has few tiles (waves of ONE workgroup run in
+  // lockstep between barriers, so more waves per workgroup do not help: measured with the 64x64 KW=2 tile).
+  static constexpr int WGM = (BM >= 64) ? 2 : 1;
+  static constexpr int G = WGM * 2;
+  static constexpr int NT = 64 * G * KW;
   static constexpr int LDA = A_KC ? (BK + 4) : BM;
   static constexpr int LDB = B_KC ? (BK + 4) : BN;
   static constexpr int A_STAGE = (A_KC ? BM : BK) * LDA;  // floats
   static constexpr int B_STAGE = (B_KC ? BN : BK) * LDB;
   static constexpr int STAGE = A_STAGE + B_STAGE;
   static constexpr int LDS_BYTES = 2 * STAGE * 4;
-  static constexpr int WM = BM / 2, WN = BN / 2;
+  static constexpr int WM = BM / WGM, WN = BN / 2;
   static constexpr int TM = WM / 32, TN = WN / 32;
   static constexpr int A_LD4 = BM * BK / 4 / NT;  // float4 loads per thread per tile
   static constexpr int B_LD4 = BN * BK / 4 / NT;
   static_assert(A_LD4 >= 1 && B_LD4 >= 1, "tile too small for this many threads");
-  static_assert(BM % 64 == 0 && BN % 64 == 0, "tile must be a multiple of 64");
+  static_assert(BM % 32 == 0 && BN % 64 == 0, "tile must be a multiple of 32 x 64");
   struct Acc {
     f32x16 v[TM][TN];
   };
@@ -136,7 +142,7 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
   constexpr int NT = Cfg::NT;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wk = wave >> 2, w4 = wave & 3;
+  const int wk = wave / Cfg::G, w4 = wave % Cfg::G;
   const int wm = w4 >> 1, wn = w4 & 1;
   const int h = lane >> 5, r = lane & 31;
   auto& acc = accs.v;
@@ -276,7 +282,7 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
     // the loop ended with a barrier).  Layout [w4][element][lane] => conflict-free 4-byte accesses.
     static_assert(KW == 2, "intra-workgroup split-K is built for 2 wave groups");
     constexpr int NE = Cfg::TM * Cfg::TN * 16;
-    static_assert(4 * NE * 64 <= 2 * Cfg::STAGE, "accumulator exchange does not fit in the staging LDS");
+    static_assert(Cfg::G * NE * 64 <= 2 * Cfg::STAGE, "accumulator exchange does not fit in the staging LDS");
     float* ex = smem + (w4 * NE) * 64 + lane;
     if (wk == 1) {
 #pragma unroll

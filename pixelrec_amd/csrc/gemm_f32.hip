@@ -21,7 +21,7 @@ __device__ __forceinline__ float dgelu_erf(float x) {
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1>
-__global__ void __launch_bounds__(GEMM_THREADS * KW)
+__global__ void __launch_bounds__((GemmCfg<BM, BN, A_KC, B_KC, KW>::NT))
 gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
             float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
             float* __restrict__ aux, int64_t ldaux, int tiles_m, int tiles_n, int ksplit_len,
@@ -41,8 +41,8 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
 
   auto& acc = accs.v;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (KW > 1 && wave >= 4) return;  // the second wave group handed its partial sums over in the main loop
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  if (KW > 1 && wave >= Cfg::G) return;  // the second wave group handed its partial sums over in the main loop
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;   // (wave < G: wm is 0 for one-row grids)
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
     const int col = n0 + wn * Cfg::WN + j * 32 + r;
@@ -174,7 +174,7 @@ static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb,
                        int64_t split_stride, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD>), dim3(tiles_m * tiles_n, splits),
-                     dim3(GEMM_THREADS * KW), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
+                     dim3(GemmCfg<BM, BN, A_KC, B_KC, KW>::NT), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
                      tiles_n, ksplit_len, split_stride);
   return pxr_check_launch("pxr_gemm_f32");
 }
@@ -200,6 +200,8 @@ static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, 
     case 64128: PXR_TILE(64, 128, 1);
     case 642:  // 64x64 tile, 8 waves: two wave groups split the k-steps (see GemmCfg KW)
       PXR_TILE(64, 64, 2);
+    case 3264:  // 32x64 tile, 4 waves = 1x2 wave grid x 2 k-groups: twice as many (independent) workgroups
+      PXR_TILE(32, 64, 2);
     default: PXR_TILE(64, 64, 1);
   }
 #undef PXR_TILE_PD
@@ -239,8 +241,8 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   bool big = (t128 >= 384);  // >= 1.5 waves of 128x128 tiles over 256 CUs; otherwise 64x64 tiles fill the chip better
   int tile = big ? 128 : 64;
-  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642) tile = tile_hint;
-  const int bm = (tile == 128 || tile == 12864) ? 128 : 64;
+  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264) tile = tile_hint;
+  const int bm = (tile == 128 || tile == 12864) ? 128 : (tile == 3264 ? 32 : 64);
   const int bn = (tile == 128 || tile == 64128) ? 128 : 64;
   const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   PXR_REQUIRE(tiles < (1ll << 31), "pxr_gemm_f32: too many tiles");

@@ -85,7 +85,7 @@ def embed_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ GEMMs
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_ADD = 0, 1, 2, 3, 4
 
 
 def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc, epilogue=EPI_NONE, bias=None,
