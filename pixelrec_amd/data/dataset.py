@@ -151,3 +151,46 @@ def seq_eval_collate(batch):
     history_i = torch.cat(history_i)
     positive_u = torch.arange(item_seq.shape[0])
     return item_seq, (history_u, history_i), positive_u, item_target
+
+
+class SeqEvalBatcher:
+    """Vectorised equivalent of DataLoader(SeqEvalDataset, sampler=NonConsecutiveSequentialDistributedSampler,
+    collate_fn=seq_eval_collate) (reference evalset.py:4-36, collate_fn.py:6-32, data/utils.py:134-159): yields the same
+    `(item_seq [b,L], (history_u, history_i), positive_u [b], item_target [b])` batches, built from a CSR image of the
+    user sequences with numpy index arithmetic instead of one Python __getitem__ per user (200 K users: 1.6 s -> ms).
+    Duck-types what the Trainer reads from a DataLoader: iteration, `len()`, `.dataset.dataload`, `.sampler.dataset`."""
+
+    def __init__(self, config, dataload, phase="valid", rank=0, world=1):
+        self.dataset = SeqEvalDataset(config, dataload, phase=phase)       # keeps the per-user API (and the tests) alive
+        self.sampler = type("Sampler", (), {"dataset": self.dataset})()
+        self.batch_size = config["eval_batch_size"]
+        self.L = config["MAX_ITEM_LIST_LENGTH"]
+        seqs = self.dataset.user_seq
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+        self.offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum(lens, out=self.offsets[1:])
+        self.flat = np.concatenate([np.asarray(s, dtype=np.int64) for s in seqs]) if len(seqs) else np.zeros(0, np.int64)
+        self.cut = lens - (2 if phase == "valid" else 1)                   # history = seq[:cut], target = seq[cut]
+        self.users = np.arange(rank, len(seqs), world, dtype=np.int64)     # rank r takes users r, r+W, ... (no padding)
+
+    def __len__(self):
+        return -(-len(self.users) // self.batch_size)
+
+    def __iter__(self):
+        L = self.L
+        for b0 in range(0, len(self.users), self.batch_size):
+            u = self.users[b0:b0 + self.batch_size]
+            start, cut = self.offsets[u], self.cut[u]
+            target = self.flat[start + cut]
+            # history pairs (row in batch, item) for every past interaction
+            hist_u = np.repeat(np.arange(len(u), dtype=np.int64), cut)
+            first = np.cumsum(cut) - cut                                   # first pair of each user
+            within = np.arange(int(cut.sum()), dtype=np.int64) - np.repeat(first, cut)
+            hist_i = self.flat[np.repeat(start, cut) + within]
+            # the last L history items, left-padded with 0
+            col = np.arange(L, dtype=np.int64)[None, :]
+            src = cut[:, None] - L + col                                   # position inside the history
+            ok = src >= 0
+            item_seq = np.where(ok, self.flat[np.where(ok, start[:, None] + src, 0)], 0)
+            yield (torch.from_numpy(item_seq), (torch.from_numpy(hist_u), torch.from_numpy(hist_i)),
+                   torch.arange(len(u)), torch.from_numpy(target))

@@ -14,7 +14,7 @@ from torch.utils.data import DataLoader
 
 from ..parallel import world_info
 from .dataload import Data
-from .dataset import SeqEvalDataset, SeqTrainBatcher, seq_eval_collate
+from .dataset import SeqEvalBatcher, SeqEvalDataset, SeqTrainBatcher, seq_eval_collate
 
 SUPPORTED = {"SASRec": "SEQ", "MOSASRec": "SEQ"}
 
@@ -68,6 +68,10 @@ def bulid_dataloader(config, dataload):
     loaders = []
     workers = int(config["eval_num_workers"] or 0)
     for phase in ("valid", "test"):
+        if config["eval_vectorized"] is None or bool(config["eval_vectorized"]):
+            loaders.append(SeqEvalBatcher(config, dataload, phase=phase, rank=rank, world=world))
+            continue
+        # literal form of the reference's loaders (data/utils.py:95-110); `eval_vectorized: False` selects it
         ds = SeqEvalDataset(config, dataload, phase=phase)
         sampler = NonConsecutiveSequentialDistributedSampler(ds, rank=rank, num_replicas=world)
         loaders.append(DataLoader(ds, batch_size=config["eval_batch_size"], num_workers=workers, pin_memory=False,
