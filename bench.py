@@ -206,15 +206,21 @@ def main():
         return
 
     # ---- roofline of the dominant kernel: the fp32-MFMA GEMM (all launches of the timed steps, HIP events) ------
-    g_s = sum(s.elapsed_time(e) for s, e, _ in gemm_events) * 1e-3 or float("nan")
-    g_fl = sum(f for _, _, f in gemm_events)
+    g_s = sum(s.elapsed_time(e) for s, e, _, _ in gemm_events) * 1e-3 or float("nan")
+    g_fl = sum(f for _, _, f, _ in gemm_events)
     n_launch = len(gemm_events)
+    per_kernel = {}
+    for s_, e_, f_, tag in gemm_events:     # one entry per kernel instantiation, comparable with rocprofv3's rows
+        k = per_kernel.setdefault(tag, [0, 0.0, 0.0])
+        k[0] += 1; k[1] += s_.elapsed_time(e_) * 1e-3; k[2] += f_
+    per_kernel = {t: {"launches_per_step": c / max(n_inst, 1), "avg_kernel_us": sec / c * 1e6,
+                      "tflops": fl / sec / 1e12} for t, (c, sec, fl) in per_kernel.items()}
     roof = {"bound": "mfma", "kernel": "gemm_kernel (v_mfma_f32_32x32x2_f32; every nn.Linear fwd/bwd of the step)",
             "achieved": g_fl / g_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": g_fl / g_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
             "launches_per_step": n_launch / max(n_inst, 1), "avg_kernel_us": g_s / max(n_launch, 1) * 1e6,
             "algorithmic_flops_per_step": g_fl / max(n_inst, 1),
-            "gemm_time_per_step_us": g_s / max(n_inst, 1) * 1e6,
+            "gemm_time_per_step_us": g_s / max(n_inst, 1) * 1e6, "kernels": per_kernel,
             "note": f"HIP events around every GEMM launch of {n_inst} extra eager steps issued right after the timed "
                     "region (bracketing launches inside it would make the step host-bound)"}
 

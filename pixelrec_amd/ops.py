@@ -52,8 +52,9 @@ GEMM_TIMING = None
 
 
 class _gemm_timer:
-    def __init__(self, flops):
+    def __init__(self, flops, tag="gemm"):
         self.flops = flops
+        self.tag = tag          # names the kernel instantiation the launch resolves to (see bench.py's roofline)
         self.on = GEMM_TIMING is not None
 
     def __enter__(self):
@@ -64,7 +65,7 @@ class _gemm_timer:
     def __exit__(self, *exc):
         if self.on:
             self.ev[1].record()
-            GEMM_TIMING.append((self.ev[0], self.ev[1], self.flops))
+            GEMM_TIMING.append((self.ev[0], self.ev[1], self.flops, self.tag))
 
 
 # ------------------------------------------------------------------------------------------------ K1 gather
@@ -113,7 +114,8 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: b
     M = x.numel() // K
     y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if gelu else None
-    with _gemm_timer(2.0 * M * N * K):
+    with _gemm_timer(2.0 * M * N * K, "gemm_kernel<KC,KC,EPI_BIAS_GELU> (fwd + erf-GELU)" if gelu else
+                     "gemm_kernel<KC,KC,EPI_BIAS> (fwd)"):
         _l.check(L.pxr_linear_fwd_f32(_l.ptr(x), _l.ptr(W), _l.ptr(b), _l.ptr(y), _l.ptr(pre), M, N, K, int(gelu),
                                       _l.stream_ptr()), "pxr_linear_fwd_f32")
     return (y, pre) if gelu else y
@@ -127,7 +129,8 @@ def linear_bwd_input(dy: torch.Tensor, W: torch.Tensor, dgelu_pre: torch.Tensor 
     N, K = W.shape
     M = dy.numel() // N
     dx = torch.empty(*dy.shape[:-1], K, dtype=torch.float32, device=dy.device)
-    with _gemm_timer(2.0 * M * N * K):
+    with _gemm_timer(2.0 * M * N * K, "gemm_kernel<KC,XC,EPI_MUL_DGELU> (dX through GELU)" if dgelu_pre is not None else
+                     ("gemm_kernel<KC,XC,EPI_ADD> (dX + residual grad)" if add is not None else "gemm_kernel<KC,XC,EPI_NONE> (dX)")):
         _l.check(L.pxr_linear_bwd_input_f32(_l.ptr(dy), _l.ptr(W), _l.ptr(dx), _l.ptr(dgelu_pre), _l.ptr(add), M, N,
                                             K, _l.stream_ptr()), "pxr_linear_bwd_input_f32")
     return dx
@@ -142,7 +145,7 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor | Non
     dW = out if out is not None else torch.empty(N, K, dtype=torch.float32, device=dy.device)
     ws_bytes = min(int(L.pxr_gemm_ws_bytes(0, 0, N, K, M)), 1 << 30)
     ws = _ws.get(ws_bytes, dy.device)
-    with _gemm_timer(2.0 * M * N * K):
+    with _gemm_timer(2.0 * M * N * K, "gemm_kernel<XC,XC> (dW, split-K)"):
         _l.check(L.pxr_linear_bwd_weight_f32(_l.ptr(dy), _l.ptr(x), _l.ptr(dW), M, N, K, _l.ptr(ws), ws_bytes,
                                              _l.stream_ptr()), "pxr_linear_bwd_weight_f32")
     return dW
@@ -163,7 +166,7 @@ def grouped_linear_bwd_weight(problems):
     N = I(*[p[0].shape[1] for p in problems])
     K = I(*[p[1].shape[1] for p in problems])
     flops = sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in problems)
-    with _gemm_timer(flops):
+    with _gemm_timer(flops, "grouped_dw_kernel (all dW + db of the step)"):
         _l.check(L.pxr_grouped_linear_bwd_weight_f32(n, dy, x, dW, db, M, N, K, _l.stream_ptr()),
                  "pxr_grouped_linear_bwd_weight_f32")
 
