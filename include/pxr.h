@@ -100,17 +100,20 @@ int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xhat, const fl
 
 /* ---- fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32) --------------------------------------------------------------- */
 /* General: C[M,N] = A_op x B_op; a_kc/b_kc select k-contiguous ([M][K] / [N][K]) or x-contiguous ([K][M] / [K][N])
- * storage.  epilogue: 0 none, 1 +bias[n], 2 +bias then erf-GELU (pre-activation -> aux), 3 *= gelu'(aux), 4 += aux. */
+ * storage.  epilogue: 0 none, 1 +bias[n], 2 +bias then erf-GELU (pre-activation -> aux), 3 *= gelu'(aux), 4 += aux,
+ * 5 +bias then erf-GELU (gelu'(pre-activation) -> aux), 6 *= aux. */
 int64_t pxr_gemm_ws_bytes(int a_kc, int b_kc, int M, int N, int K);
 int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                  float* C, int64_t ldc, int epilogue, const float* bias, float* aux, int64_t ldaux, void* ws,
                  int64_t ws_bytes, int tile_hint, int split_hint, void* stream);
-/* y = x W^T + b (act=1: erf-GELU, pre-activation saved)   layers.py:586-588,613,666-667,669; sasrec.py:112 */
+/* y = x W^T + b (act=1: erf-GELU, pre-activation saved; act=2: erf-GELU, gelu'(pre-activation) saved)
+ *                                                          layers.py:586-588,613,666-667,669; sasrec.py:112 */
 int pxr_linear_fwd_f32(const float* x, const float* W, const float* b, float* y, float* pre, int M, int N, int K,
                        int act, void* stream);
-/* dx = dy W, optionally * gelu'(dgelu_pre) OR + add (residual gradient);  dW = dy^T x  -- autograd of nn.Linear */
+/* dx = dy W, optionally * gelu'(dgelu_pre) OR + add (residual gradient) OR * mul (gelu' saved by act=2);
+ * dW = dy^T x  -- autograd of nn.Linear */
 int pxr_linear_bwd_input_f32(const float* dy, const float* W, float* dx, const float* dgelu_pre, const float* add,
-                             int M, int N, int K, void* stream);
+                             const float* mul, int M, int N, int K, void* stream);
 int pxr_linear_bwd_weight_f32(const float* dy, const float* x, float* dW, int M, int N, int K, void* ws,
                               int64_t ws_bytes, void* stream);
 /* Weight AND bias gradients of up to 16 nn.Linear layers in ONE launch (host arrays of n device pointers / sizes):

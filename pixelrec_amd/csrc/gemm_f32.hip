@@ -10,7 +10,7 @@
 
 namespace pxr {
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD = 4 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD = 4, EPI_BIAS_GELU_GRAD = 5, EPI_MUL = 6 };
 
 // erf-GELU exactly as the reference writes it: x * 0.5 * (1 + erf(x / sqrt(2)))  (layers.py:651-660)
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
@@ -36,19 +36,39 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
   const int kend = min(K, kbeg + ksplit_len);
   C += (int64_t)blockIdx.y * split_stride;
 
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave % Cfg::G) >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  // epilogue operands that are READ (residual-branch gradient / saved pre-activation) are fetched before the main
+  // loop: the loads complete under the MFMAs instead of stalling every wave after its last one
+  constexpr bool READS_AUX = (EPI == EPI_MUL_DGELU || EPI == EPI_ADD || EPI == EPI_MUL);
+  float auxv[READS_AUX ? Cfg::TM : 1][READS_AUX ? Cfg::TN : 1][READS_AUX ? 16 : 1];
+  if constexpr (READS_AUX) {
+    if (!(KW > 1 && wave >= Cfg::G)) {
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int col = n0 + wn * Cfg::WN + j * 32 + r;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            auxv[i][j][e] = (col < N && row < M) ? aux[(int64_t)row * ldaux + col] : 0.f;
+          }
+      }
+    }
+  }
+
   typename Cfg::Acc accs;
   gemm_mainloop<BM, BN, A_KC, B_KC, false, KW, PD>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
 
   auto& acc = accs.v;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (KW > 1 && wave >= Cfg::G) return;  // the second wave group handed its partial sums over in the main loop
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;   // (wave < G: wm is 0 for one-row grids)
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
     const int col = n0 + wn * Cfg::WN + j * 32 + r;
     if (col >= N) continue;
     float bv = 0.f;
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bv = bias[col];
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD) bv = bias[col];
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) {
 #pragma unroll
@@ -62,10 +82,16 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
           v += bv;
           aux[(int64_t)row * ldaux + col] = v;  // pre-activation, kept for the backward pass
           v = gelu_erf(v);
+        } else if constexpr (EPI == EPI_BIAS_GELU_GRAD) {
+          v += bv;
+          aux[(int64_t)row * ldaux + col] = dgelu_erf(v);  // gelu'(pre-activation): the backward is then one multiply
+          v = gelu_erf(v);
+        } else if constexpr (EPI == EPI_MUL) {
+          v *= auxv[i][j][e];
         } else if constexpr (EPI == EPI_MUL_DGELU) {
-          v *= dgelu_erf(aux[(int64_t)row * ldaux + col]);
+          v *= dgelu_erf(auxv[i][j][e]);
         } else if constexpr (EPI == EPI_ADD) {
-          v += aux[(int64_t)row * ldaux + col];  // residual-branch gradient joins here
+          v += auxv[i][j][e];  // residual-branch gradient joins here
         }
         C[(int64_t)row * ldc + col] = v;
       }
@@ -232,9 +258,10 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   // the contiguous extent of each operand is read as float4
   PXR_REQUIRE(a_kc ? (K % 4 == 0) : (M % 4 == 0), "pxr_gemm_f32: A contiguous extent must be a multiple of 4");
   PXR_REQUIRE(b_kc ? (K % 4 == 0) : (N % 4 == 0), "pxr_gemm_f32: B contiguous extent must be a multiple of 4");
-  PXR_REQUIRE(epilogue >= 0 && epilogue <= 4, "pxr_gemm_f32: bad epilogue %d", epilogue);
-  PXR_REQUIRE(!(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU) || bias, "pxr_gemm_f32: epilogue needs bias");
-  PXR_REQUIRE(!(epilogue == EPI_BIAS_GELU || epilogue == EPI_MUL_DGELU || epilogue == EPI_ADD) || aux,
+  PXR_REQUIRE(epilogue >= 0 && epilogue <= 6, "pxr_gemm_f32: bad epilogue %d", epilogue);
+  PXR_REQUIRE(!(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_GELU_GRAD) || bias,
+              "pxr_gemm_f32: epilogue needs bias");
+  PXR_REQUIRE(!(epilogue >= EPI_BIAS_GELU) || aux,
               "pxr_gemm_f32: epilogue needs aux");
   hipStream_t st = (hipStream_t)stream;
 
@@ -284,6 +311,7 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
       case EPI_NONE: PXR_GEMM_CASE(true, true, EPI_NONE); break;
       case EPI_BIAS: PXR_GEMM_CASE(true, true, EPI_BIAS); break;
       case EPI_BIAS_GELU: PXR_GEMM_CASE(true, true, EPI_BIAS_GELU); break;
+      case EPI_BIAS_GELU_GRAD: PXR_GEMM_CASE(true, true, EPI_BIAS_GELU_GRAD); break;
       default: pxr_set_error("pxr_gemm_f32: epilogue %d unsupported for (KC,KC)", epilogue); return PXR_ERR_BAD_ARG;
     }
   } else if (a_kc && !b_kc) {
@@ -291,6 +319,7 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
       case EPI_NONE: PXR_GEMM_CASE(true, false, EPI_NONE); break;
       case EPI_MUL_DGELU: PXR_GEMM_CASE(true, false, EPI_MUL_DGELU); break;
       case EPI_ADD: PXR_GEMM_CASE(true, false, EPI_ADD); break;
+      case EPI_MUL: PXR_GEMM_CASE(true, false, EPI_MUL); break;
       default: pxr_set_error("pxr_gemm_f32: epilogue %d unsupported for (KC,XC)", epilogue); return PXR_ERR_BAD_ARG;
     }
   } else if (!a_kc && !b_kc) {
@@ -312,19 +341,23 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   return PXR_OK;
 }
 
-// y[M,N] = x[M,K] W[N,K]^T + b   (act: 0 none, 1 erf-GELU with pre-activation saved to `pre`)
+// y[M,N] = x[M,K] W[N,K]^T + b   (act: 0 none, 1 erf-GELU with the pre-activation saved to `pre`, 2 erf-GELU with
+// gelu'(pre-activation) saved to `pre` instead -- the form the training step uses: the backward is one multiply)
 extern "C" int pxr_linear_fwd_f32(const float* x, const float* W, const float* b, float* y, float* pre, int M,
                                   int N, int K, int act, void* stream) {
-  const int epi = act ? EPI_BIAS_GELU : (b ? EPI_BIAS : EPI_NONE);
+  PXR_REQUIRE(act >= 0 && act <= 2, "pxr_linear_fwd_f32: bad act %d", act);
+  const int epi = act == 2 ? EPI_BIAS_GELU_GRAD : (act == 1 ? EPI_BIAS_GELU : (b ? EPI_BIAS : EPI_NONE));
   return pxr_gemm_f32(1, 1, M, N, K, x, K, W, K, y, N, epi, b, pre, N, nullptr, 0, 0, 0, stream);
 }
-// dx[M,K] = dy[M,N] W[N,K]     dgelu_pre != NULL: dx *= gelu'(dgelu_pre) (through the FFN activation);
-//                              add != NULL: dx += add (the residual branch's gradient).  At most one of the two.
+// dx[M,K] = dy[M,N] W[N,K]     dgelu_pre != NULL: dx *= gelu'(dgelu_pre) (through the FFN activation, from the saved
+//                              pre-activation);  mul != NULL: dx *= mul (gelu' saved by act = 2);
+//                              add != NULL: dx += add (the residual branch's gradient).  At most one of the three.
 extern "C" int pxr_linear_bwd_input_f32(const float* dy, const float* W, float* dx, const float* dgelu_pre,
-                                        const float* add, int M, int N, int K, void* stream) {
-  PXR_REQUIRE(!(dgelu_pre && add), "pxr_linear_bwd_input_f32: dgelu_pre and add are mutually exclusive");
-  const float* aux = dgelu_pre ? dgelu_pre : add;
-  const int epi = dgelu_pre ? EPI_MUL_DGELU : (add ? EPI_ADD : EPI_NONE);
+                                        const float* add, const float* mul, int M, int N, int K, void* stream) {
+  PXR_REQUIRE((dgelu_pre != nullptr) + (add != nullptr) + (mul != nullptr) <= 1,
+              "pxr_linear_bwd_input_f32: dgelu_pre, add and mul are mutually exclusive");
+  const float* aux = dgelu_pre ? dgelu_pre : (add ? add : mul);
+  const int epi = dgelu_pre ? EPI_MUL_DGELU : (add ? EPI_ADD : (mul ? EPI_MUL : EPI_NONE));
   return pxr_gemm_f32(1, 0, M, K, N, dy, N, W, K, dx, K, epi, nullptr, const_cast<float*>(aux), K, nullptr, 0, 0, 0,
                       stream);
 }

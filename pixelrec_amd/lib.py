@@ -50,7 +50,7 @@ _SIGNATURES = {
     "pxr_gemm_ws_bytes": (_I64, [_I, _I, _I, _I, _I]),
     "pxr_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _I64, _P, _I64, _I, _I, _P]),
     "pxr_linear_fwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "pxr_linear_bwd_input_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "pxr_linear_bwd_input_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pxr_linear_bwd_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _I64, _P]),
     "pxr_grouped_linear_bwd_weight_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pxr_colsum_ws_bytes": (_I64, [_I, _I]),

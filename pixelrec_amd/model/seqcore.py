@@ -192,7 +192,7 @@ class SeqRecCore(BaseModel):
             a = ops.linear_fwd(ctx, self._p(f"{i}.o.w"), self._p(f"{i}.o.b"))
             h1, xhat1, rstd1 = ops.ln_residual_fwd(a, h, self._p(f"{i}.ln1.w"), self._p(f"{i}.ln1.b"), eps, ph, seed,
                                                    2 + 3 * i, save=train, step_dev=sdv)
-            f, u = ops.linear_fwd(h1, self._p(f"{i}.f1.w"), self._p(f"{i}.f1.b"), gelu=True)
+            f, u = ops.linear_fwd(h1, self._p(f"{i}.f1.w"), self._p(f"{i}.f1.b"), gelu=True, save_grad=train)
             f2 = ops.linear_fwd(f, self._p(f"{i}.f2.w"), self._p(f"{i}.f2.b"))
             h2, xhat2, rstd2 = ops.ln_residual_fwd(f2, h1, self._p(f"{i}.ln2.w"), self._p(f"{i}.ln2.b"), eps, ph, seed,
                                                    3 + 3 * i, save=train, step_dev=sdv)
@@ -267,7 +267,7 @@ class SeqRecCore(BaseModel):
             if dxf2 is None:
                 dxf2 = dz2
             weight_grads(dxf2.view(T, D), a["f"].view(T, -1), f"{i}.f2.w", f"{i}.f2.b")
-            du = ops.linear_bwd_input(dxf2, self._p(f"{i}.f2.w"), dgelu_pre=a["u"])
+            du = ops.linear_bwd_input(dxf2, self._p(f"{i}.f2.w"), mul=a["u"])      # a["u"] holds gelu'(pre-activation)
             weight_grads(du.view(T, -1), a["h1"].view(T, D), f"{i}.f1.w", f"{i}.f1.b")
             dh1 = ops.linear_bwd_input(du, self._p(f"{i}.f1.w"), add=dz2)
             # attention block: h1 = LN(dropout(a) + h)

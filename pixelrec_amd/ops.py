@@ -106,33 +106,37 @@ def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc,
     return C
 
 
-def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: bool = False):
-    """y = x W^T + b (nn.Linear, layers.py:586-588,613,666,669).  gelu=True also returns the pre-activation."""
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: bool = False, save_grad: bool = False):
+    """y = x W^T + b (nn.Linear, layers.py:586-588,613,666,669).  gelu=True also returns the pre-activation, or with
+    save_grad=True gelu'(pre-activation) (what linear_bwd_input(mul=...) multiplies by)."""
     L = _l.load()
     _req(x, torch.float32, "x"); _req(W, torch.float32, "W")
     N, K = W.shape
     M = x.numel() // K
     y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if gelu else None
-    with _gemm_timer(2.0 * M * N * K, "gemm_kernel<KC,KC,EPI_BIAS_GELU> (fwd + erf-GELU)" if gelu else
+    with _gemm_timer(2.0 * M * N * K, "gemm_kernel<KC,KC,EPI_BIAS_GELU*> (fwd + erf-GELU)" if gelu else
                      "gemm_kernel<KC,KC,EPI_BIAS> (fwd)"):
-        _l.check(L.pxr_linear_fwd_f32(_l.ptr(x), _l.ptr(W), _l.ptr(b), _l.ptr(y), _l.ptr(pre), M, N, K, int(gelu),
-                                      _l.stream_ptr()), "pxr_linear_fwd_f32")
+        _l.check(L.pxr_linear_fwd_f32(_l.ptr(x), _l.ptr(W), _l.ptr(b), _l.ptr(y), _l.ptr(pre), M, N, K,
+                                      (2 if save_grad else 1) if gelu else 0, _l.stream_ptr()), "pxr_linear_fwd_f32")
     return (y, pre) if gelu else y
 
 
 def linear_bwd_input(dy: torch.Tensor, W: torch.Tensor, dgelu_pre: torch.Tensor | None = None,
-                     add: torch.Tensor | None = None):
-    """dx = dy W, optionally times gelu'(pre) (through the FFN activation) or plus `add` (residual gradient)."""
+                     add: torch.Tensor | None = None, mul: torch.Tensor | None = None):
+    """dx = dy W, optionally times gelu'(pre) (from the saved pre-activation), times `mul` (gelu' saved by the forward),
+    or plus `add` (residual gradient)."""
     L = _l.load()
     _req(dy, torch.float32, "dy"); _req(W, torch.float32, "W")
     N, K = W.shape
     M = dy.numel() // N
     dx = torch.empty(*dy.shape[:-1], K, dtype=torch.float32, device=dy.device)
-    with _gemm_timer(2.0 * M * N * K, "gemm_kernel<KC,XC,EPI_MUL_DGELU> (dX through GELU)" if dgelu_pre is not None else
-                     ("gemm_kernel<KC,XC,EPI_ADD> (dX + residual grad)" if add is not None else "gemm_kernel<KC,XC,EPI_NONE> (dX)")):
-        _l.check(L.pxr_linear_bwd_input_f32(_l.ptr(dy), _l.ptr(W), _l.ptr(dx), _l.ptr(dgelu_pre), _l.ptr(add), M, N,
-                                            K, _l.stream_ptr()), "pxr_linear_bwd_input_f32")
+    tag = ("gemm_kernel<KC,XC,EPI_MUL_DGELU> (dX through GELU)" if dgelu_pre is not None else
+           "gemm_kernel<KC,XC,EPI_MUL> (dX x saved gelu')" if mul is not None else
+           "gemm_kernel<KC,XC,EPI_ADD> (dX + residual grad)" if add is not None else "gemm_kernel<KC,XC,EPI_NONE> (dX)")
+    with _gemm_timer(2.0 * M * N * K, tag):
+        _l.check(L.pxr_linear_bwd_input_f32(_l.ptr(dy), _l.ptr(W), _l.ptr(dx), _l.ptr(dgelu_pre), _l.ptr(add),
+                                            _l.ptr(mul), M, N, K, _l.stream_ptr()), "pxr_linear_bwd_input_f32")
     return dx
 
 

@@ -50,3 +50,27 @@ def test_weight_grad_flavour_xc_xc(tile, split, M, N, K):
     ops.gemm(False, False, M, N, K, A.cuda(), M, Bm.cuda(), N, out, N, ops.EPI_NONE, use_ws=True, tile_hint=tile,
              split_hint=split)
     _check(out, A.double().t() @ Bm.double(), K)
+
+
+def test_gelu_epilogues_save_activation_or_its_derivative():
+    """epilogue 2 saves the pre-activation (backward: 3 = *gelu'(aux)); epilogue 5 saves gelu'(pre-activation)
+    (backward: 6 = *aux).  Both pairs give the same forward output and the same input gradient."""
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 256, 128
+    x, W, b = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda() * 0.1, torch.randn(N, generator=g).cuda()
+    y1, pre = ops.linear_fwd(x, W, b, gelu=True)
+    y2, dg = ops.linear_fwd(x, W, b, gelu=True, save_grad=True)
+    assert torch.equal(y1, y2)
+    z = (x.double() @ W.double().t() + b.double()).cpu()
+    ref_y = z * 0.5 * (1 + torch.erf(z / 2 ** 0.5))
+    ref_dg = 0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-0.5 * z * z) / (2 * torch.pi) ** 0.5
+    assert (y1.cpu().double() - ref_y).abs().max().item() < 1e-5
+    assert (pre.cpu().double() - z).abs().max().item() < 1e-5
+    assert (dg.cpu().double() - ref_dg).abs().max().item() < 1e-5
+    dy, W2 = torch.randn(M, 64, generator=g).cuda(), torch.randn(64, N, generator=g).cuda() * 0.1
+    d1 = ops.linear_bwd_input(dy, W2, dgelu_pre=pre)
+    d2 = ops.linear_bwd_input(dy, W2, mul=dg)
+    assert torch.equal(d1, d2)
+    assert (d1.cpu().double() - (dy.double().cpu() @ W2.double().cpu()) * ref_dg).abs().max().item() < 1e-5
