@@ -55,15 +55,32 @@ __device__ __forceinline__ void pxr_st_stream(float* p, const float4& v) {
 }
 
 // ---------------------------------------------------------------- wave / block reductions
+// Wave64 reductions on the VALU's DPP path instead of six ds_bpermute round trips through the LDS crossbar
+// (__shfl_xor): quad swaps, mirror within 8 / 16 lanes, then the gfx9 row broadcasts -- lane 63 ends up with the total
+// and v_readlane hands it to every lane.  ~6 dependent VALU ops (tens of cycles) vs ~6 x 100+ cycles; the row softmax
+// of the attention kernels does 2 reductions per query row.  Must be called with all 64 lanes active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float pxr_dpp(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                              CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += pxr_dpp<0xB1, 0xf>(0.f, v);    // quad_perm [1,0,3,2]
+  v += pxr_dpp<0x4E, 0xf>(0.f, v);    // quad_perm [2,3,0,1]
+  v += pxr_dpp<0x141, 0xf>(0.f, v);   // row_half_mirror
+  v += pxr_dpp<0x140, 0xf>(0.f, v);   // row_mirror: every lane of a 16-lane row holds the row sum
+  v += pxr_dpp<0x142, 0xa>(0.f, v);   // row_bcast:15 into rows 1, 3
+  v += pxr_dpp<0x143, 0xc>(0.f, v);   // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  v = fmaxf(v, pxr_dpp<0xB1, 0xf>(v, v));
+  v = fmaxf(v, pxr_dpp<0x4E, 0xf>(v, v));
+  v = fmaxf(v, pxr_dpp<0x141, 0xf>(v, v));
+  v = fmaxf(v, pxr_dpp<0x140, 0xf>(v, v));
+  v = fmaxf(v, pxr_dpp<0x142, 0xa>(v, v));
+  v = fmaxf(v, pxr_dpp<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---------------------------------------------------------------- fixed-order reduction of per-block partials
