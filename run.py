@@ -1,7 +1,13 @@
-"""Per-rank driver -- counterpart of the reference's code/run.py:18-82 on the MI355X-native path:
-init RCCL process group (backend "nccl" is RCCL on ROCm) -> Config -> seed -> logger -> data -> model ->
-DataParallel (flat all-reduce + sparse row exchange instead of DDP's dense 836 MB all-reduce) -> Trainer.fit ->
-evaluate(test)."""
+"""One rank of a training job (what `main.py` launches through torch.distributed.run; the counterpart of the
+reference's code/run.py).  Stages, each a function so that they can be driven separately from tests / notebooks:
+
+    join_world()   RCCL process group when WORLD_SIZE > 1 (backend "nccl" IS RCCL on ROCm), one process per GPU
+    build()        YAML -> Config -> seeds/logger -> Data + loaders -> model -> DataParallel wrapper
+    run_loop()     build + Trainer.fit + test evaluation  (name kept: it is the reference's programmatic entry)
+
+The wrapper exchanges a 17 MB flat gradient plus the batch's sparse table rows instead of DDP's dense 836 MB
+all-reduce (pixelrec_amd/parallel.py).
+"""
 import argparse
 import os
 from logging import getLogger
@@ -9,50 +15,69 @@ from logging import getLogger
 import torch
 import torch.distributed as dist
 
-from pixelrec_amd.config import Config
-from pixelrec_amd.data import bulid_dataloader, load_data
-from pixelrec_amd.parallel import DataParallel
-from pixelrec_amd.trainer import Trainer
-from pixelrec_amd.utils import get_model, init_logger, init_seed
+
+def join_world():
+    """-> (local_rank, world_size).  Binds this process to its GPU and, for multi-rank jobs, joins the RCCL group."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    return local_rank, world
+
+
+def build(local_rank, config_file=None, config_dict=None):
+    """-> (config, dataload, (train, valid, test) loaders, wrapped model) on cuda:<local_rank>."""
+    from pixelrec_amd.config import Config
+    from pixelrec_amd.data import bulid_dataloader, load_data
+    from pixelrec_amd.parallel import DataParallel
+    from pixelrec_amd.utils import get_model, init_logger, init_seed
+
+    config = Config(config_file_list=config_file, config_dict=config_dict)
+    config["device"] = torch.device("cuda", local_rank)
+    init_seed(config["seed"], config["reproducibility"])
+    init_logger(config)
+    dataload = load_data(config)
+    loaders = bulid_dataloader(config, dataload)
+    net = get_model(config["model"])(config, dataload).to(config["device"])
+    return config, dataload, loaders, DataParallel(net)
+
+
+def _report(log, config, dataload, model):
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    log.info(f"\nWorld_Size = {world} \n")
+    for thing in (config, dataload, model.module):
+        log.info(thing)
 
 
 def run_loop(local_rank, config_file=None, saved=True, config_dict=None):
-    config = Config(config_file_list=config_file, config_dict=config_dict)
-    device = torch.device("cuda", local_rank)
-    config["device"] = device
-    init_seed(config["seed"], config["reproducibility"])
-    init_logger(config)
-    logger = getLogger()
+    from pixelrec_amd.trainer import Trainer
 
-    dataload = load_data(config)
-    train_loader, valid_loader, test_loader = bulid_dataloader(config, dataload)
-    model = get_model(config["model"])(config, dataload).to(device)
-    model = DataParallel(model)
-
-    world_size = dist.get_world_size() if dist.is_initialized() else 1
-    logger.info(f"\nWorld_Size = {world_size} \n")
-    logger.info(config)
-    logger.info(dataload)
-    logger.info(model.module)
-
+    config, dataload, (train_loader, valid_loader, test_loader), model = build(local_rank, config_file, config_dict)
+    log = getLogger()
+    _report(log, config, dataload, model)
     trainer = Trainer(config, model)
-    best_valid_score, best_valid_result = trainer.fit(train_loader, valid_loader, saved=saved,
-                                                      show_progress=config["show_progress"])
-    test_result = trainer.evaluate(test_loader, load_best_model=saved, show_progress=config["show_progress"])
-    logger.info(f"best valid : {best_valid_result}")
-    logger.info(f"test result: {test_result}")
-    return {"best_valid_score": best_valid_score, "valid_score_bigger": config["valid_metric_bigger"],
-            "best_valid_result": best_valid_result, "test_result": test_result}
+    progress = config["show_progress"]
+    best_score, best_result = trainer.fit(train_loader, valid_loader, saved=saved, show_progress=progress)
+    test_result = trainer.evaluate(test_loader, load_best_model=saved, show_progress=progress)
+    log.info(f"best valid : {best_result}")
+    log.info(f"test result: {test_result}")
+    return {"best_valid_score": best_score, "valid_score_bigger": config["valid_metric_bigger"],
+            "best_valid_result": best_result, "test_result": test_result}
+
+
+def main(argv=None):
+    cli = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    cli.add_argument("--config_file", nargs="+", type=str, help="model YAML followed by the overall YAML")
+    args = cli.parse_args(argv)
+    local_rank, _ = join_world()
+    try:
+        run_loop(local_rank=local_rank, config_file=args.config_file)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--config_file", nargs="+", type=str)
-    args = parser.parse_args()
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    run_loop(local_rank=local_rank, config_file=args.config_file)
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    main()
