@@ -97,11 +97,17 @@ def main():
     ap.add_argument("--no-group", action="store_true", help="per-layer weight-gradient GEMMs instead of one grouped launch")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--emb", type=int, default=NS["D"], help="embedding size (default: the north-star 512)")
+    ap.add_argument("--heads", type=int, default=NS["H"])
+    ap.add_argument("--items", type=int, default=NS["n_items"], help="catalogue size incl. the padding id")
+    ap.add_argument("--seq-len", type=int, default=NS["L"])
     ap.add_argument("--force-collectives", action="store_true",
                     help="1-GPU validation knob: create a 1-rank RCCL group and run every gradient collective anyway")
     ap.add_argument("--graph-collectives", action="store_true",
                     help="capture the RCCL collectives inside the step hipGraph too (opt-in for world > 1)")
     args = ap.parse_args()
+    custom = (args.emb, args.heads, args.items, args.seq_len) != (NS["D"], NS["H"], NS["n_items"], NS["L"])
+    NS.update(D=args.emb, H=args.heads, n_items=args.items, L=args.seq_len)   # other BASELINE configs on request
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -225,19 +231,22 @@ def main():
                     "region (bracketing launches inside it would make the step host-bound)"}
 
     out = {
-        "metric": "user-sequences/sec at emb=512 seq_len=50 (SASRec IDNet training step: fwd+bwd+AdamW)",
+        "metric": (f"user-sequences/sec at emb={D} seq_len={L} (SASRec IDNet training step: fwd+bwd+AdamW)" if custom else
+                   "user-sequences/sec at emb=512 seq_len=50 (SASRec IDNet training step: fwd+bwd+AdamW)"),
         "value": world * B * args.steps / dt, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: SASRec IDNet emb=512 seq_len=50, 400001 items, 4 heads, "
-                               "inner 2x, 2 layers, BPR loss vs 1 sampled negative, dropout 0.1, AdamW lr 1e-4 wd 0.1",
+        "config": {"workload": (f"custom shape (NOT the headline config): SASRec IDNet emb={D} seq_len={L}, {N} items, "
+                                f"{NS['H']} heads, inner 2x, 2 layers" if custom else
+                                "BASELINE.json configs[1]: SASRec IDNet emb=512 seq_len=50, 400001 items, 4 heads, "
+                                "inner 2x, 2 layers, BPR loss vs 1 sampled negative, dropout 0.1, AdamW lr 1e-4 wd 0.1"),
                    "batch_per_gpu": B, "global_batch": world * B, "seq_len": L, "n_items": N, "embedding_size": D,
                    "parallelism": f"dp{world}", "hip_graph": bool(use_graph)},
         "final_loss": final_loss, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
         "roofline": roof,
     }
 
-    if not args.no_extras and world == 1 and B == 64:
+    if not args.no_extras and world == 1 and B == 64 and not custom:
         # (0) the same step at throughput-oriented batch sizes (SURVEY.md §8d asks for B=64 AND 512 / 2048 per GPU)
         from pixelrec_amd.graph import GraphedTrainStep as _G
 
@@ -267,7 +276,7 @@ def main():
                                               "ms_per_step": tb * 1e3, "steps": n_b})
             del g2, bt
 
-    if not args.no_extras and world == 1:
+    if not args.no_extras and world == 1 and not custom:
         # (1) embedding gather, north-star HBM target: uniform ids (worst case for caches), B=2048-equivalent rows
         n_rows = 2048 * 2 * (L + 1)
         idx = torch.randint(1, N, (n_rows,), device=dev)

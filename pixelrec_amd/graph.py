@@ -20,6 +20,7 @@ class GraphedTrainStep:
         self.model = dp_model.module if hasattr(dp_model, "module") else dp_model
         self.items = items.clone()
         self.mask = masked_index.clone()
+        self._one = torch.ones((), dtype=torch.float32, device=items.device)   # d(loss)/d(loss): no fill kernel per step
         cur = torch.cuda.current_stream()
         s = torch.cuda.Stream()
         s.wait_stream(cur)
@@ -63,7 +64,7 @@ class GraphedTrainStep:
     def _eager(self):
         self.opt.zero_grad()
         loss = self.dp((self.items, self.mask))
-        loss.backward()
+        loss.backward(self._one)
         if hasattr(self.dp, "sync_gradients"):
             self.dp.sync_gradients()
         if self.clip:
