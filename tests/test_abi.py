@@ -47,3 +47,35 @@ def test_no_cpu_fallback():
 
     with pytest.raises(lib.PxrError):
         ops.embed_gather(torch.zeros(4, 8), torch.zeros(2, dtype=torch.int64))
+
+
+def _header_prototypes():
+    """name -> list of C parameter type strings, parsed from include/pxr.h."""
+    text = open(os.path.join(ROOT, "include", "pxr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(pxr_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = [a.strip() for a in m.group(2).replace("\n", " ").split(",")]
+        protos[m.group(1)] = [] if args in ([""], ["void"]) else args
+    return protos
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every binding in lib._SIGNATURES has the header's arity and, per argument, the right ctypes class (pointer vs
+    32/64-bit integer vs float/double): a drifted prototype would otherwise corrupt the call silently."""
+    protos = _header_prototypes()
+    for name, (_, argtypes) in lib._SIGNATURES.items():
+        cargs = protos[name]
+        assert len(cargs) == len(argtypes), (name, len(cargs), len(argtypes))
+        for c, t in zip(cargs, argtypes):
+            if "*" in c:
+                want = ("c_void_p", "c_char_p", "LP_", "Array")
+                assert any(w in t.__name__ for w in want) or t is ctypes.c_void_p, (name, c, t)
+            elif re.search(r"\b(int64_t|uint64_t|size_t)\b", c):
+                assert t in (ctypes.c_int64, ctypes.c_uint64, ctypes.c_size_t), (name, c, t)
+            elif re.search(r"\bdouble\b", c):
+                assert t is ctypes.c_double, (name, c, t)
+            elif re.search(r"\bfloat\b", c):
+                assert t is ctypes.c_float, (name, c, t)
+            else:
+                assert t in (ctypes.c_int, ctypes.c_int32, ctypes.c_uint32), (name, c, t)
