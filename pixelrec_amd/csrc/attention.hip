@@ -317,13 +317,15 @@ __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TN], float* out, i
 // stage rows < L of a [L][w] global tile into LDS with the given stride; rows L..63 are zero-filled.
 // All of a thread's global loads are issued BEFORE its first LDS store: with one workgroup per CU a
 // load -> wait -> ds_write loop would serialise ~8 HBM round trips per tile (measured: 20 of the kernel's 25 us).
+template <int NT = 256>
 __device__ __forceinline__ void stage_tile_z(float* tile, int tstride, const float* src, int64_t ld, int L, int w) {
   const int q4 = w >> 2;
   const int total = ATT_MAXL * q4;            // <= 64 * 32 = 2048 float4 => <= 8 per thread at 256 threads
-  float4 v[8];
+  constexpr int NP = 2048 / NT;
+  float4 v[NP];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int f = threadIdx.x + p * 256;
+  for (int p = 0; p < NP; ++p) {
+    const int f = threadIdx.x + p * NT;
     v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (f < total) {
       const int row = f / q4, c = (f - row * q4) * 4;
@@ -331,8 +333,8 @@ __device__ __forceinline__ void stage_tile_z(float* tile, int tstride, const flo
     }
   }
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int f = threadIdx.x + p * 256;
+  for (int p = 0; p < NP; ++p) {
+    const int f = threadIdx.x + p * NT;
     if (f < total) {
       const int row = f / q4, c = (f - row * q4) * 4;
       *reinterpret_cast<float4*>(tile + row * tstride + c) = v[p];
@@ -491,27 +493,32 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(AttnArgs a) {
 // ds_read_b32 along x for "XC" uses) -- so the kernel is one load phase followed by back-to-back MFMA phases.
 // Backward keeps dS in registers while the probability tile is used for dV, so one 64x68 tile suffices:
 // 4 x 33 KB + 17 KB = 152 KB of the CU's 160 KB.
-__global__ void __launch_bounds__(256) attn_fwd_mfma1_kernel(AttnArgs a) {
+// NW = 4 or 8 waves.  The 64x64 score tile is always computed by waves 0-3 (one 32x32 block each); with 8 waves the
+// row softmax handles 7 instead of 13 rows per wave, the staging issues half as many loads per thread and the
+// 64x128 output is 8 blocks of 32x32 (one per wave) instead of 4 slabs of 32x64.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) attn_fwd_mfma1_kernel(AttnArgs a) {
   if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  constexpr int NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) float sQ[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sK[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sV[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
-  stage_tile_z(sQ, ATT_KLD, a.q + base, a.ld, L, d);
-  stage_tile_z(sK, ATT_KLD, a.k + base, a.ld, L, d);
-  stage_tile_z(sV, ATT_KLD, a.v + base, a.ld, L, d);
+  stage_tile_z<NT>(sQ, ATT_KLD, a.q + base, a.ld, L, d);
+  stage_tile_z<NT>(sK, ATT_KLD, a.k + base, a.ld, L, d);
+  stage_tile_z<NT>(sV, ATT_KLD, a.v + base, a.ld, L, d);
   const bool key_real = (lane < L) && (a.keymask[(int64_t)b * a.km_bstride + lane] != 0);
   __syncthreads();
 
-  f32x16 accS[1];
-  zero_acc<1>(accS);
-  lds_mma<true, true, 1>(accS, sQ, ATT_KLD, sK, ATT_KLD, wm * 32, wn * 32, d, lane);
-  {
+  if (wave < 4) {
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 accS[1];
+    zero_acc<1>(accS);
+    lds_mma<true, true, 1>(accS, sQ, ATT_KLD, sK, ATT_KLD, wm * 32, wn * 32, d, lane);
     const int hh = lane >> 5, r = lane & 31;
 #pragma unroll
     for (int e = 0; e < 16; ++e)
@@ -520,7 +527,7 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma1_kernel(AttnArgs a) {
   __syncthreads();
   const bool drop = a.drop_thr != 0u;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
-  for (int i = wave; i < L; i += 4) {
+  for (int i = wave; i < L; i += NW) {
     float s = sS[i * ATT_SLD + lane] / a.sqrt_d + ((key_real && lane <= i) ? 0.0f : -1e9f);
     if (lane >= L) s = -INFINITY;
     const float m = wave_max(s);
@@ -537,43 +544,56 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma1_kernel(AttnArgs a) {
     sS[i * ATT_SLD + lane] = pd;
   }
   __syncthreads();
-  f32x16 accO[2];
-  zero_acc<2>(accO);
-  if (wn * 64 < d) lds_mma<true, false, 2>(accO, sS, ATT_SLD, sV, ATT_KLD, wm * 32, wn * 64, 64, lane);
-  store_acc<2>(accO, a.ctx + (int64_t)b * L * a.ld_ctx + (int64_t)h * d, a.ld_ctx, wm * 32, wn * 64, L, d, lane);
+  float* ctx = a.ctx + (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
+  if constexpr (NW == 4) {
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 accO[2];
+    zero_acc<2>(accO);
+    if (wn * 64 < d) lds_mma<true, false, 2>(accO, sS, ATT_SLD, sV, ATT_KLD, wm * 32, wn * 64, 64, lane);
+    store_acc<2>(accO, ctx, a.ld_ctx, wm * 32, wn * 64, L, d, lane);
+  } else {
+    const int wm = wave >> 2, wn = wave & 3;
+    f32x16 accO[1];
+    zero_acc<1>(accO);
+    if (wn * 32 < d) lds_mma<true, false, 1>(accO, sS, ATT_SLD, sV, ATT_KLD, wm * 32, wn * 32, 64, lane);
+    store_acc<1>(accO, ctx, a.ld_ctx, wm * 32, wn * 32, L, d, lane);
+  }
 }
 
-__global__ void __launch_bounds__(256) attn_bwd_mfma1_kernel(AttnArgs a) {
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  constexpr int NT = 64 * NW;
+  constexpr int ROWS = 64 / NW;   // query rows per wave (row i = wave + NW * g)
   __shared__ __attribute__((aligned(16))) float sQ[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sK[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sV[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sO[ATT_MAXL * ATT_KLD];   // dctx
   __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];   // dP -> Pd -> dS/sqrt(d)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
   const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
   const int64_t dbase = (int64_t)b * L * a.ld_d + (int64_t)h * d;
-  stage_tile_z(sO, ATT_KLD, a.dctx + cbase, a.ld_ctx, L, d);
-  stage_tile_z(sV, ATT_KLD, a.v + base, a.ld, L, d);
-  stage_tile_z(sK, ATT_KLD, a.k + base, a.ld, L, d);
-  stage_tile_z(sQ, ATT_KLD, a.q + base, a.ld, L, d);
+  stage_tile_z<NT>(sO, ATT_KLD, a.dctx + cbase, a.ld_ctx, L, d);
+  stage_tile_z<NT>(sV, ATT_KLD, a.v + base, a.ld, L, d);
+  stage_tile_z<NT>(sK, ATT_KLD, a.k + base, a.ld, L, d);
+  stage_tile_z<NT>(sQ, ATT_KLD, a.q + base, a.ld, L, d);
   // this wave's probability rows (saved by the forward pass) -- issued before the barrier so they overlap the staging
-  float prow[16];
+  float prow[ROWS];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int i = wave + 4 * g;
+  for (int g = 0; g < ROWS; ++g) {
+    const int i = wave + NW * g;
     prow[g] = (i < L && lane < L) ? a.probs[(((int64_t)b * a.H + h) * L + i) * L + lane] : 0.f;
   }
   __syncthreads();
 
-  f32x16 accP[1];
-  zero_acc<1>(accP);
-  lds_mma<true, true, 1>(accP, sO, ATT_KLD, sV, ATT_KLD, wm * 32, wn * 32, d, lane);   // dPd = dctx V^T
-  {
+  if (wave < 4) {
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 accP[1];
+    zero_acc<1>(accP);
+    lds_mma<true, true, 1>(accP, sO, ATT_KLD, sV, ATT_KLD, wm * 32, wn * 32, d, lane);   // dPd = dctx V^T
     const int hh = lane >> 5, r = lane & 31;
 #pragma unroll
     for (int e = 0; e < 16; ++e)
@@ -582,10 +602,10 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma1_kernel(AttnArgs a) {
   __syncthreads();
   const bool drop = a.drop_thr != 0u;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
-  float dsrow[16];
+  float dsrow[ROWS];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int i = wave + 4 * g;
+  for (int g = 0; g < ROWS; ++g) {
+    const int i = wave + NW * g;
     dsrow[g] = 0.f;
     if (i < L) {   // wave-uniform
       const float p = prow[g];
@@ -603,29 +623,39 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma1_kernel(AttnArgs a) {
     }
   }
   __syncthreads();
-  const bool mine = wn * 64 < d;
-  f32x16 acc[2];
-  zero_acc<2>(acc);
-  if (mine) lds_mma<false, false, 2>(acc, sS, ATT_SLD, sO, ATT_KLD, wm * 32, wn * 64, 64, lane);   // dV = Pd^T dctx
-  store_acc<2>(acc, a.dv + dbase, a.ld_d, wm * 32, wn * 64, L, d, lane);
+  // output blocks: NW = 4 -> 32x64 slab per wave; NW = 8 -> one 32x32 block per wave
+  constexpr int TN = (NW == 4) ? 2 : 1;
+  const int wm = (NW == 4) ? (wave >> 1) : (wave >> 2);
+  const int n_base = (NW == 4) ? (wave & 1) * 64 : (wave & 3) * 32;
+  const bool mine = n_base < d;
+  f32x16 acc[TN];
+  zero_acc<TN>(acc);
+  if (mine) lds_mma<false, false, TN>(acc, sS, ATT_SLD, sO, ATT_KLD, wm * 32, n_base, 64, lane);   // dV = Pd^T dctx
+  store_acc<TN>(acc, a.dv + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
   __syncthreads();
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int i = wave + 4 * g;
+  for (int g = 0; g < ROWS; ++g) {
+    const int i = wave + NW * g;
     if (i < L) sS[i * ATT_SLD + lane] = dsrow[g];
   }
   __syncthreads();
-  zero_acc<2>(acc);
-  if (mine) lds_mma<true, false, 2>(acc, sS, ATT_SLD, sK, ATT_KLD, wm * 32, wn * 64, 64, lane);    // dQ = dS K
-  store_acc<2>(acc, a.dq + dbase, a.ld_d, wm * 32, wn * 64, L, d, lane);
-  zero_acc<2>(acc);
-  if (mine) lds_mma<false, false, 2>(acc, sS, ATT_SLD, sQ, ATT_KLD, wm * 32, wn * 64, 64, lane);   // dK = dS^T Q
-  store_acc<2>(acc, a.dk + dbase, a.ld_d, wm * 32, wn * 64, L, d, lane);
+  zero_acc<TN>(acc);
+  if (mine) lds_mma<true, false, TN>(acc, sS, ATT_SLD, sK, ATT_KLD, wm * 32, n_base, 64, lane);    // dQ = dS K
+  store_acc<TN>(acc, a.dq + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
+  zero_acc<TN>(acc);
+  if (mine) lds_mma<false, false, TN>(acc, sS, ATT_SLD, sQ, ATT_KLD, wm * 32, n_base, 64, lane);   // dK = dS^T Q
+  store_acc<TN>(acc, a.dk + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
 }
 
 }  // namespace pxr
 
 using namespace pxr;
+
+// waves per workgroup of the single-phase MFMA kernels: PXR_ATTN_MFMA_WAVES=4|8 (tuning knob)
+static int attn_mfma_waves() {
+  static const int nw = getenv("PXR_ATTN_MFMA_WAVES") ? atoi(getenv("PXR_ATTN_MFMA_WAVES")) : 8;
+  return nw == 8 ? 8 : 4;
+}
 
 // waves per (batch, head) workgroup: 8 by default; PXR_ATTN_WAVES=4|8|16 overrides it (tuning knob)
 static int attn_waves() {
@@ -672,7 +702,10 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
   if (attn_use_mfma(d)) {
-    if (d <= ATT_DC) hipLaunchKernelGGL(attn_fwd_mfma1_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    if (d <= ATT_DC) {
+      if (attn_mfma_waves() == 8) hipLaunchKernelGGL(attn_fwd_mfma1_kernel<8>, dim3(B * H), dim3(512), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL(attn_fwd_mfma1_kernel<4>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    }
     else hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
     return pxr_check_launch("pxr_attn_fwd_f32(mfma)");
   }
@@ -701,7 +734,10 @@ extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* 
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
   if (attn_use_mfma(d)) {
-    if (d <= ATT_DC) hipLaunchKernelGGL(attn_bwd_mfma1_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    if (d <= ATT_DC) {
+      if (attn_mfma_waves() == 8) hipLaunchKernelGGL(attn_bwd_mfma1_kernel<8>, dim3(B * H), dim3(512), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL(attn_bwd_mfma1_kernel<4>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    }
     else hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
     return pxr_check_launch("pxr_attn_bwd_f32(mfma)");
   }
