@@ -398,7 +398,7 @@ extern "C" int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* 
   int rc = pxr_check_launch("pxr_colsum_f32(partial)");
   if (rc) return rc;
   if (!out) return PXR_OK;  // deferred: ws holds pxr_colsum_partial_rows(M) x N partial sums for a later multi-reduce
-  hipLaunchKernelGGL(pxr_reduce_partials_kernel, dim3((N + 31) / 32), dim3(256), 0, st, (const float*)ws, chunks, N,
+  hipLaunchKernelGGL(pxr_reduce_partials_kernel, dim3((N + PXR_RED_CX - 1) / PXR_RED_CX), dim3(256), 0, st, (const float*)ws, chunks, N,
                      out, out, N);
   return pxr_check_launch("pxr_colsum_f32(final)");
 }

@@ -281,7 +281,9 @@ static int launch_ln_bwd(const LnBwdArgs& a, int nblk, hipStream_t st) {
 }
 
 static inline int ln_bwd_blocks(int rows, int* rows_per_block) {
-  int rpb = (rows + 255) / 256;  // <= 256 blocks (one per CU) => <= 256 partial rows for the stage-2 reduction
+  // <= 1024 blocks (4 per CU: a lone workgroup per CU walks its rows at load latency) => <= 1024 partial rows for
+  // the stage-2 reduction, which sums them with 8 independent loads in flight per lane
+  int rpb = (rows + 1023) / 1024;
   if (rpb < 4) rpb = 4;
   *rows_per_block = rpb;
   return (rows + rpb - 1) / rpb;
@@ -361,7 +363,7 @@ extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xha
   if (rc) return rc;
   if (!dgamma) return PXR_OK;  // deferred: the caller reduces ws ([pxr_ln_bwd_partial_rows, 2*D]) later, e.g. with
                                // pxr_reduce_partials_multi_f32 together with the other sites of the backward pass
-  hipLaunchKernelGGL(pxr_reduce_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, st, (const float*)ws, nblk,
+  hipLaunchKernelGGL(pxr_reduce_partials_kernel, dim3((2 * D + PXR_RED_CX - 1) / PXR_RED_CX), dim3(256), 0, st, (const float*)ws, nblk,
                      2 * D, dgamma, dbeta, D);
   return pxr_check_launch("pxr_ln_bwd_f32(reduce)");
 }
@@ -373,22 +375,17 @@ struct MultiReduce {
   int n;
 };
 __global__ void __launch_bounds__(256) reduce_partials_multi_kernel(MultiReduce m) {
-  __shared__ float red[8][33];
+  __shared__ float red[PXR_RED_CY][PXR_RED_CX + 1];
   int pi = 0;
   for (int i = 1; i < m.n; ++i)
     if ((int)blockIdx.x >= m.blk_begin[i]) pi = i;
   const float* part = m.part[pi];
   const int P = m.P[pi], N = m.N[pi];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int col = ((int)blockIdx.x - m.blk_begin[pi]) * 32 + tx;
-  float s = 0.f;
-  if (col < N)
-    for (int p = ty; p < P; p += 8) s += part[(int64_t)p * N + col];
-  red[ty][tx] = s;
-  __syncthreads();
+  const int tx = threadIdx.x % PXR_RED_CX, ty = threadIdx.x / PXR_RED_CX;
+  const int col = ((int)blockIdx.x - m.blk_begin[pi]) * PXR_RED_CX + tx;
+  const float s = (col < N) ? pxr_strided_column_sum(part, P, N, col, ty) : 0.f;
+  const float v = pxr_combine_row_lanes(s, red, tx, ty);
   if (ty == 0 && col < N) {
-    const float v = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) +
-                    ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
     if (col < m.split[pi]) m.out_a[pi][col] = v;
     else m.out_b[pi][col - m.split[pi]] = v;
   }
@@ -408,7 +405,7 @@ extern "C" int pxr_reduce_partials_multi_f32(int n, const float* const* part, co
     m.part[i] = part[i]; m.out_a[i] = out_a[i]; m.out_b[i] = out_b[i] ? out_b[i] : out_a[i];
     m.P[i] = P[i]; m.N[i] = N[i]; m.split[i] = out_b[i] ? split[i] : N[i];
     m.blk_begin[i] = blocks;
-    blocks += (N[i] + 31) / 32;
+    blocks += (N[i] + PXR_RED_CX - 1) / PXR_RED_CX;
   }
   m.blk_begin[n] = blocks;
   hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m);

@@ -84,23 +84,55 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------- fixed-order reduction of per-block partials
-// out[n] = sum_p part[p][n] for n < N.  Block = 32 columns x 8 row-lanes; lane r sums p = r, r+8, ... then the 8
-// lanes are combined in a fixed tree => deterministic.  Columns n < split go to out_a[n], the rest to
+// out[n] = sum_p part[p][n] for n < N.  Block = PXR_RED_CX columns x PXR_RED_CY row-lanes; row-lane r sums
+// p = r, r+CY, ... with 8 independent loads in flight (a plain loop is one dependent L2 round trip per partial row),
+// then the CY lanes are combined in a fixed tree => deterministic.  Columns n < split go to out_a[n], the rest to
 // out_b[n - split] (LayerNorm dgamma | dbeta share one partial buffer); pass split = N for a single output.
+constexpr int PXR_RED_CX = 16, PXR_RED_CY = 16;
+static_assert(PXR_RED_CX * PXR_RED_CY == 256, "reduction kernels run 256 threads");
+
+__device__ __forceinline__ float pxr_strided_column_sum(const float* __restrict__ part, int P, int N, int col, int ty) {
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  int p = ty;
+  for (; p + 7 * PXR_RED_CY < P; p += 8 * PXR_RED_CY) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(p + PXR_RED_CY * u) * N + col];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += v[u];
+  }
+  for (int u = 0; p < P; p += PXR_RED_CY, ++u) acc[u & 7] += part[(int64_t)p * N + col];
+  return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+// block-level tail shared by the reduction kernels: returns (on row-lane 0) the total of the CY row-lane sums
+__device__ __forceinline__ float pxr_combine_row_lanes(float s, float (&red)[PXR_RED_CY][PXR_RED_CX + 1], int tx, int ty) {
+  red[ty][tx] = s;
+  __syncthreads();
+  float v = 0.f;
+  if (ty == 0) {
+    float t[PXR_RED_CY];
+#pragma unroll
+    for (int r = 0; r < PXR_RED_CY; ++r) t[r] = red[r][tx];
+#pragma unroll
+    for (int w = PXR_RED_CY / 2; w >= 1; w >>= 1)
+#pragma unroll
+      for (int r = 0; r < w; ++r) t[r] = t[2 * r] + t[2 * r + 1];
+    v = t[0];
+  }
+  return v;
+}
+
 static __global__ void __launch_bounds__(256) pxr_reduce_partials_kernel(const float* __restrict__ part, int P, int N,
                                                                   float* __restrict__ out_a,
                                                                   float* __restrict__ out_b, int split) {
-  __shared__ float red[8][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + tx;
-  float s = 0.f;
-  if (col < N)
-    for (int p = ty; p < P; p += 8) s += part[(int64_t)p * N + col];
-  red[ty][tx] = s;
-  __syncthreads();
+  __shared__ float red[PXR_RED_CY][PXR_RED_CX + 1];
+  const int tx = threadIdx.x % PXR_RED_CX, ty = threadIdx.x / PXR_RED_CX;
+  const int col = blockIdx.x * PXR_RED_CX + tx;
+  const float s = (col < N) ? pxr_strided_column_sum(part, P, N, col, ty) : 0.f;
+  const float v = pxr_combine_row_lanes(s, red, tx, ty);
   if (ty == 0 && col < N) {
-    const float v = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) +
-                    ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
     if (col < split) out_a[col] = v;
     else out_b[col - split] = v;
   }
