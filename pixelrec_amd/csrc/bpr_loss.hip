@@ -68,8 +68,17 @@ __global__ void __launch_bounds__(256) bpr_reduce_kernel(const float* __restrict
   __shared__ float red[256];
   float s = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
+    const float* row = lossrow + (int64_t)b * L;
     float sb = 0.f;
-    for (int t = 0; t < L; ++t) sb += lossrow[(int64_t)b * L + t];
+    int t = 0;
+    for (; t + 8 <= L; t += 8) {   // 8 independent loads per round trip, added in position order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = row[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sb += v[u];
+    }
+    for (; t < L; ++t) sb += row[t];
     s += sb;
   }
   red[threadIdx.x] = s;

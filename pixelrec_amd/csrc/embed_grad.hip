@@ -433,91 +433,135 @@ struct SegSumArgs {
   int D, T;
 };
 
-// One block per unique row.  The 512 threads form G = 512/dv groups (dv = D/4 float4 columns, G >= 1); group g
-// sums occurrences s0+g, s0+g+G, ... in order, then the G partial rows are added in group order through LDS:
-// a fixed summation tree => bit-reproducible, and popular items (hundreds of occurrences under the Zipf
-// popularity) no longer serialise on one chain of dependent 2 KB row reads.
+// 512 threads = G = 512/dv groups of dv threads (dv = D/4 float4 columns; D = 512: 4 groups of 128).
+//  * Short segments (<= SEG_SHORT occurrences -- almost every row: the negatives and the tail of the Zipf
+//    popularity): each GROUP sums one unique row on its own -- resolves the occurrences, has all their row loads
+//    in flight at once and adds them in occurrence order.  No LDS, no barrier: the latency chain is
+//    seg_start -> sorted ids -> rows, and a workgroup retires G rows per pass.
+//  * Long segments (a popular item: hundreds of occurrences): all G groups cooperate on the row -- per chunk of
+//    <= 512 occurrences the (source row, coefficient) pairs are resolved into LDS, group g adds occurrences g, g+G,
+//    ... with 8 row loads in flight, and the G partial rows are combined in group order through LDS.
+// Both are fixed summation orders => bit-reproducible.
 constexpr int SEG_THREADS = 512;
-constexpr int SEG_CHUNK = 512;   // occurrences staged per pass
+constexpr int SEG_CHUNK = 512;   // occurrences staged per pass (long segments)
+constexpr int SEG_SHORT = 8;     // longest segment a single group handles
 
-// One block per unique row.  Per chunk of <= 512 occurrences the block first resolves every occurrence to
-// (source row offset, coefficient) cooperatively into LDS -- one coalesced read of the sorted ids instead of a
-// dependent load chain per occurrence -- then the 512 threads form G = 512/dv groups (dv = D/4 float4 columns);
-// group g adds occurrences g, g+G, ... in order with 8 independent row loads in flight, and the G partial rows are
-// combined in group order through LDS: a fixed summation tree => bit-reproducible, and a popular item (hundreds of
-// occurrences under the Zipf popularity) costs ~15 load round trips instead of hundreds.
+template <int MODE>
+__device__ __forceinline__ void seg_resolve(const SegSumArgs& a, int o, int64_t& off, float& cf) {
+  if constexpr (MODE == MODE_ROWS) {
+    off = (int64_t)o * a.D;
+    cf = 1.f;
+  } else {
+    const int type = o / a.T, r = o - type * a.T;
+    // type 0 reads src0 (dx0); types 1/2 read src1 (out): the source is encoded in the sign bit of the offset
+    off = (type == 0) ? (int64_t)r * a.D : ~((int64_t)r * a.D);
+    cf = (type == 0) ? 1.f : (type == 1 ? a.coef[r] : -a.coef[r]);
+  }
+}
+template <int MODE>
+__device__ __forceinline__ const float* seg_row(const SegSumArgs& a, int64_t off) {
+  if constexpr (MODE == MODE_ROWS) return a.src0 + off;
+  else return off >= 0 ? a.src0 + off : a.src1 + ~off;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(SEG_THREADS) segsum_kernel(SegSumArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 sred[];  // [G][dv]
   __shared__ int64_t s_off[SEG_CHUNK];
   __shared__ float s_cf[SEG_CHUNK];
+  __shared__ int s_long[SEG_THREADS / 64];
   const int nu = *a.n_uniq;
   const int dv = a.D >> 2;
-  const int G = dv >= SEG_THREADS ? 1 : SEG_THREADS / dv;
-  const int g = (dv >= SEG_THREADS) ? 0 : threadIdx.x / dv;
-  const int c0 = (dv >= SEG_THREADS) ? threadIdx.x : threadIdx.x - g * dv;
+  const bool wide = dv > SEG_THREADS;                 // D > 2048: one row per workgroup, column blocks
+  const int G = wide ? 1 : SEG_THREADS / dv;          // <= 8 for D >= 256
+  const int g = wide ? 0 : threadIdx.x / dv;
+  const int c0 = wide ? threadIdx.x : threadIdx.x - g * dv;
   const bool active = g < G;
-  for (int u = blockIdx.x; u < nu; u += gridDim.x) {
-    const int s0 = a.seg_start[u], s1 = a.seg_start[u + 1];
-    for (int cb = 0; cb < dv; cb += SEG_THREADS) {  // dv > 512 (D > 2048): column blocks
-      const int c4 = cb + c0;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int sb = s0; sb < s1; sb += SEG_CHUNK) {
-        const int cnt = min(SEG_CHUNK, s1 - sb);
-        __syncthreads();
-        for (int j = threadIdx.x; j < cnt; j += SEG_THREADS) {
-          const int o = a.vals[sb + j];
-          if constexpr (MODE == MODE_ROWS) {
-            s_off[j] = (int64_t)o * a.D;
-            s_cf[j] = 1.f;
-          } else {
-            const int type = o / a.T, r = o - type * a.T;
-            // type 0 reads src0 (dx0); types 1/2 read src1 (out): encode the source in the sign bit of the offset
-            s_off[j] = (type == 0) ? (int64_t)r * a.D : ~((int64_t)r * a.D);
-            s_cf[j] = (type == 0) ? 1.f : (type == 1 ? a.coef[r] : -a.coef[r]);
-          }
-        }
-        __syncthreads();
-        if (active && c4 < dv) {
-          auto rowp = [&](int j) -> const float* {
-            const int64_t off = s_off[j];
-            if constexpr (MODE == MODE_ROWS) return a.src0 + off;
-            else return off >= 0 ? a.src0 + off : a.src1 + ~off;
-          };
-          int j = g;
-          for (; j + 7 * G < cnt; j += 8 * G) {
-            float4 v[8];
+  const int rows_per_pass = (wide || G > SEG_THREADS / 64) ? 1 : G;
+  for (int u0 = blockIdx.x * rows_per_pass; u0 < nu; u0 += gridDim.x * rows_per_pass) {
+    // ---- short segments: one group per row
+    bool is_long = false;
+    if (rows_per_pass > 1) {
+      const int u = u0 + g;
+      if (active && u < nu) {
+        const int s0 = a.seg_start[u], cnt = a.seg_start[u + 1] - s0;
+        if (cnt > SEG_SHORT) {
+          is_long = true;
+        } else {
+          float4 v[SEG_SHORT];
+          float cf[SEG_SHORT];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(rowp(j + q * G) + c4 * 4);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const float cf = s_cf[j + q * G];
-              acc.x += cf * v[q].x; acc.y += cf * v[q].y; acc.z += cf * v[q].z; acc.w += cf * v[q].w;
+          for (int j = 0; j < SEG_SHORT; ++j) {
+            cf[j] = 0.f;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < cnt) {
+              int64_t off;
+              seg_resolve<MODE>(a, a.vals[s0 + j], off, cf[j]);
+              v[j] = *reinterpret_cast<const float4*>(seg_row<MODE>(a, off) + c0 * 4);
             }
           }
-          for (; j < cnt; j += G) {
-            const float cf = s_cf[j];
-            const float4 v = *reinterpret_cast<const float4*>(rowp(j) + c4 * 4);
-            acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
-          }
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int j = 0; j < SEG_SHORT; ++j)
+            if (j < cnt) { acc.x += cf[j] * v[j].x; acc.y += cf[j] * v[j].y; acc.z += cf[j] * v[j].z; acc.w += cf[j] * v[j].w; }
+          acc.x *= a.scale; acc.y *= a.scale; acc.z *= a.scale; acc.w *= a.scale;
+          *reinterpret_cast<float4*>(a.uniq_rows + (int64_t)u * a.D + c0 * 4) = acc;
         }
       }
-      if (G > 1) {
-        __syncthreads();
-        if (active) sred[g * dv + c0] = acc;
-        __syncthreads();
-        if (g == 0) {
-          for (int k = 1; k < G; ++k) {
-            const float4 t = sred[k * dv + c0];
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      if (active && c0 == 0) s_long[g] = is_long ? 1 : 0;
+      __syncthreads();
+    }
+    // ---- long segments (or D too wide for row groups): the whole workgroup cooperates on one row at a time
+    for (int gg = 0; gg < rows_per_pass; ++gg) {
+      const int u = u0 + gg;
+      if (rows_per_pass > 1 && !s_long[gg]) continue;   // block-uniform
+      if (u >= nu) continue;
+      const int s0 = a.seg_start[u], s1 = a.seg_start[u + 1];
+      for (int cb = 0; cb < dv; cb += SEG_THREADS) {  // dv > 512 (D > 2048): column blocks
+        const int c4 = cb + c0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sb = s0; sb < s1; sb += SEG_CHUNK) {
+          const int cnt = min(SEG_CHUNK, s1 - sb);
+          __syncthreads();
+          for (int j = threadIdx.x; j < cnt; j += SEG_THREADS) seg_resolve<MODE>(a, a.vals[sb + j], s_off[j], s_cf[j]);
+          __syncthreads();
+          if (active && c4 < dv) {
+            int j = g;
+            for (; j + 7 * G < cnt; j += 8 * G) {
+              float4 v[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(seg_row<MODE>(a, s_off[j + q * G]) + c4 * 4);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const float cf = s_cf[j + q * G];
+                acc.x += cf * v[q].x; acc.y += cf * v[q].y; acc.z += cf * v[q].z; acc.w += cf * v[q].w;
+              }
+            }
+            for (; j < cnt; j += G) {
+              const float cf = s_cf[j];
+              const float4 v = *reinterpret_cast<const float4*>(seg_row<MODE>(a, s_off[j]) + c4 * 4);
+              acc.x += cf * v.x; acc.y += cf * v.y; acc.z += cf * v.z; acc.w += cf * v.w;
+            }
           }
         }
-      }
-      if (g == 0 && c4 < dv) {
-        acc.x *= a.scale; acc.y *= a.scale; acc.z *= a.scale; acc.w *= a.scale;
-        *reinterpret_cast<float4*>(a.uniq_rows + (int64_t)u * a.D + c4 * 4) = acc;
+        if (G > 1) {
+          __syncthreads();
+          if (active) sred[g * dv + c0] = acc;
+          __syncthreads();
+          if (g == 0) {
+            for (int k = 1; k < G; ++k) {
+              const float4 t = sred[k * dv + c0];
+              acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+          }
+        }
+        if (g == 0 && c4 < dv) {
+          acc.x *= a.scale; acc.y *= a.scale; acc.z *= a.scale; acc.w *= a.scale;
+          *reinterpret_cast<float4*>(a.uniq_rows + (int64_t)u * a.D + c4 * 4) = acc;
+        }
       }
     }
+    if (rows_per_pass > 1) __syncthreads();   // s_long is rewritten by the next pass
   }
 }
 
