@@ -13,8 +13,8 @@
 //
 // Tiling: 256 threads = 4 waves arranged 2x2; block tile BM x BN, K step BK = 32; each wave owns
 // (BM/2)x(BN/2) made of 32x32 MFMA blocks.  LDS images need no transposes in either flavour:
-//   KC operand -> LDS [row][k] with row stride BK+4 floats (ds_write_b128 / ds_read_b128 conflict-free:
-//                 36*r mod 64 is a bijection on 16-byte slots for the 16 rows of a b128 lane group);
+//   KC operand -> LDS [row][k], 32 floats per row, 16-byte slots XOR-swizzled by the row (kc_slot: conflict-free
+//                 ds_write_b128 / ds_read_b128 without padding);
 //                 a lane reads 4 consecutive k; lanes 0-31 take k 0..3, lanes 32-63 take k 4..7 of the
 //                 8-wide k sub-step, so register t feeds MFMA t with k = 4*(lane>>5)+t on BOTH operands.
 //   XC operand -> LDS [k][x] with row stride BM (or BN) floats; per MFMA one ds_read_b32 at
@@ -42,8 +42,8 @@ struct GemmCfg {
   static constexpr int WGM = (BM >= 64) ? 2 : 1;
   static constexpr int G = WGM * 2;
   static constexpr int NT = 64 * G * KW;
-  static constexpr int LDA = A_KC ? (BK + 4) : BM;
-  static constexpr int LDB = B_KC ? (BK + 4) : BN;
+  static constexpr int LDA = A_KC ? BK : BM;   // KC tiles are XOR-swizzled, not padded (see kc_slot)
+  static constexpr int LDB = B_KC ? BK : BN;
   static constexpr int A_STAGE = (A_KC ? BM : BK) * LDA;  // floats
   static constexpr int B_STAGE = (B_KC ? BN : BK) * LDB;
   static constexpr int STAGE = A_STAGE + B_STAGE;
@@ -88,13 +88,20 @@ __device__ __forceinline__ void fetch_kc(float4 (&r)[NLD], bufrsrc rs, int ld, i
     r[p] = buf_ld16(rs, ok ? (unsigned)(row * ld + gk) * 4u : BUF_OOB);
   }
 }
+// A KC tile is [row][32 floats] = 8 sixteen-byte slots per row, UNPADDED; logical slot q of `row` lives in physical slot
+// q ^ ((row >> 1) & 7).  A 16-lane group of a ds_read_b128 / ds_write_b128 then touches 16 distinct 16-byte bank
+// groups (rows r, r+1 differ in the 128-byte half, rows r, r+2 in the slot), i.e. the same conflict-freedom as a
+// 36-float padded stride at 32 KB instead of 36.9 KB per 64x64 double-buffered tile: FIVE workgroups per CU instead of
+// four, so the 1200-tile QKV GEMM of the training step is resident in one round.
+__device__ __forceinline__ int kc_slot(int row, int q) { return (q ^ ((row >> 1) & 7)) * 4; }
+
 template <int BX, int NLD, int NT>
 __device__ __forceinline__ void stash_kc(const float4 (&r)[NLD], float* lds, int tid) {
 #pragma unroll
   for (int p = 0; p < NLD; ++p) {
     const int f = tid + p * NT;
     const int row = f >> 3, q = f & 7;
-    *reinterpret_cast<float4*>(lds + row * (GEMM_BK + 4) + q * 4) = r[p];
+    *reinterpret_cast<float4*>(lds + row * GEMM_BK + kc_slot(row, q)) = r[p];
   }
 }
 // XC operand: matrix [K][X] (row stride ld); `rs` starts at element [k0][x0], krows_left = kend - k0,
@@ -205,7 +212,7 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
     for (int i = 0; i < Cfg::TM; ++i) {
       const int row = wm * Cfg::WM + i * 32 + r;
       if constexpr (A_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(sa + row * Cfg::LDA + ks * 8 + h * 4);
+        const float4 v = *reinterpret_cast<const float4*>(sa + row * Cfg::LDA + kc_slot(row, ks * 2 + h));
         f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
       } else {
 #pragma unroll
@@ -216,7 +223,7 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
     for (int j = 0; j < Cfg::TN; ++j) {
       const int col = wn * Cfg::WN + j * 32 + r;
       if constexpr (B_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(sb + col * Cfg::LDB + ks * 8 + h * 4);
+        const float4 v = *reinterpret_cast<const float4*>(sb + col * Cfg::LDB + kc_slot(col, ks * 2 + h));
         f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
       } else {
 #pragma unroll
