@@ -159,6 +159,16 @@ class SeqRecCore(BaseModel):
             return buf[off:off + n].view(shape)
         return buf[off:off + span * n].view((span * shape[0],) + tuple(shape[1:]))
 
+    # ---- the dropout "RNG state": masks are a stateless hash of (seed, site, element, step), so the only state is
+    # the number of completed backward passes (host mirror + device counter).  Saved / restored with checkpoints.
+    def dropout_step(self) -> int:
+        return int(self._step_counter)
+
+    def set_dropout_step(self, n: int):
+        self._step_counter = int(n)
+        if getattr(self, "_drop_dev", None) is not None:
+            self._drop_dev.fill_(self._step_counter)
+
     def flat_parameters(self):
         self._ensure_packed()
         return self._flat, self._gflat

@@ -167,6 +167,8 @@ class Trainer:
                 "state_dict": {k: v.detach().cpu() for k, v in self.model.module.state_dict().items()},
                 "optimizer": {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v)
                               for k, v in self.optimizer.state_dict().items()},
+                # this path's dropout "RNG state" (the reference stores torch's generator states for the same purpose)
+                "dropout_step": self.model.module.dropout_step() if hasattr(self.model.module, "dropout_step") else 0,
                 "rng_state": torch.get_rng_state(),
                 "cuda_rng_state": torch.cuda.get_rng_state() if torch.cuda.is_available() else None,
             }
@@ -186,6 +188,9 @@ class Trainer:
         if str(checkpoint["config"]["model"]).lower() != str(self.config["model"]).lower():
             self.logger.warning("Architecture configuration given in config file is different from that of checkpoint.")
         self.optimizer.load_state_dict(checkpoint["optimizer"])
+        if hasattr(self.model.module, "set_dropout_step"):
+            self.model.module.set_dropout_step(checkpoint.get("dropout_step", 0))
+        self._gstep = None          # a captured step graph belongs to the pre-resume state
         torch.set_rng_state(checkpoint["rng_state"])
         if checkpoint.get("cuda_rng_state") is not None and torch.cuda.is_available():
             torch.cuda.set_rng_state(checkpoint["cuda_rng_state"])

@@ -136,3 +136,55 @@ def test_graph_replay_equals_eager_steps():
     assert le == lg                                   # identical losses, step by step (same kernels, same seeds)
     for k in se:
         assert torch.equal(se[k], sg[k]), k
+
+
+def test_checkpoint_round_trip_resumes_bit_identically():
+    """k steps -> state_dict (model + optimizer, lazy table flushed) -> fresh model / optimizer -> k more steps must equal
+    2k uninterrupted steps bit for bit (dropout on: the seed offset is part of the resumed state through step_count)."""
+    import numpy as np
+
+    from pixelrec_amd import synth
+    from pixelrec_amd.model import SASRec
+    from pixelrec_amd.optim import PxrAdamW
+
+    N, D, L, B, K = 3000, 64, 10, 16, 5
+    cfg = {"n_layers": 2, "n_heads": 2, "embedding_size": D, "inner_size": 2, "hidden_dropout_prob": 0.1,
+           "attn_dropout_prob": 0.1, "hidden_act": "gelu", "layer_norm_eps": 1e-12, "initializer_range": 0.02,
+           "MAX_ITEM_LIST_LENGTH": L, "seed": 2020}
+
+    class DL:
+        item_num = N
+
+    rng = np.random.default_rng(1)
+    z = synth.ZipfItems(N, seed=2)
+    batches = [tuple(torch.from_numpy(a).cuda() for a in synth.train_batch(N, B, L, rng, z)) for _ in range(2 * K)]
+
+    def fresh():
+        torch.manual_seed(3)
+        m = SASRec(cfg, DL()).cuda().train()
+        return m, PxrAdamW(m, lr=1e-3, weight_decay=0.1)
+
+    def run(m, opt, bs):
+        for b in bs:
+            opt.zero_grad()
+            m(b).backward()
+            opt.step()
+
+    m_ref, o_ref = fresh()
+    run(m_ref, o_ref, batches)
+    ref = {k: v.detach().clone() for k, v in m_ref.state_dict().items()}
+
+    m1, o1 = fresh()
+    run(m1, o1, batches[:K])
+    ckpt = {"state_dict": {k: v.detach().cpu().clone() for k, v in m1.state_dict().items()},
+            "dropout_step": m1.dropout_step(),
+            "optimizer": {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in o1.state_dict().items()}}
+    m2, o2 = fresh()
+    m2.load_state_dict(ckpt["state_dict"], strict=True)
+    o2.load_state_dict({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ckpt["optimizer"].items()})
+    m2.set_dropout_step(ckpt["dropout_step"])
+    assert ckpt["dropout_step"] == K
+    run(m2, o2, batches[K:])
+    got = m2.state_dict()
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
