@@ -46,10 +46,10 @@ __global__ void __launch_bounds__(256) embed_gather_kernel(const gvec4* __restri
 
 extern "C" int pxr_embed_gather_f32(const float* table, int64_t N, int D, const int64_t* idx, int64_t n,
                                     float* out, void* stream) {
+  PXR_REQUIRE(n >= 0, "pxr_embed_gather_f32: negative n");
+  if (n == 0) return PXR_OK;   // an empty index list is legal (and its tensors have null data pointers)
   PXR_REQUIRE(table && idx && out, "pxr_embed_gather_f32: null pointer");
   PXR_REQUIRE(N > 0 && D > 0 && (D % 4) == 0, "pxr_embed_gather_f32: need N>0 and D %% 4 == 0 (D=%d)", D);
-  PXR_REQUIRE(n >= 0, "pxr_embed_gather_f32: negative n");
-  if (n == 0) return PXR_OK;
   const int dv = D / 4;
   const int64_t total = n * dv;
   // A/B knob (bit 0: non-temporal loads, bit 1: non-temporal stores, +4: 2 chunks per lane instead of 4).  Measured

@@ -167,3 +167,40 @@ def test_clip_grad_norm_matches_torch(max_norm):
     for k in ("position_embedding.weight", "trm_encoder.layer.0.multi_head_attention.query.weight", "LayerNorm.bias"):
         got = dict(m.named_parameters())[k].grad.cpu()
         assert (got - clipped[k]).abs().max().item() <= 1e-7 + 2e-4 * clipped[k].abs().max().item(), k
+
+
+def test_degenerate_inputs():
+    """Empty / all-padding inputs through the same entry points: no launch failure, zero loss, an empty sparse
+    gradient, and an optimizer step that only applies weight decay / stale moments."""
+    from pixelrec_amd import ops
+    from pixelrec_amd.optim import PxrAdamW
+
+    table = torch.randn(50, 16, device="cuda")
+    assert ops.embed_gather(table, torch.zeros(0, dtype=torch.int64, device="cuda")).shape == (0, 16)
+    sp = ops.embed_grad_rows(torch.zeros(37, dtype=torch.int64, device="cuda"), torch.randn(37, 16, device="cuda"), 50)
+    assert sp.count() == 0                                            # only padding ids: nothing to update
+
+    meta, z = load_case("tiny")
+    m, p = _model(meta, p_drop=0.1)
+    m.train()
+    opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1)
+    B, L = 4, meta["L"]
+    items = torch.zeros(B, 2, L + 1, dtype=torch.int64, device="cuda")
+    mask = torch.zeros(B, L, dtype=torch.int64, device="cuda")
+    loss = m((items, mask))
+    loss.backward()
+    assert float(loss.detach()) == 0.0
+    assert m.sparse_table_grad.count() == 0
+    for k, v in m.named_parameters():
+        if v.grad is not None and k != "item_embedding.weight":
+            assert float(v.grad.abs().max()) == 0.0, k
+    before = m.state_dict()["position_embedding.weight"].clone()
+    opt.step()
+    after = m.state_dict()["position_embedding.weight"]
+    assert torch.allclose(after, before * (1 - 1e-3 * 0.1), atol=1e-7)     # zero gradient: decoupled weight decay only
+    # one real sequence among padding rows still trains
+    it = torch.from_numpy(z["items"][:1]).cuda()
+    items[0], mask[0] = it[0], torch.from_numpy(z["masked_index"][:1]).cuda()[0]
+    loss = m((items, mask))
+    loss.backward()
+    assert float(loss.detach()) > 0.0 and m.sparse_table_grad.count() > 0
