@@ -36,7 +36,10 @@ def train_batch(n_items: int, B: int, L: int, rng: np.random.Generator, zipf: Zi
     """Returns (items [B,2,L+1] int64, masked_index [B,L] int64)."""
     items = np.zeros((B, 2, L + 1), dtype=np.int64)
     mask = np.zeros((B, L), dtype=np.int64)
-    lens = np.where(rng.random(B) < full_frac, L + 1, rng.integers(min(min_len, L + 1), L + 1, size=B))
+    lo = max(min(min_len, L), 2)              # shortest window: 2 items (one input, one target) when L is tiny
+    full = rng.random(B) < full_frac          # (draw order kept: the fixtures / benches depend on this stream)
+    short = rng.integers(lo, L + 1, size=B) if lo < L + 1 else np.full(B, L + 1)
+    lens = np.where(full, L + 1, short)
     for b in range(B):
         n = int(lens[b])
         if uniform_ids or zipf is None:

@@ -67,7 +67,11 @@ def test_one_step_at_full_size_matches_oracle(N, D, L, H, B):
     sd = m.state_dict()                                                            # flushes the lazy table
     rows = torch.cat([idx[:200], torch.tensor([0, 1, 2, N - 1])])
     assert (sd["item_embedding.weight"][rows.cuda()].cpu() - tr.p["item_embedding.weight"][rows]).abs().max().item() < 1e-5
-    assert abs(float(sd["item_embedding.weight"].double().sum()) - float(tr.p["item_embedding.weight"].double().sum())) < 0.05
+    diff = (sd["item_embedding.weight"].cpu() - tr.p["item_embedding.weight"]).abs()
+    assert diff[~touched].max().item() < 1e-7                      # untouched rows: weight decay only (lazy replay exact)
+    # touched rows: Adam moves an entry whose gradient is rounding noise by +-lr whatever its sign, so a few entries
+    # may differ by 2*lr; everything else agrees to 1e-5
+    assert diff.max().item() <= 2.1e-4 and (diff[touched] > 1e-5).float().mean().item() < 1e-3
     for k in ("position_embedding.weight", "trm_encoder.layer.1.feed_forward.dense_2.weight"):
         assert (sd[k].cpu() - tr.p[k]).abs().max().item() < 1e-5, k
 
@@ -162,3 +166,42 @@ def test_wide_embedding_4096_and_chunked_attention():
     solid = g["item_embedding.weight"].abs() > 1e-6
     assert diff[solid].max().item() < 2e-5
     assert diff.max().item() <= 2.1e-4 and (diff > 2e-5).float().mean().item() < 1e-3
+
+
+@pytest.mark.parametrize("N,D,L,H,B", [(97, 96, 7, 4, 5), (300, 80, 13, 4, 3), (150, 64, 64, 1, 2), (5000, 256, 64, 8, 9),
+                                        (60, 32, 2, 2, 4), (1000, 1024, 33, 16, 2), (211, 192, 50, 3, 7)])
+def test_unusual_shapes_match_oracle(N, D, L, H, B):
+    """Head sizes that are not powers of two (24, 20), one head, the longest supported sequence (64), two positions,
+    16 heads: loss, every gradient, predict scores and one AdamW step against the oracle."""
+    from pixelrec_amd.optim import PxrAdamW
+
+    params = O.synth_params(N, D, L, 2, 2, seed=N + D, perturb=True)
+    m = _model(N, D, L, H, params)
+    opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1)
+    items, mask = _batch(N, B, L, 3)
+    loss = m((items.cuda(), mask.cuda()))
+    loss.backward()
+    cfg = {"n_layers": 2, "n_heads": H, "layer_norm_eps": 1e-12}
+    tr = O.OracleTrainer(params, cfg, lr=1e-3, weight_decay=0.1)
+    ref_loss, g = O.loss_and_grads(tr.p, items, mask, tr.cfg)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 3e-5 * max(1.0, abs(float(ref_loss)))
+    dense = m.sparse_table_grad.to_dense(N).cpu()
+    assert (dense - g["item_embedding.weight"]).abs().max().item() <= 3e-6 + 3e-4 * g["item_embedding.weight"].abs().max().item()
+    for k, v in m.named_parameters():
+        if k != "item_embedding.weight":
+            assert (v.grad.cpu() - g[k]).abs().max().item() <= 5e-6 + 3e-4 * g[k].abs().max().item(), k
+    m.eval()                                # logits +-1e-4 on identical parameters (before the optimizer moves them)
+    seq = items[:, 0, 1:].contiguous().cuda()
+    with torch.no_grad():
+        scores = m.predict(seq, m.compute_item_all()).cpu()
+    ref_scores = O.predict(tr.p, seq.cpu(), tr.p["item_embedding.weight"], tr.cfg)
+    assert (scores - ref_scores).abs().max().item() <= 1e-4
+    m.train()
+    opt.step()
+    tr.step(items, mask)
+    sd = m.state_dict()
+    for k in ("item_embedding.weight", "position_embedding.weight", "trm_encoder.layer.1.feed_forward.dense_1.weight"):
+        d = (sd[k].cpu() - tr.p[k]).abs()
+        solid = g[k].abs() > 1e-6          # Adam's sign(g) is rounding noise where |g| ~ 0 (moves such entries by +-lr)
+        assert d[solid].max().item() < 2e-5 if solid.any() else True, k
+        assert d.max().item() <= 2.1e-3, k
