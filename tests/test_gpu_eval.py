@@ -28,7 +28,8 @@ def test_fused_score_topk_matches_reference_topk(case):
     assert np.abs(val.cpu().numpy() - z["eval.topk_val"]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("B,N,D,K", [(300, 50001, 64, 10), (130, 777, 128, 5), (64, 20000, 512, 20)])
+@pytest.mark.parametrize("B,N,D,K", [(300, 50001, 64, 10), (130, 777, 128, 5), (64, 20000, 512, 20), (1, 130, 32, 1),
+                                     (5, 97, 96, 32), (129, 4097, 1024, 16)])
 def test_fused_score_topk_random_ragged(B, N, D, K):
     from pixelrec_amd import ops
 
