@@ -32,15 +32,19 @@ constexpr int GEMM_THREADS = 256;
 // KW = number of wave groups that split the k-steps of each K tile between them (intra-workgroup split-K): KW=2
 // doubles the waves per output tile, which is what hides the LDS/global latency bubbles when a GEMM has too few
 // output tiles to fill the chip (M = B*L = 3200 tokens); the KW partial accumulators are added through LDS.
-template <int BM, int BN, bool A_KC, bool B_KC, int KW = 1>
+template <int BM, int BN, bool A_KC, bool B_KC, int KW = 1, int FINE = 0>
 struct GemmCfg {
   static constexpr int BK = GEMM_BK;
   // wave grid of one k-group: WGM x 2.  BM = 32 tiles use one wave row; with KW = 2 that is still a 256-thread
   // workgroup, but each output tile is half as large: twice as many, independently synchronised workgroups per CU --
   // what overlaps one workgroup's barrier / LDS bubbles when a GEMM has few tiles (waves of ONE workgroup run in
   // lockstep between barriers, so more waves per workgroup do not help: measured with the 64x64 KW=2 tile).
-  static constexpr int WGM = (BM >= 64) ? 2 : 1;
-  static constexpr int G = WGM * 2;
+  // FINE = 1: every wave owns ONE 32x32 block of the tile (a 128x128 tile = 16 waves).  The 64x64 kernels turned out
+  // to be bound by L2 -> LDS traffic (16 flop per byte staged: ~6 TB/s at 94 TFLOP/s), not by occupancy; a big tile
+  // cut into many small wave tiles halves that traffic while keeping the same number of waves in flight.
+  static constexpr int WGM = FINE ? BM / 32 : ((BM >= 64) ? 2 : 1);
+  static constexpr int WGN = FINE ? BN / 32 : 2;
+  static constexpr int G = WGM * WGN;
   static constexpr int NT = 64 * G * KW;
   static constexpr int LDA = A_KC ? BK : BM;   // KC tiles are XOR-swizzled, not padded (see kc_slot)
   static constexpr int LDB = B_KC ? BK : BN;
@@ -48,7 +52,7 @@ struct GemmCfg {
   static constexpr int B_STAGE = (B_KC ? BN : BK) * LDB;
   static constexpr int STAGE = A_STAGE + B_STAGE;
   static constexpr int LDS_BYTES = 2 * STAGE * 4;
-  static constexpr int WM = BM / WGM, WN = BN / 2;
+  static constexpr int WM = BM / WGM, WN = BN / WGN;
   static constexpr int TM = WM / 32, TN = WN / 32;
   static constexpr int A_LD4 = BM * BK / 4 / NT;  // float4 loads per thread per tile
   static constexpr int B_LD4 = BN * BK / 4 / NT;
@@ -139,18 +143,18 @@ __device__ __forceinline__ void stash_xc(const float4 (&r)[NLD], float* lds, int
 // that is alone on its CU (M = B*L = 3200 tokens => ~1.5 workgroups per CU) stalls on every K tile; PD = 3..4 keeps
 // enough loads in flight (16 VGPRs per slot at 64x64).  LDS stays double-buffered: slot (kt+1) % PD is written to
 // the other buffer while tile kt is read.
-template <int BM, int BN, bool A_KC, bool B_KC, bool CS = false, int KW = 1, int PD = 2>
-__device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_KC, KW>::Acc& accs,
+template <int BM, int BN, bool A_KC, bool B_KC, bool CS = false, int KW = 1, int PD = 2, int ST = 2, int FINE = 0>
+__device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::Acc& accs,
                                               const float* __restrict__ A, int64_t lda,
                                               const float* __restrict__ B, int64_t ldb, int M, int N,
                                               int kbeg, int kend, int m0, int n0, float* smem,
                                               float4* cs = nullptr) {
-  using Cfg = GemmCfg<BM, BN, A_KC, B_KC, KW>;
+  using Cfg = GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>;
   constexpr int NT = Cfg::NT;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wk = wave / Cfg::G, w4 = wave % Cfg::G;
-  const int wm = w4 >> 1, wn = w4 & 1;
+  const int wm = w4 / Cfg::WGN, wn = w4 % Cfg::WGN;
   const int h = lane >> 5, r = lane & 31;
   auto& acc = accs.v;
 
@@ -257,12 +261,16 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
   // overlap with):  fragments of sub-step q+1 are read before sub-step q multiplies; the next tile is written to the
   // other LDS buffer before the last sub-step; the barrier sits in the MIDDLE of the last sub-step and the first
   // fragment read of the next tile follows it immediately, so both run under the remaining MFMAs.
+  // ST = 2: the next tile goes to the OTHER LDS buffer (one barrier per K tile).  ST = 1: a single LDS buffer (half the
+  // LDS, so twice the resident workgroups per CU): two barriers per K tile -- everybody finished reading, everybody
+  // finished writing -- whose latency is covered by the other workgroups' waves instead of by a second buffer.
   for (int kt0 = 0; kt0 < nk; kt0 += PD) {
 #pragma unroll
     for (int s = 0; s < PD; ++s) {
       const int kt = kt0 + s;
       if (kt < nk) {   // block-uniform
-        const int buf = kt & 1;
+        const int buf = (ST == 2) ? (kt & 1) : 0;
+        const int nxt = (ST == 2) ? (buf ^ 1) : 0;
         fetch(kt + PD, ra[s], rb[s]);   // slot s held tile kt, which already sits in LDS
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -272,11 +280,18 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
           mfma(fr[q & 1], 0, 4);
           __builtin_amdgcn_sched_barrier(0);
         }
-        stash(buf ^ 1, ra[(s + 1) % PD], rb[(s + 1) % PD]);   // (zeros after the last tile)
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(fr[(NS - 1) & 1], 0, 2);
-        __syncthreads();
-        read_frag(fr[0], buf ^ 1, 0);
+        if constexpr (ST == 2) {
+          stash(nxt, ra[(s + 1) % PD], rb[(s + 1) % PD]);   // (zeros after the last tile)
+          __builtin_amdgcn_sched_barrier(0);
+          mfma(fr[(NS - 1) & 1], 0, 2);
+          __syncthreads();
+        } else {
+          mfma(fr[(NS - 1) & 1], 0, 2);
+          __syncthreads();                                    // all fragments of tile kt are in registers
+          stash(nxt, ra[(s + 1) % PD], rb[(s + 1) % PD]);
+          __syncthreads();
+        }
+        read_frag(fr[0], nxt, 0);
         __builtin_amdgcn_sched_barrier(0);
         mfma(fr[(NS - 1) & 1], 2, 4);
         __builtin_amdgcn_sched_barrier(0);
@@ -289,7 +304,7 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
     // the loop ended with a barrier).  Layout [w4][element][lane] => conflict-free 4-byte accesses.
     static_assert(KW == 2, "intra-workgroup split-K is built for 2 wave groups");
     constexpr int NE = Cfg::TM * Cfg::TN * 16;
-    static_assert(Cfg::G * NE * 64 <= 2 * Cfg::STAGE, "accumulator exchange does not fit in the staging LDS");
+    static_assert(Cfg::G * NE * 64 <= ST * Cfg::STAGE, "accumulator exchange does not fit in the staging LDS");
     float* ex = smem + (w4 * NE) * 64 + lane;
     if (wk == 1) {
 #pragma unroll

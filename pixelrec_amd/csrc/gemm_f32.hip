@@ -20,14 +20,14 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1>
-__global__ void __launch_bounds__((GemmCfg<BM, BN, A_KC, B_KC, KW>::NT))
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1, int ST = 2, int FINE = 0>
+__global__ void __launch_bounds__((GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT))
 gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
             float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
             float* __restrict__ aux, int64_t ldaux, int tiles_m, int tiles_n, int ksplit_len,
             int64_t split_stride) {
-  using Cfg = GemmCfg<BM, BN, A_KC, B_KC, KW>;
-  __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
+  using Cfg = GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>;
+  __shared__ __attribute__((aligned(16))) float smem[ST * Cfg::STAGE];
 
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = t % tiles_m, tn = t / tiles_m;  // m fastest: blocks sharing a B panel are neighbours on one XCD
@@ -37,7 +37,7 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
   C += (int64_t)blockIdx.y * split_stride;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave % Cfg::G) >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  const int wm = (wave % Cfg::G) / Cfg::WGN, wn = (wave % Cfg::G) % Cfg::WGN, h = lane >> 5, r = lane & 31;
   // epilogue operands that are READ (residual-branch gradient / saved pre-activation) are fetched before the main
   // loop: the loads complete under the MFMAs instead of stalling every wave after its last one
   constexpr bool READS_AUX = (EPI == EPI_MUL_DGELU || EPI == EPI_ADD || EPI == EPI_MUL);
@@ -59,7 +59,7 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
   }
 
   typename Cfg::Acc accs;
-  gemm_mainloop<BM, BN, A_KC, B_KC, false, KW, PD>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
+  gemm_mainloop<BM, BN, A_KC, B_KC, false, KW, PD, ST, FINE>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
 
   auto& acc = accs.v;
   if (KW > 1 && wave >= Cfg::G) return;  // the second wave group handed its partial sums over in the main loop
@@ -194,13 +194,13 @@ __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_kernel(DwGroup g) {
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1, int ST = 2, int FINE = 0>
 static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                        int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
                        int64_t split_stride, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD>), dim3(tiles_m * tiles_n, splits),
-                     dim3(GemmCfg<BM, BN, A_KC, B_KC, KW>::NT), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD, ST, FINE>), dim3(tiles_m * tiles_n, splits),
+                     dim3(GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
                      tiles_n, ksplit_len, split_stride);
   return pxr_check_launch("pxr_gemm_f32");
 }
@@ -210,15 +210,19 @@ static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, 
                          int M, int N, int K, const float* bias, float* aux, int64_t ldaux, int splits,
                          int ksplit_len, int64_t split_stride, hipStream_t st) {
   static const int pd = getenv("PXR_GEMM_PD") ? atoi(getenv("PXR_GEMM_PD")) : 2;   // prefetch depth (tuning knob)
-#define PXR_TILE_PD(BM_, BN_, KW_, PD_)                                                                          \
-  return launch_gemm<BM_, BN_, A_KC, B_KC, EPI, KW_, PD_>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits, \
-                                                          ksplit_len, split_stride, st)
+  static const int st1 = getenv("PXR_GEMM_STAGES") ? atoi(getenv("PXR_GEMM_STAGES")) == 1 : 0;   // single LDS buffer
+#define PXR_TILE_PD(BM_, BN_, KW_, PD_)                                                                              \
+  do {                                                                                                               \
+    if (st1)                                                                                                         \
+      return launch_gemm<BM_, BN_, A_KC, B_KC, EPI, KW_, PD_, 1>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux,  \
+                                                                 splits, ksplit_len, split_stride, st);             \
+    return launch_gemm<BM_, BN_, A_KC, B_KC, EPI, KW_, PD_, 2>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux,    \
+                                                               splits, ksplit_len, split_stride, st);               \
+  } while (0)
 #define PXR_TILE(BM_, BN_, KW_)                  \
   do {                                           \
-    if (pd >= 4) PXR_TILE_PD(BM_, BN_, KW_, 4);  \
-    if (pd == 3) PXR_TILE_PD(BM_, BN_, KW_, 3);  \
-    if (pd == 2) PXR_TILE_PD(BM_, BN_, KW_, 2);  \
-    PXR_TILE_PD(BM_, BN_, KW_, 1);               \
+    if (pd == 1) PXR_TILE_PD(BM_, BN_, KW_, 1);  \
+    PXR_TILE_PD(BM_, BN_, KW_, 2);               \
   } while (0)
   switch (tile) {
     case 128: PXR_TILE_PD(128, 128, 1, 1);   // 1.7 us of MFMA work per K tile: one tile of prefetch is enough
@@ -228,6 +232,12 @@ static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, 
       PXR_TILE(64, 64, 2);
     case 3264:  // 32x64 tile, 4 waves = 1x2 wave grid x 2 k-groups: twice as many (independent) workgroups
       PXR_TILE(32, 64, 2);
+    case 1281:   // 128x128 tile cut into 16 wave tiles of 32x32 (1024 threads): half the L2 -> LDS traffic of 64x64
+      return launch_gemm<128, 128, A_KC, B_KC, EPI, 1, 2, 2, 1>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
+                                                                ksplit_len, split_stride, st);
+    case 12861:  // 128x64 tile, 8 wave tiles of 32x32 (512 threads)
+      return launch_gemm<128, 64, A_KC, B_KC, EPI, 1, 2, 2, 1>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
+                                                               ksplit_len, split_stride, st);
     default: PXR_TILE(64, 64, 1);
   }
 #undef PXR_TILE_PD
@@ -268,9 +278,9 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   bool big = (t128 >= 384);  // >= 1.5 waves of 128x128 tiles over 256 CUs; otherwise 64x64 tiles fill the chip better
   int tile = big ? 128 : 64;
-  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264) tile = tile_hint;
-  const int bm = (tile == 128 || tile == 12864) ? 128 : (tile == 3264 ? 32 : 64);
-  const int bn = (tile == 128 || tile == 64128) ? 128 : 64;
+  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861) tile = tile_hint;
+  const int bm = (tile == 128 || tile == 12864 || tile == 1281 || tile == 12861) ? 128 : (tile == 3264 ? 32 : 64);
+  const int bn = (tile == 128 || tile == 64128 || tile == 1281) ? 128 : 64;
   const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   PXR_REQUIRE(tiles < (1ll << 31), "pxr_gemm_f32: too many tiles");
 
