@@ -62,6 +62,14 @@ int64_t pxr_merge_rows_ws_bytes(int W, int64_t cap);
 int pxr_merge_sorted_rows_f32(const int64_t* idx_all, const float* rows_all, int W, int64_t cap, int D,
                               int64_t n_table, float scale, int64_t* out_idx, float* out_rows, int32_t* n_out_dev,
                               void* ws, int64_t ws_bytes, void* stream);
+/* Row-sharded table (north_star "embedding table optionally row-sharded", BASELINE configs[3]): owner of id =
+ * id % W, its row in the owner's shard = id / W + 1 (local row 0 = all-zero dummy).  local_rows[i] = that row if this
+ * rank owns ids[i] (0 < id < n_table), else 0.  pxr_ids_to_compact: out[i] = 1 + position of ids[i] in the ascending
+ * unique list (0 for padding): re-indexes a batch onto the [n_uniq+1, D] block of rows fetched from the owners. */
+int pxr_shard_local_rows_i64(const int64_t* ids, int64_t n, int W, int rank, int64_t n_table, int64_t* local_rows,
+                             void* stream);
+int pxr_ids_to_compact_i64(const int64_t* ids, int64_t n, const int64_t* uniq_idx, const int32_t* n_uniq_dev,
+                           int64_t* out, void* stream);
 /* The same for the three uses of the table inside SASRec.forward (sasrec.py:68-74,88-89) without materialising the
  * [B,2,L+1,D] gather: items[B,2,L+1]; dx0 = grad of (table row + pos) [B*L,D]; out = last-layer states [B*L,D];
  * coef[B*L] from pxr_bpr_loss_bwd_f32.  n_occ = 3*B*L for the workspace size. */

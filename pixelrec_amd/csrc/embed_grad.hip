@@ -836,3 +836,51 @@ extern "C" int pxr_merge_sorted_rows_f32(const int64_t* idx_all, const float* ro
                      (int)cap, D, scale, out_idx, out_rows, n_out_dev);
   return pxr_check_launch("pxr_merge_sorted_rows_f32");
 }
+
+// ---- row-sharded table helpers (BASELINE configs[3]; pixelrec_amd/model/sharded.py) ---------------------------------
+// Owner of item id = id % W; its row in the owner's shard = id / W + 1 (local row 0 is an all-zero dummy, so the
+// "index 0 = skip / contributes zeros" convention of the gather and AdamW-rows kernels keeps working).
+namespace pxr {
+__global__ void __launch_bounds__(256) shard_local_rows_kernel(const int64_t* __restrict__ ids, int64_t n, int W, int rank,
+                                                               int64_t n_table, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  out[i] = (id > 0 && id < n_table && id % W == rank) ? id / W + 1 : 0;
+}
+// out[i] = 1 + position of ids[i] in the ascending list uniq[0..n_uniq)  (0 for padding / absent ids)
+__global__ void __launch_bounds__(256) ids_to_compact_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                             const int64_t* __restrict__ uniq,
+                                                             const int32_t* __restrict__ n_uniq,
+                                                             int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  int lo = 0, hi = *n_uniq;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (uniq[mid] < id) lo = mid + 1; else hi = mid;
+  }
+  out[i] = (id > 0 && lo < *n_uniq && uniq[lo] == id) ? lo + 1 : 0;
+}
+}  // namespace pxr
+
+extern "C" int pxr_shard_local_rows_i64(const int64_t* ids, int64_t n, int W, int rank, int64_t n_table,
+                                        int64_t* local_rows, void* stream) {
+  PXR_REQUIRE(n >= 0 && W >= 1 && rank >= 0 && rank < W && n_table > 0, "pxr_shard_local_rows_i64: bad args");
+  if (n == 0) return PXR_OK;
+  PXR_REQUIRE(ids && local_rows, "pxr_shard_local_rows_i64: null pointer");
+  hipLaunchKernelGGL(pxr::shard_local_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     ids, n, W, rank, n_table, local_rows);
+  return pxr_check_launch("pxr_shard_local_rows_i64");
+}
+
+extern "C" int pxr_ids_to_compact_i64(const int64_t* ids, int64_t n, const int64_t* uniq_idx, const int32_t* n_uniq_dev,
+                                      int64_t* out, void* stream) {
+  PXR_REQUIRE(n >= 0, "pxr_ids_to_compact_i64: negative n");
+  if (n == 0) return PXR_OK;
+  PXR_REQUIRE(ids && uniq_idx && n_uniq_dev && out, "pxr_ids_to_compact_i64: null pointer");
+  hipLaunchKernelGGL(pxr::ids_to_compact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     ids, n, uniq_idx, n_uniq_dev, out);
+  return pxr_check_launch("pxr_ids_to_compact_i64");
+}

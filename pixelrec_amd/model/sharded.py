@@ -1,0 +1,210 @@
+"""Row-sharded item-embedding table for SASRec -- north_star "embedding table optionally row-sharded with an all-gather
+of hit rows", BASELINE.json configs[3] (emb 4096).  The reference has no such mode (it replicates the table under DDP,
+code/run.py:40); this is the build's design for catalogues whose table + moments outgrow one GPU (DESIGN.md §6 argues
+it is NOT needed for configs[3] on 288 GB parts; it exists for completeness and is exactly equivalent to the replicated
+data-parallel step -- tested bit for bit).
+
+Layout: owner(id) = id % W; the owner keeps row id at local row id // W + 1 of a [ceil(N/W) + 1, D] shard whose row 0 is
+an all-zero dummy ("index 0 = not mine / contributes zeros").  AdamW moments and the lazy `last[]` exist for the local
+rows only (PxrAdamW sizes itself from `item_embedding.weight`).  Per training step and rank:
+
+  1. occurrence sort of the batch -> this rank's ascending unique ids U_r (padded to a fixed capacity);
+  2. all-gather of the W id lists; every rank brings the requested rows IT owns up to date (lazy AdamW catch-up) and
+     gathers them into a [W, cap, D] block that is zero wherever it is not the owner;
+  3. reduce-scatter(SUM) of those blocks: rank q receives the rows of U_q -- exactly one non-zero contribution per
+     slot, so the sum is exact;  the forward / backward kernels then run on that [cap + 1, D] block with the batch
+     re-indexed onto it (`pxr_ids_to_compact_i64`): same kernels, same arithmetic as the replicated model;
+  4. the sparse gradient (global ids, rows) is exchanged and merged exactly as in the replicated mode
+     (pixelrec_amd.parallel.GradSync); each rank then keeps only the rows it owns (`pxr_shard_local_rows_i64`) and its
+     AdamW touches its shard only.
+Evaluation / checkpoints all-gather the shards into a full [N, D] table (cached until the next training step), so
+`state_dict()` keys and shapes stay the reference's.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .. import ops
+from ..parallel import PAD_ID, DataParallel, GradSync, world_info
+from .sasrec import SASRec
+
+
+class ShardedSASRec(SASRec):
+    def __init__(self, config, dataload):
+        super().__init__(config, dataload)
+        self._shard_rank, self._shard_world = 0, 1
+        self._sharded = False
+        self._full_cache = None
+        self._group = None
+        self._force_collectives = False     # tests: run the collectives even in a world of one (1-rank RCCL group)
+
+    # ------------------------------------------------------------------------------------------ (re)sharding
+    def shard(self, rank: int | None = None, world: int | None = None, group=None):
+        """Replace the full [N, D] table (identical on every rank at this point) by this rank's shard."""
+        r, w = world_info()
+        rank = r if rank is None else rank
+        world = w if world is None else world
+        full = self.item_embedding.weight.data
+        assert not self._sharded and full.shape[0] == self.item_num
+        self._install_shard(full, rank, world)
+        self._group = group
+        return self
+
+    def _install_shard(self, full, rank, world):
+        D = full.shape[1]
+        mine = full[rank::world]
+        local = torch.zeros(mine.shape[0] + 1, D, dtype=full.dtype, device=full.device)
+        local[1:] = mine
+        emb = nn.Embedding(local.shape[0], D, padding_idx=0, device=full.device)
+        emb.weight.data = local
+        self.item_embedding = emb
+        self._shard_rank, self._shard_world, self._sharded = rank, world, True
+        self._full_cache = None
+
+    def _full_table(self):
+        """All shards -> [N, D] (every rank gets the whole table; cached until the next training forward)."""
+        if not self._sharded:
+            return self.item_embedding.weight.data
+        if self._full_cache is not None:
+            return self._full_cache
+        self.sync_table()
+        local = self.item_embedding.weight.data
+        W, N, D = self._shard_world, self.item_num, local.shape[1]
+        rows_max = (N + W - 1) // W + 1
+        mine = torch.zeros(rows_max, D, dtype=local.dtype, device=local.device)
+        mine[:local.shape[0]] = local
+        if W > 1 or self._force_collectives:
+            parts = [torch.empty_like(mine) for _ in range(W)]
+            dist.all_gather(parts, mine, group=self._group)
+        else:
+            parts = [mine]
+        full = torch.empty(N, D, dtype=local.dtype, device=local.device)
+        for r in range(W):
+            cnt = (N - r + W - 1) // W
+            full[r::W] = parts[r][1:1 + cnt]
+        self._full_cache = full
+        return full
+
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        if self._sharded:
+            key = [k for k in sd if k.endswith("item_embedding.weight")][0]
+            sd[key] = self._full_table()
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        if self._sharded and "item_embedding.weight" in state_dict and state_dict["item_embedding.weight"].shape[0] == self.item_num:
+            full = state_dict["item_embedding.weight"].to(self.item_embedding.weight.device)
+            state_dict = dict(state_dict)
+            self._install_shard(full, self._shard_rank, self._shard_world)
+            state_dict["item_embedding.weight"] = self.item_embedding.weight.data
+        return super().load_state_dict(state_dict, strict=strict)
+
+    # ------------------------------------------------------------------------------------------ training step
+    def _forward_train(self, items, masked_index):
+        if not self._sharded:
+            return super()._forward_train(items, masked_index)
+        if not self.training:
+            return self._forward_core(self._full_table(), items, masked_index, False)
+        self._full_cache = None
+        B, L, D = items.shape[0], self.max_seq_length, self.hidden_size
+        W, rank = self._shard_world, self._shard_rank
+        cap = B * (2 * L + 1)
+        sp = self._local_sparse
+        if sp is None or sp.cap != cap or sp.rows.shape[1] != D or sp.rows.device != items.device:
+            sp = self._local_sparse = ops.SparseRows(cap, D, items.device)
+        need = ops.occ_ws_bytes(B, L)
+        if self._occ_ws is None or self._occ_ws.numel() < need or self._occ_ws.device != items.device:
+            self._occ_ws = torch.empty(need, dtype=torch.uint8, device=items.device)
+        ops.sasrec_occ_sort(items, self.item_num, sp, self._occ_ws)                       # 1. U_r
+        ar = torch.arange(cap, device=items.device, dtype=torch.int32)
+        ids_mine = torch.where(ar < sp.n, sp.idx, PAD_ID)
+        comm = W > 1 or self._force_collectives
+        if comm:                                                                          # 2. who needs what
+            ids_all = torch.empty(W * cap, dtype=torch.int64, device=items.device)
+            dist.all_gather(list(ids_all.chunk(W)), ids_mine, group=self._group)
+        else:
+            ids_all = ids_mine
+        loc = ops.shard_local_rows(ids_all, W, rank, self.item_num)
+        if self._table_hooks is not None:                                                 #    owned rows up to date
+            n_all = torch.full((1,), W * cap, dtype=torch.int32, device=items.device)
+            self._table_hooks.catch_up_rows(loc, n_all, W * cap)
+        serve = ops.embed_gather(self.item_embedding.weight.data, loc)                    #    zeros where not the owner
+        if comm:                                                                          # 3. rows of U_r arrive
+            if dist.get_backend(self._group) == "nccl":
+                mine = torch.empty(cap, D, dtype=torch.float32, device=items.device)
+                dist.reduce_scatter_tensor(mine, serve, op=dist.ReduceOp.SUM, group=self._group)
+            else:   # gloo (tests): no reduce-scatter -> all-reduce and keep this rank's slice
+                dist.all_reduce(serve, op=dist.ReduceOp.SUM, group=self._group)
+                mine = serve.view(W, cap, D)[rank]
+        else:
+            mine = serve
+        block = torch.zeros(cap + 1, D, dtype=torch.float32, device=items.device)
+        block[1:] = mine
+        items_c = ops.ids_to_compact(items, sp.idx, sp.n)
+        self._block = block
+        return self._forward_core(block, items_c, masked_index, True)
+
+    def _backward_train(self, grad_out):
+        if not self._sharded:
+            return super()._backward_train(grad_out)
+        self._backward_core(grad_out, self._block)
+        self._block = None
+
+    # ------------------------------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def encode_last(self, item_seq):
+        if not self._sharded:
+            return super().encode_last(item_seq)
+        self._ensure_packed()
+        item_seq = item_seq.contiguous()
+        B, L = item_seq.shape
+        out, _ = self._encode(self._full_table(), item_seq, L, B, item_seq, L, train=False)
+        return out, out[:, -1]
+
+    @torch.no_grad()
+    def compute_item_all(self):
+        return self._full_table() if self._sharded else super().compute_item_all()
+
+
+class ShardedGradSync(GradSync):
+    """GradSync + ownership filter: after the (unchanged) exchange and merge, the merged list keeps only the rows
+    this rank owns, re-indexed to its shard, so the optimizer applies them to the local table."""
+
+    def __init__(self, model, group=None):
+        super().__init__(model, group=group, force=True if (dist.is_available() and dist.is_initialized()) else False)
+        self._local_view = None
+
+    def sync(self):
+        m = self.model
+        if self.active:
+            super().sync()
+        sp = m.sparse_table_grad
+        loc = ops.shard_local_rows(sp.idx, m._shard_world, m._shard_rank, m.item_num)
+        view = self._local_view
+        if view is None or view.cap != sp.cap:
+            view = self._local_view = ops.SparseRows.__new__(ops.SparseRows)
+            view.cap = sp.cap
+        view.idx, view.rows, view.n = loc, sp.rows, sp.n
+        if not self.active:                   # single rank: slots beyond n hold stale ids -> make them skip
+            ar = torch.arange(sp.cap, device=loc.device, dtype=torch.int32)
+            view.idx = torch.where(ar < sp.n, loc, 0)
+        m.sparse_table_grad = view
+
+
+class ShardedDataParallel(DataParallel):
+    """DataParallel for a ShardedSASRec: broadcast the replicated initial state, THEN cut the table into shards."""
+
+    def __init__(self, module: ShardedSASRec, group=None, force_collectives: bool = False):
+        torch.nn.Module.__init__(self)
+        self.module = module
+        module._force_collectives = bool(force_collectives) and dist.is_available() and dist.is_initialized()
+        boot = GradSync(module, group=group)
+        boot.broadcast_parameters(0)
+        module._sparse_ready_hook = None
+        rank, world = world_info()
+        module.shard(rank, world, group)
+        self.grad_sync = ShardedGradSync(module, group=group)

@@ -385,6 +385,26 @@ def merge_sorted_rows(idx_all, rows_all, world, n_table, scale=1.0, out: SparseR
     return sp
 
 
+def shard_local_rows(ids: torch.Tensor, world: int, rank: int, n_table: int) -> torch.Tensor:
+    """Row-sharded table: local row (id // world + 1) of the ids this rank owns (id % world == rank), 0 elsewhere."""
+    Lb = _l.load()
+    _req(ids, torch.int64, "ids")
+    out = torch.empty_like(ids)
+    _l.check(Lb.pxr_shard_local_rows_i64(_l.ptr(ids), ids.numel(), world, rank, n_table, _l.ptr(out), _l.stream_ptr()),
+             "pxr_shard_local_rows_i64")
+    return out
+
+
+def ids_to_compact(ids: torch.Tensor, uniq_idx: torch.Tensor, n_uniq: torch.Tensor) -> torch.Tensor:
+    """1 + position of every id in the ascending unique list (0 for padding): indices into a fetched row block."""
+    Lb = _l.load()
+    _req(ids, torch.int64, "ids"); _req(uniq_idx, torch.int64, "uniq_idx"); _req(n_uniq, torch.int32, "n_uniq")
+    out = torch.empty_like(ids)
+    _l.check(Lb.pxr_ids_to_compact_i64(_l.ptr(ids), ids.numel(), _l.ptr(uniq_idx), _l.ptr(n_uniq), _l.ptr(out),
+                                       _l.stream_ptr()), "pxr_ids_to_compact_i64")
+    return out
+
+
 def sasrec_embed_grad(items, dx0, out, coef, n_table, scale=1.0, sp: SparseRows | None = None) -> SparseRows:
     Lb = _l.load()
     _req(items, torch.int64, "items"); _req(dx0, torch.float32, "dx0"); _req(out, torch.float32, "out")

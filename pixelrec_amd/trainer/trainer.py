@@ -93,7 +93,8 @@ class Trainer:
         # whole-step hipGraph replay for full-size batches (single rank, ID model): the host issues one graph launch
         # per step instead of ~65 kernel launches.  `use_hip_graph: False` keeps the eager sequence.
         g = config["use_hip_graph"]
-        self.use_graph = (g is None or bool(g)) and self.world == 1 and not self.use_modality
+        sharded = getattr(model.module, "_sharded", False)      # collectives inside forward: issued eagerly
+        self.use_graph = (g is None or bool(g)) and self.world == 1 and not self.use_modality and not sharded
         self._gstep = None
 
     # ---------------------------------------------------------------------------------------------- optimizer

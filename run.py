@@ -40,6 +40,14 @@ def build(local_rank, config_file=None, config_dict=None):
     init_logger(config)
     dataload = load_data(config)
     loaders = bulid_dataloader(config, dataload)
+    if str(config["table_sharding"] or "").lower() == "row":
+        # row-sharded item table (BASELINE configs[3]): owner(id) = id % world, see pixelrec_amd/model/sharded.py
+        from pixelrec_amd.model import ShardedDataParallel, ShardedSASRec
+
+        if config["model"] != "SASRec":
+            raise NotImplementedError("table_sharding: row is built for the ID model (SASRec)")
+        net = ShardedSASRec(config, dataload).to(config["device"])
+        return config, dataload, loaders, ShardedDataParallel(net)
     net = get_model(config["model"])(config, dataload).to(config["device"])
     return config, dataload, loaders, DataParallel(net)
 

@@ -84,3 +84,44 @@ def test_rccl_collectives_replay_from_hipgraph(rccl_world1):
     assert l0 == l1
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
+
+
+def test_row_sharded_table_through_rccl(rccl_world1):
+    """The sharded step's collectives (id all-gather, reduce_scatter_tensor of the served rows, shard all-gather for
+    evaluation) on the real RCCL backend with one rank: identical to the plain model."""
+    from pixelrec_amd import synth
+    from pixelrec_amd.model import SASRec, ShardedDataParallel, ShardedSASRec
+    from pixelrec_amd.optim import PxrAdamW
+    from pixelrec_amd.parallel import DataParallel
+
+    class DL:
+        item_num = N
+
+    rng = np.random.default_rng(3)
+    z = synth.ZipfItems(N, seed=1)
+    batches = [tuple(torch.from_numpy(a).cuda() for a in synth.train_batch(N, B, 10, rng, z)) for _ in range(STEPS)]
+
+    def run(sharded):
+        torch.manual_seed(7)
+        if sharded:
+            m = ShardedSASRec(CFG, DL()).cuda().train()
+            dp = ShardedDataParallel(m, force_collectives=True)
+        else:
+            m = SASRec(CFG, DL()).cuda().train()
+            dp = DataParallel(m)
+        opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1)
+        losses = []
+        for b in batches:
+            opt.zero_grad()
+            loss = dp(b)
+            loss.backward()
+            dp.sync_gradients()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+    l0, sd0 = run(False)
+    l1, sd1 = run(True)
+    assert l0 == l1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k

@@ -16,6 +16,7 @@ attn_dropout_prob: 0.1
 hidden_act: 'gelu'
 layer_norm_eps: 1e-12
 initializer_range: 0.02
+${EXTRA_MODEL_YAML:-}
 Y
 cat > $W/cfg/overall.yaml <<Y
 seed: 2020
