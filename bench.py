@@ -101,12 +101,14 @@ def main():
     ap.add_argument("--heads", type=int, default=NS["H"])
     ap.add_argument("--items", type=int, default=NS["n_items"], help="catalogue size incl. the padding id")
     ap.add_argument("--seq-len", type=int, default=NS["L"])
+    ap.add_argument("--table-sharding", action="store_true",
+                    help="row-shard the item table over the ranks (pixelrec_amd/model/sharded.py) instead of replicating it")
     ap.add_argument("--force-collectives", action="store_true",
                     help="1-GPU validation knob: create a 1-rank RCCL group and run every gradient collective anyway")
     ap.add_argument("--graph-collectives", action="store_true",
                     help="capture the RCCL collectives inside the step hipGraph too (opt-in for world > 1)")
     args = ap.parse_args()
-    custom = (args.emb, args.heads, args.items, args.seq_len) != (NS["D"], NS["H"], NS["n_items"], NS["L"])
+    custom = (args.emb, args.heads, args.items, args.seq_len) != (NS["D"], NS["H"], NS["n_items"], NS["L"]) or args.table_sharding
     NS.update(D=args.emb, H=args.heads, n_items=args.items, L=args.seq_len)   # other BASELINE configs on request
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,13 +134,16 @@ def main():
         item_num = NS["n_items"]
 
     B, L, D, N = args.batch, NS["L"], NS["D"], NS["n_items"]
+    if args.table_sharding:
+        from pixelrec_amd.model import ShardedDataParallel, ShardedSASRec as SASRec   # noqa: F811
     with torch.device(dev):
         model = SASRec(model_config(0.1), DL())  # random-init weights of the reference architecture
     model.train()
     if args.no_group:
         model.group_weight_grads = False
         model.overlap_weight_grads = not args.no_overlap
-    dp = DataParallel(model, force_collectives=args.force_collectives)
+    dp = (ShardedDataParallel(model, force_collectives=args.force_collectives) if args.table_sharding
+          else DataParallel(model, force_collectives=args.force_collectives))
     opt = PxrAdamW(model, lr=1e-4, weight_decay=0.1)
 
     # synthetic batches, rank-distinct, resident in HBM before the timed region
@@ -152,6 +157,7 @@ def main():
     gemm_events = []
     # replaying RCCL collectives from a hipGraph is opt-in: it cannot be validated on the 1-GPU development box
     use_graph = (not args.no_graph) and ((world == 1 and not args.force_collectives) or args.graph_collectives)
+    use_graph = use_graph and not args.table_sharding      # the sharded forward issues collectives: eager only
     gstep = None
     if use_graph:
         from pixelrec_amd.graph import GraphedTrainStep
@@ -241,7 +247,8 @@ def main():
                                 "BASELINE.json configs[1]: SASRec IDNet emb=512 seq_len=50, 400001 items, 4 heads, "
                                 "inner 2x, 2 layers, BPR loss vs 1 sampled negative, dropout 0.1, AdamW lr 1e-4 wd 0.1"),
                    "batch_per_gpu": B, "global_batch": world * B, "seq_len": L, "n_items": N, "embedding_size": D,
-                   "parallelism": f"dp{world}", "hip_graph": bool(use_graph)},
+                   "parallelism": f"dp{world}" + ("+row-sharded-table" if args.table_sharding else ""),
+                   "hip_graph": bool(use_graph)},
         "final_loss": final_loss, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
         "roofline": roof,
     }

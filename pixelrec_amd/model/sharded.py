@@ -125,7 +125,10 @@ class ShardedSASRec(SASRec):
         comm = W > 1 or self._force_collectives
         if comm:                                                                          # 2. who needs what
             ids_all = torch.empty(W * cap, dtype=torch.int64, device=items.device)
-            dist.all_gather(list(ids_all.chunk(W)), ids_mine, group=self._group)
+            if dist.get_backend(self._group) == "nccl":
+                dist.all_gather_into_tensor(ids_all, ids_mine, group=self._group)
+            else:   # gloo (tests)
+                dist.all_gather(list(ids_all.chunk(W)), ids_mine, group=self._group)
         else:
             ids_all = ids_mine
         loc = ops.shard_local_rows(ids_all, W, rank, self.item_num)
