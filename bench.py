@@ -284,6 +284,15 @@ def main():
             del g2, bt
 
     if not args.no_extras and world == 1 and not custom:
+        # (0b) what this box's HBM delivers on a plain device copy (quote the measured peak next to the
+        # datasheet one): 1 GiB read + 1 GiB written per launch
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        t_c = time_kernel(lambda: dst.copy_(src), iters=10)
+        out["hbm_stream_copy"] = {"achieved": 2.0 * src.numel() * 4 / t_c / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                  "frac": 2.0 * src.numel() * 4 / t_c / 1e9 / HBM_PEAK_GBS,
+                                  "note": "torch D2D copy of 1 GiB (read + write counted)"}
+        del src, dst
         # (1) embedding gather, north-star HBM target: uniform ids (worst case for caches), B=2048-equivalent rows
         n_rows = 2048 * 2 * (L + 1)
         idx = torch.randint(1, N, (n_rows,), device=dev)
