@@ -70,6 +70,11 @@ int pxr_shard_local_rows_i64(const int64_t* ids, int64_t n, int W, int rank, int
                              void* stream);
 int pxr_ids_to_compact_i64(const int64_t* ids, int64_t n, const int64_t* uniq_idx, const int32_t* n_uniq_dev,
                            int64_t* out, void* stream);
+/* ids_all[W,cap]: W ascending request lists (tail >= n_table).  Like pxr_shard_local_rows_i64, but an id requested by
+ * several ranks keeps its local row only in the lowest-ranked list: the duplicate-free work list of the owner's lazy
+ * AdamW catch-up. */
+int pxr_shard_first_rows_i64(const int64_t* ids_all, int W, int64_t cap, int rank, int64_t n_table,
+                             int64_t* local_rows, void* stream);
 /* The same for the three uses of the table inside SASRec.forward (sasrec.py:68-74,88-89) without materialising the
  * [B,2,L+1,D] gather: items[B,2,L+1]; dx0 = grad of (table row + pos) [B*L,D]; out = last-layer states [B*L,D];
  * coef[B*L] from pxr_bpr_loss_bwd_f32.  n_occ = 3*B*L for the workspace size. */

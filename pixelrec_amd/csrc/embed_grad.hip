@@ -848,6 +848,30 @@ __global__ void __launch_bounds__(256) shard_local_rows_kernel(const int64_t* __
   const int64_t id = ids[i];
   out[i] = (id > 0 && id < n_table && id % W == rank) ? id / W + 1 : 0;
 }
+// W ascending id lists of length cap (tail = ids >= n_table): like shard_local_rows, but an id requested by several
+// ranks keeps its local row only in the LOWEST-ranked list that contains it -- a duplicate-free work list for the lazy
+// AdamW catch-up (two waves replaying the same row concurrently would race on p/m/v/last).
+__global__ void __launch_bounds__(256) shard_first_rows_kernel(const int64_t* __restrict__ ids, int W, int cap, int rank,
+                                                               int64_t n_table, int64_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)W * cap) return;
+  const int64_t id = ids[t];
+  int64_t r = 0;
+  if (id > 0 && id < n_table && id % W == rank) {
+    r = id / W + 1;
+    const int q = (int)(t / cap);
+    for (int p = 0; p < q && r; ++p) {
+      const int64_t* list = ids + (int64_t)p * cap;
+      int lo = 0, hi = cap;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (list[mid] < id) lo = mid + 1; else hi = mid;
+      }
+      if (lo < cap && list[lo] == id) r = 0;
+    }
+  }
+  out[t] = r;
+}
 // out[i] = 1 + position of ids[i] in the ascending list uniq[0..n_uniq)  (0 for padding / absent ids)
 __global__ void __launch_bounds__(256) ids_to_compact_kernel(const int64_t* __restrict__ ids, int64_t n,
                                                              const int64_t* __restrict__ uniq,
@@ -883,4 +907,16 @@ extern "C" int pxr_ids_to_compact_i64(const int64_t* ids, int64_t n, const int64
   hipLaunchKernelGGL(pxr::ids_to_compact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      ids, n, uniq_idx, n_uniq_dev, out);
   return pxr_check_launch("pxr_ids_to_compact_i64");
+}
+
+extern "C" int pxr_shard_first_rows_i64(const int64_t* ids_all, int W, int64_t cap, int rank, int64_t n_table,
+                                        int64_t* local_rows, void* stream) {
+  PXR_REQUIRE(W >= 1 && rank >= 0 && rank < W && cap >= 0 && n_table > 0 && (int64_t)W * cap < (1ll << 31),
+              "pxr_shard_first_rows_i64: bad args");
+  if (cap == 0) return PXR_OK;
+  PXR_REQUIRE(ids_all && local_rows, "pxr_shard_first_rows_i64: null pointer");
+  const int64_t n = (int64_t)W * cap;
+  hipLaunchKernelGGL(pxr::shard_first_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     ids_all, W, (int)cap, rank, n_table, local_rows);
+  return pxr_check_launch("pxr_shard_first_rows_i64");
 }

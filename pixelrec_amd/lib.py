@@ -37,6 +37,7 @@ _SIGNATURES = {
     "pxr_embed_grad_rows_f32": (_I, [_P, _I64, _P, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
     "pxr_shard_local_rows_i64": (_I, [_P, _I64, _I, _I, _I64, _P, _P]),
     "pxr_ids_to_compact_i64": (_I, [_P, _I64, _P, _P, _P, _P]),
+    "pxr_shard_first_rows_i64": (_I, [_P, _I, _I64, _I, _I64, _P, _P]),
     "pxr_merge_rows_ws_bytes": (_I64, [_I, _I64]),
     "pxr_merge_sorted_rows_f32": (_I, [_P, _P, _I, _I64, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
     "pxr_sasrec_embed_grad_f32": (_I, [_P, _I, _I, _P, _P, _P, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),

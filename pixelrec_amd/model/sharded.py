@@ -133,8 +133,10 @@ class ShardedSASRec(SASRec):
             ids_all = ids_mine
         loc = ops.shard_local_rows(ids_all, W, rank, self.item_num)
         if self._table_hooks is not None:                                                 #    owned rows up to date
+            # an id requested by several ranks must be replayed by ONE wave: work list = first request only
+            first = ops.shard_first_rows(ids_all, W, rank, self.item_num) if W > 1 else loc
             n_all = torch.full((1,), W * cap, dtype=torch.int32, device=items.device)
-            self._table_hooks.catch_up_rows(loc, n_all, W * cap)
+            self._table_hooks.catch_up_rows(first, n_all, W * cap)
         serve = ops.embed_gather(self.item_embedding.weight.data, loc)                    #    zeros where not the owner
         if comm:                                                                          # 3. rows of U_r arrive
             if dist.get_backend(self._group) == "nccl":

@@ -395,6 +395,17 @@ def shard_local_rows(ids: torch.Tensor, world: int, rank: int, n_table: int) -> 
     return out
 
 
+def shard_first_rows(ids_all: torch.Tensor, world: int, rank: int, n_table: int) -> torch.Tensor:
+    """shard_local_rows over `world` ascending request lists, keeping each owned id only where it is requested FIRST
+    (lowest rank): a duplicate-free work list."""
+    Lb = _l.load()
+    _req(ids_all, torch.int64, "ids_all")
+    out = torch.empty_like(ids_all)
+    _l.check(Lb.pxr_shard_first_rows_i64(_l.ptr(ids_all), world, ids_all.numel() // world, rank, n_table, _l.ptr(out),
+                                         _l.stream_ptr()), "pxr_shard_first_rows_i64")
+    return out
+
+
 def ids_to_compact(ids: torch.Tensor, uniq_idx: torch.Tensor, n_uniq: torch.Tensor) -> torch.Tensor:
     """1 + position of every id in the ascending unique list (0 for padding): indices into a fetched row block."""
     Lb = _l.load()
