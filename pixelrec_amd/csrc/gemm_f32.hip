@@ -277,7 +277,10 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
 
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   bool big = (t128 >= 384);  // >= 1.5 waves of 128x128 tiles over 256 CUs; otherwise 64x64 tiles fill the chip better
-  int tile = big ? 128 : 64;
+  // big problems: the 128x128 tile cut into 16 wave tiles of 32x32 (1024 threads, 8 waves per SIMD at 2 workgroups
+  // per CU) beats 4 waves of 64x64 by 7-20 % (tools/big_gemm_tiles.py: scoring GEMM 120 -> 133 TFLOP/s)
+  static const int big_tile = getenv("PXR_GEMM_BIG_TILE") ? atoi(getenv("PXR_GEMM_BIG_TILE")) : 1281;
+  int tile = big ? big_tile : 64;
   if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861) tile = tile_hint;
   const int bm = (tile == 128 || tile == 12864 || tile == 1281 || tile == 12861) ? 128 : (tile == 3264 ? 32 : 64);
   const int bn = (tile == 128 || tile == 64128 || tile == 1281) ? 128 : 64;
