@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--no-group", action="store_true", help="per-layer weight-gradient GEMMs instead of one grouped launch")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
-    ap.add_argument("--clock-ramp-steps", type=int, default=250, help="extra untimed steps before the warm-up")
+    ap.add_argument("--clock-ramp-s", type=float, default=0.3, help="seconds of extra untimed steps before the warm-up")
     ap.add_argument("--emb", type=int, default=NS["D"], help="embedding size (default: the north-star 512)")
     ap.add_argument("--heads", type=int, default=NS["H"])
     ap.add_argument("--items", type=int, default=NS["n_items"], help="catalogue size incl. the padding id")
@@ -188,8 +188,14 @@ def main():
 
     # clock ramp: a cold process starts with the GPU at its idle clocks (sclk ~600 MHz); ~0.3 s of the same work before
     # the W counted warm-up steps keeps short runs from timing the governor instead of the step (untimed, like warm-up)
-    for i in range(args.clock_ramp_steps):
-        step(i)
+    t_ramp, i_ramp = time.perf_counter(), 0
+    while args.clock_ramp_s > 0:
+        for _ in range(8):
+            step(i_ramp)
+            i_ramp += 1
+        torch.cuda.synchronize()
+        if time.perf_counter() - t_ramp >= args.clock_ramp_s:
+            break
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
