@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) bpr_reduce_kernel(const float* __restrict
   red[threadIdx.x] = s;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
   if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
