@@ -281,6 +281,9 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   // per CU) beats 4 waves of 64x64 by 7-20 % (tools/big_gemm_tiles.py: scoring GEMM 120 -> 133 TFLOP/s)
   static const int big_tile = getenv("PXR_GEMM_BIG_TILE") ? atoi(getenv("PXR_GEMM_BIG_TILE")) : 1281;
   int tile = big ? big_tile : 64;
+  // 192..256 tiles of 128x128 = one 16-wave workgroup on (almost) every CU in a single round: +3..9 % over 64x64 at
+  // a dozen shapes, while 150/175/304 tiles lose 13-28 % (tools/tile_rule_check.py)
+  if (!big && t128 >= 192 && t128 <= 256) tile = 1281;
   if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861) tile = tile_hint;
   const int bm = (tile == 128 || tile == 12864 || tile == 1281 || tile == 12861) ? 128 : (tile == 3264 ? 32 : 64);
   const int bn = (tile == 128 || tile == 64128 || tile == 1281) ? 128 : 64;
