@@ -138,9 +138,10 @@ int pxr_grouped_linear_bwd_weight_f32(int n, const float* const* dy, const float
 int64_t pxr_colsum_ws_bytes(int M, int N);
 int pxr_colsum_partial_rows(int M);      /* rows of the [P, N] partial buffer left in ws when out is NULL */
 /* out_a[i][c] (c < split[i]) / out_b[i][c-split[i]] = sum_p part[i][p][c] for up to 16 partial buffers in one launch
- * (host arrays of n entries; out_b[i] may be NULL => single output). */
+ * (host arrays of n entries; out_b[i] may be NULL => single output).  bump_counter (optional): a device counter
+ * incremented by one by the same launch (the dropout step counter at the end of a backward pass). */
 int pxr_reduce_partials_multi_f32(int n, const float* const* part, const int* P, const int* N, float* const* out_a,
-                                  float* const* out_b, const int* split, void* stream);
+                                  float* const* out_b, const int* split, int64_t* bump_counter, void* stream);
 int pxr_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- masked multi-head self-attention core ------------------------------------------------------------------ */

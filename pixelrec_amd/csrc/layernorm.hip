@@ -373,6 +373,8 @@ struct MultiReduce {
   const float* part[16]; float* out_a[16]; float* out_b[16];
   int P[16], N[16], split[16], blk_begin[17];
   int n;
+  int64_t* bump;   // optional device counter incremented by one (e.g. the dropout step counter: this is the last
+                   // kernel of a backward pass that could read it, so the separate 1-thread launch is saved)
 };
 __global__ void __launch_bounds__(256) reduce_partials_multi_kernel(MultiReduce m) {
   __shared__ float red[PXR_RED_CY][PXR_RED_CX + 1];
@@ -389,16 +391,18 @@ __global__ void __launch_bounds__(256) reduce_partials_multi_kernel(MultiReduce 
     if (col < m.split[pi]) m.out_a[pi][col] = v;
     else m.out_b[pi][col - m.split[pi]] = v;
   }
+  if (m.bump && blockIdx.x == 0 && threadIdx.x == 0) m.bump[0] += 1;
 }
 
 // out_a[i][c] (c < split[i]) / out_b[i][c - split[i]] = sum_p part[i][p][c], c < N[i], for up to 16 independent
 // partial buffers in ONE launch (same fixed-order tree as the single form => same bits).
 extern "C" int pxr_reduce_partials_multi_f32(int n, const float* const* part, const int* P, const int* N,
                                              float* const* out_a, float* const* out_b, const int* split,
-                                             void* stream) {
+                                             int64_t* bump_counter, void* stream) {
   PXR_REQUIRE(n >= 1 && n <= 16 && part && P && N && out_a && out_b && split, "pxr_reduce_partials_multi_f32: bad args");
   MultiReduce m{};
   m.n = n;
+  m.bump = bump_counter;
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
     PXR_REQUIRE(part[i] && out_a[i] && P[i] > 0 && N[i] > 0, "pxr_reduce_partials_multi_f32: problem %d is bad", i);

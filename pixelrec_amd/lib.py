@@ -48,7 +48,7 @@ _SIGNATURES = {
     "pxr_ln_bwd_ws_bytes": (_I64, [_I, _I]),
     "pxr_ln_bwd_partial_rows": (_I, [_I]),
     "pxr_colsum_partial_rows": (_I, [_I]),
-    "pxr_reduce_partials_multi_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
+    "pxr_reduce_partials_multi_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pxr_ln_bwd_f32": (_I, [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64, _P]),
     "pxr_gemm_ws_bytes": (_I64, [_I, _I, _I, _I, _I]),
     "pxr_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _I64, _P, _I64, _I, _I, _P]),

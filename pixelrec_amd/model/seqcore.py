@@ -293,14 +293,17 @@ class SeqRecCore(BaseModel):
         dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,
                             step_dev=sdv, defer=defer)
         ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1), defer=defer)
-        defer.flush()
+        # every dropout-mask consumer of this pass has been issued: the reduction launch also advances the dropout
+        # step counter (saves a 1-thread launch per step)
+        bumped = defer.flush(bump=self._drop_dev)
         self._after_input_grads(dx0, coef, s)   # model-specific tail that only needs dx0/coef (table rows, exchange)
         if pending:
             ops.grouped_linear_bwd_weight(pending)
         if use_side:
             main.wait_stream(side)
         self._saved = None
-        ops.counter_add(self._drop_dev, 1)
+        if not bumped:
+            ops.counter_add(self._drop_dev, 1)
         self._step_counter += 1
         return dx0, coef, s
 

@@ -233,21 +233,26 @@ class DeferredReductions:
     def add(self, part, P, N, out_a, out_b=None, split=0):
         self.items.append((part, P, N, out_a, out_b, split))
 
-    def flush(self):
+    def flush(self, bump: torch.Tensor | None = None) -> bool:
+        """One launch (per 16 problems).  `bump`: an int64 device counter the LAST launch increments by one; returns
+        whether it did (False when there was nothing to reduce: the caller then bumps it itself)."""
         import ctypes
 
         if not self.items:
-            return
+            return False
         Lb = _l.load()
         for c0 in range(0, len(self.items), 16):
             it = self.items[c0:c0 + 16]
             n = len(it)
+            last = c0 + 16 >= len(self.items)
             Pp, I = ctypes.c_void_p * n, ctypes.c_int * n
             _l.check(Lb.pxr_reduce_partials_multi_f32(
                 n, Pp(*[x[0].data_ptr() for x in it]), I(*[x[1] for x in it]), I(*[x[2] for x in it]),
                 Pp(*[x[3].data_ptr() for x in it]), Pp(*[(x[4].data_ptr() if x[4] is not None else None) for x in it]),
-                I(*[x[5] for x in it]), _l.stream_ptr()), "pxr_reduce_partials_multi_f32")
+                I(*[x[5] for x in it]), _l.ptr(bump) if (bump is not None and last) else None, _l.stream_ptr()),
+                "pxr_reduce_partials_multi_f32")
         self.items = []
+        return bump is not None
 
 
 def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0, stream_id=0, need_dx=False,
