@@ -202,9 +202,11 @@ int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_rows, int D,
  * (double[capacity]) hold each step's scalars, appended once per step.  pxr_adamw_rows_f32 replays a row's missed
  * zero-gradient steps (bit-identical to the sweep for gaps <= 256 steps, closed-form weight decay beyond) through
  * t_prev and, if t_apply = t_prev+1, applies that step with gradient rows grows[i,:].  rows == NULL: all N rows
- * (flush before evaluation / checkpointing). */
-int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, const int64_t* step_dev,
-                           double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
+ * (flush before evaluation / checkpointing).  hyper_append with advance != 0 is the end-of-step form: it first counts
+ * the finished step (*step_dev += 1) and then appends the scalars of the next one, in one launch. */
+int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, int64_t* step_dev,
+                           double lr, double beta1, double beta2, double eps, double weight_decay, int advance,
+                           void* stream);
 int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D, const int64_t* rows,
                        const int32_t* n_rows_dev, int64_t max_rows, const float* grows, const void* hyper,
                        const void* cumlog, int64_t t_prev, int64_t t_apply, const int64_t* step_dev, double beta1,

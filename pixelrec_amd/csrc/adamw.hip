@@ -230,9 +230,12 @@ __global__ void __launch_bounds__(256) adamw_rows_kernel(RowsArgs a) {
 
 // One thread computes the scalars of optimizer step `step` in double precision (same formulas as make_hyper) and
 // appends them.  step_dev != null: step = *step_dev + 1 (device counter => valid under hipGraph replay).
+// advance != 0 (needs step_dev): FIRST count the step that just finished (*step_dev += 1), then append the entry of the
+// next one -- the end-of-step form: one launch closes step t and prepares step t+1.
 __global__ void hyper_append_kernel(float4* hyper, double* cumlog, int64_t capacity, int64_t step,
-                                    const int64_t* step_dev, double lr, double b1, double b2, double wd) {
+                                    int64_t* step_dev, double lr, double b1, double b2, double wd, int advance) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (step_dev && advance) step_dev[0] += 1;
   if (step_dev) step = step_dev[0] + 1;
   if (step < 1 || step >= capacity) return;
   if (step == 1) { hyper[0] = make_float4(1.f, 0.f, 1.f, 0.f); cumlog[0] = 0.0; }
@@ -340,14 +343,15 @@ extern "C" int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_r
 // ---- lazy (exact catch-up) table AdamW ----------------------------------------------------------------------
 // hyper: float4[capacity], cumlog: double[capacity]; appends the scalars of optimizer step `step` (1-based), or of
 // step *step_dev + 1 when a device counter is given (hipGraph-replayable).
-extern "C" int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, const int64_t* step_dev,
+extern "C" int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, int64_t* step_dev,
                                       double lr, double beta1, double beta2, double eps, double weight_decay,
-                                      void* stream) {
+                                      int advance, void* stream) {
   (void)eps;
   PXR_REQUIRE(hyper && cumlog && (step_dev || (step >= 1 && step < capacity)),
               "pxr_adamw_hyper_append: bad args (step %lld, capacity %lld)", (long long)step, (long long)capacity);
+  PXR_REQUIRE(!advance || step_dev, "pxr_adamw_hyper_append: advance needs the device step counter");
   hipLaunchKernelGGL(hyper_append_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (float4*)hyper, (double*)cumlog,
-                     capacity, step, step_dev, lr, beta1, beta2, weight_decay);
+                     capacity, step, step_dev, lr, beta1, beta2, weight_decay, advance);
   return pxr_check_launch("pxr_adamw_hyper_append");
 }
 

@@ -537,10 +537,13 @@ def adamw_table(table, m, v, slot, sp: SparseRows | None, lr, beta1, beta2, eps,
                                     weight_decay, step, _l.stream_ptr()), "pxr_adamw_table_f32")
 
 
-def adamw_hyper_append(hyper, cumlog, step, lr, beta1, beta2, eps, weight_decay, step_dev=None):
+def adamw_hyper_append(hyper, cumlog, step, lr, beta1, beta2, eps, weight_decay, step_dev=None, advance=False):
+    """Append the per-step scalars of `step` (or of *step_dev + 1).  advance=True: end-of-step form -- count the finished
+    step on the device first, then append the next step's entry (one launch)."""
     Lb = _l.load()
     _l.check(Lb.pxr_adamw_hyper_append(_l.ptr(hyper), _l.ptr(cumlog), cumlog.numel(), step, _l.ptr(step_dev), lr, beta1,
-                                       beta2, eps, weight_decay, _l.stream_ptr()), "pxr_adamw_hyper_append")
+                                       beta2, eps, weight_decay, int(bool(advance)), _l.stream_ptr()),
+             "pxr_adamw_hyper_append")
 
 
 def adamw_rows(table, m, v, last, hyper, cumlog, t_prev, t_apply, beta1, beta2, eps, rows=None, n_rows=None,

@@ -33,6 +33,7 @@ class PxrAdamW:
         self._m = self._v = self._tm = self._tv = self._slot = None
         self._last = self._hyper = self._cumlog = self._step_dev = None
         self._dirty = False          # lazy mode: some rows lag behind step_count (set by step, cleared by flush)
+        self._seeded_cfg = None      # hyper-parameters the table entry of step_count+1 was written with (None: not yet)
         self.param_groups = [{"lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}]
         self.has_table = hasattr(model, "item_embedding")
         if table_update == "lazy" and self.has_table:
@@ -48,6 +49,7 @@ class PxrAdamW:
                 self._hyper = torch.zeros(HYPER_CAPACITY, 4, dtype=torch.float32, device=dev)
                 self._cumlog = torch.zeros(HYPER_CAPACITY, dtype=torch.float64, device=dev)
                 self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=dev)
+                self._seeded_cfg = None
             return flat, None
         table = self.model.item_embedding.weight.data
         if self._tm is None or self._tm.device != dev or self._tm.shape != table.shape:
@@ -58,6 +60,7 @@ class PxrAdamW:
             self._hyper = torch.zeros(HYPER_CAPACITY, 4, dtype=torch.float32, device=dev)
             self._cumlog = torch.zeros(HYPER_CAPACITY, dtype=torch.float64, device=dev)
             self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=dev)
+            self._seeded_cfg = None
         return flat, table
 
     def zero_grad(self, set_to_none: bool = False):
@@ -92,8 +95,12 @@ class PxrAdamW:
         if self.step_count + 2 >= HYPER_CAPACITY:
             raise RuntimeError("PxrAdamW: per-step scalar table exhausted (raise optim.HYPER_CAPACITY)")
         sd = self._step_dev
-        ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 1, g["lr"], b1, b2, g["eps"],
-                               g["weight_decay"], step_dev=sd)
+        cfg = (g["lr"], b1, b2, g["eps"], g["weight_decay"])
+        if self._seeded_cfg != cfg:
+            # first step, after load_state_dict, or the hyper-parameters changed since the entry of this step was
+            # prepared (at the end of the previous step): (re)write it now
+            ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 1, *cfg, step_dev=sd)
+            self._seeded_cfg = cfg
         ops.adamw_flat_tab(flat, gflat, self._m, self._v, self._hyper, self.step_count + 1, b1, b2, g["eps"], step_dev=sd)
         sp = self.model.sparse_table_grad if self.has_table else None
         if not self.has_table:
@@ -107,7 +114,8 @@ class PxrAdamW:
                            self.step_count + 1, b1, b2, g["eps"], rows=sp.idx, n_rows=sp.n, max_rows=sp.cap,
                            grows=sp.rows, step_dev=sd)
             self._dirty = True
-        ops.counter_add(sd, 1)
+        # close the step: count it on the device and prepare the next step's scalars -- one 1-thread launch
+        ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 2, *cfg, step_dev=sd, advance=True)
         self.step_count += 1
 
     def state_dict(self):
@@ -128,6 +136,7 @@ class PxrAdamW:
         self._step_dev.fill_(self.step_count)
         self._cumlog.zero_()
         self._dirty = False
+        self._seeded_cfg = None          # the entry of step_count+1 is rewritten by the next step()
         if not self.has_table:
             return
         # a checkpoint is always flushed: every row is current through `step`; earlier per-step scalars are never
