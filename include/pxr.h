@@ -62,6 +62,12 @@ int64_t pxr_merge_rows_ws_bytes(int W, int64_t cap);
 int pxr_merge_sorted_rows_f32(const int64_t* idx_all, const float* rows_all, int W, int64_t cap, int D,
                               int64_t n_table, float scale, int64_t* out_idx, float* out_rows, int32_t* n_out_dev,
                               void* ws, int64_t ws_bytes, void* stream);
+/* On-device train-batch construction (data/dataset/trainset.py:40-63): pos int64 [B,W] left-padded windows (W = L+1)
+ * -> items [B,2,W] (positives | one negative per target position, uniform over [1, n_items-1] minus the window's own
+ * items) and masked_index [B,W-1].  Stateless: (seed, batch_counter) select the random stream. */
+int pxr_sample_negatives_i64(const int64_t* pos, int B, int W, int64_t n_items, uint64_t seed, uint64_t batch_counter,
+                             int64_t* items, int64_t* masked_index, void* stream);
+
 /* Row-sharded table (north_star "embedding table optionally row-sharded", BASELINE configs[3]): owner of id =
  * id % W, its row in the owner's shard = id / W + 1 (local row 0 = all-zero dummy).  local_rows[i] = that row if this
  * rank owns ids[i] (0 < id < n_table), else 0.  pxr_ids_to_compact: out[i] = 1 + position of ids[i] in the ascending

@@ -46,6 +46,7 @@ class _TrainLoader:
         self.batcher = batcher
         self.sampler = batcher
         self.dataset = batcher
+        self.item_num = batcher.item_num
 
     def __len__(self):
         return len(self.batcher)

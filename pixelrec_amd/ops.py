@@ -390,6 +390,20 @@ def merge_sorted_rows(idx_all, rows_all, world, n_table, scale=1.0, out: SparseR
     return sp
 
 
+def sample_negatives(pos: torch.Tensor, n_items: int, seed: int, batch_counter: int):
+    """pos int64 [B, L+1] left-padded positive windows -> (items [B,2,L+1], masked_index [B,L]) with one negative per
+    target position drawn on the device (trainset.py:40-63 semantics; stream selected by (seed, batch_counter))."""
+    Lb = _l.load()
+    _req(pos, torch.int64, "pos")
+    B, W = pos.shape
+    items = torch.empty(B, 2, W, dtype=torch.int64, device=pos.device)
+    mask = torch.empty(B, W - 1, dtype=torch.int64, device=pos.device)
+    _l.check(Lb.pxr_sample_negatives_i64(_l.ptr(pos), B, W, n_items, seed & 0xFFFFFFFFFFFFFFFF,
+                                         batch_counter & 0xFFFFFFFFFFFFFFFF, _l.ptr(items), _l.ptr(mask),
+                                         _l.stream_ptr()), "pxr_sample_negatives_i64")
+    return items, mask
+
+
 def shard_local_rows(ids: torch.Tensor, world: int, rank: int, n_table: int) -> torch.Tensor:
     """Row-sharded table: local row (id // world + 1) of the ids this rank owns (id % world == rank), 0 elsewhere."""
     Lb = _l.load()

@@ -56,6 +56,10 @@ class _Prefetcher:
                 return
             if isinstance(b, BaseException):
                 raise b
+            if isinstance(b[1], tuple):      # device sampler: (positive windows, (seed, batch counter))
+                pos = b[0].to(self.device, non_blocking=True)
+                yield ops.sample_negatives(pos, self.loader.item_num, *b[1])
+                continue
             yield tuple(x.to(self.device, non_blocking=True) for x in b)
 
 
