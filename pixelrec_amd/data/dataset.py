@@ -76,7 +76,10 @@ class SeqTrainBatcher:
         # device_sampler: yield only the positive windows ([B, L+1] int64, pinned-copy friendly); the negatives and
         # the mask are then drawn on the GPU by ops.sample_negatives (pxr_sample_negatives_i64) -- the host work per
         # batch drops from ~0.8 ms of numpy to one fancy-index gather
-        ds = config["device_sampler"]
+        try:
+            ds = config["device_sampler"]       # Config returns None for missing keys, plain dicts raise
+        except KeyError:
+            ds = None
         self.device_sampler = bool(ds) if ds is not None else False
         self._batch_counter = 0
 
