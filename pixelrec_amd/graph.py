@@ -14,8 +14,10 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, dp_model, optimizer, items, masked_index, warmup=3, clip_grad_norm=None):
+    def __init__(self, dp_model, optimizer, items, masked_index, warmup=3, clip_grad_norm=None, loss_sum=None):
         self.dp, self.opt = dp_model, optimizer
+        self.loss_sum = loss_sum          # optional 0-dim device tensor: every replay adds its loss (epoch totals
+                                          # without an eager add per step)
         self.clip = clip_grad_norm        # dict(max_norm=..., norm_type=2) as in the reference YAML, or None
         self.model = dp_model.module if hasattr(dp_model, "module") else dp_model
         self.items = items.clone()
@@ -51,7 +53,10 @@ class GraphedTrainStep:
             o.flush()
             table_state = [t.clone() for t in (m.item_embedding.weight.data, o._tm, o._tv, o._last)]
         counters = (o.step_count, m._step_counter, o._dirty, o._step_dev.clone(), m._drop_dev.clone())
+        acc = self.loss_sum.clone() if self.loss_sum is not None else None
         self._eager()
+        if acc is not None:
+            self.loss_sum.copy_(acc)
         for dst, src in zip((flat, o._m, o._v), keep):
             dst.copy_(src)
         if table_state is not None:
@@ -65,6 +70,8 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         loss = self.dp((self.items, self.mask))
         loss.backward(self._one)
+        if self.loss_sum is not None:
+            self.loss_sum.add_(loss.detach().view(()))
         if hasattr(self.dp, "sync_gradients"):
             self.dp.sync_gradients()
         if self.clip:

@@ -43,7 +43,10 @@ class _Prefetcher:
 
     def _run(self):
         try:
-            for batch in self.loader:
+            pin = self.device.type == "cuda"
+            for batch in self.loader:   # pinned staging (in this thread) makes the consumer's H2D copies asynchronous
+                if pin:
+                    batch = tuple(x.pin_memory() if isinstance(x, torch.Tensor) else x for x in batch)
                 self.q.put(batch)
         except BaseException as e:  # surfaced in the consumer
             self.q.put(e)
@@ -125,10 +128,11 @@ class Trainer:
                 if self._gstep is None and data[0].shape[0] == self.config["train_batch_size"]:
                     from ..graph import GraphedTrainStep
 
+                    self._graph_loss = torch.zeros((), dtype=torch.float32, device=self.device)
                     self._gstep = GraphedTrainStep(self.model, self.optimizer, data[0], data[1], warmup=0,
-                                                   clip_grad_norm=self.clip_grad_norm)
+                                                   clip_grad_norm=self.clip_grad_norm, loss_sum=self._graph_loss)
                 if self._gstep is not None and self._gstep.matches(data[0], data[1]):
-                    total = total + self._gstep(data[0], data[1])
+                    self._gstep(data[0], data[1])       # the replay adds its loss to self._graph_loss on the device
                     continue
             self.optimizer.zero_grad()
             if self.use_modality:   # assemble the image batch on the device from the HBM-resident store
@@ -143,6 +147,9 @@ class Trainer:
                 clip_grad_norm_(self.model, **self.clip_grad_norm)
             self.optimizer.step()
             total = total + losses.detach()
+        if self._gstep is not None:
+            total = total + self._graph_loss
+            self._graph_loss.zero_()
         total_loss = float(total.item())          # the only host sync of the epoch
         self._check_nan(total_loss)
         return total_loss
