@@ -647,6 +647,211 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   store_acc<TN>(acc, a.dk + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
 }
 
+// ---- sequences of 65..128 positions ------------------------------------------------------------------------------
+// Same algorithm as the d-chunked kernels above on 128-row tiles: 8 waves, the 128x128 score tile (4x4 blocks of 32x32,
+// two per wave) stays in LDS, the row softmax gives every lane TWO keys (lane, lane + 64), Q/K/V/dO are staged in
+// chunks of 64 head columns.  LDS: 67.6 KB (scores) + 2 x 34.8 KB (chunks) = 137 KB.
+constexpr int ATTL_MAXL = 128;
+constexpr int ATTL_SLD = ATTL_MAXL + 4;    // score / probability tile stride
+constexpr int ATTL_DC = 64;                // head columns per staged chunk
+constexpr int ATTL_KLD = ATTL_DC + 4;      // padded stride of a k-contiguous chunk tile
+constexpr int ATTL_NT = 512;
+
+// rows < L of a [L][w] global tile -> LDS with the given stride; rows L..127 zero-filled (w <= 64)
+__device__ __forceinline__ void stage_tile_long(float* tile, int tstride, const float* src, int64_t ld, int L, int w) {
+  const int q4 = w >> 2;
+  const int total = ATTL_MAXL * q4;            // <= 128 * 16 = 2048 float4 => <= 4 per thread at 512 threads
+  float4 v[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int f = threadIdx.x + p * ATTL_NT;
+    v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < total) {
+      const int row = f / q4, c = (f - row * q4) * 4;
+      if (row < L) v[p] = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int f = threadIdx.x + p * ATTL_NT;
+    if (f < total) {
+      const int row = f / q4, c = (f - row * q4) * 4;
+      *reinterpret_cast<float4*>(tile + row * tstride + c) = v[p];
+    }
+  }
+}
+
+// acc (two 32x32 blocks at rows wm*32, columns wn*64 + {0, 32}) -> score tile
+__device__ __forceinline__ void acc2_to_tile(const f32x16 (&acc)[2], float* sS, int wm, int wn, int lane) {
+  const int hh = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      sS[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ATTL_SLD + wn * 64 + j * 32 + r] = acc[j][e];
+}
+
+__global__ void __launch_bounds__(ATTL_NT) attn_fwd_long_kernel(AttnArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  __shared__ __attribute__((aligned(16))) float sA[ATTL_MAXL * ATTL_KLD];   // Q chunk (KC); later V chunk (XC, stride 64)
+  __shared__ __attribute__((aligned(16))) float sB[ATTL_MAXL * ATTL_KLD];   // K chunk (KC)
+  __shared__ __attribute__((aligned(16))) float sS[ATTL_MAXL * ATTL_SLD];   // scores -> dropped probabilities
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int L = a.L, d = a.d;
+  const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
+
+  f32x16 accS[2];
+  zero_acc<2>(accS);
+  for (int dc0 = 0; dc0 < d; dc0 += ATTL_DC) {
+    const int w = min(ATTL_DC, d - dc0);
+    stage_tile_long(sA, ATTL_KLD, a.q + base + dc0, a.ld, L, w);
+    stage_tile_long(sB, ATTL_KLD, a.k + base + dc0, a.ld, L, w);
+    __syncthreads();
+    lds_mma<true, true, 2>(accS, sA, ATTL_KLD, sB, ATTL_KLD, wm * 32, wn * 64, w, lane);
+    __syncthreads();
+  }
+  acc2_to_tile(accS, sS, wm, wn, lane);
+  __syncthreads();
+
+  const int k0 = lane, k1 = lane + 64;
+  const bool real0 = (k0 < L) && (a.keymask[(int64_t)b * a.km_bstride + k0] != 0);
+  const bool real1 = (k1 < L) && (a.keymask[(int64_t)b * a.km_bstride + k1] != 0);
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  for (int i = wave; i < L; i += ATTL_NT / 64) {
+    float s0 = sS[i * ATTL_SLD + k0] / a.sqrt_d + ((real0 && k0 <= i) ? 0.0f : -1e9f);
+    float s1 = sS[i * ATTL_SLD + k1] / a.sqrt_d + ((real1 && k1 <= i) ? 0.0f : -1e9f);
+    if (k0 >= L) s0 = -INFINITY;
+    if (k1 >= L) s1 = -INFINITY;
+    const float m = wave_max(fmaxf(s0, s1));
+    const float e0 = (k0 < L) ? expf(s0 - m) : 0.f;
+    const float e1 = (k1 < L) ? expf(s1 - m) : 0.f;
+    const float sum = wave_sum(e0 + e1);
+    const float p0 = e0 / sum, p1 = e1 / sum;
+    float pd0 = 0.f, pd1 = 0.f;
+    const int64_t rowi = (((int64_t)b * a.H + h) * L + i) * L;
+    if (k0 < L) {
+      if (a.probs) a.probs[rowi + k0] = p0;
+      pd0 = (!drop || pxr_keep(a.seed, a.stream, (uint64_t)(rowi + k0), a.drop_thr)) ? p0 * (drop ? inv_keep : 1.f) : 0.f;
+    }
+    if (k1 < L) {
+      if (a.probs) a.probs[rowi + k1] = p1;
+      pd1 = (!drop || pxr_keep(a.seed, a.stream, (uint64_t)(rowi + k1), a.drop_thr)) ? p1 * (drop ? inv_keep : 1.f) : 0.f;
+    }
+    sS[i * ATTL_SLD + k0] = pd0;   // keys >= L: exact zeros, so the padded V rows never contribute
+    sS[i * ATTL_SLD + k1] = pd1;
+  }
+  __syncthreads();
+
+  float* out = a.ctx + (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
+  for (int dc0 = 0; dc0 < d; dc0 += ATTL_DC) {
+    const int w = min(ATTL_DC, d - dc0);
+    stage_tile_long(sA, ATTL_DC, a.v + base + dc0, a.ld, L, w);
+    __syncthreads();
+    f32x16 accO[1];
+    zero_acc<1>(accO);
+    if (wn * 32 < w) lds_mma<true, false, 1>(accO, sS, ATTL_SLD, sA, ATTL_DC, wm * 32, wn * 32, ATTL_MAXL, lane);
+    store_acc<1>(accO, out + dc0, a.ld_ctx, wm * 32, wn * 32, L, w, lane);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(ATTL_NT) attn_bwd_long_kernel(AttnArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  __shared__ __attribute__((aligned(16))) float sA[ATTL_MAXL * ATTL_KLD];   // dO chunk (KC) / generic XC tile (stride 64)
+  __shared__ __attribute__((aligned(16))) float sB[ATTL_MAXL * ATTL_KLD];   // V chunk (KC)
+  __shared__ __attribute__((aligned(16))) float sS[ATTL_MAXL * ATTL_SLD];   // dPd -> Pd -> dS / sqrt(d)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int L = a.L, d = a.d;
+  const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
+  const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
+  const int64_t dbase = (int64_t)b * L * a.ld_d + (int64_t)h * d;
+
+  f32x16 accP[2];
+  zero_acc<2>(accP);
+  for (int dc0 = 0; dc0 < d; dc0 += ATTL_DC) {      // dPd[i][j] = sum_c dctx[i][c] * V[j][c]
+    const int w = min(ATTL_DC, d - dc0);
+    stage_tile_long(sA, ATTL_KLD, a.dctx + cbase + dc0, a.ld_ctx, L, w);
+    stage_tile_long(sB, ATTL_KLD, a.v + base + dc0, a.ld, L, w);
+    __syncthreads();
+    lds_mma<true, true, 2>(accP, sA, ATTL_KLD, sB, ATTL_KLD, wm * 32, wn * 64, w, lane);
+    __syncthreads();
+  }
+  acc2_to_tile(accP, sS, wm, wn, lane);
+  __syncthreads();
+
+  constexpr int NW = ATTL_NT / 64, ROWS = ATTL_MAXL / NW;   // 16 query rows per wave
+  const int k0 = lane, k1 = lane + 64;
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  float ds0[ROWS], ds1[ROWS];
+#pragma unroll
+  for (int g = 0; g < ROWS; ++g) {
+    const int i = wave + NW * g;
+    ds0[g] = ds1[g] = 0.f;
+    if (i < L) {   // wave-uniform
+      const int64_t rowi = (((int64_t)b * a.H + h) * L + i) * L;
+      float p0 = 0.f, p1 = 0.f, pd0 = 0.f, pd1 = 0.f, dp0 = 0.f, dp1 = 0.f;
+      if (k0 < L) {
+        p0 = a.probs[rowi + k0];
+        const float kf = drop ? (pxr_keep(a.seed, a.stream, (uint64_t)(rowi + k0), a.drop_thr) ? inv_keep : 0.f) : 1.f;
+        pd0 = p0 * kf;
+        dp0 = sS[i * ATTL_SLD + k0] * kf;
+      }
+      if (k1 < L) {
+        p1 = a.probs[rowi + k1];
+        const float kf = drop ? (pxr_keep(a.seed, a.stream, (uint64_t)(rowi + k1), a.drop_thr) ? inv_keep : 0.f) : 1.f;
+        pd1 = p1 * kf;
+        dp1 = sS[i * ATTL_SLD + k1] * kf;
+      }
+      const float t = wave_sum(dp0 * p0 + dp1 * p1);
+      ds0[g] = (k0 < L) ? p0 * (dp0 - t) / a.sqrt_d : 0.f;   // softmax backward, then the 1/sqrt(d) of layers.py:597
+      ds1[g] = (k1 < L) ? p1 * (dp1 - t) / a.sqrt_d : 0.f;
+      sS[i * ATTL_SLD + k0] = pd0;                             // tile now holds Pd (rows >= L stay 0: dctx rows are 0)
+      sS[i * ATTL_SLD + k1] = pd1;
+    }
+  }
+  __syncthreads();
+
+  for (int dc0 = 0; dc0 < d; dc0 += ATTL_DC) {       // dV[j][c] = sum_i Pd[i][j] * dctx[i][c]
+    const int w = min(ATTL_DC, d - dc0);
+    stage_tile_long(sA, ATTL_DC, a.dctx + cbase + dc0, a.ld_ctx, L, w);
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc<1>(acc);
+    if (wn * 32 < w) lds_mma<false, false, 1>(acc, sS, ATTL_SLD, sA, ATTL_DC, wm * 32, wn * 32, ATTL_MAXL, lane);
+    store_acc<1>(acc, a.dv + dbase + dc0, a.ld_d, wm * 32, wn * 32, L, w, lane);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int g = 0; g < ROWS; ++g) {
+    const int i = wave + NW * g;
+    if (i < L) { sS[i * ATTL_SLD + k0] = ds0[g]; sS[i * ATTL_SLD + k1] = ds1[g]; }
+  }
+  __syncthreads();
+  for (int dc0 = 0; dc0 < d; dc0 += ATTL_DC) {
+    const int w = min(ATTL_DC, d - dc0);
+    const bool mine = wn * 32 < w;
+    f32x16 acc[1];
+    stage_tile_long(sA, ATTL_DC, a.k + base + dc0, a.ld, L, w);          // dQ[i][c] = sum_j dS[i][j] * K[j][c]
+    __syncthreads();
+    zero_acc<1>(acc);
+    if (mine) lds_mma<true, false, 1>(acc, sS, ATTL_SLD, sA, ATTL_DC, wm * 32, wn * 32, ATTL_MAXL, lane);
+    store_acc<1>(acc, a.dq + dbase + dc0, a.ld_d, wm * 32, wn * 32, L, w, lane);
+    __syncthreads();
+    stage_tile_long(sA, ATTL_DC, a.q + base + dc0, a.ld, L, w);          // dK[j][c] = sum_i dS[i][j] * Q[i][c]
+    __syncthreads();
+    zero_acc<1>(acc);
+    if (mine) lds_mma<false, false, 1>(acc, sS, ATTL_SLD, sA, ATTL_DC, wm * 32, wn * 32, ATTL_MAXL, lane);
+    store_acc<1>(acc, a.dk + dbase + dc0, a.ld_d, wm * 32, wn * 32, L, w, lane);
+    __syncthreads();
+  }
+}
+
 }  // namespace pxr
 
 using namespace pxr;
@@ -680,7 +885,9 @@ static bool attn_use_mfma(int d) {
 
 static int attn_check(int B, int H, int L, int d, int64_t ld, const char* who) {
   PXR_REQUIRE(B >= 0 && H > 0 && L > 0 && d > 0, "%s: bad shape", who);
-  PXR_REQUIRE(L <= ATT_MAXL, "%s: L=%d > %d keys is not supported by the wave-wide softmax", who, L, ATT_MAXL);
+  PXR_REQUIRE(L <= ATTL_MAXL, "%s: L=%d > %d positions is not supported", who, L, ATTL_MAXL);
+  PXR_REQUIRE(L <= ATT_MAXL || (attn_use_mfma(d)), "%s: L=%d > %d needs the MFMA kernels (head size %d %% 8 == 0)", who, L,
+              ATT_MAXL, d);
   PXR_REQUIRE(d % 4 == 0 && ld % 4 == 0, "%s: d and ld must be multiples of 4", who);
   return PXR_OK;
 }
@@ -701,6 +908,10 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
+  if (L > ATT_MAXL) {   // 65..128 positions: two keys per lane, 128-row tiles
+    hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(B * H), dim3(ATTL_NT), 0, (hipStream_t)stream, a);
+    return pxr_check_launch("pxr_attn_fwd_f32(long)");
+  }
   if (attn_use_mfma(d)) {
     if (d <= ATT_DC) {
       if (attn_mfma_waves() == 8) hipLaunchKernelGGL(attn_fwd_mfma1_kernel<8>, dim3(B * H), dim3(512), 0, (hipStream_t)stream, a);
@@ -733,6 +944,10 @@ extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* 
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
+  if (L > ATT_MAXL) {
+    hipLaunchKernelGGL(attn_bwd_long_kernel, dim3(B * H), dim3(ATTL_NT), 0, (hipStream_t)stream, a);
+    return pxr_check_launch("pxr_attn_bwd_f32(long)");
+  }
   if (attn_use_mfma(d)) {
     if (d <= ATT_DC) {
       if (attn_mfma_waves() == 8) hipLaunchKernelGGL(attn_bwd_mfma1_kernel<8>, dim3(B * H), dim3(512), 0, (hipStream_t)stream, a);

@@ -169,10 +169,11 @@ def test_wide_embedding_4096_and_chunked_attention():
 
 
 @pytest.mark.parametrize("N,D,L,H,B", [(97, 96, 7, 4, 5), (300, 80, 13, 4, 3), (150, 64, 64, 1, 2), (5000, 256, 64, 8, 9),
-                                        (60, 32, 2, 2, 4), (1000, 1024, 33, 16, 2), (211, 192, 50, 3, 7)])
+                                        (60, 32, 2, 2, 4), (1000, 1024, 33, 16, 2), (211, 192, 50, 3, 7),
+                                        (300, 64, 100, 2, 3), (500, 512, 128, 4, 2), (200, 96, 65, 3, 2), (400, 256, 127, 1, 2)])
 def test_unusual_shapes_match_oracle(N, D, L, H, B):
-    """Head sizes that are not powers of two (24, 20), one head, the longest supported sequence (64), two positions,
-    16 heads: loss, every gradient, predict scores and one AdamW step against the oracle."""
+    """Head sizes that are not powers of two (24, 20), one head, the longest single-wave sequence (64), the two-keys-per-lane kernels
+    (65..128 positions), two positions, 16 heads: loss, every gradient, predict scores and one AdamW step against the oracle."""
     from pixelrec_amd.optim import PxrAdamW
 
     params = O.synth_params(N, D, L, 2, 2, seed=N + D, perturb=True)
@@ -205,3 +206,25 @@ def test_unusual_shapes_match_oracle(N, D, L, H, B):
         solid = g[k].abs() > 1e-6          # Adam's sign(g) is rounding noise where |g| ~ 0 (moves such entries by +-lr)
         assert d[solid].max().item() < 2e-5 if solid.any() else True, k
         assert d.max().item() <= 2.1e-3, k
+
+
+@pytest.mark.parametrize("N,D,L,H,B", [(300, 64, 100, 2, 3), (500, 256, 128, 4, 2)])
+def test_long_sequence_dropout_parity(N, D, L, H, B):
+    """65..128 positions with dropout ON: the long attention kernels regenerate the same counter-hash masks in forward
+    and backward; the masks, restated in numpy, are injected into the oracle."""
+    from oracle import dropout_rng as R
+
+    params = O.synth_params(N, D, L, 2, 2, seed=L, perturb=True)
+    m = _model(N, D, L, H, params, p=0.1)
+    m.train()
+    items, mask = _batch(N, B, L, 9)
+    seed = (m._drop_seed * 1000003 + m._step_counter) & 0xFFFFFFFFFFFFFFFF
+    loss = m((items.cuda(), mask.cuda()))
+    loss.backward()
+    drop = R.sasrec_masks(seed, B, L, D, H, 2, 0.1, 0.1)
+    cfg = {"n_layers": 2, "n_heads": H, "layer_norm_eps": 1e-12, "hidden_dropout_prob": 0.1, "attn_dropout_prob": 0.1}
+    ref_loss, g = O.loss_and_grads(params, items, mask, cfg, drop)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 3e-5 * max(1.0, abs(float(ref_loss)))
+    for k, v in m.named_parameters():
+        got = m.sparse_table_grad.to_dense(N).cpu() if k == "item_embedding.weight" else v.grad.detach().cpu()
+        assert (got - g[k]).abs().max().item() <= 5e-6 + 3e-4 * g[k].abs().max().item(), k
