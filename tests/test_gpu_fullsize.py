@@ -131,8 +131,10 @@ def test_edge_cases_all_padding_and_min_length():
     assert torch.isfinite(loss) and abs(float(loss.detach()) - float(ref)) < 3e-5 * max(1.0, abs(float(ref)))
     dense = m.sparse_table_grad.to_dense(N).cpu()
     assert (dense - gr["item_embedding.weight"]).abs().max().item() < 5e-6 + 2e-4 * gr["item_embedding.weight"].abs().max().item()
-    with pytest.raises(Exception):
-        _model(N, D, 65, H)((torch.zeros(1, 2, 66, dtype=torch.int64).cuda(), torch.zeros(1, 65, dtype=torch.int64).cuda()))
+    with pytest.raises(Exception):      # beyond the 128-position kernels: a loud error, no fallback
+        _model(N, D, 129, H)((torch.zeros(1, 2, 130, dtype=torch.int64).cuda(), torch.zeros(1, 129, dtype=torch.int64).cuda()))
+    with pytest.raises(Exception):      # 65..128 positions need a head size that is a multiple of 8 (here 20)
+        _model(N, 40, 70, 2)((torch.zeros(1, 2, 71, dtype=torch.int64).cuda(), torch.zeros(1, 70, dtype=torch.int64).cuda()))
 
 
 def test_wide_embedding_4096_and_chunked_attention():
