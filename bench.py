@@ -80,9 +80,17 @@ def cpu_baseline(batch, budget_s=20.0):
         tr.step(items, mask)
         steps += 1
     dt = time.perf_counter() - t0
+    # the reference launcher pins OMP_NUM_THREADS=1 (main.py:5): one step at one thread, for the record
+    torch.set_num_threads(1)
+    t1 = time.perf_counter()
+    tr.step(items, mask)
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(cores)
     return {"value": batch * steps / dt, "unit": "sequences/s", "cores": cores, "kind": "port",
             "sample": f"{steps} full training steps (fwd+bwd+dense AdamW, dropout off) of B={batch} at the same "
-                      f"N=400001/D=512/L=50 config, torch {torch.__version__} CPU fp32, {dt / max(steps, 1):.2f} s/step"}
+                      f"N=400001/D=512/L=50 config, torch {torch.__version__} CPU fp32, {dt / max(steps, 1):.2f} s/step",
+            "one_thread": {"value": batch / dt1, "unit": "sequences/s", "cores": 1,
+                           "sample": f"1 step, {dt1:.2f} s (the reference's own launcher setting, OMP_NUM_THREADS=1)"}}
 
 
 def main():
