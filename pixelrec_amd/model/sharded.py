@@ -53,24 +53,16 @@ class ShardedSASRec(SASRec):
         return self
 
     def _install_shard(self, full, rank, world):
-        D = full.shape[1]
-        mine = full[rank::world]
-        local = torch.zeros(mine.shape[0] + 1, D, dtype=full.dtype, device=full.device)
-        local[1:] = mine
-        emb = nn.Embedding(local.shape[0], D, padding_idx=0, device=full.device)
+        self._shard_rank, self._shard_world, self._sharded = rank, world, True
+        local = self.scatter_rows(full)
+        emb = nn.Embedding(local.shape[0], full.shape[1], padding_idx=0, device=full.device)
         emb.weight.data = local
         self.item_embedding = emb
-        self._shard_rank, self._shard_world, self._sharded = rank, world, True
         self._full_cache = None
 
-    def _full_table(self):
-        """All shards -> [N, D] (every rank gets the whole table; cached until the next training forward)."""
-        if not self._sharded:
-            return self.item_embedding.weight.data
-        if self._full_cache is not None:
-            return self._full_cache
-        self.sync_table()
-        local = self.item_embedding.weight.data
+    def gather_rows(self, local: torch.Tensor) -> torch.Tensor:
+        """[n_local + 1, D] per-rank rows (table, AdamW moments, ...) -> the full [N, D] tensor on every rank.
+        Collective: every rank must call it."""
         W, N, D = self._shard_world, self.item_num, local.shape[1]
         rows_max = (N + W - 1) // W + 1
         mine = torch.zeros(rows_max, D, dtype=local.dtype, device=local.device)
@@ -84,8 +76,23 @@ class ShardedSASRec(SASRec):
         for r in range(W):
             cnt = (N - r + W - 1) // W
             full[r::W] = parts[r][1:1 + cnt]
-        self._full_cache = full
         return full
+
+    def scatter_rows(self, full: torch.Tensor) -> torch.Tensor:
+        """The inverse of gather_rows for this rank: [N, D] -> [n_local + 1, D] (row 0 = the all-zero dummy)."""
+        mine = full[self._shard_rank::self._shard_world]
+        local = torch.zeros(mine.shape[0] + 1, full.shape[1], dtype=full.dtype, device=full.device)
+        local[1:] = mine
+        return local
+
+    def _full_table(self):
+        """All shards -> [N, D] (every rank gets the whole table; cached until the next training forward)."""
+        if not self._sharded:
+            return self.item_embedding.weight.data
+        if self._full_cache is None:
+            self.sync_table()
+            self._full_cache = self.gather_rows(self.item_embedding.weight.data)
+        return self._full_cache
 
     # ------------------------------------------------------------------------------------------ checkpoints
     def state_dict(self, *args, **kwargs):
@@ -213,3 +220,22 @@ class ShardedDataParallel(DataParallel):
         rank, world = world_info()
         module.shard(rank, world, group)
         self.grad_sync = ShardedGradSync(module, group=group)
+
+
+def optimizer_state_full(opt, model: ShardedSASRec) -> dict:
+    """PxrAdamW.state_dict() with the per-rank table moments gathered to the reference-shaped [N, D] (collective)."""
+    sd = dict(opt.state_dict())
+    for k in ("table_m", "table_v"):
+        if k in sd:
+            sd[k] = model.gather_rows(sd[k])
+    return sd
+
+
+def load_optimizer_state_full(opt, model: ShardedSASRec, sd: dict):
+    """Inverse of optimizer_state_full: keeps this rank's rows of the full moments."""
+    sd = dict(sd)
+    dev = model.item_embedding.weight.device
+    for k in ("table_m", "table_v"):
+        if k in sd and sd[k].shape[0] == model.item_num:
+            sd[k] = model.scatter_rows(sd[k].to(dev))
+    opt.load_state_dict(sd)

@@ -169,16 +169,34 @@ class Trainer:
         if self.world > 1:
             torch.distributed.barrier()
 
+    def _checkpoint_tensors(self):
+        """(model state_dict, optimizer state) on the host.  A row-sharded model gathers its table and the table
+        moments with collectives, so EVERY rank must get here; otherwise only rank 0 does the work."""
+        m = self.model.module
+        sharded = getattr(m, "_sharded", False)
+        if not sharded and self.rank != 0:
+            return None, None
+        model_sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        if sharded:
+            from ..model.sharded import optimizer_state_full
+
+            rec = self.optimizer.opts[-1] if isinstance(self.optimizer, OptimizerGroup) else self.optimizer
+            opt_sd = optimizer_state_full(rec, m)
+        else:
+            opt_sd = self.optimizer.state_dict()
+        opt_sd = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in opt_sd.items()}
+        return model_sd, opt_sd
+
     def _save_checkpoint(self, epoch, verbose=True):
+        model_sd, opt_sd = self._checkpoint_tensors()
         if self.rank == 0:
             state = {
                 "config": dict(self.config.final_config_dict) if hasattr(self.config, "final_config_dict") else self.config,
                 "epoch": epoch,
                 "cur_step": self.cur_step,
                 "best_valid_score": self.best_valid_score,
-                "state_dict": {k: v.detach().cpu() for k, v in self.model.module.state_dict().items()},
-                "optimizer": {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v)
-                              for k, v in self.optimizer.state_dict().items()},
+                "state_dict": model_sd,
+                "optimizer": opt_sd,
                 # this path's dropout "RNG state" (the reference stores torch's generator states for the same purpose)
                 "dropout_step": self.model.module.dropout_step() if hasattr(self.model.module, "dropout_step") else 0,
                 "rng_state": torch.get_rng_state(),
@@ -199,7 +217,12 @@ class Trainer:
         self.best_valid_score = checkpoint["best_valid_score"]
         if str(checkpoint["config"]["model"]).lower() != str(self.config["model"]).lower():
             self.logger.warning("Architecture configuration given in config file is different from that of checkpoint.")
-        self.optimizer.load_state_dict(checkpoint["optimizer"])
+        if getattr(self.model.module, "_sharded", False):
+            from ..model.sharded import load_optimizer_state_full
+
+            load_optimizer_state_full(self.optimizer, self.model.module, checkpoint["optimizer"])
+        else:
+            self.optimizer.load_state_dict(checkpoint["optimizer"])
         if hasattr(self.model.module, "set_dropout_step"):
             self.model.module.set_dropout_step(checkpoint.get("dropout_step", 0))
         self._gstep = None          # a captured step graph belongs to the pre-resume state

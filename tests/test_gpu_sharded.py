@@ -84,6 +84,37 @@ def _worker(rank, port, mode, results):
 
         batches = _batches(2 * STEPS)[rank::2]                     # rank-distinct batches, same on both modes
         torch.manual_seed(4 + rank)                                # different inits: the broadcast must fix that
+        if mode == "sharded_resume":
+            # STEPS-1 steps -> full-shape checkpoint (collective gathers) -> fresh sharded model/optimizer -> last step
+            from pixelrec_amd.model.sharded import load_optimizer_state_full, optimizer_state_full
+            from pixelrec_amd.optim import PxrAdamW
+
+            def one(dp, m, opt, b):
+                opt.zero_grad()
+                loss = dp((torch.from_numpy(b[0]).cuda(), torch.from_numpy(b[1]).cuda()))
+                loss.backward()
+                dp.sync_gradients()
+                opt.step()
+                return float(loss.detach())
+
+            m = ShardedSASRec(CFG, DL()).cuda().train()
+            dp = ShardedDataParallel(m)
+            opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1)
+            losses = [one(dp, m, opt, b) for b in batches[:-1]]
+            ck_model = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+            ck_opt = {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in optimizer_state_full(opt, m).items()}
+            assert ck_model["item_embedding.weight"].shape[0] == N and ck_opt["table_m"].shape[0] == N
+            ck_drop = m.dropout_step()
+            torch.manual_seed(99)
+            m2 = ShardedSASRec(CFG, DL()).cuda().train()
+            dp2 = ShardedDataParallel(m2)
+            m2.load_state_dict(ck_model, strict=True)
+            opt2 = PxrAdamW(m2, lr=1e-3, weight_decay=0.1)
+            load_optimizer_state_full(opt2, m2, ck_opt)
+            m2.set_dropout_step(ck_drop)
+            losses.append(one(dp2, m2, opt2, batches[-1]))
+            results[(mode, rank)] = (losses, {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
+            return
         if mode == "sharded":
             m = ShardedSASRec(CFG, DL()).cuda().train()
             dp = ShardedDataParallel(m)
@@ -100,7 +131,7 @@ def _worker(rank, port, mode, results):
 def test_two_rank_sharded_equals_replicated():
     out = {}
     with mp.Manager() as mgr:
-        for mode in ("replicated", "sharded"):
+        for mode in ("replicated", "sharded", "sharded_resume"):
             results = mgr.dict()
             mp.spawn(_worker, args=(_free_port(), mode, results), nprocs=2, join=True)
             out.update(dict(results))
@@ -110,5 +141,9 @@ def test_two_rank_sharded_equals_replicated():
         assert l_rep == l_sh
         for k in sd_rep:
             assert torch.equal(sd_rep[k], sd_sh[k]), (rank, k)
+        l_res, sd_res = out[("sharded_resume", rank)]                  # checkpoint round trip in the middle: same bits
+        assert l_res == l_rep
+        for k in sd_rep:
+            assert torch.equal(sd_rep[k], sd_res[k]), (rank, k)
     for k in out[("sharded", 0)][1]:                               # and both ranks agree on the gathered state
         assert torch.equal(out[("sharded", 0)][1][k], out[("sharded", 1)][1][k]), k
