@@ -2,14 +2,19 @@
 // (batch, head).  Replaces layers.py:590-612 (scores = QK^T / sqrt(d) + mask; softmax; dropout; PV; head merge)
 // together with the mask construction of sasrec.py:119-126, and their autograd.
 //
-// Shapes are tiny (L <= 64 keys, d = D/H per head): the work is latency/LDS-bound, not MFMA-shaped
-// (0.33 GFLOP per layer at B=64).  Design:
+// Shapes are tiny (L <= 128 keys, d = D/H per head): the work is latency/LDS-bound (0.33 GFLOP per layer at B=64,
+// SURVEY.md §8 a6).  Kernel families in this file, picked by pxr_attn_{fwd,bwd}_f32:
+//   attn_{fwd,bwd}_mfma1_kernel<NW>  L <= 64, d <= 128: every operand staged once, back-to-back MFMA phases (default, 8 waves)
+//   attn_{fwd,bwd}_mfma_kernel      L <= 64, any d % 8 == 0: d-chunked (emb 4096: d = 1024)
+//   attn_{fwd,bwd}_long_kernel      65 <= L <= 128, d % 8 == 0: 128-row tiles, two keys per lane
+//   attn_{fwd,bwd}_kernel<NW>       L <= 64, d % 4 == 0: VALU fallback (PXR_ATTN_MFMA=0 or d % 8 != 0)
+// Common design:
 //   * q/k/v are read in place from the fused QKV projection output [B, L, 3D] (row stride `ld`), the context
 //     is written head-merged into [B, L, D]: no permute/contiguous copies (layers.py:590-592,610-612);
 //   * Q/K (then V) tiles are staged through LDS in d-chunks of <= 128 columns, so any head size works
 //     (d = 32 for emb 128, 128 for emb 512, 1024 for emb 4096) with a fixed LDS footprint;
-//   * NW (default 8) waves per workgroup; a wave owns query rows {w, w+NW, ...}; lane j owns key j: one score per lane, so the row softmax is a pair
-//     of 64-lane shuffle reductions -- no LDS round trip;
+//   * a wave owns query rows {w, w+NW, ...}; lane j owns key j (and j + 64 in the long kernels): the row softmax is a
+//     pair of wave reductions on the DPP path (pxr_common.h) -- no LDS round trip;
 //   * mask semantics are the reference's ADDITIVE -1e9 in fp32 (not -inf): score + (-1e9) == -1e9 exactly, a
 //     fully masked (left-padded) query row therefore becomes a uniform 1/L distribution over ALL L keys
 //     (SURVEY.md §7 hard part 4) -- reproduced by doing the same arithmetic;

@@ -18,4 +18,4 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record()
 for _ in range(200): f()
 e.record(); torch.cuda.synchronize()
-print("npass", os.environ.get("PXR_DBG_NPASS"), "small", os.environ.get("PXR_SMALL_SORT"), f"{s.elapsed_time(e) / 200 * 1e3:.1f} us/call")
+print("fused sort:", os.environ.get("PXR_FUSED_SORT", "1"), f"{s.elapsed_time(e) / 200 * 1e3:.1f} us/call")
