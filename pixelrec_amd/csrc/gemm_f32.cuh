@@ -42,7 +42,8 @@ struct GemmCfg {
   // FINE = 1: every wave owns ONE 32x32 block of the tile (a 128x128 tile = 16 waves).  The 64x64 kernels turned out
   // to be bound by L2 -> LDS traffic (16 flop per byte staged: ~6 TB/s at 94 TFLOP/s), not by occupancy; a big tile
   // cut into many small wave tiles halves that traffic while keeping the same number of waves in flight.
-  static constexpr int WGM = FINE ? BM / 32 : ((BM >= 64) ? 2 : 1);
+  // FINE = 2: 64x32 per wave (a 128x128 tile = 8 waves, 2 x 4): half the accumulator registers of the 64x64 wave tile.
+  static constexpr int WGM = FINE == 1 ? BM / 32 : (FINE == 2 ? BM / 64 : ((BM >= 64) ? 2 : 1));
   static constexpr int WGN = FINE ? BN / 32 : 2;
   static constexpr int G = WGM * WGN;
   static constexpr int NT = 64 * G * KW;

@@ -235,6 +235,9 @@ static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, 
     case 1281:   // 128x128 tile cut into 16 wave tiles of 32x32 (1024 threads): half the L2 -> LDS traffic of 64x64
       return launch_gemm<128, 128, A_KC, B_KC, EPI, 1, 2, 2, 1>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
                                                                 ksplit_len, split_stride, st);
+    case 1282:   // 128x128 tile, 8 wave tiles of 64x32 (512 threads)
+      return launch_gemm<128, 128, A_KC, B_KC, EPI, 1, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
+                                                                ksplit_len, split_stride, st);
     case 12861:  // 128x64 tile, 8 wave tiles of 32x32 (512 threads)
       return launch_gemm<128, 64, A_KC, B_KC, EPI, 1, 2, 2, 1>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
                                                                ksplit_len, split_stride, st);
@@ -284,9 +287,9 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   // 192..256 tiles of 128x128 = one 16-wave workgroup on (almost) every CU in a single round: +3..9 % over 64x64 at
   // a dozen shapes, while 150/175/304 tiles lose 13-28 % (tools/tile_rule_check.py)
   if (!big && t128 >= 192 && t128 <= 256) tile = 1281;
-  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861) tile = tile_hint;
-  const int bm = (tile == 128 || tile == 12864 || tile == 1281 || tile == 12861) ? 128 : (tile == 3264 ? 32 : 64);
-  const int bn = (tile == 128 || tile == 64128 || tile == 1281) ? 128 : 64;
+  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861 || tile_hint == 1282) tile = tile_hint;
+  const int bm = (tile == 128 || tile == 12864 || tile == 1281 || tile == 12861 || tile == 1282) ? 128 : (tile == 3264 ? 32 : 64);
+  const int bn = (tile == 128 || tile == 64128 || tile == 1281 || tile == 1282) ? 128 : 64;
   const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   PXR_REQUIRE(tiles < (1ll << 31), "pxr_gemm_f32: too many tiles");
 

@@ -5,7 +5,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TILES = [0, 64, 128, 12864, 64128, 642, 3264, 1281, 12861]
+TILES = [0, 64, 128, 12864, 64128, 642, 3264, 1281, 12861, 1282]
 
 
 def _check(got, ref, K):
