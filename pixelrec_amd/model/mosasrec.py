@@ -14,7 +14,6 @@ no sort, no sparse rows.  Autograd then continues into the visual encoder (torch
 from __future__ import annotations
 
 import torch
-import torch.nn as nn
 
 from .. import ops
 from ..utils.enum_type import InputType

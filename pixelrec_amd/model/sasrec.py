@@ -17,7 +17,6 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..lib import PxrError
 from ..utils.enum_type import InputType
 from .seqcore import SeqRecCore
 

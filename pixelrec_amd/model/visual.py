@@ -15,11 +15,9 @@ What runs where (round 1): the PATCH PROJECTION (conv 3->7
 """
 from __future__ import annotations
 
-import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 
