@@ -179,7 +179,7 @@ def main():
         opt.zero_grad()
         loss = dp(pool[i % len(pool)])
         loss.backward()
-        dp.sync_gradients()
+        dp.sync_gradients(defer_flat=True)
         opt.step()
         return loss
 
@@ -189,7 +189,7 @@ def main():
         opt.zero_grad()
         loss = dp(pool[i % len(pool)])
         loss.backward()
-        dp.sync_gradients()
+        dp.sync_gradients(defer_flat=True)
         opt.step()
         ops.GEMM_TIMING = None
         return loss
@@ -286,7 +286,7 @@ def main():
                     return g2(*bt[i % 4])
                 opt.zero_grad()
                 dp(bt[i % 4]).backward()
-                dp.sync_gradients()
+                dp.sync_gradients(defer_flat=True)
                 opt.step()
 
             for i in range(3):

@@ -73,7 +73,7 @@ class GraphedTrainStep:
         if self.loss_sum is not None:
             self.loss_sum.add_(loss.detach().view(()))
         if hasattr(self.dp, "sync_gradients"):
-            self.dp.sync_gradients()
+            self.dp.sync_gradients(defer_flat=True)
         if self.clip:
             from .optim import clip_grad_norm_
 

@@ -173,6 +173,15 @@ class SeqRecCore(BaseModel):
         self._ensure_packed()
         return self._flat, self._gflat
 
+    _flat_grad_waits = ()   # handles of an in-flight all-reduce of the flat gradient (parallel.GradSync, defer_flat)
+
+    def wait_flat_grads(self):
+        """Make the current stream wait for a deferred all-reduce of the flat gradient buffer (no-op otherwise).
+        Every consumer of the reduced flat gradient calls this first: PxrAdamW.step, clip_grad_norm_."""
+        waits, self._flat_grad_waits = self._flat_grad_waits, ()
+        for h in waits:
+            h.wait()
+
     def _after_input_grads(self, dx0, coef, saved):
         """Hook: runs inside the backward right after the gradient w.r.t. the gathered rows is known and BEFORE the
         grouped weight-gradient GEMM (so whatever it launches -- e.g. a data-parallel row exchange -- overlaps it)."""

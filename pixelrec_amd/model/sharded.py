@@ -190,10 +190,10 @@ class ShardedGradSync(GradSync):
         super().__init__(model, group=group, force=True if (dist.is_available() and dist.is_initialized()) else False)
         self._local_view = None
 
-    def sync(self):
+    def sync(self, defer_flat: bool = False):
         m = self.model
         if self.active:
-            super().sync()
+            super().sync(defer_flat=defer_flat)
         sp = m.sparse_table_grad
         loc = ops.shard_local_rows(sp.idx, m._shard_world, m._shard_rank, m.item_num)
         view = self._local_view

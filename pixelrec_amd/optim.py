@@ -101,7 +101,9 @@ class PxrAdamW:
             # prepared (at the end of the previous step): (re)write it now
             ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 1, *cfg, step_dev=sd)
             self._seeded_cfg = cfg
-        ops.adamw_flat_tab(flat, gflat, self._m, self._v, self._hyper, self.step_count + 1, b1, b2, g["eps"], step_dev=sd)
+        # table rows first, flat buffer last: the two updates are independent, and under data parallelism the flat
+        # gradient's all-reduce may still be in flight (GradSync.sync(defer_flat=True)) -- it then runs under the
+        # row update instead of in front of it
         sp = self.model.sparse_table_grad if self.has_table else None
         if not self.has_table:
             pass
@@ -114,6 +116,10 @@ class PxrAdamW:
                            self.step_count + 1, b1, b2, g["eps"], rows=sp.idx, n_rows=sp.n, max_rows=sp.cap,
                            grows=sp.rows, step_dev=sd)
             self._dirty = True
+        wait = getattr(self.model, "wait_flat_grads", None)
+        if wait is not None:
+            wait()
+        ops.adamw_flat_tab(flat, gflat, self._m, self._v, self._hyper, self.step_count + 1, b1, b2, g["eps"], step_dev=sd)
         # close the step: count it on the device and prepare the next step's scalars -- one 1-thread launch
         ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 2, *cfg, step_dev=sd, advance=True)
         self.step_count += 1
@@ -155,6 +161,8 @@ def clip_grad_norm_(model, max_norm, norm_type=2.0, **_ignored):
     if float(norm_type) != 2.0:
         raise NotImplementedError("clip_grad_norm_: only the 2-norm is built (torch's default)")
     model = model.module if hasattr(model, "module") else model
+    if hasattr(model, "wait_flat_grads"):
+        model.wait_flat_grads()
     _, gflat = model.flat_parameters()
     sq = gflat.pow(2).sum()
     sp = getattr(model, "sparse_table_grad", None) if hasattr(model, "item_embedding") else None

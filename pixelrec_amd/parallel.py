@@ -100,13 +100,17 @@ class GradSync:
         enc = getattr(self.model, "visual_encoder", None)
         return list(enc.parameters()) if enc is not None else []
 
-    def sync(self):
+    def sync(self, defer_flat: bool = False):
         """Order matters for overlap: the flat all-reduce is only ENQUEUED (async, on RCCL's stream) and runs under
-        the merge of the gathered sparse rows (radix sort + segmented sum); the compute stream waits for it last."""
+        the merge of the gathered sparse rows; the compute stream waits for it last.  With `defer_flat` that wait is
+        left to the consumer of the flat gradient (`model.wait_flat_grads()`, called by PxrAdamW.step between the
+        table-row update and the flat update, and by clip_grad_norm_), so the all-reduce also hides the row update
+        -- W times one rank's rows, the part of the step that grows with the world size."""
         if not self.active:
             return
         _, gflat = self.model.flat_parameters()
-        waits = [dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        flat_wait = dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        waits = []
         for p in self._extra_params():      # trainable tail of the visual encoder (frozen parameters have no grads)
             if p.grad is not None:
                 waits.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -129,6 +133,11 @@ class GradSync:
         for h in waits:
             if h is not None:
                 h.wait()
+        if flat_wait is not None:
+            if defer_flat and hasattr(self.model, "wait_flat_grads"):
+                self.model._flat_grad_waits = (flat_wait,)
+            else:
+                flat_wait.wait()
 
 
 class DataParallel(torch.nn.Module):
@@ -143,5 +152,5 @@ class DataParallel(torch.nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
-    def sync_gradients(self):
-        self.grad_sync.sync()
+    def sync_gradients(self, defer_flat: bool = False):
+        self.grad_sync.sync(defer_flat=defer_flat)

@@ -142,7 +142,7 @@ class Trainer:
             losses = self.model(data)
             losses.backward()
             if hasattr(self.model, "sync_gradients"):
-                self.model.sync_gradients()
+                self.model.sync_gradients(defer_flat=True)    # the consumers below wait for it
             if self.clip_grad_norm:                                   # trainer.py:123-124
                 clip_grad_norm_(self.model, **self.clip_grad_norm)
             self.optimizer.step()

@@ -24,10 +24,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(force, graphed=False):
+def _run(force, graphed=False, defer=False, clip=None):
     from pixelrec_amd import synth
     from pixelrec_amd.model import SASRec
-    from pixelrec_amd.optim import PxrAdamW
+    from pixelrec_amd.optim import PxrAdamW, clip_grad_norm_
     from pixelrec_amd.parallel import DataParallel
 
     class DL:
@@ -53,8 +53,12 @@ def _run(force, graphed=False):
             opt.zero_grad()
             loss = dp(b)
             loss.backward()
-            dp.sync_gradients()
+            dp.sync_gradients(defer_flat=defer)
+            assert bool(model._flat_grad_waits) == (defer and force)
+            if clip:
+                clip_grad_norm_(dp, max_norm=clip)
             opt.step()
+            assert not model._flat_grad_waits
             losses.append(float(loss.detach()))
     opt.flush()
     torch.cuda.synchronize()
@@ -73,6 +77,17 @@ def rccl_world1():
 def test_forced_rccl_collectives_are_identity(rccl_world1):
     l0, sd0 = _run(force=False)
     l1, sd1 = _run(force=True)
+    assert l0 == l1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+
+
+@pytest.mark.parametrize("clip", [None, 0.05])
+def test_deferred_flat_allreduce_wait(rccl_world1, clip):
+    """sync_gradients(defer_flat=True): the flat all-reduce is waited for by its consumer (PxrAdamW.step after the
+    table-row update, or clip_grad_norm_) instead of by sync -- same result, bit for bit."""
+    l0, sd0 = _run(force=False, clip=clip)
+    l1, sd1 = _run(force=True, defer=True, clip=clip)
     assert l0 == l1
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k

@@ -56,6 +56,16 @@ class _FakeModel:
         return self.flat, self.gflat
 
 
+class _DeferringModel(_FakeModel):
+    """Adds the consumer-side wait of SeqRecCore (model/seqcore.py wait_flat_grads)."""
+    _flat_grad_waits = ()
+
+    def wait_flat_grads(self):
+        waits, self._flat_grad_waits = self._flat_grad_waits, ()
+        for h in waits:
+            h.wait()
+
+
 def _cpu_merge(idx_all, rows_all, n_table):
     dense = torch.zeros(n_table, rows_all.shape[1])
     idx_all = torch.where(idx_all < n_table, idx_all, 0)       # tail slots carry parallel.PAD_ID
@@ -87,6 +97,14 @@ def _worker(rank, port, results):
             _, idx, rows = _rank_data(r)
             exp_dense.index_add_(0, idx, rows)
         assert torch.allclose(m.sparse_table_grad, exp_dense, atol=1e-6)
+        # deferred flat wait: sync leaves the all-reduce handle with the model; the consumer completes it
+        m2 = _DeferringModel(rank)
+        gs2 = GradSync(m2, merge_fn=_cpu_merge)
+        gs2.sync(defer_flat=True)
+        assert len(m2._flat_grad_waits) == 1
+        assert torch.allclose(m2.sparse_table_grad, exp_dense, atol=1e-6)   # the row exchange is complete already
+        m2.wait_flat_grads()
+        assert m2._flat_grad_waits == () and torch.allclose(m2.gflat, exp_flat)
         # eval sharding: rank r takes users r, r+W, ... with no padding (reference data/utils.py:153-156)
         smp = NonConsecutiveSequentialDistributedSampler(list(range(11)))
         assert list(smp) == list(range(rank, 11, WORLD)) and len(smp) == len(list(smp))
