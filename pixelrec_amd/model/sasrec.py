@@ -66,6 +66,12 @@ class SASRec(SeqRecCore):
         self.sync_table()
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        # updates a lazy optimizer still owes belong to the rows being REPLACED: apply them first, so that none is left
+        # to land on the loaded weights (the reference's dense AdamW has applied them by the time it loads)
+        self.sync_table()
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
+
     def _forward_train(self, items, masked_index):
         B = items.shape[0]
         L = self.max_seq_length

@@ -134,6 +134,7 @@ class PxrAdamW:
 
     def load_state_dict(self, sd):
         self._ensure_state()
+        self.flush()                     # updates still owed under the OLD state are applied with the old state
         self.step_count = int(sd["step"])
         self.param_groups = sd["param_groups"]
         pairs = [(self._m, "m"), (self._v, "v")] + ([(self._tm, "table_m"), (self._tv, "table_v")] if self.has_table else [])

@@ -188,3 +188,35 @@ def test_checkpoint_round_trip_resumes_bit_identically():
     got = m2.state_dict()
     for k in ref:
         assert torch.equal(ref[k], got[k]), k
+
+
+def test_load_state_dict_while_rows_lag():
+    """Loading weights while the lazy optimizer still owes updates (no flush since the last steps): the owed updates
+    belong to the REPLACED rows -- the loaded table must come back from state_dict() untouched, and training on from it
+    must equal the dense-sweep optimizer doing the same thing."""
+    make, rng, zipf, synth = _setup(n_items=1500)
+    batches = [tuple(torch.from_numpy(x).cuda() for x in synth.train_batch(1500, 4, 10, rng, zipf)) for _ in range(12)]
+
+    def scenario(mode):
+        from pixelrec_amd.optim import PxrAdamW
+
+        m = make()
+        opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1, table_update=mode)
+        start = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        for it, mk in batches[:6]:
+            m((it, mk)).backward()
+            opt.step()
+        if mode == "lazy":
+            assert opt._dirty                                     # rows lag behind the step counter right now
+        m.load_state_dict(start, strict=True)                     # e.g. evaluate(load_best_model=True) mid-run
+        after_load = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        for k in start:
+            assert torch.equal(start[k], after_load[k]), (mode, k)
+        for it, mk in batches[6:]:
+            m((it, mk)).backward()
+            opt.step()
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    dense, lazy = scenario("dense"), scenario("lazy")
+    for k in dense:
+        assert torch.equal(dense[k], lazy[k]), k
