@@ -102,13 +102,14 @@ class ShardedSASRec(SASRec):
             sd[key] = self._full_table()
         return sd
 
-    def load_state_dict(self, state_dict, strict=True):
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        self.sync_table()       # owed lazy updates land on the shard being replaced, not on the loaded one
         if self._sharded and "item_embedding.weight" in state_dict and state_dict["item_embedding.weight"].shape[0] == self.item_num:
             full = state_dict["item_embedding.weight"].to(self.item_embedding.weight.device)
             state_dict = dict(state_dict)
             self._install_shard(full, self._shard_rank, self._shard_world)
             state_dict["item_embedding.weight"] = self.item_embedding.weight.data
-        return super().load_state_dict(state_dict, strict=strict)
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
 
     # ------------------------------------------------------------------------------------------ training step
     def _forward_train(self, items, masked_index):
