@@ -8,8 +8,9 @@ kernel (pxr_image_u8_to_f32: gather + /255 + Normalize(0.5,0.5) + HWC->CHW; id 0
 
 Backends for filling the store (indexed by INTERNAL item id, row 0 = padding):
   * `<path>.npy`  uint8 [n, H, W, 3] + `<path>.tokens.txt` (one item token per line, same order)   -- native format;
-  * LMDB in the reference's format (needs the `lmdb` module, absent in this image) -- key = ascii item token, value =
-    pickle of an object with `.image` bytes, `.size`, `.channels` (generate_lmdb.py / data/utils.py:192-201);
+  * LMDB in the reference's format -- key = ascii item token, value = pickle of an object with `.image` bytes,
+    `.size`, `.channels` (generate_lmdb.py / data/utils.py:192-201); read through the `lmdb` module when it is
+    installed, otherwise through the build's own read-only parser (data/lmdb_read.py);
   * `synthetic:<H>`  deterministic pseudo-random images (benchmarks / tests; no dataset is available offline).
 """
 from __future__ import annotations
@@ -67,18 +68,29 @@ class ImageStore:
             return ImageStore(out.to(device))
         try:
             import lmdb
-        except ImportError as e:
-            raise RuntimeError(f"image_path {path!r} looks like an LMDB but the `lmdb` module is not installed; "
-                               "convert it to <name>.npy + <name>.tokens.txt") from e
-        env = lmdb.open(path, subdir=os.path.isdir(path), readonly=True, lock=False, readahead=False, meminit=False)
+        except ImportError:
+            lmdb = None
+        if lmdb is not None:
+            env = lmdb.open(path, subdir=os.path.isdir(path), readonly=True, lock=False, readahead=False, meminit=False)
+            txn = env.begin()
+            fetch = txn.get
+        else:   # no liblmdb binding: the build's own read-only parser of the same file
+            from .lmdb_read import LmdbFile
+
+            fetch = LmdbFile(path).get
         out = None
-        with env.begin() as txn:
-            for iid in range(1, dataload.item_num):
-                obj = _Unpickler(io.BytesIO(txn.get(str(id2token[iid]).encode("ascii")))).load()
-                img = obj.get_image()[..., :3]
-                if out is None:
-                    out = torch.zeros(dataload.item_num, *img.shape, dtype=torch.uint8)
-                out[iid] = torch.from_numpy(np.ascontiguousarray(img))
+        for iid in range(1, dataload.item_num):
+            token = str(id2token[iid])
+            blob = fetch(token.encode("ascii"))
+            if blob is None:
+                raise KeyError(f"image_path {path!r}: no image stored for item {token!r}")
+            obj = _Unpickler(io.BytesIO(bytes(blob))).load()
+            img = obj.get_image()[..., :3]
+            if out is None:
+                out = torch.zeros(dataload.item_num, *img.shape, dtype=torch.uint8)
+            out[iid] = torch.from_numpy(np.array(img))      # copy: the pickled bytes are read-only
+        if out is None:
+            raise ValueError(f"image_path {path!r}: the catalogue has no items")
         return ImageStore(out.to(device))
 
     def batch(self, ids: torch.Tensor) -> torch.Tensor:
