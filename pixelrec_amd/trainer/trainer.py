@@ -123,6 +123,7 @@ class Trainer:
     def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
         self.model.train()
         total = torch.zeros((), dtype=torch.float32, device=self.device)
+        self._one = torch.ones((), dtype=torch.float32, device=self.device)
         for data in _Prefetcher(train_data, self.device):
             if self.use_graph:
                 if self._gstep is None and data[0].shape[0] == self.config["train_batch_size"]:
@@ -140,7 +141,7 @@ class Trainer:
 
                 data = (self._image_store(train_data).batch(interleave_pos_neg(data[0])), data[1])
             losses = self.model(data)
-            losses.backward()
+            losses.backward(self._one)     # preallocated unit gradient: no ones_like fill per step
             if hasattr(self.model, "sync_gradients"):
                 self.model.sync_gradients(defer_flat=True)    # the consumers below wait for it
             if self.clip_grad_norm:                                   # trainer.py:123-124
