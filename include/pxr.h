@@ -62,6 +62,16 @@ int64_t pxr_merge_rows_ws_bytes(int W, int64_t cap);
 int pxr_merge_sorted_rows_f32(const int64_t* idx_all, const float* rows_all, int W, int64_t cap, int D,
                               int64_t n_table, float scale, int64_t* out_idx, float* out_rows, int32_t* n_out_dev,
                               void* ws, int64_t ws_bytes, void* stream);
+/* The same merge on the layout a ONE-collective exchange delivers: packed_all = W blocks of pxr_packed_rows_bytes(cap, D)
+ * bytes, block = { int64 ids[cap] ascending over the first `count` entries; int32 count; zero padding to a 16-byte
+ * boundary (rows start at pxr_packed_rows_offset(cap)); float rows[cap][D] }.  Entries at or beyond a block's count
+ * are ignored whatever they hold, so a rank sends its sort/segment output as it is (no PAD fill, no second
+ * all-gather for the ids).  Same output convention, same summation order as pxr_merge_sorted_rows_f32. */
+int64_t pxr_packed_rows_offset(int64_t cap);
+int64_t pxr_packed_rows_bytes(int64_t cap, int D);
+int pxr_merge_packed_rows_f32(const void* packed_all, int W, int64_t cap, int D, int64_t n_table, float scale,
+                              int64_t* out_idx, float* out_rows, int32_t* n_out_dev, void* ws, int64_t ws_bytes,
+                              void* stream);
 /* On-device train-batch construction (data/dataset/trainset.py:40-63): pos int64 [B,W] left-padded windows (W = L+1)
  * -> items [B,2,W] (positives | one negative per target position, uniform over [1, n_items-1] minus the window's own
  * items) and masked_index [B,W-1].  Stateless: (seed, batch_counter) select the random stream. */

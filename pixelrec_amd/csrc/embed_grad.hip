@@ -617,26 +617,49 @@ static int sort_and_segment(SortWs& w, int n, int64_t n_table, int64_t* uniq_idx
 // order -- a fixed order that is the same on every replica, so replicas stay bit-identical.  The output is NOT
 // compacted: slot e = (rank, i) carries (id, summed row) if that rank owns the id, else id 0 (= padding_idx, which
 // every consumer skips); *n_out = W * cap.
-__global__ void __launch_bounds__(256) merge_locate_kernel(const int64_t* __restrict__ idx_all, int W, int cap,
-                                                           int64_t n_table, int* __restrict__ pos) {
+// Where the W lists live.  Two layouts share the kernels: separate contiguous arrays idx_all [W, cap] / rows_all
+// [W, cap, D] whose tails are PAD-terminated (counts == nullptr), and W packed blocks {ids[cap], int32 count, pad to
+// 16 bytes, rows[cap][D]} as one all-gather delivers them (counts != nullptr: entries at or beyond a list's count are
+// ignored, whatever they hold).
+struct MergeSrc {
+  const char* ids;    int64_t ids_stride;      // byte stride between consecutive ranks' lists
+  const char* rows;   int64_t rows_stride;
+  const char* counts; int64_t counts_stride;   // int32 per rank, or nullptr
+};
+__device__ __forceinline__ const int64_t* merge_ids(const MergeSrc& s, int q) {
+  return reinterpret_cast<const int64_t*>(s.ids + (int64_t)q * s.ids_stride);
+}
+__device__ __forceinline__ const float* merge_rows(const MergeSrc& s, int q) {
+  return reinterpret_cast<const float*>(s.rows + (int64_t)q * s.rows_stride);
+}
+__device__ __forceinline__ int merge_count(const MergeSrc& s, int q, int cap) {
+  if (!s.counts) return cap;
+  const int n = *reinterpret_cast<const int*>(s.counts + (int64_t)q * s.counts_stride);
+  return n < 0 ? 0 : (n > cap ? cap : n);
+}
+
+__global__ void __launch_bounds__(256) merge_locate_kernel(MergeSrc s, int W, int cap, int64_t n_table,
+                                                           int* __restrict__ pos) {
   const int64_t total = (int64_t)W * cap * W;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int64_t e = t / W;
     const int q = (int)(t - e * W);
     const int r = (int)(e / cap);
-    const int64_t key = idx_all[e];
+    const int i = (int)(e - (int64_t)r * cap);
+    const int64_t key = i < merge_count(s, r, cap) ? merge_ids(s, r)[i] : 0;
     int p = -1;
     if (key > 0 && key < n_table) {
       if (q == r) {
-        p = (int)(e - (int64_t)r * cap);
+        p = i;
       } else {
-        const int64_t* list = idx_all + (int64_t)q * cap;
-        int lo = 0, hi = cap;
+        const int64_t* list = merge_ids(s, q);
+        const int nq = merge_count(s, q, cap);
+        int lo = 0, hi = nq;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
           if (list[mid] < key) lo = mid + 1; else hi = mid;
         }
-        if (lo < cap && list[lo] == key) p = lo;
+        if (lo < nq && list[lo] == key) p = lo;
       }
     }
     pos[t] = p;
@@ -644,11 +667,9 @@ __global__ void __launch_bounds__(256) merge_locate_kernel(const int64_t* __rest
 }
 
 // one wave per output slot
-__global__ void __launch_bounds__(256) merge_sum_kernel(const int64_t* __restrict__ idx_all,
-                                                        const float* __restrict__ rows_all,
-                                                        const int* __restrict__ pos, int W, int cap, int D, float scale,
-                                                        int64_t* __restrict__ out_idx, float* __restrict__ out_rows,
-                                                        int32_t* __restrict__ n_out) {
+__global__ void __launch_bounds__(256) merge_sum_kernel(MergeSrc s, const int* __restrict__ pos, int W, int cap, int D,
+                                                        float scale, int64_t* __restrict__ out_idx,
+                                                        float* __restrict__ out_rows, int32_t* __restrict__ n_out) {
   const int lane = threadIdx.x & 63;
   const int64_t E = (int64_t)W * cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = (int32_t)E;
@@ -669,13 +690,13 @@ __global__ void __launch_bounds__(256) merge_sum_kernel(const int64_t* __restric
         const int q = __ffsll((long long)m) - 1;
         m &= m - 1;
         const int pq = __shfl(p, q, 64);
-        const float4 v = *reinterpret_cast<const float4*>(rows_all + ((int64_t)q * cap + pq) * D + c * 4);
+        const float4 v = *reinterpret_cast<const float4*>(merge_rows(s, q) + (int64_t)pq * D + c * 4);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
       acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
       *reinterpret_cast<float4*>(out_rows + e * D + c * 4) = acc;
     }
-    if (lane == 0) out_idx[e] = idx_all[e];
+    if (lane == 0) out_idx[e] = merge_ids(s, r)[e - (int64_t)r * cap];
   }
 }
 
@@ -819,6 +840,17 @@ extern "C" int64_t pxr_merge_rows_ws_bytes(int W, int64_t cap) {
   return align256((int64_t)W * cap * W * 4);
 }
 
+static int launch_merge(const MergeSrc& src, int W, int64_t cap, int D, int64_t n_table, float scale, int64_t* out_idx,
+                        float* out_rows, int32_t* n_out_dev, void* ws, hipStream_t st, const char* what) {
+  const int64_t total = (int64_t)W * cap * W, E = (int64_t)W * cap;
+  int64_t b1 = (total + 255) / 256; if (b1 > 8192) b1 = 8192;
+  hipLaunchKernelGGL(merge_locate_kernel, dim3((unsigned)b1), dim3(256), 0, st, src, W, (int)cap, n_table, (int*)ws);
+  int64_t b2 = (E + 3) / 4; if (b2 > 8192) b2 = 8192;
+  hipLaunchKernelGGL(merge_sum_kernel, dim3((unsigned)b2), dim3(256), 0, st, src, (const int*)ws, W, (int)cap, D, scale,
+                     out_idx, out_rows, n_out_dev);
+  return pxr_check_launch(what);
+}
+
 // See merge_locate_kernel: merges W sorted-unique sparse gradients without re-sorting.
 extern "C" int pxr_merge_sorted_rows_f32(const int64_t* idx_all, const float* rows_all, int W, int64_t cap, int D,
                                          int64_t n_table, float scale, int64_t* out_idx, float* out_rows,
@@ -827,14 +859,33 @@ extern "C" int pxr_merge_sorted_rows_f32(const int64_t* idx_all, const float* ro
   PXR_REQUIRE(W >= 1 && W <= 64 && cap > 0 && (int64_t)W * cap * W < (1ll << 31) && D > 0 && D % 4 == 0 &&
               n_table > 0, "pxr_merge_sorted_rows_f32: bad shape");
   if (pxr_merge_rows_ws_bytes(W, cap) > ws_bytes) { pxr_set_error("pxr_merge_sorted_rows_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t total = (int64_t)W * cap * W, E = (int64_t)W * cap;
-  int64_t b1 = (total + 255) / 256; if (b1 > 8192) b1 = 8192;
-  hipLaunchKernelGGL(merge_locate_kernel, dim3((unsigned)b1), dim3(256), 0, st, idx_all, W, (int)cap, n_table, (int*)ws);
-  int64_t b2 = (E + 3) / 4; if (b2 > 8192) b2 = 8192;
-  hipLaunchKernelGGL(merge_sum_kernel, dim3((unsigned)b2), dim3(256), 0, st, idx_all, rows_all, (const int*)ws, W,
-                     (int)cap, D, scale, out_idx, out_rows, n_out_dev);
-  return pxr_check_launch("pxr_merge_sorted_rows_f32");
+  MergeSrc src{};
+  src.ids = (const char*)idx_all;   src.ids_stride = cap * 8;
+  src.rows = (const char*)rows_all; src.rows_stride = cap * (int64_t)D * 4;
+  return launch_merge(src, W, cap, D, n_table, scale, out_idx, out_rows, n_out_dev, ws, (hipStream_t)stream,
+                      "pxr_merge_sorted_rows_f32");
+}
+
+// The packed block one rank contributes to a ONE-collective exchange: {int64 ids[cap]; int32 count; zero padding up to a
+// 16-byte boundary; float rows[cap][D]}.
+extern "C" int64_t pxr_packed_rows_offset(int64_t cap) { return ((cap + 1) * 8 + 15) & ~(int64_t)15; }
+extern "C" int64_t pxr_packed_rows_bytes(int64_t cap, int D) { return pxr_packed_rows_offset(cap) + cap * (int64_t)D * 4; }
+
+extern "C" int pxr_merge_packed_rows_f32(const void* packed_all, int W, int64_t cap, int D, int64_t n_table, float scale,
+                                         int64_t* out_idx, float* out_rows, int32_t* n_out_dev, void* ws,
+                                         int64_t ws_bytes, void* stream) {
+  PXR_REQUIRE(packed_all && out_idx && out_rows && n_out_dev && ws, "pxr_merge_packed_rows_f32: null pointer");
+  PXR_REQUIRE(W >= 1 && W <= 64 && cap > 0 && (int64_t)W * cap * W < (1ll << 31) && D > 0 && D % 4 == 0 &&
+              n_table > 0, "pxr_merge_packed_rows_f32: bad shape");
+  PXR_REQUIRE(((uintptr_t)packed_all & 15) == 0, "pxr_merge_packed_rows_f32: packed_all must be 16-byte aligned");
+  if (pxr_merge_rows_ws_bytes(W, cap) > ws_bytes) { pxr_set_error("pxr_merge_packed_rows_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
+  const int64_t block = pxr_packed_rows_bytes(cap, D);
+  MergeSrc src{};
+  src.ids = (const char*)packed_all;                                   src.ids_stride = block;
+  src.rows = (const char*)packed_all + pxr_packed_rows_offset(cap);    src.rows_stride = block;
+  src.counts = (const char*)packed_all + cap * 8;                      src.counts_stride = block;
+  return launch_merge(src, W, cap, D, n_table, scale, out_idx, out_rows, n_out_dev, ws, (hipStream_t)stream,
+                      "pxr_merge_packed_rows_f32");
 }
 
 // ---- row-sharded table helpers (BASELINE configs[3]; pixelrec_amd/model/sharded.py) ---------------------------------

@@ -41,6 +41,9 @@ _SIGNATURES = {
     "pxr_shard_first_rows_i64": (_I, [_P, _I, _I64, _I, _I64, _P, _P]),
     "pxr_merge_rows_ws_bytes": (_I64, [_I, _I64]),
     "pxr_merge_sorted_rows_f32": (_I, [_P, _P, _I, _I64, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
+    "pxr_packed_rows_offset": (_I64, [_I64]),
+    "pxr_packed_rows_bytes": (_I64, [_I64, _I]),
+    "pxr_merge_packed_rows_f32": (_I, [_P, _I, _I64, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
     "pxr_sasrec_embed_grad_f32": (_I, [_P, _I, _I, _P, _P, _P, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
     "pxr_sasrec_occ_sort": (_I, [_P, _I, _I, _I64, _P, _P, _P, _I64, _P]),
     "pxr_sasrec_occ_segsum": (_I, [_P, _I64, _I, _I, _P, _P, _P, _I, _I64, _F, _P, _P, _P]),

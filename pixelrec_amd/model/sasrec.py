@@ -84,7 +84,7 @@ class SASRec(SeqRecCore):
             cap = B * (2 * L + 1)
             sp = self._local_sparse
             if sp is None or sp.cap != cap or sp.rows.shape[1] != D or sp.rows.device != items.device:
-                sp = self._local_sparse = ops.SparseRows(cap, D, items.device)
+                sp = self._local_sparse = ops.SparseRows(cap, D, items.device, packed=True)
             need = ops.occ_ws_bytes(B, L)
             if self._occ_ws is None or self._occ_ws.numel() < need or self._occ_ws.device != items.device:
                 self._occ_ws = torch.empty(need, dtype=torch.uint8, device=items.device)

@@ -343,11 +343,23 @@ def bpr_loss_bwd(pos, neg, table, items, masked_index, D, grad_scale=1.0, grad_s
 class SparseRows:
     """(uniq_idx [cap] int64 ascending, rows [cap, D], n [1] int32 on device): the table gradient of one step."""
 
-    def __init__(self, cap: int, D: int, device):
+    def __init__(self, cap: int, D: int, device, packed: bool = False):
+        self.cap = cap
+        self.packed = None
+        if packed:
+            # idx | n | rows are views of ONE buffer laid out as pxr.h's packed block, so a data-parallel exchange
+            # sends it with a single all-gather (parallel.GradSync) and pxr_merge_packed_rows_f32 reads it as it is
+            Lb = _l.load()
+            off = int(Lb.pxr_packed_rows_offset(cap))
+            buf = torch.zeros(int(Lb.pxr_packed_rows_bytes(cap, D)), dtype=torch.uint8, device=device)
+            self.idx = buf[:cap * 8].view(torch.int64)
+            self.n = buf[cap * 8:cap * 8 + 4].view(torch.int32)
+            self.rows = buf[off:].view(torch.float32).view(cap, D)
+            self.packed = buf
+            return
         self.idx = torch.zeros(cap, dtype=torch.int64, device=device)
         self.rows = torch.empty(cap, D, dtype=torch.float32, device=device)
         self.n = torch.zeros(1, dtype=torch.int32, device=device)
-        self.cap = cap
 
     def count(self) -> int:  # host sync; tests / logging only
         return int(self.n.item())
@@ -387,6 +399,22 @@ def merge_sorted_rows(idx_all, rows_all, world, n_table, scale=1.0, out: SparseR
     _l.check(Lb.pxr_merge_sorted_rows_f32(_l.ptr(idx_all), _l.ptr(rows_all), world, cap, D, n_table, float(scale),
                                           _l.ptr(sp.idx), _l.ptr(sp.rows), _l.ptr(sp.n), _l.ptr(ws), ws_bytes,
                                           _l.stream_ptr()), "pxr_merge_sorted_rows_f32")
+    return sp
+
+
+def merge_packed_rows(packed_all, world, cap, D, n_table, scale=1.0, out: SparseRows | None = None) -> SparseRows:
+    """merge_sorted_rows on `world` packed blocks (SparseRows(packed=True).packed of every rank, concatenated by one
+    all-gather): counts travel inside the blocks, so the lists need no PAD tail (see pxr.h)."""
+    Lb = _l.load()
+    _req(packed_all, torch.uint8, "packed_all")
+    if packed_all.numel() != world * int(Lb.pxr_packed_rows_bytes(cap, D)):
+        raise ValueError("merge_packed_rows: packed_all has the wrong size for (world, cap, D)")
+    sp = out if out is not None else SparseRows(world * cap, D, packed_all.device)
+    ws_bytes = int(Lb.pxr_merge_rows_ws_bytes(world, cap))
+    ws = _ws.get(ws_bytes, packed_all.device)
+    _l.check(Lb.pxr_merge_packed_rows_f32(_l.ptr(packed_all), world, cap, D, n_table, float(scale), _l.ptr(sp.idx),
+                                          _l.ptr(sp.rows), _l.ptr(sp.n), _l.ptr(ws), ws_bytes, _l.stream_ptr()),
+             "pxr_merge_packed_rows_f32")
     return sp
 
 

@@ -5,10 +5,11 @@ The reference all-reduces the DENSE 836 MB gradient every step (SURVEY.md §2.2 
 embedding gradient.  Here:
   * the 4.2 M transformer / position / LayerNorm gradients live in ONE flat buffer -> one all-reduce (SUM; every
     rank pre-scales its loss gradient by 1/world so the sum IS DDP's mean);
-  * the table gradient stays sparse: each rank contributes its (uniq_idx, uniq_rows) padded to a fixed capacity
-    (padding ids are 0 = padding_idx, which the merge drops) -> one all-gather of ids + one of rows -> every
-    rank merges the W (already sorted, unique) lists with the same rank-ordered merge kernel -- no second sort --
-    so replicas stay bit-identical.
+  * the table gradient stays sparse: each rank contributes its (uniq_idx, count, uniq_rows) at a fixed capacity as ONE
+    packed block (ops.SparseRows(packed=True)) -> one all-gather -> every rank merges the W (already sorted, unique)
+    lists with the same rank-ordered merge kernel -- no second sort -- so replicas stay bit-identical.  (An injected
+    merge function, or a gradient that is not packed, takes the two-collective form: PAD-terminated id lists + rows,
+    `gather_sparse`.)
 No host synchronisation: counts stay on the device, shapes are static.
 
 `DataParallel` mirrors the only DDP surface the reference's Trainer uses: `.module`, `__call__`, `.train()`,
@@ -74,6 +75,7 @@ class GradSync:
         self._merge = merge_fn
         self._merged = None
         self._pending = None
+        self._packed_all = self._packed_key = None   # persistent receive buffer of the one-collective exchange
         if self.active:
             model.grad_scale = 1.0 / self.world
             # start the row exchange as soon as the sparse rows exist, i.e. BEFORE the grouped weight-gradient GEMM of
@@ -82,7 +84,20 @@ class GradSync:
 
     def start_sparse_exchange(self):
         sp = self.model.sparse_table_grad
-        self._pending = gather_sparse(sp.idx, sp.rows, sp.n, self.group, async_op=True)
+        if self._merge is None and getattr(sp, "packed", None) is not None:
+            # one collective: ids, count and rows of a rank are one packed block (ops.SparseRows(packed=True)); the
+            # merge kernel reads the counts from the blocks, so no PAD fill and no separate id all-gather
+            key = (sp.packed.numel(), str(sp.packed.device))
+            if self._packed_all is None or self._packed_key != key:
+                self._packed_all = torch.empty(self.world * sp.packed.numel(), dtype=torch.uint8, device=sp.packed.device)
+                self._packed_key = key
+            if dist.get_backend(self.group) == "nccl":
+                h = dist.all_gather_into_tensor(self._packed_all, sp.packed, group=self.group, async_op=True)
+            else:   # gloo (tests): same result through the list form
+                h = dist.all_gather(list(self._packed_all.chunk(self.world)), sp.packed, group=self.group, async_op=True)
+            self._pending = ("packed", self._packed_all, [h] if h is not None else [], sp)
+            return
+        self._pending = ("lists",) + gather_sparse(sp.idx, sp.rows, sp.n, self.group, async_op=True)
 
     def broadcast_parameters(self, src: int = 0):
         """DDP's construction-time broadcast: make every replica start from rank `src`."""
@@ -117,19 +132,31 @@ class GradSync:
         if hasattr(self.model, "item_embedding"):
             if self._pending is None:
                 self.start_sparse_exchange()
-            idx_all, rows_all, (handles, *_keepalive) = self._pending
-            for h in handles:
-                h.wait()
-            self._pending = None
-            if self._merge is None:
+            pending, self._pending = self._pending, None
+            if pending[0] == "packed":
                 from . import ops
 
-                if self._merged is None or self._merged.cap != idx_all.numel():
-                    self._merged = ops.SparseRows(idx_all.numel(), rows_all.shape[1], rows_all.device)
-                self.model.sparse_table_grad = ops.merge_sorted_rows(idx_all, rows_all, self.world,
+                _, packed_all, handles, sp = pending
+                for h in handles:
+                    h.wait()
+                D = sp.rows.shape[1]
+                if self._merged is None or self._merged.cap != self.world * sp.cap or self._merged.rows.shape[1] != D:
+                    self._merged = ops.SparseRows(self.world * sp.cap, D, packed_all.device)
+                self.model.sparse_table_grad = ops.merge_packed_rows(packed_all, self.world, sp.cap, D,
                                                                      self.model.item_num, 1.0, out=self._merged)
             else:
-                self.model.sparse_table_grad = self._merge(idx_all, rows_all, self.model.item_num)
+                _, idx_all, rows_all, (handles, *_keepalive) = pending
+                for h in handles:
+                    h.wait()
+                if self._merge is None:
+                    from . import ops
+
+                    if self._merged is None or self._merged.cap != idx_all.numel():
+                        self._merged = ops.SparseRows(idx_all.numel(), rows_all.shape[1], rows_all.device)
+                    self.model.sparse_table_grad = ops.merge_sorted_rows(idx_all, rows_all, self.world,
+                                                                         self.model.item_num, 1.0, out=self._merged)
+                else:
+                    self.model.sparse_table_grad = self._merge(idx_all, rows_all, self.model.item_num)
         for h in waits:
             if h is not None:
                 h.wait()

@@ -106,3 +106,34 @@ def test_merge_sorted_rows_kernel(W, cap, D, n_table):
     assert torch.allclose(got, 0.5 * dense, atol=1e-5)
     sp2 = ops.merge_sorted_rows(idx_all.reshape(-1).cuda(), rows_all.reshape(W * cap, D).cuda(), W, n_table, 0.5)
     assert torch.equal(sp2.idx, sp.idx) and torch.equal(sp2.to_dense(n_table), sp.to_dense(n_table))
+
+
+@pytest.mark.parametrize("W,cap,D,n_table", [(1, 37, 64, 50), (2, 100, 128, 300), (8, 257, 512, 900), (5, 64, 4096, 40),
+                                             (3, 7, 8, 1000)])
+def test_merge_packed_rows_kernel(W, cap, D, n_table):
+    """pxr_merge_packed_rows_f32 (one-collective layout, counts inside the blocks, garbage beyond a list's count)
+    must reproduce pxr_merge_sorted_rows_f32 on the same lists bit for bit."""
+    from pixelrec_amd import ops
+    from pixelrec_amd.parallel import PAD_ID
+
+    g = torch.Generator().manual_seed(W * 77 + cap)
+    blocks, idx_all, rows_all = [], torch.full((W, cap), PAD_ID, dtype=torch.int64), torch.randn(W, cap, D, generator=g)
+    for r in range(W):
+        n = int(torch.randint(0, min(cap, n_table - 1) + 1, (1,), generator=g))
+        ids = torch.sort(torch.randperm(n_table - 1, generator=g)[:n] + 1).values
+        idx_all[r, :n] = ids
+        sp = ops.SparseRows(cap, D, "cuda", packed=True)
+        assert sp.packed.data_ptr() == sp.idx.data_ptr() and sp.rows.data_ptr() % 16 == 0
+        sp.idx.copy_(torch.randint(1, n_table, (cap,), generator=g))       # stale ids beyond n: must be ignored
+        sp.idx[:n] = ids.cuda()
+        sp.rows.copy_(rows_all[r])
+        sp.n.fill_(n)
+        blocks.append(sp.packed)
+    ref = ops.merge_sorted_rows(idx_all.reshape(-1).cuda(), rows_all.reshape(W * cap, D).cuda(), W, n_table, 0.25)
+    got = ops.merge_packed_rows(torch.cat(blocks), W, cap, D, n_table, 0.25)
+    assert got.count() == ref.count() == W * cap
+    assert torch.equal(got.idx, ref.idx)
+    live = ref.idx > 0
+    assert torch.equal(got.rows[live], ref.rows[live])
+    with pytest.raises(ValueError):
+        ops.merge_packed_rows(torch.cat(blocks)[:-16], W, cap, D, n_table)
