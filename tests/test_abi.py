@@ -79,3 +79,25 @@ def test_ctypes_signatures_match_the_header():
                 assert t is ctypes.c_float, (name, c, t)
             else:
                 assert t in (ctypes.c_int, ctypes.c_int32, ctypes.c_uint32), (name, c, t)
+
+
+def test_packed_block_layout_host_side():
+    """The packed exchange block of include/pxr.h: sizes are host arithmetic (no GPU), and ops.SparseRows(packed=True)
+    lays its three views over one buffer exactly there."""
+    import torch
+
+    from pixelrec_amd import ops
+
+    L = lib.load()
+    for cap, D in [(1, 4), (7, 8), (6464, 512), (100, 4096)]:
+        off = L.pxr_packed_rows_offset(cap)
+        assert off % 16 == 0 and (cap + 1) * 8 <= off < (cap + 1) * 8 + 16
+        assert L.pxr_packed_rows_bytes(cap, D) == off + cap * D * 4
+        sp = ops.SparseRows(cap, D, "cpu", packed=True)        # a host buffer is enough to check the aliasing
+        assert sp.packed.numel() == off + cap * D * 4 and int(sp.packed.sum()) == 0
+        sp.idx.fill_(-1); sp.n.fill_(5); sp.rows.fill_(1.0)
+        raw = sp.packed
+        assert raw[:cap * 8].view(torch.int64).eq(-1).all()
+        assert int(raw[cap * 8:cap * 8 + 8].view(torch.int64)) == 5          # the count's upper half stays zero
+        assert raw[cap * 8 + 8:off].eq(0).all()                               # alignment padding untouched
+        assert raw[off:].view(torch.float32).eq(1.0).all()
