@@ -7,9 +7,8 @@ embedding gradient.  Here:
     rank pre-scales its loss gradient by 1/world so the sum IS DDP's mean);
   * the table gradient stays sparse: each rank contributes its (uniq_idx, count, uniq_rows) at a fixed capacity as ONE
     packed block (ops.SparseRows(packed=True)) -> one all-gather -> every rank merges the W (already sorted, unique)
-    lists with the same rank-ordered merge kernel -- no second sort -- so replicas stay bit-identical.  (An injected
-    merge function, or a gradient that is not packed, takes the two-collective form: PAD-terminated id lists + rows,
-    `gather_sparse`.)
+    lists with the same rank-ordered merge kernel -- no second sort -- so replicas stay bit-identical.  (A gradient
+    that is not packed takes the two-collective form: PAD-terminated id lists + rows, `gather_sparse`.)
 No host synchronisation: counts stay on the device, shapes are static.
 
 `DataParallel` mirrors the only DDP surface the reference's Trainer uses: `.module`, `__call__`, `.train()`,
@@ -51,6 +50,19 @@ def gather_sparse(idx: torch.Tensor, rows: torch.Tensor, n: torch.Tensor, group=
     return idx_all, rows_all, ([x for x in h if x is not None], idx_masked, rows)
 
 
+def unpack_blocks(packed_all: torch.Tensor, world: int, cap: int, D: int):
+    """`world` packed blocks (include/pxr.h: ids[cap] | int32 count | pad | rows[cap][D]) -> (idx_all [world*cap] with
+    PAD_ID beyond each block's count, rows_all [world*cap, D]): the two-array form of the same lists, for a merge
+    function that is not the HIP kernel (tests).  Copies; the product path reads the blocks in place."""
+    blocks = packed_all.view(world, -1)
+    off = blocks.shape[1] - cap * D * 4
+    idx = blocks[:, :cap * 8].contiguous().view(torch.int64).view(world, cap)
+    counts = blocks[:, cap * 8:cap * 8 + 4].contiguous().view(torch.int32).view(world, 1)
+    rows_all = blocks[:, off:].contiguous().view(torch.float32).view(world * cap, D)
+    ar = torch.arange(cap, device=packed_all.device, dtype=torch.int32).unsqueeze(0)
+    return torch.where(ar < counts, idx, PAD_ID).reshape(-1), rows_all
+
+
 _ARANGE = {}
 
 
@@ -84,7 +96,7 @@ class GradSync:
 
     def start_sparse_exchange(self):
         sp = self.model.sparse_table_grad
-        if self._merge is None and getattr(sp, "packed", None) is not None:
+        if getattr(sp, "packed", None) is not None:
             # one collective: ids, count and rows of a rank are one packed block (ops.SparseRows(packed=True)); the
             # merge kernel reads the counts from the blocks, so no PAD fill and no separate id all-gather
             key = (sp.packed.numel(), str(sp.packed.device))
@@ -140,10 +152,14 @@ class GradSync:
                 for h in handles:
                     h.wait()
                 D = sp.rows.shape[1]
-                if self._merged is None or self._merged.cap != self.world * sp.cap or self._merged.rows.shape[1] != D:
-                    self._merged = ops.SparseRows(self.world * sp.cap, D, packed_all.device)
-                self.model.sparse_table_grad = ops.merge_packed_rows(packed_all, self.world, sp.cap, D,
-                                                                     self.model.item_num, 1.0, out=self._merged)
+                if self._merge is not None:     # injected merge (CPU tests): hand it the blocks as PAD-terminated lists
+                    idx_all, rows_all = unpack_blocks(packed_all, self.world, sp.cap, D)
+                    self.model.sparse_table_grad = self._merge(idx_all, rows_all, self.model.item_num)
+                else:
+                    if self._merged is None or self._merged.cap != self.world * sp.cap or self._merged.rows.shape[1] != D:
+                        self._merged = ops.SparseRows(self.world * sp.cap, D, packed_all.device)
+                    self.model.sparse_table_grad = ops.merge_packed_rows(packed_all, self.world, sp.cap, D,
+                                                                         self.model.item_num, 1.0, out=self._merged)
             else:
                 _, idx_all, rows_all, (handles, *_keepalive) = pending
                 for h in handles:

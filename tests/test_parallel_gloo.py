@@ -1,5 +1,6 @@
 """N>1 path on CPU: two processes, gloo backend (the GPU box runs the same code over RCCL).  Covers the gradient
-exchange of pixelrec_amd.parallel (flat all-reduce; sparse id/row all-gather + merge), the parameter broadcast,
+exchange of pixelrec_amd.parallel (flat all-reduce; sparse row exchange -- the one-collective packed form and the
+two-array form -- + merge), the parameter broadcast,
 the eval sharding sampler and the metric averaging.  The HIP merge kernel cannot run here, so the merge step is
 injected (an index_add on CPU) -- the exchange layout and the averaging convention are what is under test."""
 import os
@@ -34,13 +35,15 @@ def _rank_data(rank):
 
 
 class _FakeModel:
+    packed = False      # True: the product's one-collective layout (ops.SparseRows(packed=True))
+
     def __init__(self, rank):
         from pixelrec_amd.ops import SparseRows
 
         gflat, idx, rows = _rank_data(rank)
         self.flat = torch.full((40,), float(rank))
         self.gflat = gflat.clone()
-        sp = SparseRows(CAP, D, "cpu")
+        sp = SparseRows(CAP, D, "cpu", packed=self.packed)
         sp.idx[:len(idx)] = idx
         sp.idx[len(idx):] = 7            # garbage beyond n must be ignored
         sp.rows[:len(idx)] = rows
@@ -54,6 +57,10 @@ class _FakeModel:
 
     def flat_parameters(self):
         return self.flat, self.gflat
+
+
+class _PackedModel(_FakeModel):
+    packed = True
 
 
 class _DeferringModel(_FakeModel):
@@ -97,6 +104,14 @@ def _worker(rank, port, results):
             _, idx, rows = _rank_data(r)
             exp_dense.index_add_(0, idx, rows)
         assert torch.allclose(m.sparse_table_grad, exp_dense, atol=1e-6)
+        # the product's exchange layout: ONE all-gather of packed (ids | count | rows) blocks, garbage beyond n ignored
+        m3 = _PackedModel(rank)
+        assert m3.sparse_table_grad.packed is not None
+        gs3 = GradSync(m3, merge_fn=_cpu_merge)
+        m3._sparse_ready_hook()
+        assert gs3._pending[0] == "packed" and gs3._pending[1].numel() == WORLD * m3.sparse_table_grad.packed.numel()
+        gs3.sync()
+        assert torch.allclose(m3.gflat, exp_flat) and torch.allclose(m3.sparse_table_grad, exp_dense, atol=1e-6)
         # deferred flat wait: sync leaves the all-reduce handle with the model; the consumer completes it
         m2 = _DeferringModel(rank)
         gs2 = GradSync(m2, merge_fn=_cpu_merge)
