@@ -105,7 +105,13 @@ def main():
     ap.add_argument("--no-group", action="store_true", help="per-layer weight-gradient GEMMs instead of one grouped launch")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
-    ap.add_argument("--clock-ramp-s", type=float, default=0.3, help="seconds of extra untimed steps before the warm-up")
+    ap.add_argument("--clock-ramp-s", type=float, default=0.0, help="seconds of extra untimed steps before the warm-up")
+    ap.add_argument("--age-steps", type=int, default=600,
+                    help="untimed steps on DISTINCT batches before the warm-up: they bring the lazily updated table rows "
+                         "to the steady-state distribution of gaps an epoch presents (and ramp the clocks)")
+    ap.add_argument("--table-update", choices=("lazy", "dense"), default="lazy",
+                    help="table AdamW schedule (dense = sweep all rows every step; eager only)")
+    ap.add_argument("--dw-mode", default=None, help="weight-gradient placement: grouped | fork_layer | fork_half")
     ap.add_argument("--emb", type=int, default=NS["D"], help="embedding size (default: the north-star 512)")
     ap.add_argument("--heads", type=int, default=NS["H"])
     ap.add_argument("--items", type=int, default=NS["n_items"], help="catalogue size incl. the padding id")
@@ -151,22 +157,42 @@ def main():
     if args.no_group:
         model.group_weight_grads = False
         model.overlap_weight_grads = not args.no_overlap
+    if args.dw_mode:
+        model.weight_grad_mode = args.dw_mode
+    model.defer_weight_grad_join = True      # every step below ends in opt.step(), which joins the side stream
     dp = (ShardedDataParallel(model, force_collectives=args.force_collectives) if args.table_sharding
           else DataParallel(model, force_collectives=args.force_collectives))
-    opt = PxrAdamW(model, lr=1e-4, weight_decay=0.1)
+    opt = PxrAdamW(model, lr=1e-4, weight_decay=0.1, table_update=args.table_update)
 
-    # synthetic batches, rank-distinct, resident in HBM before the timed region
+    # synthetic batches, rank-distinct, resident in HBM before the timed region.  The stream does NOT repeat inside
+    # ageing + warm-up + timed steps (+ the instrumented steps after them): a lazily updated table row returns after the
+    # gap its popularity dictates (Zipf positives, uniform negatives: mean ~120 steps at B=64), and the catch-up that
+    # replays those steps is paid inside the timed region.
     rng = np.random.default_rng(2020 + 1000 * rank)
     zipf = synth.ZipfItems(N, seed=2020)
-    pool = []
-    for _ in range(8):
-        it, mk = synth.train_batch(N, B, L, rng, zipf)
-        pool.append((torch.from_numpy(it).to(dev), torch.from_numpy(mk).to(dev)))
+    n_inst_plan = 0 if args.no_gemm_events else min(args.steps, 20)
+    n_stream = min(args.age_steps + args.warmup + args.steps + n_inst_plan + 40, 4096)
+    t_gen = time.perf_counter()
+    its, mks = zip(*(synth.train_batch(N, B, L, rng, zipf) for _ in range(n_stream)))
+    items_all = torch.from_numpy(np.stack(its)).to(dev)
+    mask_all = torch.from_numpy(np.stack(mks)).to(dev)
+    t_gen = time.perf_counter() - t_gen
+    del its, mks
+
+    class _Pool:
+        def __len__(self):
+            return n_stream
+
+        def __getitem__(self, i):
+            return items_all[i], mask_all[i]
+
+    pool = _Pool()
 
     gemm_events = []
     # replaying RCCL collectives from a hipGraph is opt-in: it cannot be validated on the 1-GPU development box
     use_graph = (not args.no_graph) and ((world == 1 and not args.force_collectives) or args.graph_collectives)
     use_graph = use_graph and not args.table_sharding      # the sharded forward issues collectives: eager only
+    use_graph = use_graph and args.table_update == "lazy"   # the dense sweep takes host-computed scalars
     gstep = None
     if use_graph:
         from pixelrec_amd.graph import GraphedTrainStep
@@ -174,25 +200,32 @@ def main():
         gstep = GraphedTrainStep(dp, opt, *pool[0])
 
     one = torch.ones((), dtype=torch.float32, device=dev)
+    cursor = [0]          # position in the batch stream: every step of every phase consumes the NEXT batch
 
-    def step(i, record=False):
-        if gstep is not None:
-            return gstep(*pool[i % len(pool)])
+    def next_batch():
+        b = pool[cursor[0] % len(pool)]
+        cursor[0] += 1
+        return b
+
+    def eager_step(batch):
         opt.zero_grad()
-        loss = dp(pool[i % len(pool)])
+        loss = dp(batch)
         loss.backward(one)       # preallocated d(loss)/d(loss): no ones_like fill per step
         dp.sync_gradients(defer_flat=True)
         opt.step()
         return loss
 
-    def instrumented_step(i):
+    def step(i=None, record=False):
+        if gstep is not None:
+            return gstep(*next_batch())
+        return eager_step(next_batch())
+
+    ref_ev = torch.cuda.Event(enable_timing=True)
+
+    def instrumented_step(i=None):
         """Same step, eager, with HIP events around every GEMM launch (run AFTER the timed region)."""
         ops.GEMM_TIMING = gemm_events
-        opt.zero_grad()
-        loss = dp(pool[i % len(pool)])
-        loss.backward(one)       # preallocated d(loss)/d(loss): no ones_like fill per step
-        dp.sync_gradients(defer_flat=True)
-        opt.step()
+        loss = eager_step(next_batch())
         ops.GEMM_TIMING = None
         return loss
 
@@ -206,6 +239,13 @@ def main():
         torch.cuda.synchronize()
         if time.perf_counter() - t_ramp >= args.clock_ramp_s:
             break
+    # ageing: real steps on distinct batches (untimed, like warm-up).  Afterwards the per-row "current through" stamps
+    # have the gap distribution of a running epoch instead of a freshly initialised optimizer's
+    t_age = time.perf_counter()
+    for i in range(args.age_steps):
+        step(i)
+    torch.cuda.synchronize()
+    t_age = time.perf_counter() - t_age
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -226,12 +266,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
+    stream_repeats = cursor[0] > len(pool)
+    # what the lazy schedule replayed in the steps just timed: gaps (in steps) of the NEXT batches' unique rows
+    lazy_gaps = None
+    if args.table_update == "lazy" and opt._last is not None:
+        g_all = []
+        for j in range(8):
+            ids = torch.unique(pool[(cursor[0] + j) % len(pool)][0])
+            ids = ids[ids > 0]
+            g_all.append((opt.step_count + j - opt._last[ids].long()).clamp_(min=0).float())
+        gaps = torch.cat(g_all)
+        qs = torch.quantile(gaps, torch.tensor([0.5, 0.9, 0.99], device=dev)).tolist()
+        lazy_gaps = {"unique_rows_per_step": gaps.numel() / 8.0, "mean": float(gaps.mean()), "p50": qs[0], "p90": qs[1],
+                     "p99": qs[2], "max": float(gaps.max()), "frac_ge_256": float((gaps >= 256).float().mean()),
+                     "mean_replayed_steps": float(gaps.clamp(max=256).mean()),
+                     "note": "steps since each unique row of the next 8 batches was last brought current (= zero-gradient "
+                             "AdamW steps replayed per row, exactly for <= 256, closed form beyond)"}
     n_inst = 0
     if not args.no_gemm_events:
-        n_inst = min(args.steps, 20)
+        n_inst = n_inst_plan
+        ref_ev.record()
         for i in range(n_inst):
             instrumented_step(i)
         torch.cuda.synchronize()
+    # the same eager step without the event brackets (the host keeps up at B=64): reference point for the dense A/B
+    t_eager = None
+    if world == 1 and not args.no_extras:
+        for _ in range(3):
+            eager_step(next_batch())
+        torch.cuda.synchronize()
+        t_eager = time.perf_counter()
+        for _ in range(20):
+            eager_step(next_batch())
+        torch.cuda.synchronize()
+        t_eager = (time.perf_counter() - t_eager) / 20
 
     if rank != 0:
         if dist.is_initialized():
@@ -239,23 +307,61 @@ def main():
         return
 
     # ---- roofline of the dominant kernel: the fp32-MFMA GEMM (all launches of the timed steps, HIP events) ------
-    g_s = sum(s.elapsed_time(e) for s, e, _, _ in gemm_events) * 1e-3 or float("nan")
+    is_gemm = lambda tag: tag.startswith("gemm") or tag.startswith("grouped_dw")
+    other_events = [ev for ev in gemm_events if not is_gemm(ev[3])]
+    gemm_events = [ev for ev in gemm_events if is_gemm(ev[3])]
+    # The weight-gradient launches run on a side stream BESIDE the input-gradient chain (seqcore weight_grad_mode), so
+    # kernel durations overlap: the family's time is the UNION of the [start, end] intervals of its launches (absolute
+    # times = elapsed since one reference event), not their sum.  Both are reported.
+    iv = sorted((ref_ev.elapsed_time(s_) * 1e-3, ref_ev.elapsed_time(e_) * 1e-3) for s_, e_, _, _ in gemm_events)
+    g_union, cur_s, cur_e = 0.0, None, None
+    for a_, b_ in iv:
+        if cur_e is None or a_ > cur_e:
+            if cur_e is not None:
+                g_union += cur_e - cur_s
+            cur_s, cur_e = a_, b_
+        else:
+            cur_e = max(cur_e, b_)
+    if cur_e is not None:
+        g_union += cur_e - cur_s
+    g_union = g_union or float("nan")
+    g_sum = sum(s_.elapsed_time(e_) for s_, e_, _, _ in gemm_events) * 1e-3 or float("nan")
     g_fl = sum(f for _, _, f, _ in gemm_events)
     n_launch = len(gemm_events)
-    per_kernel = {}
-    for s_, e_, f_, tag in gemm_events:     # one entry per kernel instantiation, comparable with rocprofv3's rows
-        k = per_kernel.setdefault(tag, [0, 0.0, 0.0])
-        k[0] += 1; k[1] += s_.elapsed_time(e_) * 1e-3; k[2] += f_
-    per_kernel = {t: {"launches_per_step": c / max(n_inst, 1), "avg_kernel_us": sec / c * 1e6,
-                      "tflops": fl / sec / 1e12} for t, (c, sec, fl) in per_kernel.items()}
-    roof = {"bound": "mfma", "kernel": "gemm_kernel (v_mfma_f32_32x32x2_f32; every nn.Linear fwd/bwd of the step)",
-            "achieved": g_fl / g_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-            "frac": g_fl / g_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-            "launches_per_step": n_launch / max(n_inst, 1), "avg_kernel_us": g_s / max(n_launch, 1) * 1e6,
+
+    def per_tag(events, unit_scale, unit_name):
+        acc = {}
+        for s_, e_, f_, tag in events:     # one entry per kernel instantiation, comparable with rocprofv3's rows
+            k = acc.setdefault(tag, [0, 0.0, 0.0])
+            k[0] += 1; k[1] += s_.elapsed_time(e_) * 1e-3; k[2] += f_
+        return {t: {"launches_per_step": c / max(n_inst, 1), "avg_kernel_us": sec / c * 1e6,
+                    unit_name: fl / sec / unit_scale} for t, (c, sec, fl) in acc.items()}
+
+    per_kernel = per_tag(gemm_events, 1e12, "tflops")
+    traffic = None
+    tr_file = os.path.join(ROOT, "profiles", "r02", "pmc", "gemm_traffic_summary.json")
+    if os.path.exists(tr_file) and not custom and B == 64:
+        try:
+            traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roof = {"bound": "mfma", "kernel": "gemm_kernel / grouped_dw_kernel (v_mfma_f32_32x32x2_f32; every nn.Linear "
+                                       "fwd/bwd of the step)",
+            "achieved": g_fl / g_union / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": g_fl / g_union / 1e12 / MFMA_F32_PEAK_TF, "traffic": traffic,
+            "launches_per_step": n_launch / max(n_inst, 1), "avg_kernel_us": g_union / max(n_launch, 1) * 1e6,
             "algorithmic_flops_per_step": g_fl / max(n_inst, 1),
-            "gemm_time_per_step_us": g_s / max(n_inst, 1) * 1e6, "kernels": per_kernel,
-            "note": f"HIP events around every GEMM launch of {n_inst} extra eager steps issued right after the timed "
-                    "region (bracketing launches inside it would make the step host-bound)"}
+            "gemm_time_per_step_us": g_union / max(n_inst, 1) * 1e6,
+            "gemm_time_per_step_us_sum_of_durations": g_sum / max(n_inst, 1) * 1e6,
+            "achieved_sum_of_durations": g_fl / g_sum / 1e12,
+            "weight_grad_mode": getattr(model, "weight_grad_mode", None) if getattr(model, "group_weight_grads", False) else "per-layer",
+            "kernels": per_kernel,
+            "note": f"HIP events (each on the stream its kernel runs on) around every GEMM launch of {n_inst} extra "
+                    "eager steps issued right after the timed region (bracketing launches inside it would make the step "
+                    "host-bound); achieved = algorithmic flops / UNION of the launches' [start,end] intervals, because "
+                    "the weight-gradient launches co-run with the input-gradient chain on a second stream; `traffic` = "
+                    "HBM bytes per launch from the separate rocprofv3 --pmc pass of this command (profiles/r02/pmc)"}
+    hbm_kernels = per_tag(other_events, 1e9, "gbs")
 
     out = {
         "metric": (f"user-sequences/sec at emb={D} seq_len={L} (SASRec IDNet training step: fwd+bwd+AdamW)" if custom else
@@ -272,7 +378,25 @@ def main():
                    "hip_graph": bool(use_graph)},
         "final_loss": final_loss, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
         "roofline": roof,
+        "stream": {"distinct_batches": n_stream, "age_steps": args.age_steps, "age_s": t_age, "host_gen_s": t_gen,
+                   "repeats_inside_run": bool(stream_repeats), "optimizer_steps_before_timed_region": args.age_steps + args.warmup,
+                   "table_update": args.table_update},
     }
+    if lazy_gaps is not None:
+        # the lazy table AdamW as it runs in the timed steps: catch-up (before the forward reads the rows) + apply
+        rows_us = sum(v["avg_kernel_us"] * v["launches_per_step"] for t, v in hbm_kernels.items() if t.startswith("adamw_rows"))
+        out["roofline_adamw_rows"] = {
+            "bound": "valu/latency", "kernel": "adamw_rows_kernel (catch-up + apply)", "us_per_step": rows_us,
+            "kernels": {t: v for t, v in hbm_kernels.items() if t.startswith("adamw_rows")}, "gaps": lazy_gaps,
+            "note": "HIP events around both launches in the instrumented eager steps; work is data dependent (replayed "
+                    "steps per row), so time and the gap histogram are reported instead of GB/s"}
+    gf = [v for t, v in hbm_kernels.items() if t.startswith("ln_fwd_kernel<GATHER>")]
+    if gf:
+        out["roofline_gather_fused"] = [{"bound": "hbm", "kernel": "ln_fwd_kernel<GATHER>", "batch_per_gpu": B,
+                                         "achieved": gf[0]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": gf[0]["gbs"] / HBM_PEAK_GBS, "avg_kernel_us": gf[0]["avg_kernel_us"],
+                                         "note": "the gather as the step runs it: B*L table rows read + y + xhat written "
+                                                 "(3 x B*L*D*4 bytes)"}]
 
     if not args.no_extras and world == 1 and B == 64 and not custom:
         # (0) the same step at throughput-oriented batch sizes (SURVEY.md §8d asks for B=64 AND 512 / 2048 per GPU)
@@ -280,28 +404,42 @@ def main():
 
         out["throughput_batches"] = []
         for Bt in (512, 2048):
-            bt = [tuple(torch.from_numpy(a).to(dev) for a in synth.train_batch(N, Bt, L, rng, zipf)) for _ in range(4)]
+            n_bt = 26 if Bt == 512 else 12     # distinct batches: warm-up + timed + instrumented steps never repeat one
+            bt = [tuple(torch.from_numpy(a).to(dev) for a in synth.train_batch(N, Bt, L, rng, zipf)) for _ in range(n_bt)]
             g2 = _G(dp, opt, *bt[0]) if use_graph else None
+            cur = [0]
 
-            def step_b(i):
-                if g2 is not None:
-                    return g2(*bt[i % 4])
-                opt.zero_grad()
-                dp(bt[i % 4]).backward(one)
-                dp.sync_gradients(defer_flat=True)
-                opt.step()
+            def step_b(eager=False):
+                b = bt[cur[0] % n_bt]
+                cur[0] += 1
+                if g2 is not None and not eager:
+                    return g2(*b)
+                return eager_step(b)
 
             for i in range(3):
-                step_b(i)
+                step_b()
             torch.cuda.synchronize()
             tb = time.perf_counter()
             n_b = 20 if Bt == 512 else 8
             for i in range(n_b):
-                step_b(i)
+                step_b()
             torch.cuda.synchronize()
             tb = (time.perf_counter() - tb) / n_b
             out["throughput_batches"].append({"batch_per_gpu": Bt, "value": Bt / tb, "unit": "sequences/s",
                                               "ms_per_step": tb * 1e3, "steps": n_b})
+            # the fused gather (ln_fwd_kernel<GATHER>) where it runs, at this batch size
+            evs = []
+            ops.GEMM_TIMING = evs
+            for i in range(2):
+                step_b(eager=True)
+            ops.GEMM_TIMING = None
+            torch.cuda.synchronize()
+            gl = [(s_.elapsed_time(e_) * 1e-3, w) for s_, e_, w, t in evs if t.startswith("ln_fwd_kernel<GATHER>")]
+            if gl and "roofline_gather_fused" in out:
+                sec = sum(x for x, _ in gl) / len(gl)
+                out["roofline_gather_fused"].append({"bound": "hbm", "kernel": "ln_fwd_kernel<GATHER>", "batch_per_gpu": Bt,
+                                                     "achieved": gl[0][1] / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                     "frac": gl[0][1] / sec / 1e9 / HBM_PEAK_GBS, "avg_kernel_us": sec * 1e6})
             del g2, bt
 
     if not args.no_extras and world == 1 and not custom:
@@ -348,6 +486,49 @@ def main():
                                              "avg_kernel_us": t_a * 1e6,
                                              "note": "24 B x N x D (read+write p,m,v) + 4 B x N slot map per launch"}
         del tm, tv, slot, tcopy
+
+    if not args.no_extras and world == 1 and not custom and B == 64 and args.table_update == "lazy" and not args.table_sharding:
+        # (4) what the lazy schedule costs against the dense sweep it replaces: the amortised flush
+        # (every row brought current before an evaluation / checkpoint), and the same eager step with
+        # table_update="dense" minus its measured sweep kernel.
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        opt.flush()
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf
+        steps_per_epoch = 200_000 // B      # Pixel200K: one full-sort evaluation (hence one flush) per epoch
+        out["lazy_flush"] = {"ms": tf * 1e3, "rows": N, "optimizer_steps_behind_max": opt.step_count,
+                             "amortised_us_per_step": tf * 1e6 / steps_per_epoch,
+                             "note": f"one flush per epoch of {steps_per_epoch} steps (Pixel200K users / {B}); every row "
+                                     "is replayed <= 256 steps exactly + closed form"}
+        model._table_hooks = None
+        opt_d = PxrAdamW(model, lr=1e-4, weight_decay=0.1, table_update="dense")
+        model._table_hooks = None            # (dense: nothing to catch up before the forward)
+        opt_l, opt = opt, opt_d
+        evs = []
+        for _ in range(3):
+            eager_step(next_batch())
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        for _ in range(20):
+            eager_step(next_batch())
+        torch.cuda.synchronize()
+        td = (time.perf_counter() - td) / 20
+        ops.GEMM_TIMING = evs
+        for _ in range(5):
+            eager_step(next_batch())
+        ops.GEMM_TIMING = None
+        torch.cuda.synchronize()
+        sw = [s_.elapsed_time(e_) * 1e-3 for s_, e_, w, t in evs if t.startswith("adamw_table_kernel")]
+        sweep = sum(sw) / max(len(sw), 1)
+        opt = opt_l
+        model.register_table_hooks(opt)
+        out["lazy_vs_dense"] = {"lazy_eager_ms_per_step": (t_eager or float("nan")) * 1e3, "dense_eager_ms_per_step": td * 1e3,
+                                "dense_sweep_kernel_ms": sweep * 1e3, "dense_minus_sweep_ms": (td - sweep) * 1e3,
+                                "lazy_over_dense_minus_sweep": (t_eager or float("nan")) / (td - sweep),
+                                "note": "same eager step, same stream position; `dense` sweeps p, m, v of all rows every "
+                                        "step; the lazy figure includes catch-up + apply on the aged, non-repeating stream"}
+        del opt_d
 
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(B)

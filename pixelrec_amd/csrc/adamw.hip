@@ -47,12 +47,24 @@ static AdamHyper make_hyper(double lr, double b1, double b2, double eps, double 
 
 // The operation order is PINNED with explicit fmaf / __fmul_rn so that every kernel that updates a row (dense sweep,
 // lazy replay, lazy apply) produces bit-identical results regardless of how the compiler would contract a*b+c.
+// sqrt and the division are the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 (2 quarter-rate instructions) instead of the
+// correctly rounded sequences (~25 VALU instructions): a lazily updated row REPLAYS this body once per missed step, so
+// its cost is what the lazy schedule pays per step (bench.py `roofline_adamw_rows`).  The update term is <= lr in
+// magnitude, so a 1-ulp relative difference in it is ~1e-11 absolute against the +-1e-5 parity bar on parameters.
 __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamHyper& h) {
   p = __fmul_rn(p, h.decay);
   m = fmaf(g - m, h.one_m_b1, m);
   v = fmaf(v, h.b2, __fmul_rn(__fmul_rn(h.one_m_b2, g), g));
-  const float denom = fmaf(sqrtf(v), h.inv_sqrt_bc2, h.eps);
-  p = fmaf(-h.step_size, m / denom, p);
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(v), h.inv_sqrt_bc2, h.eps);
+  p = fmaf(-h.step_size, __fmul_rn(m, __builtin_amdgcn_rcpf(denom)), p);
+}
+// zero-gradient form of adam_elem (same values bit for bit: fmaf(v, b2, +0) == v * b2, g - m == -m)
+__device__ __forceinline__ void adam_elem0(float& p, float& m, float& v, const AdamHyper& h) {
+  p = __fmul_rn(p, h.decay);
+  m = fmaf(-m, h.one_m_b1, m);
+  v = __fmul_rn(v, h.b2);
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(v), h.inv_sqrt_bc2, h.eps);
+  p = fmaf(-h.step_size, __fmul_rn(m, __builtin_amdgcn_rcpf(denom)), p);
 }
 
 __global__ void __launch_bounds__(256) adamw_flat_kernel(float4* __restrict__ p, const float4* __restrict__ g,
@@ -150,81 +162,90 @@ struct RowsArgs {
   const int64_t* step_dev;   // optional: t_prev = *step_dev (completed steps), t_apply = t_prev+1 if t_apply != 0
 };
 
-template <int VEC>
-__global__ void __launch_bounds__(256) adamw_rows_kernel(RowsArgs a) {
+// One row is spread over LPR = ceil(D/4 / 64) * 64 lanes (one float4 per lane), so a row with a long gap is a chain of
+// 4 elements per lane instead of D/64: the kernel's duration is set by the longest replay in the batch (a Zipf-tail or
+// uniformly drawn negative id returns after hundreds of steps), not by the average.  All lanes of a row sit in ONE
+// workgroup (block = max(256, LPR) threads = RPB rows): last[row] is read by every wave of the row at the top and
+// written by one lane after a barrier.  The replayed step number is wave-uniform (readfirstlane), so the per-step
+// scalars come through the scalar cache and the entry of step s+1 is fetched while step s is computed.
+template <int LPR>
+__global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(RowsArgs a,
+                                                                               const float4* __restrict__ hyper) {
+  constexpr int NT = LPR > 256 ? LPR : 256;
+  constexpr int RPB = NT / LPR;
   if (a.step_dev) {
     a.t_prev = (int)a.step_dev[0];
     if (a.t_apply) a.t_apply = a.t_prev + 1;
   }
-  const int lane = threadIdx.x & 63;
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int rib = threadIdx.x / LPR;            // row of this block's group
+  const int c = (threadIdx.x % LPR) * 4;        // first column of this lane's float4
+  const bool col_ok = c < a.D;
   const int64_t n = a.rows ? (int64_t)(*a.n_rows) : a.n_fixed;
-  for (int64_t i = wave_id; i < n; i += n_waves) {
-    const int64_t row = a.rows ? a.rows[i] : i;
-    if (a.rows && row <= 0) continue;   // id 0 = empty slot of a merged (non-compacted) row list
-    const int k0 = a.last[row];
-    if (k0 >= a.t_prev && a.t_apply == 0) continue;
-    float4 pp[VEC], mm[VEC], vv[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < a.D) {
-        const int64_t o = row * a.D + c;
-        pp[k] = *reinterpret_cast<const float4*>(a.p + o);
-        mm[k] = *reinterpret_cast<const float4*>(a.m + o);
-        vv[k] = *reinterpret_cast<const float4*>(a.v + o);
+  const int64_t n_groups = (n + RPB - 1) / RPB;
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t i = grp * RPB + rib;
+    int64_t row = 0;
+    int k0 = 0;
+    bool work = i < n;
+    if (work) {
+      row = a.rows ? a.rows[i] : i;
+      if (a.rows && row <= 0) work = false;   // id 0 = empty slot of a merged (non-compacted) row list
+    }
+    if (work) {
+      k0 = a.last[row];
+      if (k0 >= a.t_prev && a.t_apply == 0) work = false;
+    }
+    // wave-uniform by construction (a wave never straddles two rows: LPR is a multiple of 64)
+    work = __builtin_amdgcn_readfirstlane((int)work) != 0;
+    k0 = __builtin_amdgcn_readfirstlane(k0);
+    if (work) {
+      float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp;
+      const int64_t o = row * a.D + c;
+      if (col_ok) {
+        pp = *reinterpret_cast<const float4*>(a.p + o);
+        mm = *reinterpret_cast<const float4*>(a.m + o);
+        vv = *reinterpret_cast<const float4*>(a.v + o);
+      }
+      AdamHyper h;
+      h.one_m_b1 = a.one_m_b1; h.b2 = a.b2; h.one_m_b2 = a.one_m_b2; h.eps = a.eps;
+      int s = k0 + 1;
+      const int exact_end = min(a.t_prev, k0 + PXR_LAZY_EXACT);
+      auto replay = [&](const float4 hs) {
+        h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
+        adam_elem0(pp.x, mm.x, vv.x, h); adam_elem0(pp.y, mm.y, vv.y, h);
+        adam_elem0(pp.z, mm.z, vv.z, h); adam_elem0(pp.w, mm.w, vv.w, h);
+      };
+      // four steps per trip: their scalars are ONE scalar-cache request (64 B), waited for once
+      for (; s + 3 <= exact_end; s += 4) {
+        const float4 h0 = hyper[s], h1 = hyper[s + 1], h2 = hyper[s + 2], h3 = hyper[s + 3];
+        replay(h0); replay(h1); replay(h2); replay(h3);
+      }
+      for (; s <= exact_end; ++s) replay(hyper[s]);
+      if (s <= a.t_prev) {  // closed-form tail: only the weight decay still moves p
+        const int rem = a.t_prev - s + 1;
+        const float fp = (float)exp(a.cumlog[a.t_prev] - a.cumlog[s - 1]);
+        const float fm = (float)pow((double)a.b1, (double)rem);
+        const float fv = (float)pow((double)a.b2, (double)rem);
+        pp.x *= fp; pp.y *= fp; pp.z *= fp; pp.w *= fp;
+        mm.x *= fm; mm.y *= fm; mm.z *= fm; mm.w *= fm;
+        vv.x *= fv; vv.y *= fv; vv.z *= fv; vv.w *= fv;
+      }
+      if (a.t_apply) {
+        const float4 hs = hyper[a.t_apply];
+        h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
+        const float4 g = (a.grows && col_ok) ? *reinterpret_cast<const float4*>(a.grows + i * a.D + c)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        adam_elem(pp.x, mm.x, vv.x, g.x, h); adam_elem(pp.y, mm.y, vv.y, g.y, h);
+        adam_elem(pp.z, mm.z, vv.z, g.z, h); adam_elem(pp.w, mm.w, vv.w, g.w, h);
+      }
+      if (col_ok) {
+        *reinterpret_cast<float4*>(a.p + o) = pp;
+        *reinterpret_cast<float4*>(a.m + o) = mm;
+        *reinterpret_cast<float4*>(a.v + o) = vv;
       }
     }
-    AdamHyper h;
-    h.one_m_b1 = a.one_m_b1; h.b2 = a.b2; h.one_m_b2 = a.one_m_b2; h.eps = a.eps;
-    int s = k0 + 1;
-    const int exact_end = min(a.t_prev, k0 + PXR_LAZY_EXACT);
-    for (; s <= exact_end; ++s) {
-      const float4 hs = a.hyper[s];
-      h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        adam_elem(pp[k].x, mm[k].x, vv[k].x, 0.f, h); adam_elem(pp[k].y, mm[k].y, vv[k].y, 0.f, h);
-        adam_elem(pp[k].z, mm[k].z, vv[k].z, 0.f, h); adam_elem(pp[k].w, mm[k].w, vv[k].w, 0.f, h);
-      }
-    }
-    if (s <= a.t_prev) {  // closed-form tail: only the weight decay still moves p
-      const int rem = a.t_prev - s + 1;
-      const float fp = (float)exp(a.cumlog[a.t_prev] - a.cumlog[s - 1]);
-      const float fm = (float)pow((double)a.b1, (double)rem);
-      const float fv = (float)pow((double)a.b2, (double)rem);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        pp[k].x *= fp; pp[k].y *= fp; pp[k].z *= fp; pp[k].w *= fp;
-        mm[k].x *= fm; mm[k].y *= fm; mm[k].z *= fm; mm[k].w *= fm;
-        vv[k].x *= fv; vv[k].y *= fv; vv[k].z *= fv; vv[k].w *= fv;
-      }
-    }
-    if (a.t_apply) {
-      const float4 hs = a.hyper[a.t_apply];
-      h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        const int c = (k * 64 + lane) * 4;
-        if (c < a.D) {
-          const float4 g = a.grows ? *reinterpret_cast<const float4*>(a.grows + i * a.D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-          adam_elem(pp[k].x, mm[k].x, vv[k].x, g.x, h); adam_elem(pp[k].y, mm[k].y, vv[k].y, g.y, h);
-          adam_elem(pp[k].z, mm[k].z, vv[k].z, g.z, h); adam_elem(pp[k].w, mm[k].w, vv[k].w, g.w, h);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < a.D) {
-        const int64_t o = row * a.D + c;
-        *reinterpret_cast<float4*>(a.p + o) = pp[k];
-        *reinterpret_cast<float4*>(a.m + o) = mm[k];
-        *reinterpret_cast<float4*>(a.v + o) = vv[k];
-      }
-    }
-    if (lane == 0) a.last[row] = a.t_apply ? a.t_apply : a.t_prev;
+    if constexpr (LPR > 64) __syncthreads();   // every wave of the row has read last[row]
+    if (work && (threadIdx.x % LPR) == 0) a.last[row] = a.t_apply ? a.t_apply : a.t_prev;
   }
 }
 
@@ -399,14 +420,20 @@ extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* las
   a.step_dev = step_dev;
   const int64_t work = rows ? max_rows : n_table;
   if (work <= 0) return PXR_OK;
-  int64_t blocks = (work + 3) / 4;
-  if (blocks > 256 * 16) blocks = 256 * 16;
   hipStream_t st = (hipStream_t)stream;
-  const int vec = (D + 255) / 256;
-  if (vec <= 1) hipLaunchKernelGGL((adamw_rows_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else if (vec <= 2) hipLaunchKernelGGL((adamw_rows_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else if (vec <= 4) hipLaunchKernelGGL((adamw_rows_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else if (vec <= 8) hipLaunchKernelGGL((adamw_rows_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((adamw_rows_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  const int lpr = ((D / 4 + 63) / 64) * 64;          // lanes per row: one float4 per lane
+  const int tl = lpr <= 64 ? 64 : (lpr <= 128 ? 128 : (lpr <= 256 ? 256 : (lpr <= 512 ? 512 : 1024)));
+  const int rpb = tl >= 256 ? 1 : 256 / tl;          // == the kernel's RPB
+  int64_t blocks = (work + rpb - 1) / rpb;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+#define PXR_ROWS_CASE(L_) hipLaunchKernelGGL((adamw_rows_kernel<L_>), dim3((unsigned)blocks), dim3(L_ > 256 ? L_ : 256), 0, st, a, a.hyper)
+  switch (tl) {
+    case 64: PXR_ROWS_CASE(64); break;
+    case 128: PXR_ROWS_CASE(128); break;
+    case 256: PXR_ROWS_CASE(256); break;
+    case 512: PXR_ROWS_CASE(512); break;
+    default: PXR_ROWS_CASE(1024); break;
+  }
+#undef PXR_ROWS_CASE
   return pxr_check_launch("pxr_adamw_rows_f32");
 }

@@ -20,6 +20,9 @@ class GraphedTrainStep:
                                           # without an eager add per step)
         self.clip = clip_grad_norm        # dict(max_norm=..., norm_type=2) as in the reference YAML, or None
         self.model = dp_model.module if hasattr(dp_model, "module") else dp_model
+        # every step goes through optimizer.step(): the join with the weight-gradient side stream can wait until the
+        # flat gradient is consumed (seqcore.SeqRecCore.wait_flat_grads) -- inside the capture, so the graph is closed
+        self.model.defer_weight_grad_join = True
         self.items = items.clone()
         self.mask = masked_index.clone()
         self._one = torch.ones((), dtype=torch.float32, device=items.device)   # d(loss)/d(loss): no fill kernel per step
@@ -37,7 +40,9 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         host_state = (self.opt.step_count, self.model._step_counter, self.opt._dirty)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: another host thread (the trainer's batch prefetcher pins host memory) may call into the
+        # runtime while this thread captures; only THIS thread's unsafe calls should invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._eager().detach()
         # stream capture RECORDS the kernels without running them: the device counters did not advance, so the host
         # mirrors that the Python code bumped during capture are rolled back

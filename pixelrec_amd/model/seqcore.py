@@ -17,6 +17,8 @@ Everything below the class contract is hand-written HIP through the C ABI (pixel
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -97,6 +99,19 @@ class SeqRecCore(BaseModel):
         self._drop_dev = None              # device counter of completed backward passes (dropout seed offset)
         self.group_weight_grads = True     # all weight/bias gradients of a backward pass in one grouped GEMM launch
         self.overlap_weight_grads = False  # alternative: per-layer launches on a side HIP stream
+        # WHERE the grouped weight-gradient launches go (group_weight_grads only):
+        #   "grouped"    one launch on the main stream after the input-gradient chain;
+        #   "fork_layer" one launch per layer on a side stream as soon as the layer's dqkv exists: its tiles co-run with
+        #                the input-gradient chain of the layers below, whose 400-1200-tile GEMMs leave ~half of the
+        #                MFMA pipe idle (grid quantisation on 256 CUs);
+        #   "fork_half"  two launches per layer (FFN pair after du, attention pair after dqkv): starts earlier.
+        # In a captured step graph the side stream becomes a parallel branch of the graph.
+        self.weight_grad_mode = os.environ.get("PXR_DW_MODE", "fork_layer")
+        # leave the join with the side stream to the first consumer of the flat gradient (wait_flat_grads(): PxrAdamW.step,
+        # clip_grad_norm_, GradSync.sync) instead of the end of backward(): the sparse-row update of the optimizer then
+        # also runs beside the weight-gradient GEMMs.  Opt-in (GraphedTrainStep / Trainer / bench.py set it): code that
+        # reads p.grad right after backward() must not race with the side stream.
+        self.defer_weight_grad_join = False
         self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
         self._step_counter = 0
 
@@ -175,9 +190,23 @@ class SeqRecCore(BaseModel):
 
     _flat_grad_waits = ()   # handles of an in-flight all-reduce of the flat gradient (parallel.GradSync, defer_flat)
 
+    _dw_join = None         # side stream still computing weight gradients (defer_weight_grad_join)
+    _dw_keep = None         # their operands, kept alive until the join is enqueued
+
+    def join_weight_grads(self):
+        """Make the current stream wait for weight-gradient GEMMs still running on the side stream (no-op otherwise)."""
+        side, self._dw_join = self._dw_join, None
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        # the operands of the side-stream launches may be recycled by the allocator only now: whatever reuses their
+        # memory on this stream is ordered behind the join
+        self._dw_keep = None
+
     def wait_flat_grads(self):
-        """Make the current stream wait for a deferred all-reduce of the flat gradient buffer (no-op otherwise).
-        Every consumer of the reduced flat gradient calls this first: PxrAdamW.step, clip_grad_norm_."""
+        """Make the current stream wait for everything that still writes the flat gradient buffer: weight-gradient GEMMs
+        on the side stream and a deferred all-reduce (no-op otherwise).  Every consumer of the flat gradient calls this
+        first: PxrAdamW.step, clip_grad_norm_."""
+        self.join_weight_grads()
         waits, self._flat_grad_waits = self._flat_grad_waits, ()
         for h in waits:
             h.wait()
@@ -261,6 +290,23 @@ class SeqRecCore(BaseModel):
             if side is None or side.device != main.device:
                 side = self._side_stream = torch.cuda.Stream(device=main.device)
         pending = []
+        fork = self.group_weight_grads and self.weight_grad_mode in ("fork_layer", "fork_half")
+        if fork:
+            side = self._side_stream
+            if side is None or side.device != main.device:
+                side = self._side_stream = torch.cuda.Stream(device=main.device)
+        forked = []   # operands of launches already issued on the side stream: kept alive until the join is enqueued
+
+        def fork_pending():
+            """Launch the collected (dY, X) pairs on the side stream, behind everything issued so far on `main`."""
+            if not pending:
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.grouped_linear_bwd_weight(pending)
+            forked.extend(pending)
+            pending.clear()
+
         defer = ops.DeferredReductions()   # second stage of every LayerNorm dgamma|dbeta / pos-emb reduction: one launch
 
         def weight_grads(dy2d, x2d, w_name, b_name, span=1):
@@ -288,6 +334,8 @@ class SeqRecCore(BaseModel):
             weight_grads(dxf2.view(T, D), a["f"].view(T, -1), f"{i}.f2.w", f"{i}.f2.b")
             du = ops.linear_bwd_input(dxf2, self._p(f"{i}.f2.w"), mul=a["u"])      # a["u"] holds gelu'(pre-activation)
             weight_grads(du.view(T, -1), a["h1"].view(T, D), f"{i}.f1.w", f"{i}.f1.b")
+            if fork and self.weight_grad_mode == "fork_half":
+                fork_pending()
             dh1 = ops.linear_bwd_input(du, self._p(f"{i}.f1.w"), add=dz2)
             # attention block: h1 = LN(dropout(a) + h)
             dz1, dxa = ops.ln_bwd(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
@@ -298,6 +346,8 @@ class SeqRecCore(BaseModel):
             dctx = ops.linear_bwd_input(dxa, self._p(f"{i}.o.w"))
             dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv)
             weight_grads(dqkv.view(T, 3 * D), a["h_in"].view(T, D), f"{i}.q.w", f"{i}.q.b", 3)
+            if fork:
+                fork_pending()
             dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1)
         dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,
                             step_dev=sdv, defer=defer)
@@ -310,6 +360,10 @@ class SeqRecCore(BaseModel):
             ops.grouped_linear_bwd_weight(pending)
         if use_side:
             main.wait_stream(side)
+        if fork:
+            self._dw_join, self._dw_keep = side, forked
+            if not self.defer_weight_grad_join:
+                self.join_weight_grads()
         self._saved = None
         if not bumped:
             ops.counter_add(self._drop_dev, 1)

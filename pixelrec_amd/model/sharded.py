@@ -202,6 +202,9 @@ class ShardedGradSync(GradSync):
             view = self._local_view = ops.SparseRows.__new__(ops.SparseRows)
             view.cap = sp.cap
         view.idx, view.rows, view.n = loc, sp.rows, sp.n
+        # the merged GLOBAL ids: what is "live" in the dense gradient the reference clips (clip_grad_norm_ must see the
+        # same rows on every rank, not only the owned ones)
+        view.gidx = sp.idx
         if not self.active:                   # single rank: slots beyond n hold stale ids -> make them skip
             ar = torch.arange(sp.cap, device=loc.device, dtype=torch.int32)
             view.idx = torch.where(ar < sp.n, loc, 0)

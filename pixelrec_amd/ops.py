@@ -47,7 +47,9 @@ class Workspace:
 
 _ws = Workspace()
 
-# bench.py: set to a list to collect (start_event, end_event, flops) around every fp32-MFMA GEMM launch
+# bench.py: set to a list to collect (start_event, end_event, work, tag) around kernel launches: every fp32-MFMA GEMM
+# launch (work = flops) and the tagged HBM-side kernels (lazy AdamW rows, fused gather+LN, dense table sweep; work =
+# algorithmic bytes, 0 when it is data dependent).  Events are recorded on the stream the kernel is launched on.
 GEMM_TIMING = None
 
 
@@ -202,9 +204,12 @@ def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.
     y = torch.empty(B, L, D, dtype=torch.float32, device=table.device)
     xhat = torch.empty_like(y) if save else None
     rstd = torch.empty(B * L, dtype=torch.float32, device=table.device) if save else None
-    _l.check(Lb.pxr_input_ln_fwd_f32(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
-                                     _l.ptr(beta), eps, B, L, D, _l.ptr(y), _l.ptr(xhat), _l.ptr(rstd), p_drop, seed,
-                                     stream_id, _l.ptr(step_dev), _l.stream_ptr()), "pxr_input_ln_fwd_f32")
+    # algorithmic bytes: B*L table rows read once + y (+ xhat when saved) written; the [B,2,L+1,D] gather of the
+    # reference never exists (SURVEY.md §8d "fused" rule)
+    with _gemm_timer(4.0 * B * L * D * (3 if save else 2), "ln_fwd_kernel<GATHER> (gather + pos + LN + dropout)"):
+        _l.check(Lb.pxr_input_ln_fwd_f32(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
+                                         _l.ptr(beta), eps, B, L, D, _l.ptr(y), _l.ptr(xhat), _l.ptr(rstd), p_drop,
+                                         seed, stream_id, _l.ptr(step_dev), _l.stream_ptr()), "pxr_input_ln_fwd_f32")
     return y, xhat, rstd
 
 
@@ -573,10 +578,11 @@ def adamw_table(table, m, v, slot, sp: SparseRows | None, lr, beta1, beta2, eps,
     _req(table, torch.float32, "table"); _req(m, torch.float32, "m"); _req(v, torch.float32, "v")
     _req(slot, torch.int32, "slot")
     N, D = table.shape
-    _l.check(Lb.pxr_adamw_table_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), N, D, _l.ptr(slot),
-                                    _l.ptr(sp.idx) if sp else None, _l.ptr(sp.rows) if sp else None,
-                                    _l.ptr(sp.n) if sp else None, sp.cap if sp else 0, lr, beta1, beta2, eps,
-                                    weight_decay, step, _l.stream_ptr()), "pxr_adamw_table_f32")
+    with _gemm_timer(24.0 * N * D + 4.0 * N, "adamw_table_kernel (dense sweep)"):
+        _l.check(Lb.pxr_adamw_table_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), N, D, _l.ptr(slot),
+                                        _l.ptr(sp.idx) if sp else None, _l.ptr(sp.rows) if sp else None,
+                                        _l.ptr(sp.n) if sp else None, sp.cap if sp else 0, lr, beta1, beta2, eps,
+                                        weight_decay, step, _l.stream_ptr()), "pxr_adamw_table_f32")
 
 
 def adamw_hyper_append(hyper, cumlog, step, lr, beta1, beta2, eps, weight_decay, step_dev=None, advance=False):
@@ -594,9 +600,13 @@ def adamw_rows(table, m, v, last, hyper, cumlog, t_prev, t_apply, beta1, beta2, 
     step_dev (device int64 counter of completed steps) overrides t_prev / t_apply (hipGraph-replayable)."""
     Lb = _l.load()
     N, D = table.shape
-    _l.check(Lb.pxr_adamw_rows_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), _l.ptr(last), N, D, _l.ptr(rows),
-                                   _l.ptr(n_rows), max_rows, _l.ptr(grows), _l.ptr(hyper), _l.ptr(cumlog), t_prev,
-                                   t_apply, _l.ptr(step_dev), beta1, beta2, eps, _l.stream_ptr()), "pxr_adamw_rows_f32")
+    tag = ("adamw_rows_kernel (flush: every row)" if rows is None else
+           "adamw_rows_kernel (apply: batch rows + gradient)" if t_apply else "adamw_rows_kernel (catch-up: batch rows)")
+    with _gemm_timer(0.0, tag):
+        _l.check(Lb.pxr_adamw_rows_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), _l.ptr(last), N, D, _l.ptr(rows),
+                                       _l.ptr(n_rows), max_rows, _l.ptr(grows), _l.ptr(hyper), _l.ptr(cumlog), t_prev,
+                                       t_apply, _l.ptr(step_dev), beta1, beta2, eps, _l.stream_ptr()),
+                 "pxr_adamw_rows_f32")
 
 
 def adamw_flat_tab(p, g, m, v, hyper, step, beta1, beta2, eps, step_dev=None):

@@ -170,7 +170,10 @@ def clip_grad_norm_(model, max_norm, norm_type=2.0, **_ignored):
     live = None
     if sp is not None:
         ar = torch.arange(sp.rows.shape[0], device=sp.rows.device, dtype=torch.int32)
-        live = ((ar < sp.n) & (sp.idx > 0)).unsqueeze(1)          # slots beyond n / empty slots of a merged list
+        # slots beyond n / empty slots of a merged list are not rows.  A row-sharded model re-indexes sp.idx to the rows
+        # THIS rank owns (0 elsewhere): the norm is over the merged global list (sp.gidx), identical on every rank
+        ids = getattr(sp, "gidx", sp.idx)
+        live = ((ar < sp.n) & (ids > 0)).unsqueeze(1)
         sq = sq + torch.where(live, sp.rows, 0.0).pow(2).sum()
     extra = [p.grad for n, p in model.named_parameters() if "visual_encoder" in n and p.grad is not None]
     for g in extra:

@@ -135,6 +135,8 @@ class GradSync:
         -- W times one rank's rows, the part of the step that grows with the world size."""
         if not self.active:
             return
+        if hasattr(self.model, "join_weight_grads"):
+            self.model.join_weight_grads()      # weight-gradient GEMMs forked onto the side stream write gflat
         _, gflat = self.model.flat_parameters()
         flat_wait = dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         waits = []

@@ -103,6 +103,9 @@ class Trainer:
         sharded = getattr(model.module, "_sharded", False)      # collectives inside forward: issued eagerly
         self.use_graph = (g is None or bool(g)) and self.world == 1 and not self.use_modality and not sharded
         self._gstep = None
+        # every training step ends in optimizer.step(), which joins the weight-gradient side stream itself
+        if hasattr(model.module, "defer_weight_grad_join"):
+            model.module.defer_weight_grad_join = True
 
     # ---------------------------------------------------------------------------------------------- optimizer
     def _build_optimizer(self):
