@@ -274,7 +274,7 @@ def main():
         for j in range(8):
             ids = torch.unique(pool[(cursor[0] + j) % len(pool)][0])
             ids = ids[ids > 0]
-            g_all.append((opt.step_count + j - opt._last[ids].long()).clamp_(min=0).float())
+            g_all.append((opt.step_count - opt._last[ids].long()).clamp_(min=0).float())
         gaps = torch.cat(g_all)
         qs = torch.quantile(gaps, torch.tensor([0.5, 0.9, 0.99], device=dev)).tolist()
         lazy_gaps = {"unique_rows_per_step": gaps.numel() / 8.0, "mean": float(gaps.mean()), "p50": qs[0], "p90": qs[1],
