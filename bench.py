@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--table-update", choices=("lazy", "dense"), default="lazy",
                     help="table AdamW schedule (dense = sweep all rows every step; eager only)")
     ap.add_argument("--dw-mode", default=None, help="weight-gradient placement: grouped | fork_layer | fork_half")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="do not hand the next batch's ids to the model (no look-ahead catch-up of its table rows)")
     ap.add_argument("--emb", type=int, default=NS["D"], help="embedding size (default: the north-star 512)")
     ap.add_argument("--heads", type=int, default=NS["H"])
     ap.add_argument("--items", type=int, default=NS["n_items"], help="catalogue size incl. the padding id")
@@ -197,7 +199,7 @@ def main():
     if use_graph:
         from pixelrec_amd.graph import GraphedTrainStep
 
-        gstep = GraphedTrainStep(dp, opt, *pool[0])
+        gstep = GraphedTrainStep(dp, opt, *pool[0], lookahead=not args.no_lookahead)
 
     one = torch.ones((), dtype=torch.float32, device=dev)
     cursor = [0]          # position in the batch stream: every step of every phase consumes the NEXT batch
@@ -207,8 +209,14 @@ def main():
         cursor[0] += 1
         return b
 
-    def eager_step(batch):
+    def peek_items():
+        """ids of the batch AFTER the one just handed out (the look-ahead a data loader's prefetch queue provides)."""
+        return None if args.no_lookahead else pool[cursor[0] % len(pool)][0]
+
+    def eager_step(batch, nxt=None):
         opt.zero_grad()
+        if nxt is not None and hasattr(model, "set_next_batch"):
+            model.set_next_batch(nxt)
         loss = dp(batch)
         loss.backward(one)       # preallocated d(loss)/d(loss): no ones_like fill per step
         dp.sync_gradients(defer_flat=True)
@@ -216,16 +224,22 @@ def main():
         return loss
 
     def step(i=None, record=False):
+        b = next_batch()
         if gstep is not None:
-            return gstep(*next_batch())
-        return eager_step(next_batch())
+            return gstep(*b, next_items=peek_items())
+        return eager_step(b, peek_items())
+
+    def step_e():
+        b = next_batch()
+        return eager_step(b, peek_items())
 
     ref_ev = torch.cuda.Event(enable_timing=True)
 
     def instrumented_step(i=None):
         """Same step, eager, with HIP events around every GEMM launch (run AFTER the timed region)."""
         ops.GEMM_TIMING = gemm_events
-        loss = eager_step(next_batch())
+        b = next_batch()
+        loss = eager_step(b, peek_items())
         ops.GEMM_TIMING = None
         return loss
 
@@ -293,11 +307,11 @@ def main():
     t_eager = None
     if world == 1 and not args.no_extras:
         for _ in range(3):
-            eager_step(next_batch())
+            step_e()
         torch.cuda.synchronize()
         t_eager = time.perf_counter()
         for _ in range(20):
-            eager_step(next_batch())
+            step_e()
         torch.cuda.synchronize()
         t_eager = (time.perf_counter() - t_eager) / 20
 
@@ -406,15 +420,16 @@ def main():
         for Bt in (512, 2048):
             n_bt = 26 if Bt == 512 else 12     # distinct batches: warm-up + timed + instrumented steps never repeat one
             bt = [tuple(torch.from_numpy(a).to(dev) for a in synth.train_batch(N, Bt, L, rng, zipf)) for _ in range(n_bt)]
-            g2 = _G(dp, opt, *bt[0]) if use_graph else None
+            g2 = _G(dp, opt, *bt[0], lookahead=not args.no_lookahead) if use_graph else None
             cur = [0]
 
             def step_b(eager=False):
                 b = bt[cur[0] % n_bt]
                 cur[0] += 1
+                nxt = None if args.no_lookahead else bt[cur[0] % n_bt][0]
                 if g2 is not None and not eager:
-                    return g2(*b)
-                return eager_step(b)
+                    return g2(*b, next_items=nxt)
+                return eager_step(b, nxt)
 
             for i in range(3):
                 step_b()
@@ -501,6 +516,7 @@ def main():
                              "amortised_us_per_step": tf * 1e6 / steps_per_epoch,
                              "note": f"one flush per epoch of {steps_per_epoch} steps (Pixel200K users / {B}); every row "
                                      "is replayed <= 256 steps exactly + closed form"}
+        model.train()
         model._table_hooks = None
         opt_d = PxrAdamW(model, lr=1e-4, weight_decay=0.1, table_update="dense")
         model._table_hooks = None            # (dense: nothing to catch up before the forward)

@@ -41,6 +41,12 @@ const char* pxr_target_arch(void);     /* "gfx950" */
 int pxr_dropout_keep_host(uint64_t seed, uint32_t stream_id, uint64_t first_index, int64_t n, float p,
                           uint8_t* keep_out);
 
+/* Registers a caller-owned int32 in DEVICE memory as this process' status word (NULL unregisters).  Kernels that
+ * gather table rows by id (pxr_embed_gather_f32, pxr_input_ln_fwd_f32) OR bit 0 into it when an id lies outside
+ * [0, N) -- where the reference's nn.Embedding raises IndexError / a device-side assert (model/IDNet/sasrec.py:68) --
+ * and clamp the id; the host reads the word at its next synchronisation point and raises.  One process per GPU. */
+int pxr_set_status_word(int32_t* dev_word);
+
 /* ---- embedding table ---------------------------------------------------------------------------------------- */
 /* out[i,:] = table[idx[i],:]                       model/IDNet/sasrec.py:68,101; model/PixelNet/mosasrec.py:102 */
 int pxr_embed_gather_f32(const float* table, int64_t N, int D, const int64_t* idx, int64_t n, float* out,
@@ -218,15 +224,16 @@ int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_rows, int D,
  * (double[capacity]) hold each step's scalars, appended once per step.  pxr_adamw_rows_f32 replays a row's missed
  * zero-gradient steps (bit-identical to the sweep for gaps <= 256 steps, closed-form weight decay beyond) through
  * t_prev and, if t_apply = t_prev+1, applies that step with gradient rows grows[i,:].  rows == NULL: all N rows
- * (flush before evaluation / checkpointing).  hyper_append with advance != 0 is the end-of-step form: it first counts
+ * (flush before evaluation / checkpointing).  With step_dev the kernel takes t_prev = *step_dev + step_dev_bias from the
+ * device (bias 1 = "through the step being applied": the rows of the NEXT batch, prefetched).  hyper_append with advance != 0 is the end-of-step form: it first counts
  * the finished step (*step_dev += 1) and then appends the scalars of the next one, in one launch. */
 int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, int64_t* step_dev,
                            double lr, double beta1, double beta2, double eps, double weight_decay, int advance,
                            void* stream);
 int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D, const int64_t* rows,
                        const int32_t* n_rows_dev, int64_t max_rows, const float* grows, const void* hyper,
-                       const void* cumlog, int64_t t_prev, int64_t t_apply, const int64_t* step_dev, double beta1,
-                       double beta2, double eps, void* stream);
+                       const void* cumlog, int64_t t_prev, int64_t t_apply, const int64_t* step_dev,
+                       int64_t step_dev_bias, double beta1, double beta2, double eps, void* stream);
 /* pxr_adamw_flat_f32 with the step's scalars read from hyper[step] (or hyper[*step_dev + 1]). */
 int pxr_adamw_flat_tab_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper, int64_t step,
                            const int64_t* step_dev, double beta1, double beta2, double eps, void* stream);

@@ -160,25 +160,32 @@ struct RowsArgs {
   int t_prev, t_apply, D;
   float one_m_b1, b2, one_m_b2, eps, b1;
   const int64_t* step_dev;   // optional: t_prev = *step_dev (completed steps), t_apply = t_prev+1 if t_apply != 0
+  int t_prev_bias;           // added to *step_dev (1 = "through the step being applied right now": prefetched rows)
 };
 
-// One row is spread over LPR = ceil(D/4 / 64) * 64 lanes (one float4 per lane), so a row with a long gap is a chain of
-// 4 elements per lane instead of D/64: the kernel's duration is set by the longest replay in the batch (a Zipf-tail or
-// uniformly drawn negative id returns after hundreds of steps), not by the average.  All lanes of a row sit in ONE
+// One row is spread over LPR = ceil(D/EPL / 64) * 64 lanes (EPL = 2 or 4 elements per lane), so a row with a long gap is
+// a chain of EPL elements per lane instead of D/64: the kernel's duration is set by the longest replays in the batch (a
+// Zipf-tail or uniformly drawn negative id returns after hundreds of steps; measured on the aged bench stream: mean 80
+// replayed steps per row, 10 % of the rows at the 256-step cap), not by the average.  All lanes of a row sit in ONE
 // workgroup (block = max(256, LPR) threads = RPB rows): last[row] is read by every wave of the row at the top and
 // written by one lane after a barrier.  The replayed step number is wave-uniform (readfirstlane), so the per-step
-// scalars come through the scalar cache and the entry of step s+1 is fetched while step s is computed.
-template <int LPR>
+// scalars come through the scalar cache, four steps per request.
+template <int EPL> struct RowVec;
+template <> struct RowVec<2> { typedef float2 T; };
+template <> struct RowVec<4> { typedef float4 T; };
+
+template <int LPR, int EPL>
 __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(RowsArgs a,
                                                                                const float4* __restrict__ hyper) {
   constexpr int NT = LPR > 256 ? LPR : 256;
   constexpr int RPB = NT / LPR;
+  typedef typename RowVec<EPL>::T V;
   if (a.step_dev) {
-    a.t_prev = (int)a.step_dev[0];
+    a.t_prev = (int)a.step_dev[0] + a.t_prev_bias;
     if (a.t_apply) a.t_apply = a.t_prev + 1;
   }
   const int rib = threadIdx.x / LPR;            // row of this block's group
-  const int c = (threadIdx.x % LPR) * 4;        // first column of this lane's float4
+  const int c = (threadIdx.x % LPR) * EPL;      // first column of this lane's elements
   const bool col_ok = c < a.D;
   const int64_t n = a.rows ? (int64_t)(*a.n_rows) : a.n_fixed;
   const int64_t n_groups = (n + RPB - 1) / RPB;
@@ -199,12 +206,15 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
     work = __builtin_amdgcn_readfirstlane((int)work) != 0;
     k0 = __builtin_amdgcn_readfirstlane(k0);
     if (work) {
-      float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp;
+      float pe[EPL], me[EPL], ve[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) pe[e] = me[e] = ve[e] = 0.f;
       const int64_t o = row * a.D + c;
       if (col_ok) {
-        pp = *reinterpret_cast<const float4*>(a.p + o);
-        mm = *reinterpret_cast<const float4*>(a.m + o);
-        vv = *reinterpret_cast<const float4*>(a.v + o);
+        const V p4 = *reinterpret_cast<const V*>(a.p + o), m4 = *reinterpret_cast<const V*>(a.m + o),
+                v4 = *reinterpret_cast<const V*>(a.v + o);
+        pe[0] = p4.x; pe[1] = p4.y; me[0] = m4.x; me[1] = m4.y; ve[0] = v4.x; ve[1] = v4.y;
+        if constexpr (EPL == 4) { pe[2] = p4.z; pe[3] = p4.w; me[2] = m4.z; me[3] = m4.w; ve[2] = v4.z; ve[3] = v4.w; }
       }
       AdamHyper h;
       h.one_m_b1 = a.one_m_b1; h.b2 = a.b2; h.one_m_b2 = a.one_m_b2; h.eps = a.eps;
@@ -212,10 +222,10 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
       const int exact_end = min(a.t_prev, k0 + PXR_LAZY_EXACT);
       auto replay = [&](const float4 hs) {
         h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
-        adam_elem0(pp.x, mm.x, vv.x, h); adam_elem0(pp.y, mm.y, vv.y, h);
-        adam_elem0(pp.z, mm.z, vv.z, h); adam_elem0(pp.w, mm.w, vv.w, h);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) adam_elem0(pe[e], me[e], ve[e], h);
       };
-      // four steps per trip: their scalars are ONE scalar-cache request (64 B), waited for once
+      // four steps per trip: their scalars are ONE scalar-cache line (64 B), waited for once
       for (; s + 3 <= exact_end; s += 4) {
         const float4 h0 = hyper[s], h1 = hyper[s + 1], h2 = hyper[s + 2], h3 = hyper[s + 3];
         replay(h0); replay(h1); replay(h2); replay(h3);
@@ -226,22 +236,30 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
         const float fp = (float)exp(a.cumlog[a.t_prev] - a.cumlog[s - 1]);
         const float fm = (float)pow((double)a.b1, (double)rem);
         const float fv = (float)pow((double)a.b2, (double)rem);
-        pp.x *= fp; pp.y *= fp; pp.z *= fp; pp.w *= fp;
-        mm.x *= fm; mm.y *= fm; mm.z *= fm; mm.w *= fm;
-        vv.x *= fv; vv.y *= fv; vv.z *= fv; vv.w *= fv;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { pe[e] *= fp; me[e] *= fm; ve[e] *= fv; }
       }
       if (a.t_apply) {
         const float4 hs = hyper[a.t_apply];
         h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
-        const float4 g = (a.grows && col_ok) ? *reinterpret_cast<const float4*>(a.grows + i * a.D + c)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        adam_elem(pp.x, mm.x, vv.x, g.x, h); adam_elem(pp.y, mm.y, vv.y, g.y, h);
-        adam_elem(pp.z, mm.z, vv.z, g.z, h); adam_elem(pp.w, mm.w, vv.w, g.w, h);
+        float ge[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ge[e] = 0.f;
+        if (a.grows && col_ok) {
+          const V g4 = *reinterpret_cast<const V*>(a.grows + i * a.D + c);
+          ge[0] = g4.x; ge[1] = g4.y;
+          if constexpr (EPL == 4) { ge[2] = g4.z; ge[3] = g4.w; }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) adam_elem(pe[e], me[e], ve[e], ge[e], h);
       }
       if (col_ok) {
-        *reinterpret_cast<float4*>(a.p + o) = pp;
-        *reinterpret_cast<float4*>(a.m + o) = mm;
-        *reinterpret_cast<float4*>(a.v + o) = vv;
+        V p4, m4, v4;
+        p4.x = pe[0]; p4.y = pe[1]; m4.x = me[0]; m4.y = me[1]; v4.x = ve[0]; v4.y = ve[1];
+        if constexpr (EPL == 4) { p4.z = pe[2]; p4.w = pe[3]; m4.z = me[2]; m4.w = me[3]; v4.z = ve[2]; v4.w = ve[3]; }
+        *reinterpret_cast<V*>(a.p + o) = p4;
+        *reinterpret_cast<V*>(a.m + o) = m4;
+        *reinterpret_cast<V*>(a.v + o) = v4;
       }
     }
     if constexpr (LPR > 64) __syncthreads();   // every wave of the row has read last[row]
@@ -402,11 +420,14 @@ extern "C" int pxr_counter_add_i64(int64_t* counter, int64_t delta, void* stream
 // Brings rows up to date through step t_prev (replaying their missed zero-gradient steps) and, if t_apply != 0,
 // applies step t_apply with gradient rows grows[i,:] (row i of the list).  rows == NULL: every row of the table
 // (flush; n_rows_dev ignored).  last: int32[N] "up to date through" step per row.  step_dev != NULL: t_prev is read
-// from the device counter (and t_apply = t_prev + 1 when t_apply != 0), which makes the call hipGraph-replayable.
+// from the device counter, t_prev = *step_dev + step_dev_bias (and t_apply = t_prev + 1 when t_apply != 0), which makes
+// the call hipGraph-replayable.  step_dev_bias = 1 brings rows current through the step that is being applied right
+// now (its scalars are in the table): used for the rows of the NEXT batch, so that its forward finds them current.
 extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D,
                                   const int64_t* rows, const int32_t* n_rows_dev, int64_t max_rows, const float* grows,
                                   const void* hyper, const void* cumlog, int64_t t_prev, int64_t t_apply,
-                                  const int64_t* step_dev, double beta1, double beta2, double eps, void* stream) {
+                                  const int64_t* step_dev, int64_t step_dev_bias, double beta1, double beta2,
+                                  double eps, void* stream) {
   PXR_REQUIRE(table && m && v && last && hyper && cumlog, "pxr_adamw_rows_f32: null pointer");
   PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 4096, "pxr_adamw_rows_f32: bad shape (D <= 4096)");
   PXR_REQUIRE(!rows || n_rows_dev, "pxr_adamw_rows_f32: row list needs its device count");
@@ -418,21 +439,28 @@ extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* las
   a.one_m_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_m_b2 = (float)(1.0 - beta2); a.eps = (float)eps;
   a.b1 = (float)beta1;
   a.step_dev = step_dev;
+  a.t_prev_bias = (int)step_dev_bias;
   const int64_t work = rows ? max_rows : n_table;
   if (work <= 0) return PXR_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int lpr = ((D / 4 + 63) / 64) * 64;          // lanes per row: one float4 per lane
+  // 2 elements per lane up to D = 2048 (a 512-wide row = 4 waves), 4 beyond (block size caps at 1024 threads)
+  const int epl = D <= 2048 ? 2 : 4;
+  const int lpr = ((D / epl + 63) / 64) * 64;          // lanes per row
   const int tl = lpr <= 64 ? 64 : (lpr <= 128 ? 128 : (lpr <= 256 ? 256 : (lpr <= 512 ? 512 : 1024)));
   const int rpb = tl >= 256 ? 1 : 256 / tl;          // == the kernel's RPB
   int64_t blocks = (work + rpb - 1) / rpb;
   if (blocks > 256 * 64) blocks = 256 * 64;
-#define PXR_ROWS_CASE(L_) hipLaunchKernelGGL((adamw_rows_kernel<L_>), dim3((unsigned)blocks), dim3(L_ > 256 ? L_ : 256), 0, st, a, a.hyper)
-  switch (tl) {
-    case 64: PXR_ROWS_CASE(64); break;
-    case 128: PXR_ROWS_CASE(128); break;
-    case 256: PXR_ROWS_CASE(256); break;
-    case 512: PXR_ROWS_CASE(512); break;
-    default: PXR_ROWS_CASE(1024); break;
+#define PXR_ROWS_CASE(L_, E_) hipLaunchKernelGGL((adamw_rows_kernel<L_, E_>), dim3((unsigned)blocks), dim3(L_ > 256 ? L_ : 256), 0, st, a, a.hyper)
+  if (epl == 2) {
+    switch (tl) {
+      case 64: PXR_ROWS_CASE(64, 2); break;
+      case 128: PXR_ROWS_CASE(128, 2); break;
+      case 256: PXR_ROWS_CASE(256, 2); break;
+      case 512: PXR_ROWS_CASE(512, 2); break;
+      default: PXR_ROWS_CASE(1024, 2); break;
+    }
+  } else {
+    if (tl <= 512) PXR_ROWS_CASE(512, 4); else PXR_ROWS_CASE(1024, 4);
   }
 #undef PXR_ROWS_CASE
   return pxr_check_launch("pxr_adamw_rows_f32");

@@ -13,7 +13,17 @@ void pxr_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int pxr_version(void) { return 100; }  // major*10000 + minor*100 + patch
+// Device status word (caller-owned int32 in device memory, one process per GPU): the gather kernels OR bit 0 into it
+// when they meet an id outside [0, N) -- the device-side counterpart of the IndexError / device assert that
+// nn.Embedding raises in the reference (sasrec.py:68) -- and then clamp the id so the access itself stays in bounds.
+static int32_t* g_status_word = nullptr;
+int32_t* pxr_status_word(void) { return g_status_word; }
+extern "C" int pxr_set_status_word(int32_t* dev_word) {
+  g_status_word = dev_word;
+  return PXR_OK;
+}
+
+extern "C" int pxr_version(void) { return 200; }  // major*10000 + minor*100 + patch
 extern "C" const char* pxr_last_error(void) { return g_err; }
 extern "C" const char* pxr_target_arch(void) { return "gfx950"; }
 

@@ -18,7 +18,7 @@ template <int U, int NT>
 __global__ void __launch_bounds__(256) embed_gather_kernel(const gvec4* __restrict__ table,
                                                            const int64_t* __restrict__ idx,
                                                            gvec4* __restrict__ out, int64_t total_chunks,
-                                                           int dv, int64_t n_rows_table) {
+                                                           int dv, int64_t n_rows_table, int32_t* status) {
   const int64_t base = ((int64_t)blockIdx.x * U) * 256 + threadIdx.x;
   gvec4 v[U];
 #pragma unroll
@@ -28,8 +28,12 @@ __global__ void __launch_bounds__(256) embed_gather_kernel(const gvec4* __restri
       const int64_t row = c / dv;
       const int col = (int)(c - row * dv);
       int64_t r = idx[row];
-      // out-of-range ids would fault; clamp (the host wrapper validates ids when PXR_CHECK_INDICES=1)
-      r = r < 0 ? 0 : (r >= n_rows_table ? n_rows_table - 1 : r);
+      // an out-of-range id is an ERROR (nn.Embedding raises, sasrec.py:68): flag it in the device status word -- the
+      // host raises IndexError at its next check (ops.raise_on_bad_indices) -- and clamp so the access stays in bounds
+      if (r < 0 || r >= n_rows_table) {
+        if (status && col == 0) atomicOr(status, PXR_STATUS_BAD_INDEX);
+        r = r < 0 ? 0 : n_rows_table - 1;
+      }
       if constexpr (NT & 1) v[u] = __builtin_nontemporal_load(&table[r * dv + col]);
       else v[u] = table[r * dv + col];
     }
@@ -60,7 +64,7 @@ extern "C" int pxr_embed_gather_f32(const float* table, int64_t N, int D, const 
   PXR_REQUIRE(blocks < (1ll << 31), "pxr_embed_gather_f32: too many rows");
 #define PXR_GATHER_LAUNCH(UU, NN)                                                                                  \
   hipLaunchKernelGGL((embed_gather_kernel<UU, NN>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,     \
-                     (const gvec4*)table, idx, (gvec4*)out, total, dv, N)
+                     (const gvec4*)table, idx, (gvec4*)out, total, dv, N, pxr_status_word())
   switch (variant) {
     case 0: PXR_GATHER_LAUNCH(4, 0); break;
     case 1: PXR_GATHER_LAUNCH(4, 1); break;

@@ -25,12 +25,17 @@ __global__ void __launch_bounds__((GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT))
 gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
             float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
             float* __restrict__ aux, int64_t ldaux, int tiles_m, int tiles_n, int ksplit_len,
-            int64_t split_stride) {
+            int64_t split_stride, int n_fastest) {
   using Cfg = GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>;
   __shared__ __attribute__((aligned(16))) float smem[ST * Cfg::STAGE];
 
+  // Each XCD (private 4 MB L2) works on one contiguous chunk of the tile sequence, so the ORDER of that sequence decides
+  // what every XCD pulls over the fabric: m fastest => an XCD owns whole B panels and streams ALL of A (8|A| + |B| in
+  // total: right for the scoring GEMM, 1024 users x 400 K table rows); n fastest => an XCD owns a band of A rows and
+  // reads all of B (|A| + 8|B|: right for the training step, where A = 3200 tokens x K is 2-6x larger than the weight.
+  // PMC FETCH_SIZE of the dX GEMM [3200,1536]x[1536,512]: 137 MB with m fastest vs 29 MB algorithmic).
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = t % tiles_m, tn = t / tiles_m;  // m fastest: blocks sharing a B panel are neighbours on one XCD
+  const int tm = n_fastest ? t / tiles_n : t % tiles_m, tn = n_fastest ? t % tiles_n : t / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = blockIdx.y * ksplit_len;
   const int kend = min(K, kbeg + ksplit_len);
@@ -199,9 +204,11 @@ static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb,
                        int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
                        int64_t split_stride, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  static const int xcd_env = getenv("PXR_GEMM_XCD") ? atoi(getenv("PXR_GEMM_XCD")) : -1;   // A/B knob: 0 = m fastest, 1 = n
+  const int n_fastest = xcd_env >= 0 ? xcd_env : (M > N ? 1 : 0);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD, ST, FINE>), dim3(tiles_m * tiles_n, splits),
                      dim3(GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
-                     tiles_n, ksplit_len, split_stride);
+                     tiles_n, ksplit_len, split_stride, n_fastest);
   return pxr_check_launch("pxr_gemm_f32");
 }
 

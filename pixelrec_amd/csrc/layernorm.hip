@@ -36,6 +36,7 @@ struct LnFwdArgs {
   uint32_t stream;
   uint64_t seed;
   const int64_t* step_dev;  // optional device counter added to the seed (hipGraph replays advance it on the device)
+  int32_t* status;          // GATHER: device status word (bad-index flag) or null
 };
 
 template <int VEC, bool GATHER>
@@ -53,7 +54,10 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
   if constexpr (GATHER) {
     const int b = row / a.L, t = row - b * a.L;
     int64_t r = a.idx[(int64_t)b * a.idx_bstride + t];
-    r = r < 0 ? 0 : (r >= a.n_table ? a.n_table - 1 : r);
+    if (r < 0 || r >= a.n_table) {   // an error in the reference (nn.Embedding raises): flag it, then clamp
+      if (a.status && lane == 0) atomicOr(a.status, PXR_STATUS_BAD_INDEX);
+      r = r < 0 ? 0 : a.n_table - 1;
+    }
     src = a.table + r * D;
     add = a.pos + (int64_t)t * D;
   } else {
@@ -306,6 +310,7 @@ extern "C" int pxr_input_ln_fwd_f32(const float* table, int64_t n_table, const i
   LnFwdArgs a{};
   a.table = table; a.idx = idx; a.pos = pos; a.gamma = gamma; a.beta = beta; a.y = y; a.xhat = xhat; a.rstd = rstd;
   a.idx_bstride = idx_bstride; a.n_table = n_table; a.rows = B * L; a.D = D; a.L = L; a.eps = eps;
+  a.status = pxr_status_word();
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
   return launch_ln_fwd<true>(a, (hipStream_t)stream);

@@ -23,6 +23,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // and the main thread do not clobber each other.
 void pxr_set_error(const char* fmt, ...);
 
+// Device status word registered with pxr_set_status_word (null when none): see api.cpp.  PXR_STATUS_BAD_INDEX is set
+// by kernels that met an embedding id outside the table.
+int32_t* pxr_status_word(void);
+#define PXR_STATUS_BAD_INDEX 1
+
 static inline int pxr_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

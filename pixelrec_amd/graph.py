@@ -14,7 +14,8 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, dp_model, optimizer, items, masked_index, warmup=3, clip_grad_norm=None, loss_sum=None):
+    def __init__(self, dp_model, optimizer, items, masked_index, warmup=3, clip_grad_norm=None, loss_sum=None,
+                 lookahead=True):
         self.dp, self.opt = dp_model, optimizer
         self.loss_sum = loss_sum          # optional 0-dim device tensor: every replay adds its loss (epoch totals
                                           # without an eager add per step)
@@ -25,6 +26,9 @@ class GraphedTrainStep:
         self.model.defer_weight_grad_join = True
         self.items = items.clone()
         self.mask = masked_index.clone()
+        # look-ahead: the NEXT batch's ids (SASRec.set_next_batch) -- its table rows are caught up beside this step's
+        # GEMMs.  Without a next batch the buffer holds this batch again (nothing left to replay: two light launches).
+        self.items_next = items.clone() if (lookahead and hasattr(self.model, "set_next_batch")) else None
         self._one = torch.ones((), dtype=torch.float32, device=items.device)   # d(loss)/d(loss): no fill kernel per step
         cur = torch.cuda.current_stream()
         s = torch.cuda.Stream()
@@ -73,6 +77,8 @@ class GraphedTrainStep:
 
     def _eager(self):
         self.opt.zero_grad()
+        if self.items_next is not None:
+            self.model.set_next_batch(self.items_next)
         loss = self.dp((self.items, self.mask))
         loss.backward(self._one)
         if self.loss_sum is not None:
@@ -89,9 +95,12 @@ class GraphedTrainStep:
     def matches(self, items, masked_index) -> bool:
         return items.shape == self.items.shape and masked_index.shape == self.mask.shape
 
-    def __call__(self, items, masked_index):
+    def __call__(self, items, masked_index, next_items=None):
         self.items.copy_(items, non_blocking=True)
         self.mask.copy_(masked_index, non_blocking=True)
+        if self.items_next is not None:
+            nxt = next_items if (next_items is not None and next_items.shape == self.items.shape) else items
+            self.items_next.copy_(nxt, non_blocking=True)
         self.graph.replay()
         self.opt.step_count += 1
         self.opt._dirty = True

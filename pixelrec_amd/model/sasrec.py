@@ -48,6 +48,13 @@ class SASRec(SeqRecCore):
         self._local_sparse = None       # reusable output buffer of this rank's backward
         self._table_hooks = None        # the lazy optimizer (catch_up_rows / flush) when one is attached
         self._occ_ws = None             # persistent workspace carrying the sorted occurrences fwd -> bwd
+        # look-ahead for a lazy table optimizer: the ids of the NEXT batch (set_next_batch).  Their rows are brought up to
+        # date on a side stream while this step's GEMMs run (MFMA pipe) instead of at the head of the next step
+        self._next_items = None
+        self._next_sparse = None        # unique ids of the next batch (own buffers: the current batch's are in use)
+        self._next_ws = None
+        self._prefetched = None         # (SparseRows of the next batch) the optimizer advances through the current step
+        self._prefetch_stream = None
 
     # state_dict key order of the reference: item_embedding first (sasrec.py:31-45); register order above differs only
     # in position, which load_state_dict does not care about.
@@ -55,6 +62,39 @@ class SASRec(SeqRecCore):
     def register_table_hooks(self, opt):
         """Attach a lazy table optimizer: it is asked to bring rows up to date before they are read."""
         self._table_hooks = opt
+
+    def set_next_batch(self, items_next):
+        """Optional look-ahead (lazy table optimizer only): `items_next` int64 [B,2,L+1] on the device = the batch the
+        NEXT forward will see.  Consumed by the next training forward.  Purely a schedule hint: the step computes the
+        same bits with or without it (rows are caught up exactly either way), the next step just starts faster."""
+        self._next_items = items_next
+
+    def _start_prefetch(self, items_next):
+        """Sort the next batch's ids and replay their rows' missed steps on a side stream (must be issued AFTER this
+        batch's own catch-up: a row in both batches is then already current and is skipped, not raced for)."""
+        B, _, W = items_next.shape
+        L = W - 1
+        cap = B * (2 * L + 1)
+        sp = self._next_sparse
+        if sp is None or sp.cap != cap or sp.idx.device != items_next.device:
+            sp = self._next_sparse = ops.SparseRows(cap, 1, items_next.device)   # ids + count only (rows unused)
+        need = ops.occ_ws_bytes(B, L)
+        if self._next_ws is None or self._next_ws.numel() < need or self._next_ws.device != items_next.device:
+            self._next_ws = torch.empty(need, dtype=torch.uint8, device=items_next.device)
+        main = torch.cuda.current_stream()
+        side = self._prefetch_stream
+        if side is None or side.device != main.device:
+            side = self._prefetch_stream = torch.cuda.Stream(device=main.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.sasrec_occ_sort(items_next, self.item_num, sp, self._next_ws)
+            self._table_hooks.catch_up_rows(sp.idx, sp.n, sp.cap)
+        self._prefetched = sp
+
+    def join_prefetch(self):
+        """Order the current stream behind the look-ahead catch-up (the optimizer calls this before it touches rows)."""
+        if self._prefetched is not None and self._prefetch_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._prefetch_stream)
 
     def sync_table(self):
         """Make every table row current (no-op without a lazy optimizer).  Called before the table is read as a
@@ -91,6 +131,9 @@ class SASRec(SeqRecCore):
             ops.sasrec_occ_sort(items, self.item_num, sp, self._occ_ws)
             if self._table_hooks is not None:
                 self._table_hooks.catch_up_rows(sp.idx, sp.n, sp.cap)
+                nxt, self._next_items = self._next_items, None
+                if nxt is not None and getattr(self._table_hooks, "table_update", None) == "lazy":
+                    self._start_prefetch(nxt.contiguous())
         elif self._table_hooks is not None:
             self.sync_table()
         return self._forward_core(self.item_embedding.weight.data, items, masked_index, self.training)
@@ -145,6 +188,7 @@ class SASRec(SeqRecCore):
         N = feat.shape[0]
         scores = torch.empty(B, N, dtype=torch.float32, device=out.device)
         ops.gemm(True, True, B, N, D, last, L * D, feat, D, scores, N, ops.EPI_NONE, use_ws=False)
+        ops.raise_on_bad_indices(out.device)     # an id outside the catalogue raises, like nn.Embedding (sasrec.py:101)
         return scores
 
     @torch.no_grad()

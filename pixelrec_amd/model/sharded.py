@@ -237,6 +237,10 @@ def optimizer_state_full(opt, model: ShardedSASRec) -> dict:
 
 def load_optimizer_state_full(opt, model: ShardedSASRec, sd: dict):
     """Inverse of optimizer_state_full: keeps this rank's rows of the full moments."""
+    from ..optim import is_torch_adamw_state, torch_to_native_state
+
+    if is_torch_adamw_state(sd):          # a reference-layout checkpoint: per-parameter state -> flat buffers first
+        sd = torch_to_native_state(sd, model)
     sd = dict(sd)
     dev = model.item_embedding.weight.device
     for k in ("table_m", "table_v"):

@@ -70,6 +70,32 @@ class _gemm_timer:
             GEMM_TIMING.append((self.ev[0], self.ev[1], self.flops, self.tag))
 
 
+# ------------------------------------------------------------------------------------------------ bad-index flag
+_status = {}
+
+
+def device_status(device=None) -> torch.Tensor:
+    """The int32 device status word of this process' GPU (created and registered with the library on first use)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    t = _status.get(dev.index)
+    if t is None:
+        t = _status[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+        _l.check(_l.load().pxr_set_status_word(_l.ptr(t)), "pxr_set_status_word")
+    return t
+
+
+def raise_on_bad_indices(device=None):
+    """Host check of the status word (synchronises): IndexError if a gather kernel met an item id outside the table
+    since the last check -- what nn.Embedding raises in the reference (sasrec.py:68).  Called where the host
+    synchronises anyway: once per training epoch (with the loss), after predict / evaluate, by embed_gather under
+    PXR_CHECK_INDICES=1."""
+    t = device_status(device)
+    v = int(t.item())
+    if v & 1:
+        t.zero_()
+        raise IndexError("index out of range in self (an item id outside [0, item_num) reached an embedding gather)")
+
+
 # ------------------------------------------------------------------------------------------------ K1 gather
 def embed_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """out[..., :] = table[idx[...], :]  (reference: nn.Embedding forward, sasrec.py:68,101)."""
@@ -77,13 +103,12 @@ def embed_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _req(table, torch.float32, "table")
     _req(idx, torch.int64, "idx")
     N, D = table.shape
-    if _CHECK_IDX and idx.numel():
-        lo, hi = int(idx.min()), int(idx.max())
-        if lo < 0 or hi >= N:
-            raise IndexError(f"index out of range in embed_gather: [{lo}, {hi}] vs N={N}")
+    device_status(table.device)       # out-of-range ids are flagged on the device (and clamped), raised at the next check
     out = torch.empty(*idx.shape, D, dtype=torch.float32, device=table.device)
     _l.check(L.pxr_embed_gather_f32(_l.ptr(table), N, D, _l.ptr(idx), idx.numel(), _l.ptr(out), _l.stream_ptr()),
              "pxr_embed_gather_f32")
+    if _CHECK_IDX:
+        raise_on_bad_indices(table.device)
     return out
 
 
@@ -201,6 +226,7 @@ def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.
     Lb = _l.load()
     _req(table, torch.float32, "table"); _req(idx, torch.int64, "idx", contiguous=False)
     N, D = table.shape
+    device_status(table.device)
     y = torch.empty(B, L, D, dtype=torch.float32, device=table.device)
     xhat = torch.empty_like(y) if save else None
     rstd = torch.empty(B * L, dtype=torch.float32, device=table.device) if save else None
@@ -595,17 +621,20 @@ def adamw_hyper_append(hyper, cumlog, step, lr, beta1, beta2, eps, weight_decay,
 
 
 def adamw_rows(table, m, v, last, hyper, cumlog, t_prev, t_apply, beta1, beta2, eps, rows=None, n_rows=None,
-               max_rows=0, grows=None, step_dev=None):
+               max_rows=0, grows=None, step_dev=None, step_dev_bias=0):
     """Lazy table AdamW: catch rows up through t_prev (+ apply step t_apply with gradient rows).  rows=None: all.
     step_dev (device int64 counter of completed steps) overrides t_prev / t_apply (hipGraph-replayable)."""
     Lb = _l.load()
     N, D = table.shape
     tag = ("adamw_rows_kernel (flush: every row)" if rows is None else
-           "adamw_rows_kernel (apply: batch rows + gradient)" if t_apply else "adamw_rows_kernel (catch-up: batch rows)")
+           "adamw_rows_kernel (apply: batch rows + gradient)" if t_apply else
+           "adamw_rows_kernel (next batch's rows, beside the GEMMs)" if step_dev_bias else
+           "adamw_rows_kernel (catch-up: batch rows)")
     with _gemm_timer(0.0, tag):
         _l.check(Lb.pxr_adamw_rows_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), _l.ptr(last), N, D, _l.ptr(rows),
                                        _l.ptr(n_rows), max_rows, _l.ptr(grows), _l.ptr(hyper), _l.ptr(cumlog), t_prev,
-                                       t_apply, _l.ptr(step_dev), beta1, beta2, eps, _l.stream_ptr()),
+                                       t_apply, _l.ptr(step_dev), int(step_dev_bias), beta1, beta2, eps,
+                                       _l.stream_ptr()),
                  "pxr_adamw_rows_f32")
 
 

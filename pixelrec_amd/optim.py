@@ -19,6 +19,107 @@ import torch
 
 from . import ops
 
+def _layer_names(i):
+    """Parameter names of encoder layer i in the order the reference registers them (layers.py:569-578, 634-638)."""
+    a, f = f"trm_encoder.layer.{i}.multi_head_attention.", f"trm_encoder.layer.{i}.feed_forward."
+    out = []
+    for mod in ("query", "key", "value", "dense", "LayerNorm"):
+        out += [a + mod + ".weight", a + mod + ".bias"]
+    for mod in ("dense_1", "dense_2", "LayerNorm"):
+        out += [f + mod + ".weight", f + mod + ".bias"]
+    return out
+
+
+def reference_rec_parameter_names(model):
+    """Names of the 'rec' parameters (everything outside `visual_encoder`) in the order the REFERENCE model yields them
+    from .parameters() -- the order torch.optim.AdamW.state_dict() numbers its per-parameter state in:
+    SASRec   (sasrec.py:31-45):   item_embedding, position_embedding, trm_encoder layers, LayerNorm;
+    MOSASRec (mosasrec.py:30-47): [visual_encoder first], position_embedding, LayerNorm, trm_encoder layers."""
+    layers = [n for i in range(model.n_layers) for n in _layer_names(i)]
+    if hasattr(model, "item_embedding"):
+        return ["item_embedding.weight", "position_embedding.weight"] + layers + ["LayerNorm.weight", "LayerNorm.bias"]
+    return ["position_embedding.weight", "LayerNorm.weight", "LayerNorm.bias"] + layers
+
+
+def is_torch_adamw_state(sd) -> bool:
+    return isinstance(sd, dict) and "state" in sd and "param_groups" in sd and "m" not in sd
+
+
+_TORCH_GROUP_DEFAULTS = {"amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                         "differentiable": False, "fused": None}
+
+
+def native_to_torch_state(sd, model, first_index=0):
+    """PxrAdamW's native state ({step, m, v, table_m, table_v, param_groups}) -> the layout of
+    torch.optim.AdamW.state_dict() over the reference's parameter order (what the reference Trainer stores under
+    'optimizer', trainer.py:153, and resumes from, trainer.py:186).  Table moments must be reference-shaped [N, D]."""
+    names = reference_rec_parameter_names(model)
+    g = dict(sd["param_groups"][0])
+    step = int(sd["step"])
+    state = {}
+    if step > 0:     # torch creates a parameter's state at its first step
+        for j, name in enumerate(names):
+            if name == "item_embedding.weight":
+                m, v = sd["table_m"], sd["table_v"]
+            else:
+                off, n, shape = model._views[_short_name(name)]
+                m, v = sd["m"][off:off + n].view(shape), sd["v"][off:off + n].view(shape)
+            state[first_index + j] = {"step": torch.tensor(float(step)), "exp_avg": m.detach().clone(),
+                                      "exp_avg_sq": v.detach().clone()}
+    group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"],
+             **_TORCH_GROUP_DEFAULTS, "params": list(range(first_index, first_index + len(names)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def torch_to_native_state(sd, model, group_index=-1):
+    """Inverse of native_to_torch_state for the rec group (the LAST param group of a reference checkpoint)."""
+    names = reference_rec_parameter_names(model)
+    g = sd["param_groups"][group_index]
+    ids = list(g["params"])
+    if len(ids) != len(names):
+        raise ValueError(f"optimizer state has {len(ids)} parameters in its rec group, this model has {len(names)}")
+    flat, _ = model.flat_parameters()
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    out = {"param_groups": [{"lr": g["lr"], "weight_decay": g["weight_decay"], "betas": tuple(g["betas"]), "eps": g["eps"]}]}
+    steps = set()
+    for pid, name in zip(ids, names):
+        st = sd["state"].get(pid)
+        if st is None:
+            continue
+        steps.add(int(float(st["step"])))
+        if name == "item_embedding.weight":
+            out["table_m"], out["table_v"] = st["exp_avg"], st["exp_avg_sq"]
+            continue
+        off, n, shape = model._views[_short_name(name)]
+        if tuple(st["exp_avg"].shape) != tuple(shape):
+            raise ValueError(f"optimizer state of {name}: shape {tuple(st['exp_avg'].shape)} != {tuple(shape)}")
+        m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+        v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+    if len(steps) > 1:
+        raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state this optimizer can resume")
+    out["step"] = steps.pop() if steps else 0
+    out["m"], out["v"] = m, v
+    if hasattr(model, "item_embedding") and "table_m" not in out:
+        t = model.item_embedding.weight
+        out["table_m"], out["table_v"] = torch.zeros_like(t), torch.zeros_like(t)
+    return out
+
+
+def _short_name(name):
+    """reference parameter name -> key of SeqRecCore._views (the flat-buffer layout)."""
+    if name == "position_embedding.weight":
+        return "pos"
+    if name.startswith("LayerNorm."):
+        return "ln0.w" if name.endswith("weight") else "ln0.b"
+    parts = name.split(".")
+    i, blk, mod, kind = parts[2], parts[3], parts[4], parts[5][0]
+    key = {("multi_head_attention", "query"): "q", ("multi_head_attention", "key"): "k",
+           ("multi_head_attention", "value"): "v", ("multi_head_attention", "dense"): "o",
+           ("multi_head_attention", "LayerNorm"): "ln1", ("feed_forward", "dense_1"): "f1",
+           ("feed_forward", "dense_2"): "f2", ("feed_forward", "LayerNorm"): "ln2"}[(blk, mod)]
+    return f"{i}.{key}.{kind}"
+
+
 HYPER_CAPACITY = 1 << 22   # steps; 96 MB of per-step scalars, sized once so graph replays never see a reallocation
 
 
@@ -105,6 +206,10 @@ class PxrAdamW:
         # gradient's all-reduce may still be in flight (GradSync.sync(defer_flat=True)) -- it then runs under the
         # row update instead of in front of it
         sp = self.model.sparse_table_grad if self.has_table else None
+        pre = getattr(self.model, "_prefetched", None) if self.has_table else None
+        if pre is not None:
+            self.model.join_prefetch()      # the look-ahead catch-up touches table rows: order this step's update behind it
+            self.model._prefetched = None
         if not self.has_table:
             pass
         elif self.table_update == "dense":
@@ -116,6 +221,13 @@ class PxrAdamW:
                            self.step_count + 1, b1, b2, g["eps"], rows=sp.idx, n_rows=sp.n, max_rows=sp.cap,
                            grows=sp.rows, step_dev=sd)
             self._dirty = True
+            if pre is not None:
+                # rows of the NEXT batch (caught up through the previous step beside this step's GEMMs) advance through
+                # THIS step too -- zero gradient unless the update above already did it -- so the next forward finds them
+                # current and its own catch-up has nothing to replay
+                ops.adamw_rows(table, self._tm, self._tv, self._last, self._hyper, self._cumlog, self.step_count + 1, 0,
+                               b1, b2, g["eps"], rows=pre.idx, n_rows=pre.n, max_rows=pre.cap, step_dev=sd,
+                               step_dev_bias=1)
         wait = getattr(self.model, "wait_flat_grads", None)
         if wait is not None:
             wait()
@@ -124,17 +236,27 @@ class PxrAdamW:
         ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 2, *cfg, step_dev=sd, advance=True)
         self.step_count += 1
 
-    def state_dict(self):
+    def state_dict(self, layout: str = "native"):
+        """layout="native": {step, param_groups, m, v, table_m, table_v} (views of the live buffers);
+        layout="torch": the dict torch.optim.AdamW.state_dict() would hold for the reference model (per-parameter
+        step / exp_avg / exp_avg_sq in the reference's parameter order), so checkpoints interchange with the
+        reference Trainer (trainer.py:153,186).  load_state_dict accepts either."""
         self._ensure_state()
         self.flush()
         sd = {"step": self.step_count, "param_groups": self.param_groups, "m": self._m, "v": self._v}
         if self.has_table:
             sd.update(table_m=self._tm, table_v=self._tv)
+        if layout == "torch":
+            return native_to_torch_state(sd, self.model)
+        if layout != "native":
+            raise ValueError("layout must be 'native' or 'torch'")
         return sd
 
     def load_state_dict(self, sd):
         self._ensure_state()
         self.flush()                     # updates still owed under the OLD state are applied with the old state
+        if is_torch_adamw_state(sd):     # a reference checkpoint (or layout="torch"): per-parameter state -> flat buffers
+            sd = torch_to_native_state(sd, self.model)
         self.step_count = int(sd["step"])
         self.param_groups = sd["param_groups"]
         pairs = [(self._m, "m"), (self._v, "v")] + ([(self._tm, "table_m"), (self._tv, "table_v")] if self.has_table else [])
@@ -208,9 +330,33 @@ class OptimizerGroup:
             if hasattr(o, "flush"):
                 o.flush()
 
-    def state_dict(self):
-        return {"group": [o.state_dict() for o in self.opts]}
+    def _split(self):
+        """(torch optimizers of the visual-encoder group, the PxrAdamW of the rec group)."""
+        rec = [o for o in self.opts if isinstance(o, PxrAdamW)]
+        vis = [o for o in self.opts if not isinstance(o, PxrAdamW)]
+        if len(rec) != 1 or len(vis) > 1:
+            raise ValueError("OptimizerGroup: expected [torch AdamW (visual_encoder group)], PxrAdamW (rec group)")
+        return (vis[0] if vis else None), rec[0]
+
+    def state_dict(self, layout: str = "native"):
+        """layout="torch": ONE torch.optim.AdamW-shaped dict with the reference's two param groups (trainer.py:86-96:
+        group 0 = trainable visual_encoder parameters, group 1 = rec parameters; state indices run through both)."""
+        if layout == "native":
+            return {"group": [o.state_dict() for o in self.opts]}
+        vis, rec = self._split()
+        v = vis.state_dict() if vis is not None else {"state": {}, "param_groups": []}
+        n0 = sum(len(g["params"]) for g in v["param_groups"])
+        r = rec.state_dict(layout="torch") if n0 == 0 else native_to_torch_state(rec.state_dict(), rec.model, first_index=n0)
+        return {"state": {**v["state"], **r["state"]}, "param_groups": list(v["param_groups"]) + r["param_groups"]}
 
     def load_state_dict(self, sd):
+        if is_torch_adamw_state(sd):
+            vis, rec = self._split()
+            if vis is not None:
+                g0 = sd["param_groups"][0]
+                vis.load_state_dict({"state": {i: sd["state"][i] for i in g0["params"] if i in sd["state"]},
+                                     "param_groups": [g0]})
+            rec.load_state_dict(torch_to_native_state(sd, rec.model, group_index=-1))
+            return
         for o, s in zip(self.opts, sd["group"]):
             o.load_state_dict(s)

@@ -3,7 +3,10 @@
 Same surface: `Trainer(config, model)` with `model` a DDP-shaped wrapper exposing `.module`; `fit(train, valid,
 saved, show_progress)`; `evaluate(loader, load_best_model, model_file)`; `resume_checkpoint(file)`; same
 checkpoint dict keys (`config, epoch, cur_step, best_valid_score, state_dict, optimizer, rng_state,
-cuda_rng_state`, trainer.py:146-155) so `.pth` files interchange; early stopping / eval_step / valid_metric logic
+cuda_rng_state`, trainer.py:146-155) with `state_dict` under the reference's parameter names and `optimizer` in
+torch.optim.AdamW.state_dict()'s layout over the reference's parameter order (optim.native_to_torch_state), so `.pth`
+files interchange in both directions (what does NOT transfer: the dropout stream -- `dropout_step` here, torch's
+generator state there); early stopping / eval_step / valid_metric logic
 as trainer.py:256-325; metric averaging = per-rank SUM -> all_gather -> / #users -> round (trainer.py:360-364,
 399-406).
 
@@ -113,6 +116,9 @@ class Trainer:
         parameter is a 'rec' parameter, so both spellings resolve to one AdamW."""
         a = self.optim_args
         m = self.model.module
+        if self.config["decay_check_name"]:
+            # trainer.py:73-91: groups split by a name fragment instead of 'visual_encoder'; not used by any shipped YAML
+            raise NotImplementedError("decay_check_name is not built (the shipped configs leave it unset)")
         if len(a) == 4:
             rec = PxrAdamW(m, lr=a["rec_lr"], weight_decay=a["rec_decay"])
             modal = [p for n, p in m.named_parameters() if "visual_encoder" in n and p.requires_grad]
@@ -127,7 +133,19 @@ class Trainer:
         self.model.train()
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
-        for data in _Prefetcher(train_data, self.device):
+        lookahead = hasattr(self.model.module, "set_next_batch") and not self.use_modality
+
+        def with_next(it):
+            """(batch, ids of the batch after it | None): one batch of look-ahead out of the prefetch queue."""
+            prev = None
+            for cur in it:
+                if prev is not None:
+                    yield prev, (cur[0] if lookahead and cur[0].shape == prev[0].shape else None)
+                prev = cur
+            if prev is not None:
+                yield prev, None
+
+        for data, next_items in with_next(_Prefetcher(train_data, self.device)):
             if self.use_graph:
                 if self._gstep is None and data[0].shape[0] == self.config["train_batch_size"]:
                     from ..graph import GraphedTrainStep
@@ -136,13 +154,16 @@ class Trainer:
                     self._gstep = GraphedTrainStep(self.model, self.optimizer, data[0], data[1], warmup=0,
                                                    clip_grad_norm=self.clip_grad_norm, loss_sum=self._graph_loss)
                 if self._gstep is not None and self._gstep.matches(data[0], data[1]):
-                    self._gstep(data[0], data[1])       # the replay adds its loss to self._graph_loss on the device
+                    # the replay adds its loss to self._graph_loss on the device
+                    self._gstep(data[0], data[1], next_items=next_items)
                     continue
             self.optimizer.zero_grad()
             if self.use_modality:   # assemble the image batch on the device from the HBM-resident store
                 from ..data.images import interleave_pos_neg
 
                 data = (self._image_store(train_data).batch(interleave_pos_neg(data[0])), data[1])
+            elif next_items is not None:
+                self.model.module.set_next_batch(next_items)   # its table rows are caught up beside this step's GEMMs
             losses = self.model(data)
             losses.backward(self._one)     # preallocated unit gradient: no ones_like fill per step
             if hasattr(self.model, "sync_gradients"):
@@ -155,6 +176,7 @@ class Trainer:
             total = total + self._graph_loss
             self._graph_loss.zero_()
         total_loss = float(total.item())          # the only host sync of the epoch
+        ops.raise_on_bad_indices(self.device)     # ... and where an out-of-catalogue item id surfaces (IndexError)
         self._check_nan(total_loss)
         return total_loss
 
@@ -185,17 +207,21 @@ class Trainer:
             from ..model.sharded import optimizer_state_full
 
             rec = self.optimizer.opts[-1] if isinstance(self.optimizer, OptimizerGroup) else self.optimizer
-            opt_sd = optimizer_state_full(rec, m)
+            from ..optim import native_to_torch_state
+
+            opt_sd = native_to_torch_state(optimizer_state_full(rec, m), m)
         else:
-            opt_sd = self.optimizer.state_dict()
-        opt_sd = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in opt_sd.items()}
+            opt_sd = self.optimizer.state_dict(layout="torch")
+        # torch.optim.AdamW.state_dict() layout (reference trainer.py:153): per-parameter tensors moved to the host
+        opt_sd = {"state": {i: {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                            for i, st in opt_sd["state"].items()}, "param_groups": opt_sd["param_groups"]}
         return model_sd, opt_sd
 
     def _save_checkpoint(self, epoch, verbose=True):
         model_sd, opt_sd = self._checkpoint_tensors()
         if self.rank == 0:
             state = {
-                "config": dict(self.config.final_config_dict) if hasattr(self.config, "final_config_dict") else self.config,
+                "config": dict(self.config.final_config_dict) if hasattr(self.config, "final_config_dict") else dict(self.config),
                 "epoch": epoch,
                 "cur_step": self.cur_step,
                 "best_valid_score": self.best_valid_score,
@@ -349,6 +375,7 @@ class Trainer:
             else:
                 scores, positive_u, positive_i = self._full_sort_batch_eval(batched_data)
                 self.eval_collector.eval_batch_collect(scores, positive_u.to(self.device), positive_i.to(self.device))
+        ops.raise_on_bad_indices(self.device)
         num_total_examples = len(eval_data.sampler.dataset)
         struct = self.eval_collector.get_data_struct()
         result = self.evaluator.evaluate(struct)

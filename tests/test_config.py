@@ -21,3 +21,26 @@ def test_yaml_merge_and_derived_keys(tmp_path):
     assert c2["MAX_ITEM_LIST_LENGTH"] == 50 and c2["topk"] == [20]
     c2["device"] = "x"
     assert "device" in c2 and c2.device == "x"
+
+
+def test_reference_parameter_order_maps_onto_the_flat_layout():
+    """torch.optim.AdamW numbers its state by the order of model.parameters(); the interchange code must know the
+    REFERENCE's order (sasrec.py:31-45 / mosasrec.py:30-47) and map every name onto this build's flat-buffer keys."""
+    from oracle import sasrec_oracle as O
+    from pixelrec_amd.optim import _short_name, reference_rec_parameter_names
+
+    class IdModel:
+        n_layers = 2
+        item_embedding = object()
+
+    class PixelModel:
+        n_layers = 2
+
+    names = reference_rec_parameter_names(IdModel())
+    assert names == list(O.synth_params(20, 8, 4, 2, 2, seed=0).keys())      # the oracle mirrors the reference module tree
+    pix = reference_rec_parameter_names(PixelModel())
+    assert pix[:3] == ["position_embedding.weight", "LayerNorm.weight", "LayerNorm.bias"] and len(pix) == len(names) - 1
+    short = [_short_name(n) for n in names[1:]]
+    assert short[0] == "pos" and short[-2:] == ["ln0.w", "ln0.b"]
+    assert short[1:5] == ["0.q.w", "0.q.b", "0.k.w", "0.k.b"] and "1.f2.b" in short and "1.ln2.w" in short
+    assert len(set(short)) == len(short)

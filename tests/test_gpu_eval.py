@@ -107,6 +107,24 @@ def test_trainer_fit_checkpoint_roundtrip(tmp_path):
     assert set(ck) >= {"config", "epoch", "cur_step", "best_valid_score", "state_dict", "optimizer", "rng_state"}
     ref_keys = set(O.param_shapes(dataload.item_num, 32, 6, 2, 2))
     assert set(ck["state_dict"]) == ref_keys                       # reference state_dict key names
+    # the 'optimizer' entry is a torch.optim.AdamW state_dict over the reference's parameter order: a REAL torch AdamW
+    # built the way the reference Trainer builds it (trainer.py:100-102) takes it as it is
+    from pixelrec_amd.optim import reference_rec_parameter_names
+
+    names = reference_rec_parameter_names(trainer.model.module)
+    tparams = [torch.nn.Parameter(ck["state_dict"][k].clone()) for k in names]
+    topt = torch.optim.AdamW(tparams, lr=1.0, weight_decay=0.5)
+    topt.load_state_dict(ck["optimizer"])
+    assert topt.param_groups[0]["lr"] == 0.001 and topt.param_groups[0]["weight_decay"] == 0.1
+    st0 = topt.state[tparams[0]]
+    assert st0["exp_avg"].shape == tparams[0].shape and float(st0["step"]) > 0
+    # ... and what torch writes back resumes this build's trainer (reference checkpoint -> resume_checkpoint)
+    ck2 = dict(ck)
+    ck2["optimizer"] = topt.state_dict()
+    torch.save(ck2, str(tmp_path / "from_torch.pth"))
+    steps_before = trainer.optimizer.step_count
+    trainer.resume_checkpoint(str(tmp_path / "from_torch.pth"))
+    assert trainer.optimizer.step_count == int(float(st0["step"])) <= steps_before
     res = trainer.evaluate(test, load_best_model=True)
     assert set(res) == {"recall@5", "recall@10", "ndcg@5", "ndcg@10"}
     # a saved state_dict loads into the CPU oracle and gives the same scores as the HIP predict

@@ -220,3 +220,42 @@ def test_load_state_dict_while_rows_lag():
     dense, lazy = scenario("dense"), scenario("lazy")
     for k in dense:
         assert torch.equal(dense[k], lazy[k]), k
+
+
+def test_lookahead_catch_up_changes_no_bit():
+    """SASRec.set_next_batch (the next batch's table rows are caught up on a side stream beside this step's GEMMs and
+    advanced through the step by the optimizer) is a pure schedule hint: with it, without it, with a WRONG hint and
+    with the dense sweep the parameters end up bit-identical -- eagerly and through the captured step graph."""
+    from pixelrec_amd.graph import GraphedTrainStep
+    from pixelrec_amd.optim import PxrAdamW
+
+    n_items = 3000
+    make, rng, zipf, synth = _setup(n_items=n_items, D=64, L=10, B=6)
+    batches = [tuple(torch.from_numpy(x).cuda() for x in synth.train_batch(n_items, 6, 10, rng, zipf)) for _ in range(40)]
+
+    def run(mode, hint, graph=False):
+        m = make()
+        opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1, table_update=mode)
+        g = GraphedTrainStep(m, opt, *batches[0], warmup=0, lookahead=hint != "none") if graph else None
+        for i, (it, mk) in enumerate(batches):
+            nxt = None
+            if hint == "next" and i + 1 < len(batches):
+                nxt = batches[i + 1][0]
+            elif hint == "wrong":
+                nxt = batches[(i * 7 + 3) % len(batches)][0]
+            if g is not None:
+                g(it, mk, next_items=nxt)
+                continue
+            if nxt is not None:
+                m.set_next_batch(nxt)
+            loss = m((it, mk))
+            loss.backward()
+            opt.step()
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    ref = run("dense", "none")
+    for mode, hint, graph in (("lazy", "none", False), ("lazy", "next", False), ("lazy", "wrong", False),
+                              ("lazy", "next", True), ("lazy", "none", True)):
+        got = run(mode, hint, graph)
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (mode, hint, graph, k)
