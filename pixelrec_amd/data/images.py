@@ -10,7 +10,8 @@ Backends for filling the store (indexed by INTERNAL item id, row 0 = padding):
   * `<path>.npy`  uint8 [n, H, W, 3] + `<path>.tokens.txt` (one item token per line, same order)   -- native format;
   * LMDB in the reference's format -- key = ascii item token, value = pickle of an object with `.image` bytes,
     `.size`, `.channels` (generate_lmdb.py / data/utils.py:192-201); read through the `lmdb` module when it is
-    installed, otherwise through the build's own read-only parser (data/lmdb_read.py);
+    installed, otherwise -- with a warning -- through the build's own EXPERIMENTAL read-only parser (data/lmdb_read.py:
+    never checked against a file written by liblmdb itself);
   * `synthetic:<H>`  deterministic pseudo-random images (benchmarks / tests; no dataset is available offline).
 """
 from __future__ import annotations
@@ -29,10 +30,14 @@ class _LmdbImage:  # stand-in for the reference's pickled LMDB_Image (any module
 
 
 class _Unpickler(pickle.Unpickler):
+    """Restricted unpickler for LMDB values: the reference's payload is `LMDB_Image{channels, size, image, id}`
+    (generate_lmdb.py:20-40) whose attributes are ints, tuples, bytes and strings -- no other global is ever needed,
+    so every other class / function reference in a value is refused (a pickle can otherwise run arbitrary code)."""
+
     def find_class(self, module, name):
         if name == "LMDB_Image":
             return _LmdbImage
-        return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"image LMDB value references {module}.{name}: only LMDB_Image is allowed")
 
 
 class ImageStore:
@@ -75,8 +80,15 @@ class ImageStore:
             txn = env.begin()
             fetch = txn.get
         else:   # no liblmdb binding: the build's own read-only parser of the same file
+            import logging
+
             from .lmdb_read import LmdbFile
 
+            # EXPERIMENTAL: written from liblmdb's published file layout and checked only against files laid out by this
+            # repo's own test fixture -- no byte produced by liblmdb was available offline (parity unpinned, see
+            # INTEGRATION.md).  The `.npy + .tokens.txt` store is the supported format; `pip install lmdb` the safe one.
+            logging.getLogger().warning("image_path %s: the `lmdb` module is not installed; reading the file with the "
+                                        "EXPERIMENTAL built-in parser (pixelrec_amd/data/lmdb_read.py)", path)
             fetch = LmdbFile(path).get
         out = None
         for iid in range(1, dataload.item_num):

@@ -162,9 +162,27 @@ class ClsItemEncoder(_ItemEncoderBase):
         return self.rec_fc(x[:, 0, :])
 
 
+def _load_pretrained_backbone(model, name, config):
+    """fine_tune_arg.pre_trained (the shipped default, overall/ViT.yaml): the reference calls
+    CLIPVisionModel.from_pretrained('openai/<name>') (load.py:94).  Same here, restricted to what is on local disk (no
+    network): `encoder_path` (a directory / checkpoint in HF format) or the local HF cache.  Returns an error string
+    when nothing could be loaded."""
+    path = config["encoder_path"] if "encoder_path" in config else None
+    try:
+        from transformers import CLIPVisionModel
+
+        hf = CLIPVisionModel.from_pretrained(path or f"openai/{name}", local_files_only=True)
+    except Exception as e:  # noqa: BLE001 - any failure means "no local weights"
+        return f"{type(e).__name__}: {e}"
+    sd = {(k if k.startswith("vision_model.") else "vision_model." + k): v for k, v in hf.state_dict().items()}
+    model.load_state_dict(sd, strict=True)      # transformers 4.16.2 names == this module's names
+    return None
+
+
 def load_model(config):
-    """ViT branch of the reference's load_model (load.py:90-120).  `pre_trained` cannot fetch weights offline: the
-    backbone is randomly initialised either way (load them afterwards with `pretrain_path` / load_state_dict)."""
+    """ViT branch of the reference's load_model (load.py:90-120).  With `pre_trained: True` the backbone weights must
+    come from local disk (`encoder_path` / the HF cache) or from `pretrain_path` (a Trainer checkpoint loaded by the
+    model afterwards); otherwise this raises instead of training on a frozen RANDOM backbone without saying so."""
     name, source = config["encoder_name"], config["encoder_source"]
     if source != "transformers" or name not in ENCODER_SHAPES:
         raise NotImplementedError(f"visual encoder {source}/{name} is outside this build's scope "
@@ -172,6 +190,18 @@ def load_model(config):
     ft = config["fine_tune_arg"] or {}
     tune_scale = ft.get("tune_scale", 0)
     model = CLIPVisionEncoder(*ENCODER_SHAPES[name])
+    if ft.get("pre_trained", True) and name != "clip-vit-tiny-test":
+        err = _load_pretrained_backbone(model, name, config)
+        if err is not None and not config["pretrain_path"]:
+            if not ft.get("allow_random_backbone", False):
+                raise RuntimeError(
+                    f"fine_tune_arg.pre_trained is set but no weights for 'openai/{name}' are available offline ({err}). "
+                    "Point `encoder_path` at a local copy of the HF checkpoint, give `pretrain_path`, or set "
+                    "fine_tune_arg.pre_trained: False (random init, as load.py:104-108) / allow_random_backbone: True.")
+            import logging
+
+            logging.getLogger().warning("visual encoder %s: NO pre-trained weights loaded (%s); the first %d parameters "
+                                        "stay frozen at their RANDOM initial values", name, err, tune_scale)
     for index, (pname, param) in enumerate(model.named_parameters()):
         if index < tune_scale:
             param.requires_grad = False                                 # load.py:97-99

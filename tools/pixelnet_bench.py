@@ -22,7 +22,7 @@ cfg = {"n_layers": 2, "n_heads": 4, "embedding_size": D, "inner_size": 2, "hidde
        "attn_dropout_prob": 0.1, "hidden_act": "gelu", "layer_norm_eps": 1e-12, "initializer_range": 0.02,
        "MAX_ITEM_LIST_LENGTH": L, "seed": 2020, "encoder_name": name, "encoder_source": "transformers",
        "pretrain_path": None,
-       "fine_tune_arg": {"tune_scale": 5 + 16 * tune_from, "pre_trained": True, "activation": "relu", "dnn_layers": [],
+       "fine_tune_arg": {"tune_scale": 5 + 16 * tune_from, "pre_trained": True, "allow_random_backbone": True, "activation": "relu", "dnn_layers": [],
                          "method": "mean"}}
 
 
