@@ -225,7 +225,8 @@ int pxr_adamw_table_f32(float* table, float* m, float* v, int64_t n_rows, int D,
  * zero-gradient steps (bit-identical to the sweep for gaps <= 256 steps, closed-form weight decay beyond) through
  * t_prev and, if t_apply = t_prev+1, applies that step with gradient rows grows[i,:].  rows == NULL: all N rows
  * (flush before evaluation / checkpointing).  With step_dev the kernel takes t_prev = *step_dev + step_dev_bias from the
- * device (bias 1 = "through the step being applied": the rows of the NEXT batch, prefetched).  hyper_append with advance != 0 is the end-of-step form: it first counts
+ * device (bias 1 = "through the step being applied": the rows of the NEXT batch, prefetched); max_blocks > 0 caps the
+ * grid (a thin launch that shares the CUs with the step's GEMMs instead of flooding them).  hyper_append with advance != 0 is the end-of-step form: it first counts
  * the finished step (*step_dev += 1) and then appends the scalars of the next one, in one launch. */
 int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t step, int64_t* step_dev,
                            double lr, double beta1, double beta2, double eps, double weight_decay, int advance,
@@ -233,7 +234,8 @@ int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacity, int64_t 
 int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D, const int64_t* rows,
                        const int32_t* n_rows_dev, int64_t max_rows, const float* grows, const void* hyper,
                        const void* cumlog, int64_t t_prev, int64_t t_apply, const int64_t* step_dev,
-                       int64_t step_dev_bias, double beta1, double beta2, double eps, void* stream);
+                       int64_t step_dev_bias, int64_t max_blocks, double beta1, double beta2, double eps,
+                       void* stream);
 /* pxr_adamw_flat_f32 with the step's scalars read from hyper[step] (or hyper[*step_dev + 1]). */
 int pxr_adamw_flat_tab_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper, int64_t step,
                            const int64_t* step_dev, double beta1, double beta2, double eps, void* stream);

@@ -423,11 +423,12 @@ extern "C" int pxr_counter_add_i64(int64_t* counter, int64_t delta, void* stream
 // from the device counter, t_prev = *step_dev + step_dev_bias (and t_apply = t_prev + 1 when t_apply != 0), which makes
 // the call hipGraph-replayable.  step_dev_bias = 1 brings rows current through the step that is being applied right
 // now (its scalars are in the table): used for the rows of the NEXT batch, so that its forward finds them current.
+// max_blocks > 0 caps the grid (grid-stride loop inside): a thin launch for side-stream work.
 extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D,
                                   const int64_t* rows, const int32_t* n_rows_dev, int64_t max_rows, const float* grows,
                                   const void* hyper, const void* cumlog, int64_t t_prev, int64_t t_apply,
-                                  const int64_t* step_dev, int64_t step_dev_bias, double beta1, double beta2,
-                                  double eps, void* stream) {
+                                  const int64_t* step_dev, int64_t step_dev_bias, int64_t max_blocks, double beta1,
+                                  double beta2, double eps, void* stream) {
   PXR_REQUIRE(table && m && v && last && hyper && cumlog, "pxr_adamw_rows_f32: null pointer");
   PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 4096, "pxr_adamw_rows_f32: bad shape (D <= 4096)");
   PXR_REQUIRE(!rows || n_rows_dev, "pxr_adamw_rows_f32: row list needs its device count");
@@ -450,6 +451,9 @@ extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* las
   const int rpb = tl >= 256 ? 1 : 256 / tl;          // == the kernel's RPB
   int64_t blocks = (work + rpb - 1) / rpb;
   if (blocks > 256 * 64) blocks = 256 * 64;
+  // max_blocks > 0: a deliberately THIN grid (e.g. one workgroup per CU) for work that runs beside the step's GEMMs on
+  // a second stream: it then takes one wave slot per SIMD instead of flooding every CU ahead of the GEMM workgroups
+  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
 #define PXR_ROWS_CASE(L_, E_) hipLaunchKernelGGL((adamw_rows_kernel<L_, E_>), dim3((unsigned)blocks), dim3(L_ > 256 ? L_ : 256), 0, st, a, a.hyper)
   if (epl == 2) {
     switch (tl) {

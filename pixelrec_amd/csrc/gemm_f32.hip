@@ -20,7 +20,7 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1, int ST = 2, int FINE = 0>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1, int ST = 2, int FINE = 0, bool DUAL = false>
 __global__ void __launch_bounds__((GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT))
 gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
             float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
@@ -64,7 +64,7 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
   }
 
   typename Cfg::Acc accs;
-  gemm_mainloop<BM, BN, A_KC, B_KC, false, KW, PD, ST, FINE>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
+  gemm_mainloop<BM, BN, A_KC, B_KC, false, KW, PD, ST, FINE, DUAL>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
 
   auto& acc = accs.v;
   if (KW > 1 && wave >= Cfg::G) return;  // the second wave group handed its partial sums over in the main loop
@@ -199,14 +199,14 @@ __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_kernel(DwGroup g) {
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1, int ST = 2, int FINE = 0>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1, int ST = 2, int FINE = 0, bool DUAL = false>
 static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                        int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
                        int64_t split_stride, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   static const int xcd_env = getenv("PXR_GEMM_XCD") ? atoi(getenv("PXR_GEMM_XCD")) : -1;   // A/B knob: 0 = m fastest, 1 = n
   const int n_fastest = xcd_env >= 0 ? xcd_env : (M > N ? 1 : 0);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD, ST, FINE>), dim3(tiles_m * tiles_n, splits),
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD, ST, FINE, DUAL>), dim3(tiles_m * tiles_n, splits),
                      dim3(GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
                      tiles_n, ksplit_len, split_stride, n_fastest);
   return pxr_check_launch("pxr_gemm_f32");
@@ -245,6 +245,12 @@ static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, 
     case 1282:   // 128x128 tile, 8 wave tiles of 64x32 (512 threads)
       return launch_gemm<128, 128, A_KC, B_KC, EPI, 1, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
                                                                 ksplit_len, split_stride, st);
+    case 641:    // 64x64 tile, 4 wave tiles of 32x32, two accumulator chains per wave (even / odd k sub-steps)
+      return launch_gemm<64, 64, A_KC, B_KC, EPI, 1, 2, 2, 0, true>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
+                                                                     ksplit_len, split_stride, st);
+    case 128611:  // 128x64 tile, 8 wave tiles of 32x32, two accumulator chains per wave
+      return launch_gemm<128, 64, A_KC, B_KC, EPI, 1, 2, 2, 1, true>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
+                                                                      ksplit_len, split_stride, st);
     case 12861:  // 128x64 tile, 8 wave tiles of 32x32 (512 threads)
       return launch_gemm<128, 64, A_KC, B_KC, EPI, 1, 2, 2, 1>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits,
                                                                ksplit_len, split_stride, st);
@@ -294,8 +300,10 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   // 192..256 tiles of 128x128 = one 16-wave workgroup on (almost) every CU in a single round: +3..9 % over 64x64 at
   // a dozen shapes, while 150/175/304 tiles lose 13-28 % (tools/tile_rule_check.py)
   if (!big && t128 >= 192 && t128 <= 256) tile = 1281;
-  if (tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861 || tile_hint == 1282) tile = tile_hint;
-  const int bm = (tile == 128 || tile == 12864 || tile == 1281 || tile == 12861 || tile == 1282) ? 128 : (tile == 3264 ? 32 : 64);
+  static const int small_tile = getenv("PXR_GEMM_SMALL_TILE") ? atoi(getenv("PXR_GEMM_SMALL_TILE")) : 64;
+  if (tile == 64) tile = small_tile;
+  if (tile_hint == 641 || tile_hint == 128611 || tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861 || tile_hint == 1282) tile = tile_hint;
+  const int bm = (tile == 128 || tile == 12864 || tile == 1281 || tile == 12861 || tile == 128611 || tile == 1282) ? 128 : (tile == 3264 ? 32 : 64);
   const int bn = (tile == 128 || tile == 64128 || tile == 1281 || tile == 1282) ? 128 : 64;
   const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   PXR_REQUIRE(tiles < (1ll << 31), "pxr_gemm_f32: too many tiles");

@@ -14,6 +14,8 @@
 //   pxr_colsum-style stage 2 (deterministic, no float atomics).
 #include "pxr_common.h"
 
+#include <cstdlib>
+
 namespace pxr {
 
 struct LnFwdArgs {
@@ -39,91 +41,112 @@ struct LnFwdArgs {
   int32_t* status;          // GATHER: device status word (bad-index flag) or null
 };
 
-template <int VEC, bool GATHER>
+// RPW = rows per wave.  RPW = 2 (large batches): both rows' ids and table rows are requested before either is reduced,
+// so twice as many random 2 KB row fetches are in flight per CU (the kernel is a chain id -> row -> two wave
+// reductions -> stores; at B >= 512 it is HBM-latency bound with one row per wave), and xhat -- written once, read
+// only by the backward pass -- goes out with streaming stores so that it does not evict y, which the QKV GEMM reads next.
+template <int VEC, bool GATHER, int RPW = 1>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
   if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= a.rows) return;
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  if (row0 >= a.rows) return;
   const int D = a.D;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
   const bool drop = a.drop_thr != 0u;
-  float4 v[VEC];
-  const float* src;
-  const float* add;
-  if constexpr (GATHER) {
-    const int b = row / a.L, t = row - b * a.L;
-    int64_t r = a.idx[(int64_t)b * a.idx_bstride + t];
-    if (r < 0 || r >= a.n_table) {   // an error in the reference (nn.Embedding raises): flag it, then clamp
-      if (a.status && lane == 0) atomicOr(a.status, PXR_STATUS_BAD_INDEX);
-      r = r < 0 ? 0 : a.n_table - 1;
-    }
-    src = a.table + r * D;
-    add = a.pos + (int64_t)t * D;
-  } else {
-    src = a.x + (int64_t)row * D;
-    add = a.res ? a.res + (int64_t)row * D : nullptr;
-  }
-  float s = 0.f;
+  float4 v[RPW][VEC];
+  float s[RPW];
+  bool live[RPW];
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    const int c = (k * 64 + lane) * 4;
-    if (c < D) {
-      float4 t4 = *reinterpret_cast<const float4*>(src + c);
-      if constexpr (!GATHER) {
-        if (drop) {  // dropout on the sub-layer output BEFORE the residual add (layers.py:614, :670)
-          const uint64_t e = (uint64_t)row * D + c;
-          t4.x = pxr_keep(a.seed, a.stream, e + 0, a.drop_thr) ? t4.x * inv_keep : 0.f;
-          t4.y = pxr_keep(a.seed, a.stream, e + 1, a.drop_thr) ? t4.y * inv_keep : 0.f;
-          t4.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? t4.z * inv_keep : 0.f;
-          t4.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? t4.w * inv_keep : 0.f;
-        }
+  for (int w = 0; w < RPW; ++w) {
+    const int row = row0 + w;
+    live[w] = row < a.rows;
+    s[w] = 0.f;
+    const float* src;
+    const float* add;
+    if constexpr (GATHER) {
+      const int rr = live[w] ? row : row0;
+      const int b = rr / a.L, t = rr - b * a.L;
+      int64_t r = a.idx[(int64_t)b * a.idx_bstride + t];
+      if (r < 0 || r >= a.n_table) {   // an error in the reference (nn.Embedding raises): flag it, then clamp
+        if (a.status && lane == 0) atomicOr(a.status, PXR_STATUS_BAD_INDEX);
+        r = r < 0 ? 0 : a.n_table - 1;
       }
-      if (add) {
-        const float4 r4 = *reinterpret_cast<const float4*>(add + c);
-        t4.x += r4.x; t4.y += r4.y; t4.z += r4.z; t4.w += r4.w;
-      }
-      v[k] = t4;
-      s += (t4.x + t4.y) + (t4.z + t4.w);
+      src = a.table + r * D;
+      add = a.pos + (int64_t)t * D;
     } else {
-      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int rr = live[w] ? row : row0;
+      src = a.x + (int64_t)rr * D;
+      add = a.res ? a.res + (int64_t)rr * D : nullptr;
     }
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    const int c = (k * 64 + lane) * 4;
-    if (c < D) {
-      const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
-      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
-  }
-  const float var = wave_sum(q) / (float)D;
-  const float rstd = 1.0f / sqrtf(var + a.eps);
-  if (a.rstd && lane == 0) a.rstd[row] = rstd;
-#pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    const int c = (k * 64 + lane) * 4;
-    if (c < D) {
-      const float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
-      const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
-      float4 xh;
-      xh.x = (v[k].x - mean) * rstd; xh.y = (v[k].y - mean) * rstd;
-      xh.z = (v[k].z - mean) * rstd; xh.w = (v[k].w - mean) * rstd;
-      if (a.xhat) *reinterpret_cast<float4*>(a.xhat + (int64_t)row * D + c) = xh;
-      float4 y;
-      y.x = xh.x * g.x + be.x; y.y = xh.y * g.y + be.y; y.z = xh.z * g.z + be.z; y.w = xh.w * g.w + be.w;
-      if constexpr (GATHER) {
-        if (drop) {  // dropout AFTER the input LayerNorm (sasrec.py:82)
-          const uint64_t e = (uint64_t)row * D + c;
-          y.x = pxr_keep(a.seed, a.stream, e + 0, a.drop_thr) ? y.x * inv_keep : 0.f;
-          y.y = pxr_keep(a.seed, a.stream, e + 1, a.drop_thr) ? y.y * inv_keep : 0.f;
-          y.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? y.z * inv_keep : 0.f;
-          y.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? y.w * inv_keep : 0.f;
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < D) {
+        float4 t4 = *reinterpret_cast<const float4*>(src + c);
+        if constexpr (!GATHER) {
+          if (drop) {  // dropout on the sub-layer output BEFORE the residual add (layers.py:614, :670)
+            const uint64_t e = (uint64_t)row * D + c;
+            t4.x = pxr_keep(a.seed, a.stream, e + 0, a.drop_thr) ? t4.x * inv_keep : 0.f;
+            t4.y = pxr_keep(a.seed, a.stream, e + 1, a.drop_thr) ? t4.y * inv_keep : 0.f;
+            t4.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? t4.z * inv_keep : 0.f;
+            t4.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? t4.w * inv_keep : 0.f;
+          }
         }
+        if (add) {
+          const float4 r4 = *reinterpret_cast<const float4*>(add + c);
+          t4.x += r4.x; t4.y += r4.y; t4.z += r4.z; t4.w += r4.w;
+        }
+        v[w][k] = t4;
+        s[w] += (t4.x + t4.y) + (t4.z + t4.w);
+      } else {
+        v[w][k] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < RPW; ++w) {
+    const int row = row0 + w;
+    if (!live[w]) continue;   // wave-uniform
+    const float mean = wave_sum(s[w]) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < D) {
+        const float dx = v[w][k].x - mean, dy = v[w][k].y - mean, dz = v[w][k].z - mean, dw = v[w][k].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    if (a.rstd && lane == 0) a.rstd[row] = rstd;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < D) {
+        const float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
+        float4 xh;
+        xh.x = (v[w][k].x - mean) * rstd; xh.y = (v[w][k].y - mean) * rstd;
+        xh.z = (v[w][k].z - mean) * rstd; xh.w = (v[w][k].w - mean) * rstd;
+        if (a.xhat) {
+          if constexpr (RPW > 1) pxr_st_stream(a.xhat + (int64_t)row * D + c, xh);
+          else *reinterpret_cast<float4*>(a.xhat + (int64_t)row * D + c) = xh;
+        }
+        float4 y;
+        y.x = xh.x * g.x + be.x; y.y = xh.y * g.y + be.y; y.z = xh.z * g.z + be.z; y.w = xh.w * g.w + be.w;
+        if constexpr (GATHER) {
+          if (drop) {  // dropout AFTER the input LayerNorm (sasrec.py:82)
+            const uint64_t e = (uint64_t)row * D + c;
+            y.x = pxr_keep(a.seed, a.stream, e + 0, a.drop_thr) ? y.x * inv_keep : 0.f;
+            y.y = pxr_keep(a.seed, a.stream, e + 1, a.drop_thr) ? y.y * inv_keep : 0.f;
+            y.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? y.z * inv_keep : 0.f;
+            y.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? y.w * inv_keep : 0.f;
+          }
+        }
+        *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
+      }
     }
   }
 }
@@ -259,6 +282,18 @@ static inline int ln_vec_for(int D) {
 
 template <bool GATHER>
 static int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
+  // large batches: two rows per wave (see ln_fwd_kernel); small ones keep one row per wave -- there the launch is a
+  // few workgroups per CU and the shortest chain wins
+  static const int rpw2_rows = getenv("PXR_LN_RPW2_ROWS") ? atoi(getenv("PXR_LN_RPW2_ROWS")) : 16384;
+  if (a.rows >= rpw2_rows && a.D <= 1024) {
+    const int blocks2 = (a.rows + 7) / 8;
+    switch (ln_vec_for(a.D)) {
+      case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, GATHER, 2>), dim3(blocks2), dim3(256), 0, st, a); break;
+      case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, GATHER, 2>), dim3(blocks2), dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((ln_fwd_kernel<4, GATHER, 2>), dim3(blocks2), dim3(256), 0, st, a); break;
+    }
+    return pxr_check_launch("pxr_ln_fwd");
+  }
   const int blocks = (a.rows + 3) / 4;
   switch (ln_vec_for(a.D)) {
     case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, GATHER>), dim3(blocks), dim3(256), 0, st, a); break;

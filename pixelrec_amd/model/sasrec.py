@@ -13,6 +13,8 @@ The sequence block itself lives in seqcore.SeqRecCore; this class adds the item-
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -84,11 +86,19 @@ class SASRec(SeqRecCore):
         main = torch.cuda.current_stream()
         side = self._prefetch_stream
         if side is None or side.device != main.device:
-            side = self._prefetch_stream = torch.cuda.Stream(device=main.device)
+            # lowest priority the device offers: the GEMM workgroups of the step are dispatched ahead of this stream's
+            lo = int(os.environ.get("PXR_PREFETCH_PRIO", "1"))
+            try:
+                side = torch.cuda.Stream(device=main.device, priority=lo)
+            except Exception:  # noqa: BLE001 - priority outside the runtime's range
+                side = torch.cuda.Stream(device=main.device)
+            self._prefetch_stream = side
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ops.sasrec_occ_sort(items_next, self.item_num, sp, self._next_ws)
-            self._table_hooks.catch_up_rows(sp.idx, sp.n, sp.cap)
+            # a THIN launch (PXR_PREFETCH_BLOCKS workgroups, default one per CU): the replay is pure VALU work with a
+            # whole forward + backward pass of time to finish in; it must not take the CUs' wave slots from the GEMMs
+            self._table_hooks.catch_up_rows(sp.idx, sp.n, sp.cap, max_blocks=int(os.environ.get("PXR_PREFETCH_BLOCKS", "256")))
         self._prefetched = sp
 
     def join_prefetch(self):

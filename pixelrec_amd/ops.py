@@ -621,19 +621,19 @@ def adamw_hyper_append(hyper, cumlog, step, lr, beta1, beta2, eps, weight_decay,
 
 
 def adamw_rows(table, m, v, last, hyper, cumlog, t_prev, t_apply, beta1, beta2, eps, rows=None, n_rows=None,
-               max_rows=0, grows=None, step_dev=None, step_dev_bias=0):
+               max_rows=0, grows=None, step_dev=None, step_dev_bias=0, max_blocks=0):
     """Lazy table AdamW: catch rows up through t_prev (+ apply step t_apply with gradient rows).  rows=None: all.
     step_dev (device int64 counter of completed steps) overrides t_prev / t_apply (hipGraph-replayable)."""
     Lb = _l.load()
     N, D = table.shape
     tag = ("adamw_rows_kernel (flush: every row)" if rows is None else
            "adamw_rows_kernel (apply: batch rows + gradient)" if t_apply else
-           "adamw_rows_kernel (next batch's rows, beside the GEMMs)" if step_dev_bias else
+           "adamw_rows_kernel (next batch's rows, beside the GEMMs)" if (step_dev_bias or max_blocks) else
            "adamw_rows_kernel (catch-up: batch rows)")
     with _gemm_timer(0.0, tag):
         _l.check(Lb.pxr_adamw_rows_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), _l.ptr(last), N, D, _l.ptr(rows),
                                        _l.ptr(n_rows), max_rows, _l.ptr(grows), _l.ptr(hyper), _l.ptr(cumlog), t_prev,
-                                       t_apply, _l.ptr(step_dev), int(step_dev_bias), beta1, beta2, eps,
+                                       t_apply, _l.ptr(step_dev), int(step_dev_bias), int(max_blocks), beta1, beta2, eps,
                                        _l.stream_ptr()),
                  "pxr_adamw_rows_f32")
 

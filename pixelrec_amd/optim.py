@@ -169,14 +169,15 @@ class PxrAdamW:
         return None
 
     # ---- hooks called by the model (lazy mode) ----------------------------------------------------------------
-    def catch_up_rows(self, idx, n_dev, cap):
-        """Bring the rows a forward pass is about to read up to date (through the last completed step)."""
+    def catch_up_rows(self, idx, n_dev, cap, max_blocks=0):
+        """Bring the rows a forward pass is about to read up to date (through the last completed step).  max_blocks: a
+        thin grid for the look-ahead call that runs beside the step's GEMMs (SASRec._start_prefetch)."""
         if self.table_update != "lazy" or self._last is None or not self.has_table:
             return
         b1, b2 = self.param_groups[0]["betas"]
         ops.adamw_rows(self.model.item_embedding.weight.data, self._tm, self._tv, self._last, self._hyper, self._cumlog,
                        self.step_count, 0, b1, b2, self.param_groups[0]["eps"], rows=idx, n_rows=n_dev, max_rows=cap,
-                       step_dev=self._step_dev)
+                       step_dev=self._step_dev, max_blocks=max_blocks)
 
     def flush(self):
         """Bring EVERY row up to date (before evaluation, checkpointing, or reading the table as a whole)."""
