@@ -112,8 +112,9 @@ def main():
     ap.add_argument("--table-update", choices=("lazy", "dense"), default="lazy",
                     help="table AdamW schedule (dense = sweep all rows every step; eager only)")
     ap.add_argument("--dw-mode", default=None, help="weight-gradient placement: grouped | fork_layer | fork_half")
-    ap.add_argument("--no-lookahead", action="store_true",
-                    help="do not hand the next batch's ids to the model (no look-ahead catch-up of its table rows)")
+    ap.add_argument("--lookahead", action="store_true",
+                    help="hand the next batch's ids to the model (look-ahead catch-up of its table rows on a side stream; "
+                         "measured slower on MI355X, off by default)")
     ap.add_argument("--emb", type=int, default=NS["D"], help="embedding size (default: the north-star 512)")
     ap.add_argument("--heads", type=int, default=NS["H"])
     ap.add_argument("--items", type=int, default=NS["n_items"], help="catalogue size incl. the padding id")
@@ -199,7 +200,7 @@ def main():
     if use_graph:
         from pixelrec_amd.graph import GraphedTrainStep
 
-        gstep = GraphedTrainStep(dp, opt, *pool[0], lookahead=not args.no_lookahead)
+        gstep = GraphedTrainStep(dp, opt, *pool[0], lookahead=not (not args.lookahead))
 
     one = torch.ones((), dtype=torch.float32, device=dev)
     cursor = [0]          # position in the batch stream: every step of every phase consumes the NEXT batch
@@ -211,7 +212,7 @@ def main():
 
     def peek_items():
         """ids of the batch AFTER the one just handed out (the look-ahead a data loader's prefetch queue provides)."""
-        return None if args.no_lookahead else pool[cursor[0] % len(pool)][0]
+        return None if (not args.lookahead) else pool[cursor[0] % len(pool)][0]
 
     def eager_step(batch, nxt=None):
         opt.zero_grad()
@@ -437,13 +438,13 @@ def main():
         for Bt in (512, 2048):
             n_bt = 26 if Bt == 512 else 12     # distinct batches: warm-up + timed + instrumented steps never repeat one
             bt = [tuple(torch.from_numpy(a).to(dev) for a in synth.train_batch(N, Bt, L, rng, zipf)) for _ in range(n_bt)]
-            g2 = _G(dp, opt, *bt[0], lookahead=not args.no_lookahead) if use_graph else None
+            g2 = _G(dp, opt, *bt[0], lookahead=not (not args.lookahead)) if use_graph else None
             cur = [0]
 
             def step_b(eager=False):
                 b = bt[cur[0] % n_bt]
                 cur[0] += 1
-                nxt = None if args.no_lookahead else bt[cur[0] % n_bt][0]
+                nxt = None if (not args.lookahead) else bt[cur[0] % n_bt][0]
                 if g2 is not None and not eager:
                     return g2(*b, next_items=nxt)
                 return eager_step(b, nxt)

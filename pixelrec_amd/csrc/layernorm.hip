@@ -284,7 +284,8 @@ template <bool GATHER>
 static int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
   // large batches: two rows per wave (see ln_fwd_kernel); small ones keep one row per wave -- there the launch is a
   // few workgroups per CU and the shortest chain wins
-  static const int rpw2_rows = getenv("PXR_LN_RPW2_ROWS") ? atoi(getenv("PXR_LN_RPW2_ROWS")) : 16384;
+  // (A/B knob, OFF by default: measured 3.75 vs 4.05 TB/s at B = 512 -- the row fetches are not what limits the kernel)
+  static const int rpw2_rows = getenv("PXR_LN_RPW2_ROWS") ? atoi(getenv("PXR_LN_RPW2_ROWS")) : 0x7fffffff;
   if (a.rows >= rpw2_rows && a.D <= 1024) {
     const int blocks2 = (a.rows + 7) / 8;
     switch (ln_vec_for(a.D)) {

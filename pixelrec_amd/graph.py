@@ -15,7 +15,7 @@ import torch
 
 class GraphedTrainStep:
     def __init__(self, dp_model, optimizer, items, masked_index, warmup=3, clip_grad_norm=None, loss_sum=None,
-                 lookahead=True):
+                 lookahead=False):
         self.dp, self.opt = dp_model, optimizer
         self.loss_sum = loss_sum          # optional 0-dim device tensor: every replay adds its loss (epoch totals
                                           # without an eager add per step)

@@ -68,7 +68,11 @@ class SASRec(SeqRecCore):
     def set_next_batch(self, items_next):
         """Optional look-ahead (lazy table optimizer only): `items_next` int64 [B,2,L+1] on the device = the batch the
         NEXT forward will see.  Consumed by the next training forward.  Purely a schedule hint: the step computes the
-        same bits with or without it (rows are caught up exactly either way), the next step just starts faster."""
+        same bits with or without it (rows are caught up exactly either way; tested).
+        OFF by default everywhere (GraphedTrainStep(lookahead=False), Trainer `lookahead_rows`, bench --lookahead):
+        measured on MI355X it takes the replay (69 -> 11 us) off the head of the step but the replay kernel running
+        beside the forward GEMMs slows them by more than that (1.205 -> 1.247 ms/step; thin grids and a low-priority
+        stream do not change it) -- see DESIGN.md "dead ends"."""
         self._next_items = items_next
 
     def _start_prefetch(self, items_next):

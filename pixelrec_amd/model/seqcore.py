@@ -100,13 +100,15 @@ class SeqRecCore(BaseModel):
         self.group_weight_grads = True     # all weight/bias gradients of a backward pass in one grouped GEMM launch
         self.overlap_weight_grads = False  # alternative: per-layer launches on a side HIP stream
         # WHERE the grouped weight-gradient launches go (group_weight_grads only):
-        #   "grouped"    one launch on the main stream after the input-gradient chain;
-        #   "fork_layer" one launch per layer on a side stream as soon as the layer's dqkv exists: its tiles co-run with
-        #                the input-gradient chain of the layers below, whose 400-1200-tile GEMMs leave ~half of the
-        #                MFMA pipe idle (grid quantisation on 256 CUs);
+        #   "grouped"    one launch on the main stream after the input-gradient chain (default);
+        #   "fork_layer" one launch per layer on a side stream as soon as the layer's dqkv exists, so that its tiles
+        #                co-run with the input-gradient chain of the layers below (a parallel branch of a captured graph);
         #   "fork_half"  two launches per layer (FFN pair after du, attention pair after dqkv): starts earlier.
-        # In a captured step graph the side stream becomes a parallel branch of the graph.
-        self.weight_grad_mode = os.environ.get("PXR_DW_MODE", "fork_layer")
+        # Measured on MI355X (profiles/r02/README.md): the kernels DO overlap (sum of durations 1190 us vs 935 us of
+        # union per step) but the aggregate rate does not rise -- both sides slow down, the step gets 2-8 % LONGER
+        # (1.199 -> 1.250 / 1.319 ms).  The chip is not short of idle MFMA slots to fill: under sustained fp32-MFMA
+        # load it runs at 2.0-2.2 GHz of its 2.4 (tools/diag/gemm_timeline), and more concurrent work lowers the clock.
+        self.weight_grad_mode = os.environ.get("PXR_DW_MODE", "grouped")
         # leave the join with the side stream to the first consumer of the flat gradient (wait_flat_grads(): PxrAdamW.step,
         # clip_grad_norm_, GradSync.sync) instead of the end of backward(): the sparse-row update of the optimizer then
         # also runs beside the weight-gradient GEMMs.  Opt-in (GraphedTrainStep / Trainer / bench.py set it): code that

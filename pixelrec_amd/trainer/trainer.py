@@ -133,7 +133,9 @@ class Trainer:
         self.model.train()
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
-        lookahead = hasattr(self.model.module, "set_next_batch") and not self.use_modality
+        # opt-in (`lookahead_rows: True`): see SASRec.set_next_batch for why it is off by default on MI355X
+        lookahead = (bool(self.config["lookahead_rows"]) and hasattr(self.model.module, "set_next_batch")
+                     and not self.use_modality)
 
         def with_next(it):
             """(batch, ids of the batch after it | None): one batch of look-ahead out of the prefetch queue."""
@@ -152,7 +154,8 @@ class Trainer:
 
                     self._graph_loss = torch.zeros((), dtype=torch.float32, device=self.device)
                     self._gstep = GraphedTrainStep(self.model, self.optimizer, data[0], data[1], warmup=0,
-                                                   clip_grad_norm=self.clip_grad_norm, loss_sum=self._graph_loss)
+                                                   clip_grad_norm=self.clip_grad_norm, loss_sum=self._graph_loss,
+                                                   lookahead=lookahead)
                 if self._gstep is not None and self._gstep.matches(data[0], data[1]):
                     # the replay adds its loss to self._graph_loss on the device
                     self._gstep(data[0], data[1], next_items=next_items)

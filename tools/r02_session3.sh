@@ -7,7 +7,7 @@ cd $REPO
 export PYTHONUNBUFFERED=1
 timeout 120 python -m pytest tests/test_gpu_gemm.py -m gpu -q -x 2>&1 | tail -3 > $OUT/pytest_gemm.log
 TILES=64,641,12861,128611 timeout 300 python tools/gemm_sweep.py > $OUT/gemm_sweep.log 2>&1
-B="--steps 100 --warmup 10 --no-cpu-baseline --no-extras --no-lookahead --dw-mode grouped"
+B="--steps 100 --warmup 10 --no-cpu-baseline --no-extras --dw-mode grouped"
 timeout 300 python bench.py $B > $OUT/bench_t64.json 2> $OUT/bench_t64.err
 PXR_GEMM_SMALL_TILE=641 timeout 300 python bench.py $B > $OUT/bench_t641.json 2> $OUT/bench_t641.err
 PXR_GEMM_SMALL_TILE=12861 timeout 300 python bench.py $B > $OUT/bench_t12861.json 2> $OUT/bench_t12861.err
