@@ -141,6 +141,29 @@ int64_t pxr_gemm_ws_bytes(int a_kc, int b_kc, int M, int N, int K);
 int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                  float* C, int64_t ldc, int epilogue, const float* bias, float* aux, int64_t ldaux, void* ws,
                  int64_t ws_bytes, int tile_hint, int split_hint, void* stream);
+/* `batch` independent GEMMs of one shape in one launch (grid.z).  Operand z starts (z / nb2) * x1 + (z % nb2) * x2
+ * floats after its base pointer (two-level strides: image n and head h of a packed [n, T, 3*heads*d] projection).  No
+ * epilogue, no split-K.  The attention contractions of the ViT image encoder (HF CLIPAttention, built by the
+ * reference at model/load.py:94): S = Q K^T, O = P V, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q. */
+int pxr_gemm_batched_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B,
+                         int64_t ldb, float* C, int64_t ldc, int batch, int nb2, int64_t a1, int64_t a2, int64_t b1,
+                         int64_t b2, int64_t c1, int64_t c2, int tile_hint, void* stream);
+
+/* ---- ViT image encoder, non-GEMM pieces (csrc/vit.hip) ------------------------------------------------------ */
+/* in place: S[row, :T] = softmax(scale * S[row, :T]), S[row, T:ld] = 0      (HF CLIPAttention, no mask / dropout) */
+int pxr_softmax_rows_f32(float* S, int64_t rows, int T, int ld, float scale, void* stream);
+/* in place on dP: dS = scale * P o (dP - rowsum(dP o P))                    (autograd of the above) */
+int pxr_softmax_rows_bwd_f32(const float* P, float* dP, int64_t rows, int T, int ld, float scale, void* stream);
+/* out[n,t,:] = (t == 0 ? cls : patches[n,t-1,:]) + pos[t,:]                (HF CLIPVisionEmbeddings.forward) */
+int pxr_vit_embed_f32(const float* patches, const float* cls, const float* pos, float* out, int64_t n, int T, int H,
+                      void* stream);
+/* out[n,:] = mean_t x[n,t,:]                                                (MeanItemEncoder, model/layers.py:128) */
+int pxr_token_mean_f32(const float* x, float* out, int64_t n, int T, int D, void* stream);
+/* dact[n,t,:] = act[n,t,:] > 0 ? dout[n,:] / T : 0                          (through the mean and rec_fc's ReLU) */
+int pxr_token_mean_relu_bwd_f32(const float* dout, const float* act, float* dact, int64_t n, int T, int D, void* stream);
+/* out = a + b (n floats, n % 4 == 0): the two branches of a residual-stream gradient */
+int pxr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
 /* y = x W^T + b (act=1: erf-GELU, pre-activation saved; act=2: erf-GELU, gelu'(pre-activation) saved)
  *                                                          layers.py:586-588,613,666-667,669; sasrec.py:112 */
 int pxr_linear_fwd_f32(const float* x, const float* W, const float* b, float* y, float* pre, int M, int N, int K,

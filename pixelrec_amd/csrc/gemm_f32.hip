@@ -10,10 +10,24 @@
 
 namespace pxr {
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD = 4, EPI_BIAS_GELU_GRAD = 5, EPI_MUL = 6 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD = 4, EPI_BIAS_GELU_GRAD = 5, EPI_MUL = 6,
+       // the ViT blocks of the PixelNet image encoder (HF CLIPEncoderLayer; reference load.py:90-120):
+       EPI_BIAS_ADD = 7,          // C = acc + bias + aux            (out_proj / fc2 + residual stream)
+       EPI_BIAS_QGELU_GRAD = 8,   // C = quick_gelu(acc + bias), aux = quick_gelu'(acc + bias)   (CLIP MLP fc1)
+       EPI_BIAS_RELU = 9,         // C = relu(acc + bias)            (rec_fc of MeanItemEncoder, layers.py:121-128)
+       EPI_LAST = 9 };
+
+// Batched launch: grid.z = batch index z; operand offsets (in floats) = (z / nb2) * x1 + (z % nb2) * x2 -- two levels, so
+// that "image n, head h" of a packed [n, T, 3, heads, d] projection is addressed without copies.
+struct GemmBatch {
+  int nb2;
+  int64_t a1, a2, b1, b2, c1, c2;
+};
 
 // erf-GELU exactly as the reference writes it: x * 0.5 * (1 + erf(x / sqrt(2)))  (layers.py:651-660)
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
+// CLIP's quick_gelu: x * sigmoid(1.702 x), and its derivative s + 1.702 x s (1 - s)
+__device__ __forceinline__ float sigmoid_1702(float x) { return 1.0f / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float dgelu_erf(float x) {
   const float cdf = 0.5f * (1.0f + erff(x / 1.41421356237309504880f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
@@ -25,9 +39,15 @@ __global__ void __launch_bounds__((GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT))
 gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
             float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
             float* __restrict__ aux, int64_t ldaux, int tiles_m, int tiles_n, int ksplit_len,
-            int64_t split_stride, int n_fastest) {
+            int64_t split_stride, int n_fastest, GemmBatch bt) {
   using Cfg = GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>;
   __shared__ __attribute__((aligned(16))) float smem[ST * Cfg::STAGE];
+  if (bt.nb2 > 0) {   // batched launch (block-uniform)
+    const int z1 = blockIdx.z / bt.nb2, z2 = blockIdx.z % bt.nb2;
+    A += z1 * bt.a1 + z2 * bt.a2;
+    B += z1 * bt.b1 + z2 * bt.b2;
+    C += z1 * bt.c1 + z2 * bt.c2;
+  }
 
   // Each XCD (private 4 MB L2) works on one contiguous chunk of the tile sequence, so the ORDER of that sequence decides
   // what every XCD pulls over the fabric: m fastest => an XCD owns whole B panels and streams ALL of A (8|A| + |B| in
@@ -45,7 +65,7 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
   const int wm = (wave % Cfg::G) / Cfg::WGN, wn = (wave % Cfg::G) % Cfg::WGN, h = lane >> 5, r = lane & 31;
   // epilogue operands that are READ (residual-branch gradient / saved pre-activation) are fetched before the main
   // loop: the loads complete under the MFMAs instead of stalling every wave after its last one
-  constexpr bool READS_AUX = (EPI == EPI_MUL_DGELU || EPI == EPI_ADD || EPI == EPI_MUL);
+  constexpr bool READS_AUX = (EPI == EPI_MUL_DGELU || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_BIAS_ADD);
   float auxv[READS_AUX ? Cfg::TM : 1][READS_AUX ? Cfg::TN : 1][READS_AUX ? 16 : 1];
   if constexpr (READS_AUX) {
     if (!(KW > 1 && wave >= Cfg::G)) {
@@ -73,7 +93,9 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
     const int col = n0 + wn * Cfg::WN + j * 32 + r;
     if (col >= N) continue;
     float bv = 0.f;
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD) bv = bias[col];
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD || EPI == EPI_BIAS_ADD ||
+                  EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU)
+      bv = bias[col];
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) {
 #pragma unroll
@@ -97,6 +119,15 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
           v *= dgelu_erf(auxv[i][j][e]);
         } else if constexpr (EPI == EPI_ADD) {
           v += auxv[i][j][e];  // residual-branch gradient joins here
+        } else if constexpr (EPI == EPI_BIAS_ADD) {
+          v = (v + bv) + auxv[i][j][e];
+        } else if constexpr (EPI == EPI_BIAS_QGELU_GRAD) {
+          v += bv;
+          const float sg = sigmoid_1702(v);
+          aux[(int64_t)row * ldaux + col] = sg + 1.702f * v * sg * (1.0f - sg);
+          v = v * sg;
+        } else if constexpr (EPI == EPI_BIAS_RELU) {
+          v = fmaxf(v + bv, 0.f);
         }
         C[(int64_t)row * ldc + col] = v;
       }
@@ -199,16 +230,22 @@ __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_kernel(DwGroup g) {
   }
 }
 
+// batch descriptor of the call in progress on this host thread (set by pxr_gemm_batched_f32; {0} / 1 otherwise)
+static thread_local GemmBatch g_bt = GemmBatch{};
+static thread_local int g_batch = 1;
+
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1, int ST = 2, int FINE = 0, bool DUAL = false>
 static int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                        int N, int K, const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len,
                        int64_t split_stride, hipStream_t st) {
+  const GemmBatch bt = g_bt;
+  const int batch = g_batch;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   static const int xcd_env = getenv("PXR_GEMM_XCD") ? atoi(getenv("PXR_GEMM_XCD")) : -1;   // A/B knob: 0 = m fastest, 1 = n
   const int n_fastest = xcd_env >= 0 ? xcd_env : (M > N ? 1 : 0);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD, ST, FINE, DUAL>), dim3(tiles_m * tiles_n, splits),
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, EPI, KW, PD, ST, FINE, DUAL>), dim3(tiles_m * tiles_n, splits, batch),
                      dim3(GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m,
-                     tiles_n, ksplit_len, split_stride, n_fastest);
+                     tiles_n, ksplit_len, split_stride, n_fastest, bt);
   return pxr_check_launch("pxr_gemm_f32");
 }
 
@@ -281,14 +318,16 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   if (M == 0 || N == 0) return PXR_OK;
   PXR_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, "pxr_gemm_f32: leading dims must be multiples of 4 floats");
   PXR_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "pxr_gemm_f32: operands must be 16-byte aligned");
-  // the contiguous extent of each operand is read as float4
-  PXR_REQUIRE(a_kc ? (K % 4 == 0) : (M % 4 == 0), "pxr_gemm_f32: A contiguous extent must be a multiple of 4");
-  PXR_REQUIRE(b_kc ? (K % 4 == 0) : (N % 4 == 0), "pxr_gemm_f32: B contiguous extent must be a multiple of 4");
-  PXR_REQUIRE(epilogue >= 0 && epilogue <= 6, "pxr_gemm_f32: bad epilogue %d", epilogue);
-  PXR_REQUIRE(!(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_GELU_GRAD) || bias,
+  // the contiguous extent of each operand is read as float4: a multiple of 4, or rows padded to one (ld >= extent rounded
+  // up; the caller keeps the pad FINITE -- zero when it lies inside the reduction -- e.g. attention scores [T, ld])
+  const int ext_a = a_kc ? K : M, ext_b = b_kc ? K : N;
+  PXR_REQUIRE(ext_a % 4 == 0 || lda >= ((ext_a + 3) & ~3), "pxr_gemm_f32: A contiguous extent must be a multiple of 4 (or padded)");
+  PXR_REQUIRE(ext_b % 4 == 0 || ldb >= ((ext_b + 3) & ~3), "pxr_gemm_f32: B contiguous extent must be a multiple of 4 (or padded)");
+  PXR_REQUIRE(epilogue >= 0 && epilogue <= EPI_LAST, "pxr_gemm_f32: bad epilogue %d", epilogue);
+  PXR_REQUIRE(!(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_GELU_GRAD ||
+                epilogue == EPI_BIAS_ADD || epilogue == EPI_BIAS_QGELU_GRAD || epilogue == EPI_BIAS_RELU) || bias,
               "pxr_gemm_f32: epilogue needs bias");
-  PXR_REQUIRE(!(epilogue >= EPI_BIAS_GELU) || aux,
-              "pxr_gemm_f32: epilogue needs aux");
+  PXR_REQUIRE(!(epilogue >= EPI_BIAS_GELU && epilogue != EPI_BIAS_RELU) || aux, "pxr_gemm_f32: epilogue needs aux");
   hipStream_t st = (hipStream_t)stream;
 
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
@@ -311,7 +350,7 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   // split-K only for the plain epilogue (weight gradients: few output tiles, long token reduction)
   int splits = 1;
   const int nk = (K + GEMM_BK - 1) / GEMM_BK;
-  if (epilogue == EPI_NONE && ws) {
+  if (epilogue == EPI_NONE && ws && g_batch == 1) {
     if (split_hint >= 1) splits = split_hint;
     else if (tiles < 256 && nk >= 16) {
       splits = (int)((512 + tiles - 1) / tiles);
@@ -346,6 +385,9 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
       case EPI_BIAS: PXR_GEMM_CASE(true, true, EPI_BIAS); break;
       case EPI_BIAS_GELU: PXR_GEMM_CASE(true, true, EPI_BIAS_GELU); break;
       case EPI_BIAS_GELU_GRAD: PXR_GEMM_CASE(true, true, EPI_BIAS_GELU_GRAD); break;
+      case EPI_BIAS_ADD: PXR_GEMM_CASE(true, true, EPI_BIAS_ADD); break;
+      case EPI_BIAS_QGELU_GRAD: PXR_GEMM_CASE(true, true, EPI_BIAS_QGELU_GRAD); break;
+      case EPI_BIAS_RELU: PXR_GEMM_CASE(true, true, EPI_BIAS_RELU); break;
       default: pxr_set_error("pxr_gemm_f32: epilogue %d unsupported for (KC,KC)", epilogue); return PXR_ERR_BAD_ARG;
     }
   } else if (a_kc && !b_kc) {
@@ -373,6 +415,29 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
     return pxr_check_launch("pxr_gemm_f32(split-K reduce)");
   }
   return PXR_OK;
+}
+
+// `batch` independent problems of one shape in ONE launch (grid.z): operand z lives at base + (z / nb2) * s1 +
+// (z % nb2) * s2 floats (two-level strides: e.g. image n and head h of a packed [n, T, 3*heads*d] projection).  No
+// split-K, no workspace; epilogues as pxr_gemm_f32 (bias / aux are shared by all problems).  Used by the attention of
+// the ViT image encoder (S = Q K^T, O = P V and their backward contractions; model/vit_native.py).
+extern "C" int pxr_gemm_batched_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B,
+                                    int64_t ldb, float* C, int64_t ldc, int batch, int nb2, int64_t a1, int64_t a2,
+                                    int64_t b1, int64_t b2, int64_t c1, int64_t c2, int tile_hint, void* stream) {
+  PXR_REQUIRE(batch >= 1 && nb2 >= 1, "pxr_gemm_batched_f32: bad batch %d / nb2 %d", batch, nb2);
+  PXR_REQUIRE(((a1 | a2 | b1 | b2) & 3) == 0, "pxr_gemm_batched_f32: operand strides must be multiples of 4 floats");
+  int rc = PXR_OK;
+  for (int z0 = 0; z0 < batch && rc == PXR_OK; z0 += 65535 / nb2 * nb2) {   // grid.z <= 65535: whole groups per launch
+    const int nz = min(batch - z0, 65535 / nb2 * nb2);
+    const int64_t g0 = z0 / nb2;
+    g_bt = GemmBatch{nb2, a1, a2, b1, b2, c1, c2};
+    g_batch = nz;
+    rc = pxr_gemm_f32(a_kc, b_kc, M, N, K, A + g0 * a1, lda, B + g0 * b1, ldb, C + g0 * c1, ldc, EPI_NONE, nullptr, nullptr,
+                      0, nullptr, 0, tile_hint ? tile_hint : 64, 1, stream);
+    g_bt = GemmBatch{};
+    g_batch = 1;
+  }
+  return rc;
 }
 
 // y[M,N] = x[M,K] W[N,K]^T + b   (act: 0 none, 1 erf-GELU with the pre-activation saved to `pre`, 2 erf-GELU with

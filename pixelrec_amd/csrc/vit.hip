@@ -1,0 +1,196 @@
+// vit.hip -- the non-GEMM pieces of the PixelNet image encoder (HF CLIPVisionModel as the reference builds it in
+// code/REC/model/load.py:90-120, wrapped by MeanItemEncoder, code/REC/model/layers.py:121-128).
+//
+// The ViT blocks run on the fp32-MFMA GEMM kernels (gemm_f32.hip: projections with the bias / residual / quick-GELU /
+// ReLU epilogues, and BATCHED launches for the attention contractions S = Q K^T, O = P V and their gradients).  What is
+// left is row-wise or elementwise and HBM-bound:
+//   * pxr_softmax_rows_f32 / _bwd_f32   softmax over the keys of one (image, head, query) row, in place on the score
+//                                       matrix [rows, ld] (ld = T rounded up to 4; the pad columns are written as zeros so
+//                                       the matrix can be a k-contiguous GEMM operand);  no mask, no dropout (CLIP has
+//                                       neither; the SASRec attention has its own fused kernels in attention.hip);
+//   * pxr_vit_embed_f32                 [class token | patch projections] + position embedding -> token matrix;
+//   * pxr_token_mean_f32 / pxr_token_mean_relu_bwd_f32   mean over the T tokens of relu(rec_fc(.)) and its gradient;
+//   * pxr_add_f32                       out = a + b (the two branches of a residual gradient).
+#include "pxr_common.h"
+
+namespace pxr {
+
+// One wave per row; lanes stride over the T columns.  p = exp(scale * (s - max)) / sum  (HF: softmax(q*scale . k)).
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S, int64_t rows, int T, int ld,
+                                                           float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* s = S + row * ld;
+  constexpr int MAXV = 8;                       // T <= 512 in registers; longer rows re-read
+  float v[MAXV];
+  float m = -3.0e38f;
+  const int nv = (T + 63) / 64;
+  if (nv <= MAXV) {
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = k * 64 + lane;
+      v[k] = (k < nv && c < T) ? s[c] * scale : -3.0e38f;
+      m = fmaxf(m, v[k]);
+    }
+    m = wave_max(m);
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = k * 64 + lane;
+      v[k] = (k < nv && c < T) ? __expf(v[k] - m) : 0.f;
+      z += v[k];
+    }
+    const float inv = 1.0f / wave_sum(z);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = k * 64 + lane;
+      if (k < nv && c < ld) s[c] = c < T ? v[k] * inv : 0.f;
+    }
+  } else {
+    for (int c = lane; c < T; c += 64) m = fmaxf(m, s[c] * scale);
+    m = wave_max(m);
+    float z = 0.f;
+    for (int c = lane; c < T; c += 64) z += __expf(s[c] * scale - m);
+    const float inv = 1.0f / wave_sum(z);
+    for (int c = lane; c < ld; c += 64) s[c] = c < T ? __expf(s[c] * scale - m) * inv : 0.f;
+  }
+}
+
+// dS = scale * P o (dP - sum_k dP o P), in place on dP (pad columns -> 0)
+__global__ void __launch_bounds__(256) softmax_rows_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP,
+                                                               int64_t rows, int T, int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = P + row * ld;
+  float* d = dP + row * ld;
+  float dot = 0.f;
+  for (int c = lane; c < T; c += 64) dot += p[c] * d[c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < ld; c += 64) d[c] = c < T ? scale * p[c] * (d[c] - dot) : 0.f;
+}
+
+// out[n, t, :] = (t == 0 ? cls : patches[n, t-1, :]) + pos[t, :]       (HF CLIPVisionEmbeddings.forward)
+__global__ void __launch_bounds__(256) vit_embed_kernel(const float4* __restrict__ patches, const float4* __restrict__ cls,
+                                                        const float4* __restrict__ pos, float4* __restrict__ out,
+                                                        int64_t n, int T, int H4) {
+  const int64_t total = n * T * H4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % H4);
+    const int64_t r = i / H4;
+    const int t = (int)(r % T);
+    const int64_t img = r / T;
+    const float4 a = t == 0 ? cls[c] : patches[(img * (T - 1) + (t - 1)) * H4 + c];
+    const float4 p = pos[(int64_t)t * H4 + c];
+    out[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+// out[n, :] = mean_t x[n, t, :]      (MeanItemEncoder: torch.mean(rec_fc(x), dim=1), layers.py:128)
+__global__ void __launch_bounds__(256) token_mean_kernel(const float4* __restrict__ x, float4* __restrict__ out, int64_t n,
+                                                         int T, int D4) {
+  const int64_t total = n * D4;
+  const float inv = 1.0f / (float)T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % D4);
+    const int64_t img = i / D4;
+    const float4* p = x + img * T * D4 + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {      // fixed order => deterministic
+      const float4 v = p[(int64_t)t * D4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+
+// dact[n, t, :] = act[n, t, :] > 0 ? dout[n, :] / T : 0     (through the token mean and the ReLU of rec_fc)
+__global__ void __launch_bounds__(256) token_mean_relu_bwd_kernel(const float4* __restrict__ dout,
+                                                                  const float4* __restrict__ act,
+                                                                  float4* __restrict__ dact, int64_t n, int T, int D4) {
+  const int64_t total = n * T * D4;
+  const float inv = 1.0f / (float)T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % D4);
+    const int64_t img = i / ((int64_t)T * D4);
+    const float4 a = act[i];
+    const float4 g = dout[img * D4 + c];
+    dact[i] = make_float4(a.x > 0.f ? g.x * inv : 0.f, a.y > 0.f ? g.y * inv : 0.f, a.z > 0.f ? g.z * inv : 0.f,
+                          a.w > 0.f ? g.w * inv : 0.f);
+  }
+}
+
+__global__ void __launch_bounds__(256) add_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                  float4* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 x = a[i], y = b[i];
+    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+static inline unsigned grid_for(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+// In place: S[row, :T] <- softmax(scale * S[row, :T]), S[row, T:ld] <- 0.   rows = images * heads * T.
+extern "C" int pxr_softmax_rows_f32(float* S, int64_t rows, int T, int ld, float scale, void* stream) {
+  PXR_REQUIRE(S && rows >= 0 && T > 0 && ld >= T, "pxr_softmax_rows_f32: bad args");
+  if (rows == 0) return PXR_OK;
+  PXR_REQUIRE((rows + 3) / 4 < (1ll << 31), "pxr_softmax_rows_f32: too many rows");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, rows, T,
+                     ld, scale);
+  return pxr_check_launch("pxr_softmax_rows_f32");
+}
+
+// In place on dP: dS = scale * P o (dP - rowsum(dP o P))   (gradient w.r.t. the UNscaled scores)
+extern "C" int pxr_softmax_rows_bwd_f32(const float* P, float* dP, int64_t rows, int T, int ld, float scale,
+                                        void* stream) {
+  PXR_REQUIRE(P && dP && rows >= 0 && T > 0 && ld >= T, "pxr_softmax_rows_bwd_f32: bad args");
+  if (rows == 0) return PXR_OK;
+  PXR_REQUIRE((rows + 3) / 4 < (1ll << 31), "pxr_softmax_rows_bwd_f32: too many rows");
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP,
+                     rows, T, ld, scale);
+  return pxr_check_launch("pxr_softmax_rows_bwd_f32");
+}
+
+extern "C" int pxr_vit_embed_f32(const float* patches, const float* cls, const float* pos, float* out, int64_t n, int T,
+                                 int H, void* stream) {
+  PXR_REQUIRE(patches && cls && pos && out && n >= 0 && T >= 2 && H > 0 && H % 4 == 0, "pxr_vit_embed_f32: bad args");
+  if (n == 0) return PXR_OK;
+  hipLaunchKernelGGL(vit_embed_kernel, dim3(grid_for(n * T * (H / 4))), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)patches, (const float4*)cls, (const float4*)pos, (float4*)out, n, T, H / 4);
+  return pxr_check_launch("pxr_vit_embed_f32");
+}
+
+extern "C" int pxr_token_mean_f32(const float* x, float* out, int64_t n, int T, int D, void* stream) {
+  PXR_REQUIRE(x && out && n >= 0 && T > 0 && D > 0 && D % 4 == 0, "pxr_token_mean_f32: bad args");
+  if (n == 0) return PXR_OK;
+  hipLaunchKernelGGL(token_mean_kernel, dim3(grid_for(n * (D / 4))), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (float4*)out, n, T, D / 4);
+  return pxr_check_launch("pxr_token_mean_f32");
+}
+
+extern "C" int pxr_token_mean_relu_bwd_f32(const float* dout, const float* act, float* dact, int64_t n, int T, int D,
+                                           void* stream) {
+  PXR_REQUIRE(dout && act && dact && n >= 0 && T > 0 && D > 0 && D % 4 == 0, "pxr_token_mean_relu_bwd_f32: bad args");
+  if (n == 0) return PXR_OK;
+  hipLaunchKernelGGL(token_mean_relu_bwd_kernel, dim3(grid_for(n * T * (D / 4))), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)dout, (const float4*)act, (float4*)dact, n, T, D / 4);
+  return pxr_check_launch("pxr_token_mean_relu_bwd_f32");
+}
+
+extern "C" int pxr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  PXR_REQUIRE(a && b && out && n >= 0 && n % 4 == 0, "pxr_add_f32: bad args (n must be a multiple of 4)");
+  if (n == 0) return PXR_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)a,
+                     (const float4*)b, (float4*)out, n / 4);
+  return pxr_check_launch("pxr_add_f32");
+}

@@ -78,6 +78,14 @@ _SIGNATURES = {
     "pxr_adamw_flat_tab_f32": (_I, [_P, _P, _P, _P, _I64, _P, _I64, _P, _D, _D, _D, _P]),
     "pxr_counter_add_i64": (_I, [_P, _I64, _P]),
     "pxr_set_status_word": (_I, [_P]),
+    "pxr_gemm_batched_f32": (_I, [_I, _I, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I64, _I64, _I64, _I64, _I64,
+                                  _I64, _I, _P]),
+    "pxr_softmax_rows_f32": (_I, [_P, _I64, _I, _I, _F, _P]),
+    "pxr_softmax_rows_bwd_f32": (_I, [_P, _P, _I64, _I, _I, _F, _P]),
+    "pxr_vit_embed_f32": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P]),
+    "pxr_token_mean_f32": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "pxr_token_mean_relu_bwd_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
+    "pxr_add_f32": (_I, [_P, _P, _P, _I64, _P]),
 }
 
 

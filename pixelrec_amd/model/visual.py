@@ -9,9 +9,9 @@ attribute the reference pokes (SURVEY.md §7 hard part 8), so the encoder is res
 SAME parameter names/order as transformers 4.16.2's `CLIPVisionModel` (`vision_model.embeddings.class_embedding`, ...,
 199 named parameters for B/32; index 165 = first parameter of block 10): reference checkpoints load by name.
 
-What runs where (round 1): the PATCH PROJECTION (conv 3->768, k=s=32 == GEMM
-[n*49, 3072] x [3072, 768]) runs on the fp32-MFMA GEMM kernel; the 12 transformer blocks ride PyTorch-ROCm ops; rec_fc
-+ ReLU + token mean are torch ops on the trainable tail.
+What runs where: on a HIP tensor the WHOLE encoder -- patch projection, every ViT block forward, the backward of the
+trainable blocks, rec_fc + ReLU + token mean -- runs on this build's kernels (model/vit_native.py); the torch modules in
+this file hold the parameters under the reference's names and restate the tower for CPU-side checks (tests/test_visual_cpu.py).
 """
 from __future__ import annotations
 
@@ -145,19 +145,37 @@ class _ItemEncoderBase(nn.Module):
         if (act_name.lower() if isinstance(act_name, str) else act_name) not in act:
             raise NotImplementedError(f"activation {act_name!r}")
         self.item_encoder = item_encoder
+        # the MI355X-native forward/backward of the whole encoder (model/vit_native.py) used for every HIP tensor; the
+        # torch modules below are parameter containers (reference names) and the CPU restatement used by CPU-only checks
+        from .vit_native import NativeTower
+
+        self._native = NativeTower(self)
+        self._anchor = None
         self.rec_fc = nn.Sequential(nn.Linear(input_dim, output_dim), act[act_name.lower() if isinstance(act_name, str) else act_name])
         nn.init.xavier_normal_(self.rec_fc[0].weight.data)
         nn.init.constant_(self.rec_fc[0].bias.data, 0)
 
 
 class MeanItemEncoder(_ItemEncoderBase):
+    native_method = "mean"
+
     def forward(self, x):                       # layers.py:125-128
+        if x.is_cuda:
+            from . import vit_native
+
+            return vit_native.run(self, x)
         x = self.item_encoder(x)[0]
         return torch.mean(self.rec_fc(x), dim=1)
 
 
 class ClsItemEncoder(_ItemEncoderBase):
+    native_method = "cls"
+
     def forward(self, x):                       # layers.py:113-117
+        if x.is_cuda:
+            from . import vit_native
+
+            return vit_native.run(self, x)
         x = self.item_encoder(x)[0]
         return self.rec_fc(x[:, 0, :])
 

@@ -1,0 +1,302 @@
+"""The PixelNet image encoder on the MI355X-native kernels: forward of every CLIP ViT block, backward of the trainable
+ones, the MeanItemEncoder head, and the flat AdamW state of the 'visual_encoder' parameter group.
+
+Reference: HF `CLIPVisionModel` as built by code/REC/model/load.py:90-120 (first `tune_scale` named parameters frozen,
+`post_layernorm` -> Identity) wrapped by `MeanItemEncoder` / the cls variant (code/REC/model/layers.py:65-128), trained
+by the 'visual_encoder' group of the reference optimizer (code/REC/trainer/trainer.py:74-96).
+
+One pre-LN block  x -> x + out_proj(attn(LN1 x)) -> (.) + fc2(quick_gelu(fc1(LN2 .)))  is, on the device:
+    LN1                          pxr_ln_residual_fwd_f32 (no residual, eps 1e-5)
+    k|v|q projection             ONE fp32-MFMA GEMM over the fused [3H, H] weight (+bias)
+    S = Q K^T, P = softmax, P V  two BATCHED GEMM launches (grid.z = image x head) + pxr_softmax_rows_f32
+    out_proj + bias + residual   GEMM, EPI_BIAS_ADD
+    LN2, fc1 + quick_gelu        GEMM, EPI_BIAS_QGELU_GRAD (saves quick_gelu' for the backward)
+    fc2 + bias + residual        GEMM, EPI_BIAS_ADD
+and the backward mirrors it with the input-gradient GEMMs (x gelu' / + residual-gradient epilogues), four batched
+attention contractions, pxr_softmax_rows_bwd_f32, pxr_ln_bwd_f32 and ONE grouped weight/bias-gradient launch per block.
+Nothing here is a torch op except tensor allocation and the im2col view/copy of the pixel tensor (a layout change).
+
+All encoder parameters live in ONE flat fp32 buffer (`nn.Parameter.data` are views; k|v|q weights adjacent so the fused
+projection needs no copy); gradients of the trainable ones are views of a flat gradient buffer that every backward
+overwrites, and `VisualAdamW` updates the trainable segments with the same fused kernel as the rest of the model.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..lib import PxrError
+
+# intra-block flat order: the three projection weights adjacent, then their biases (registration order is k, v, q)
+_BLOCK_ORDER = ("self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.q_proj.weight",
+                "self_attn.k_proj.bias", "self_attn.v_proj.bias", "self_attn.q_proj.bias",
+                "self_attn.out_proj.weight", "self_attn.out_proj.bias", "layer_norm1.weight", "layer_norm1.bias",
+                "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "layer_norm2.weight",
+                "layer_norm2.bias")
+
+
+class NativeTower:
+    """Flat packing + native forward/backward of a visual._ItemEncoderBase (`enc`)."""
+
+    def __init__(self, enc):
+        self.enc = enc
+        self.flat = self.gflat = None
+        self.views = {}          # name (relative to enc) -> (offset, numel, shape)
+        self.segments = []       # [(lo, hi)] flat ranges that receive gradients and optimizer updates
+        self._scratch = {}
+
+    # ------------------------------------------------------------------------------------------ packing
+    def _ordered(self):
+        e = self.enc
+        named = dict(e.named_parameters())
+        vm = "item_encoder.vision_model."
+        order = [vm + "embeddings.class_embedding", vm + "embeddings.patch_embedding.weight",
+                 vm + "embeddings.position_embedding.weight", vm + "pre_layrnorm.weight", vm + "pre_layrnorm.bias"]
+        n_layers = len(e.item_encoder.vision_model.encoder.layers)
+        for i in range(n_layers):
+            order += [f"{vm}encoder.layers.{i}.{s}" for s in _BLOCK_ORDER]
+        order += [vm + "post_layernorm.weight", vm + "post_layernorm.bias", "rec_fc.0.weight", "rec_fc.0.bias"]
+        assert set(order) == set(named), sorted(set(named) ^ set(order))
+        return [(k, named[k]) for k in order]
+
+    def ensure_packed(self):
+        first = self.enc.item_encoder.vision_model.embeddings.class_embedding
+        if self.flat is not None and self.flat.device == first.device and first.data_ptr() == self.flat.data_ptr():
+            return
+        dev = first.device
+        self._require_hip(dev)
+        specs = self._ordered()
+        pad4 = lambda n: (n + 3) & ~3                       # every tensor starts 16-byte aligned
+        total = sum(pad4(p.numel()) for _, p in specs)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off, views, segs = 0, {}, []
+        for name, p in specs:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            views[name] = (off, n, tuple(p.shape))
+            if p.requires_grad and "post_layernorm" not in name:     # post_layernorm: unused by 'mean'/'cls' (load.py:112)
+                p.grad = gflat[off:off + n].view(p.shape)
+                if segs and segs[-1][1] == off:
+                    segs[-1] = (segs[-1][0], off + pad4(n))
+                else:
+                    segs.append((off, off + pad4(n)))
+            off += pad4(n)
+        self.flat, self.gflat, self.views, self.segments = flat, gflat, views, segs
+
+    @staticmethod
+    def _require_hip(dev):
+        if dev.type != "cuda":
+            raise PxrError("the native image encoder runs on a HIP device only (no CPU fallback)")
+
+    def view(self, name, grad=False, span=1):
+        off, n, shape = self.views[name]
+        buf = self.gflat if grad else self.flat
+        if span == 1:
+            return buf[off:off + n].view(shape)
+        return buf[off:off + span * n].view((span * shape[0],) + tuple(shape[1:]))
+
+    def first_trainable_block(self):
+        """Index of the first block holding a trainable parameter (n_layers if none); -1 if the embeddings train."""
+        e = self.enc
+        vm = e.item_encoder.vision_model
+        emb = [vm.embeddings.class_embedding, vm.embeddings.patch_embedding.weight, vm.embeddings.position_embedding.weight,
+               vm.pre_layrnorm.weight, vm.pre_layrnorm.bias]
+        if any(p.requires_grad for p in emb):
+            return -1
+        for i, layer in enumerate(vm.encoder.layers):
+            if any(p.requires_grad for p in layer.parameters()):
+                return i
+        return len(vm.encoder.layers)
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _shape(self):
+        vm = self.enc.item_encoder.vision_model
+        H = vm.embeddings.class_embedding.shape[0]
+        heads = vm.encoder.layers[0].self_attn.heads
+        return H, heads, H // heads, vm.embeddings.num_patches + 1, vm.embeddings.patch_size
+
+    def _attn_fwd(self, qkv, n, T, heads, d, keep):
+        H, ld, Tp = heads * d, 3 * heads * d, (T + 3) & ~3
+        key = ("S", n, T)
+        S = None if keep else self._scratch.get(key)
+        if S is None:
+            S = torch.empty(n * heads, T, Tp, dtype=torch.float32, device=qkv.device)
+            if not keep:
+                self._scratch = {key: S}
+        bh = n * heads
+        # S = Q K^T (q rows at 2H + h*d, k rows at h*d of the fused k|v|q projection)
+        ops.gemm_batched(True, True, T, T, d, qkv, 2 * H, ld, qkv, 0, ld, S, 0, Tp, bh, heads, (T * ld, d), (T * ld, d),
+                         (heads * T * Tp, T * Tp))
+        ops.softmax_rows(S, bh * T, T, Tp, d ** -0.5)
+        ctx = torch.empty(n, T, H, dtype=torch.float32, device=qkv.device)
+        # O = P V (v rows at H + h*d)
+        ops.gemm_batched(True, False, T, d, T, S, 0, Tp, qkv, H, ld, ctx, 0, H, bh, heads, (heads * T * Tp, T * Tp),
+                         (T * ld, d), (T * H, d))
+        return ctx, (S if keep else None)
+
+    def _block_fwd(self, i, x, keep):
+        vm = "item_encoder.vision_model."
+        P = lambda s, **kw: self.view(f"{vm}encoder.layers.{i}.{s}", **kw)
+        H, heads, d, T, _ = self._shape()
+        n = x.shape[0]
+        h1, xh1, rs1 = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=keep)
+        qkv = ops.linear_fwd(h1, P("self_attn.k_proj.weight", span=3), P("self_attn.k_proj.bias", span=3))
+        ctx, S = self._attn_fwd(qkv, n, T, heads, d, keep)
+        x2 = ops.linear_epi(ctx, P("self_attn.out_proj.weight"), P("self_attn.out_proj.bias"), ops.EPI_BIAS_ADD, aux=x)
+        h2, xh2, rs2 = ops.ln_residual_fwd(x2, None, P("layer_norm2.weight"), P("layer_norm2.bias"), 1e-5, save=keep)
+        f, gq = ops.linear_epi(h2, P("mlp.fc1.weight"), P("mlp.fc1.bias"), ops.EPI_BIAS_QGELU_GRAD)
+        x3 = ops.linear_epi(f, P("mlp.fc2.weight"), P("mlp.fc2.bias"), ops.EPI_BIAS_ADD, aux=x2)
+        saved = dict(xh1=xh1, rs1=rs1, h1=h1, qkv=qkv, P=S, ctx=ctx, xh2=xh2, rs2=rs2, h2=h2, gq=gq, f=f) if keep else None
+        return x3, saved
+
+    def forward(self, images, need_grad: bool):
+        """images fp32 [n, 3, Hi, Wi] -> (item vectors [n, D], saved state | None)."""
+        self.ensure_packed()
+        e = self.enc
+        vm = "item_encoder.vision_model."
+        H, heads, d, T, p = self._shape()
+        n, c, Hi, Wi = images.shape
+        if (Hi // p) * (Wi // p) != T - 1:
+            raise ValueError(f"image size {Hi}x{Wi} does not give the encoder's {T - 1} patches of {p}x{p}")
+        first = self.first_trainable_block() if need_grad else 10 ** 9
+        # patch projection: conv(k = s = p, no bias) == im2col (a layout change) + GEMM on the fp32 MFMA
+        patches = images.view(n, c, Hi // p, p, Wi // p, p).permute(0, 2, 4, 1, 3, 5).reshape(-1, c * p * p).contiguous()
+        wp = self.view(vm + "embeddings.patch_embedding.weight").view(H, -1)
+        pe = ops.linear_fwd(patches, wp, None).view(n, T - 1, H)
+        x0 = ops.vit_embed(pe, self.view(vm + "embeddings.class_embedding"), self.view(vm + "embeddings.position_embedding.weight"))
+        keep0 = first < 0
+        x, xh0, rs0 = ops.ln_residual_fwd(x0, None, self.view(vm + "pre_layrnorm.weight"), self.view(vm + "pre_layrnorm.bias"),
+                                          1e-5, save=keep0)
+        n_layers = len(e.item_encoder.vision_model.encoder.layers)
+        blocks = []
+        for i in range(n_layers):
+            x, s = self._block_fwd(i, x, keep=need_grad and i >= first)
+            blocks.append(s)
+        # head: rec_fc (Linear + activation) on every token then the token mean, or on the class token only
+        act_relu = isinstance(e.rec_fc[1], torch.nn.ReLU)
+        if not act_relu and not isinstance(e.rec_fc[1], torch.nn.Identity):
+            raise NotImplementedError("native image encoder: rec_fc activation must be relu or none (overall/ViT.yaml: relu)")
+        W, b = self.view("rec_fc.0.weight"), self.view("rec_fc.0.bias")
+        head_in = x if e.native_method == "mean" else x[:, 0, :].contiguous()
+        act = ops.linear_epi(head_in, W, b, ops.EPI_BIAS_RELU) if act_relu else ops.linear_fwd(head_in, W, b)
+        out = ops.token_mean(act) if e.native_method == "mean" else act
+        saved = None
+        if need_grad:
+            saved = dict(n=n, first=first, blocks=blocks, x_last=x, head_in=head_in, act=act, act_relu=act_relu,
+                         patches=patches if keep0 else None, xh0=xh0, rs0=rs0)
+        return out, saved
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _block_bwd(self, i, dx3, s, defer):
+        vm = "item_encoder.vision_model."
+        name = lambda t: f"{vm}encoder.layers.{i}.{t}"
+        P = lambda t, **kw: self.view(name(t), **kw)
+        G = lambda t, **kw: self.view(name(t), grad=True, **kw)
+        H, heads, d, T, _ = self._shape()
+        n = dx3.shape[0]
+        M = n * T
+        ld, Tp, bh = 3 * H, (T + 3) & ~3, n * heads
+        pend = []
+        # fc2 + residual:  x3 = x2 + f W2^T + b2
+        pend.append((dx3.view(M, H), s["f"].view(M, -1), G("mlp.fc2.weight"), G("mlp.fc2.bias")))
+        du = ops.linear_bwd_input(dx3, P("mlp.fc2.weight"), mul=s["gq"])               # x quick_gelu'(pre-activation)
+        pend.append((du.view(M, -1), s["h2"].view(M, H), G("mlp.fc1.weight"), G("mlp.fc1.bias")))
+        dh2 = ops.linear_bwd_input(du, P("mlp.fc1.weight"))
+        dz2, _ = ops.ln_bwd(0, dh2, s["xh2"], s["rs2"], P("layer_norm2.weight"), G("layer_norm2.weight"),
+                            G("layer_norm2.bias"), defer=defer)
+        dx2 = ops.add(dx3, dz2)
+        # attention + residual:  x2 = x + ctx Wo^T + bo
+        pend.append((dx2.view(M, H), s["ctx"].view(M, H), G("self_attn.out_proj.weight"), G("self_attn.out_proj.bias")))
+        dctx = ops.linear_bwd_input(dx2, P("self_attn.out_proj.weight"))
+        qkv, Pm = s["qkv"], s["P"]
+        dqkv = torch.empty_like(qkv)
+        dP = torch.empty_like(Pm)
+        sP, sQ, sC = (heads * T * Tp, T * Tp), (T * ld, d), (T * H, d)
+        ops.gemm_batched(False, False, T, d, T, Pm, 0, Tp, dctx, 0, H, dqkv, H, ld, bh, heads, sP, sC, sQ)    # dV = P^T dO
+        ops.gemm_batched(True, True, T, T, d, dctx, 0, H, qkv, H, ld, dP, 0, Tp, bh, heads, sC, sQ, sP)      # dP = dO V^T
+        ops.softmax_rows_bwd(Pm, dP, bh * T, T, Tp, d ** -0.5)                                            # dP := dS
+        ops.gemm_batched(True, False, T, d, T, dP, 0, Tp, qkv, 0, ld, dqkv, 2 * H, ld, bh, heads, sP, sQ, sQ)  # dQ = dS K
+        ops.gemm_batched(False, False, T, d, T, dP, 0, Tp, qkv, 2 * H, ld, dqkv, 0, ld, bh, heads, sP, sQ, sQ)  # dK = dS^T Q
+        pend.append((dqkv.view(M, ld), s["h1"].view(M, H), G("self_attn.k_proj.weight", span=3),
+                     G("self_attn.k_proj.bias", span=3)))
+        dh1 = ops.linear_bwd_input(dqkv, P("self_attn.k_proj.weight", span=3))
+        dz1, _ = ops.ln_bwd(0, dh1, s["xh1"], s["rs1"], P("layer_norm1.weight"), G("layer_norm1.weight"),
+                            G("layer_norm1.bias"), defer=defer)
+        dx = ops.add(dx2, dz1)
+        ops.grouped_linear_bwd_weight(pend)      # all four weight + bias gradients of the block: one launch
+        return dx
+
+    def backward(self, d_out, saved):
+        """d_out [n, D] -> fills the flat gradient buffer of the trainable parameters."""
+        e = self.enc
+        vm = "item_encoder.vision_model."
+        H, heads, d, T, p = self._shape()
+        n, first = saved["n"], saved["first"]
+        G = lambda t: self.view(t, grad=True)
+        defer = ops.DeferredReductions()
+        d_out = d_out.contiguous()
+        act, head_in = saved["act"], saved["head_in"]
+        if e.native_method == "mean":
+            if saved["act_relu"]:
+                dact = ops.token_mean_relu_bwd(d_out, act)
+            else:
+                dact = ops.token_mean_relu_bwd(d_out, torch.ones_like(act))
+            M = n * T
+        else:
+            dact = torch.where(act > 0, d_out, torch.zeros_like(d_out)) if saved["act_relu"] else d_out
+            M = n
+        D = dact.shape[-1]
+        ops.grouped_linear_bwd_weight([(dact.view(M, D), head_in.view(M, H), G("rec_fc.0.weight"), G("rec_fc.0.bias"))])
+        n_layers = len(e.item_encoder.vision_model.encoder.layers)
+        if first >= n_layers:                    # only rec_fc trains
+            defer.flush()
+            return
+        dxl = ops.linear_bwd_input(dact, self.view("rec_fc.0.weight"))
+        if e.native_method == "mean":
+            dx = dxl.view(n, T, H)
+        else:
+            dx = torch.zeros(n, T, H, dtype=torch.float32, device=dxl.device)
+            dx[:, 0, :] = dxl
+        for i in reversed(range(max(first, 0), n_layers)):
+            dx = self._block_bwd(i, dx, saved["blocks"][i], defer)
+        if first < 0:                            # the embeddings train too (tune_scale < 5)
+            dx0, _ = ops.ln_bwd(0, dx, saved["xh0"], saved["rs0"], self.view(vm + "pre_layrnorm.weight"),
+                                G(vm + "pre_layrnorm.weight"), G(vm + "pre_layrnorm.bias"), defer=defer)
+            gpos = G(vm + "embeddings.position_embedding.weight")
+            ops.colsum(dx0.view(n, T * H), out=gpos.view(-1), defer=defer)
+            defer.flush()
+            G(vm + "embeddings.class_embedding").copy_(gpos[0])          # d cls = d pos[0] (both add into token 0)
+            dpe = dx0[:, 1:, :].contiguous().view(n * (T - 1), H)
+            gw = G(vm + "embeddings.patch_embedding.weight").view(H, -1)
+            ops.linear_bwd_weight(dpe, saved["patches"], out=gw)
+        else:
+            defer.flush()
+
+
+class _TowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, anchor, tower):
+        out, saved = tower.forward(images, need_grad=True)
+        ctx.tower, ctx.saved = tower, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ctx.tower.backward(d_out, ctx.saved)
+        ctx.saved = None
+        return None, None, None
+
+
+def run(enc, images):
+    """MeanItemEncoder / ClsItemEncoder forward on a HIP tensor."""
+    tower = enc._native
+    tower.ensure_packed()
+    trainable = any(p.requires_grad for p in enc.parameters())
+    if torch.is_grad_enabled() and trainable:
+        if enc._anchor is None or enc._anchor.device != images.device:
+            enc._anchor = torch.zeros((), dtype=torch.float32, device=images.device, requires_grad=True)
+        return _TowerFn.apply(images.contiguous(), enc._anchor, tower)
+    out, _ = tower.forward(images.contiguous(), need_grad=False)
+    return out

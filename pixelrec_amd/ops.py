@@ -114,6 +114,7 @@ def embed_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------ GEMMs
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_ADD = 0, 1, 2, 3, 4
+EPI_BIAS_GELU_GRAD, EPI_MUL, EPI_BIAS_ADD, EPI_BIAS_QGELU_GRAD, EPI_BIAS_RELU = 5, 6, 7, 8, 9
 
 
 def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc, epilogue=EPI_NONE, bias=None,
@@ -147,6 +148,82 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: b
         _l.check(L.pxr_linear_fwd_f32(_l.ptr(x), _l.ptr(W), _l.ptr(b), _l.ptr(y), _l.ptr(pre), M, N, K,
                                       (2 if save_grad else 1) if gelu else 0, _l.stream_ptr()), "pxr_linear_fwd_f32")
     return (y, pre) if gelu else y
+
+
+def linear_epi(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, epi: int, aux: torch.Tensor | None = None,
+               tag: str = "gemm_kernel<KC,KC,*> (ViT linear)"):
+    """y = epilogue(x W^T + b) for the ViT-block epilogues (gemm_f32.hip): EPI_BIAS_ADD (aux = residual stream, read),
+    EPI_BIAS_QGELU_GRAD (aux = quick_gelu' saved for the backward, written; returned second), EPI_BIAS_RELU."""
+    L = _l.load()
+    _req(x, torch.float32, "x"); _req(W, torch.float32, "W")
+    N, K = W.shape
+    M = x.numel() // K
+    y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+    out_aux = None
+    if epi == EPI_BIAS_QGELU_GRAD:
+        aux = out_aux = torch.empty_like(y)
+    elif epi == EPI_BIAS_ADD:
+        _req(aux, torch.float32, "aux")
+    with _gemm_timer(2.0 * M * N * K, tag):
+        _l.check(L.pxr_gemm_f32(1, 1, M, N, K, _l.ptr(x), K, _l.ptr(W), K, _l.ptr(y), N, epi, _l.ptr(b), _l.ptr(aux), N,
+                                None, 0, 0, 0, _l.stream_ptr()), "pxr_gemm_f32")
+    return (y, out_aux) if out_aux is not None else y
+
+
+def gemm_batched(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, batch, nb2,
+                 a12, b12, c12):
+    """`batch` GEMMs in one launch (pxr_gemm_batched_f32).  A/B/C are tensors, *_off element offsets of problem 0,
+    x12 = (stride1, stride2) in elements for the two batch levels (z // nb2, z % nb2)."""
+    L = _l.load()
+    cp = _l.c_void_p
+    with _gemm_timer(2.0 * M * N * K * batch, "gemm_kernel (batched: attention contraction of the ViT encoder)"):
+        _l.check(L.pxr_gemm_batched_f32(int(a_kc), int(b_kc), M, N, K, cp(A.data_ptr() + 4 * a_off), lda,
+                                        cp(B.data_ptr() + 4 * b_off), ldb, cp(C.data_ptr() + 4 * c_off), ldc, batch, nb2,
+                                        a12[0], a12[1], b12[0], b12[1], c12[0], c12[1], 0, _l.stream_ptr()),
+                 "pxr_gemm_batched_f32")
+
+
+def softmax_rows(S: torch.Tensor, rows: int, T: int, ld: int, scale: float):
+    _l.check(_l.load().pxr_softmax_rows_f32(_l.ptr(S), rows, T, ld, float(scale), _l.stream_ptr()), "pxr_softmax_rows_f32")
+
+
+def softmax_rows_bwd(P: torch.Tensor, dP: torch.Tensor, rows: int, T: int, ld: int, scale: float):
+    _l.check(_l.load().pxr_softmax_rows_bwd_f32(_l.ptr(P), _l.ptr(dP), rows, T, ld, float(scale), _l.stream_ptr()),
+             "pxr_softmax_rows_bwd_f32")
+
+
+def vit_embed(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """patches [n, T-1, H] -> tokens [n, T, H] = [cls | patches] + pos."""
+    _req(patches, torch.float32, "patches"); _req(cls, torch.float32, "cls"); _req(pos, torch.float32, "pos")
+    n, Tm1, H = patches.shape
+    out = torch.empty(n, Tm1 + 1, H, dtype=torch.float32, device=patches.device)
+    _l.check(_l.load().pxr_vit_embed_f32(_l.ptr(patches), _l.ptr(cls), _l.ptr(pos), _l.ptr(out), n, Tm1 + 1, H,
+                                         _l.stream_ptr()), "pxr_vit_embed_f32")
+    return out
+
+
+def token_mean(x: torch.Tensor) -> torch.Tensor:
+    _req(x, torch.float32, "x")
+    n, T, D = x.shape
+    out = torch.empty(n, D, dtype=torch.float32, device=x.device)
+    _l.check(_l.load().pxr_token_mean_f32(_l.ptr(x), _l.ptr(out), n, T, D, _l.stream_ptr()), "pxr_token_mean_f32")
+    return out
+
+
+def token_mean_relu_bwd(dout: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    _req(dout, torch.float32, "dout"); _req(act, torch.float32, "act")
+    n, T, D = act.shape
+    dact = torch.empty_like(act)
+    _l.check(_l.load().pxr_token_mean_relu_bwd_f32(_l.ptr(dout), _l.ptr(act), _l.ptr(dact), n, T, D, _l.stream_ptr()),
+             "pxr_token_mean_relu_bwd_f32")
+    return dact
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _req(a, torch.float32, "a"); _req(b, torch.float32, "b")
+    out = torch.empty_like(a)
+    _l.check(_l.load().pxr_add_f32(_l.ptr(a), _l.ptr(b), _l.ptr(out), a.numel(), _l.stream_ptr()), "pxr_add_f32")
+    return out
 
 
 def linear_bwd_input(dy: torch.Tensor, W: torch.Tensor, dgelu_pre: torch.Tensor | None = None,

@@ -311,6 +311,90 @@ def clip_grad_norm_(model, max_norm, norm_type=2.0, **_ignored):
     return total
 
 
+class VisualAdamW:
+    """torch.optim.AdamW semantics for the 'visual_encoder' parameter group (reference trainer.py:74-96: lr = modal_lr,
+    weight_decay = modal_decay over every trainable visual_encoder parameter) on the fused flat kernel: the encoder's
+    parameters live in one flat buffer (model/vit_native.NativeTower); each contiguous trainable segment is one
+    pxr_adamw_flat_f32 launch (one segment for a tune_scale at a block boundary: blocks >= first trainable + rec_fc).
+    A parameter that never receives a gradient (`post_layernorm`, replaced by Identity in the reference) is skipped,
+    as torch skips `p.grad is None`.  `state_dict()` is torch.optim.AdamW's layout over the trainable parameters in
+    registration order (what the reference stores for this group)."""
+
+    def __init__(self, encoder, lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.encoder = encoder
+        self.tower = encoder._native
+        self.param_groups = [{"lr": float(lr), "weight_decay": float(weight_decay), "betas": tuple(betas), "eps": float(eps)}]
+        self.step_count = 0
+        self._m = self._v = None
+
+    def _state(self):
+        t = self.tower
+        t.ensure_packed()
+        lo = min((a for a, _ in t.segments), default=0)
+        if self._m is None or self._m.device != t.flat.device or self._m.numel() != t.flat.numel() - lo:
+            self._base = lo
+            self._m = torch.zeros(t.flat.numel() - lo, dtype=torch.float32, device=t.flat.device)
+            self._v = torch.zeros_like(self._m)
+        return t
+
+    def zero_grad(self, set_to_none: bool = False):
+        return None          # every backward overwrites the flat gradient buffer
+
+    @torch.no_grad()
+    def step(self):
+        t = self._state()
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        for lo, hi in t.segments:
+            ops.adamw_flat(t.flat[lo:hi], t.gflat[lo:hi], self._m[lo - self._base:hi - self._base],
+                           self._v[lo - self._base:hi - self._base], g["lr"], b1, b2, g["eps"], g["weight_decay"],
+                           self.step_count + 1)
+        self.step_count += 1
+
+    def _trainable(self):
+        """[(name, parameter)] of the group in the reference's order: registration order, requires_grad only."""
+        return [(n, p) for n, p in self.encoder.named_parameters() if p.requires_grad]
+
+    def state_dict(self, layout: str = "torch"):
+        t = self._state()
+        names = self._trainable()
+        state = {}
+        if self.step_count > 0:
+            for i, (n, p) in enumerate(names):
+                if "post_layernorm" in n:
+                    continue
+                off, cnt, shape = t.views[n]
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self._m[off - self._base:off - self._base + cnt].view(shape).clone(),
+                            "exp_avg_sq": self._v[off - self._base:off - self._base + cnt].view(shape).clone()}
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"],
+                 **_TORCH_GROUP_DEFAULTS, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        t = self._state()
+        names = self._trainable()
+        g = sd["param_groups"][0]
+        ids = list(g["params"])
+        if len(ids) != len(names):
+            raise ValueError(f"visual optimizer state has {len(ids)} parameters, this encoder trains {len(names)}")
+        self.param_groups = [{"lr": g["lr"], "weight_decay": g["weight_decay"], "betas": tuple(g["betas"]), "eps": g["eps"]}]
+        self._m.zero_(); self._v.zero_()
+        steps = set()
+        for pid, (n, p) in zip(ids, names):
+            st = sd["state"].get(pid)
+            if st is None:
+                continue
+            off, cnt, shape = t.views[n]
+            steps.add(int(float(st["step"])))
+            self._m[off - self._base:off - self._base + cnt].copy_(st["exp_avg"].reshape(-1))
+            self._v[off - self._base:off - self._base + cnt].copy_(st["exp_avg_sq"].reshape(-1))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)})")
+        self.step_count = steps.pop() if steps else 0
+
+
 class OptimizerGroup:
     """Several optimizers stepped together (reference trainer.py:86-96 builds ONE torch AdamW with a 'visual_encoder'
     group and a rec group; here the rec group is PxrAdamW and the visual-encoder group a torch AdamW)."""
@@ -343,7 +427,8 @@ class OptimizerGroup:
         """layout="torch": ONE torch.optim.AdamW-shaped dict with the reference's two param groups (trainer.py:86-96:
         group 0 = trainable visual_encoder parameters, group 1 = rec parameters; state indices run through both)."""
         if layout == "native":
-            return {"group": [o.state_dict() for o in self.opts]}
+            return {"group": [(o.state_dict() if not isinstance(o, PxrAdamW) else o.state_dict(layout="native"))
+                              for o in self.opts]}
         vis, rec = self._split()
         v = vis.state_dict() if vis is not None else {"state": {}, "param_groups": []}
         n0 = sum(len(g["params"]) for g in v["param_groups"])

@@ -124,8 +124,10 @@ class Trainer:
             modal = [p for n, p in m.named_parameters() if "visual_encoder" in n and p.requires_grad]
             if not modal:
                 return rec
-            # the visual-encoder group (trainer.py:86-89): torch AdamW on the trainable tail of the backbone
-            return OptimizerGroup(torch.optim.AdamW(modal, lr=a["modal_lr"], weight_decay=a["modal_decay"]), rec)
+            # the visual-encoder group (trainer.py:86-89): the same fused AdamW kernel over the encoder's flat buffer
+            from ..optim import VisualAdamW
+
+            return OptimizerGroup(VisualAdamW(m.visual_encoder, lr=a["modal_lr"], weight_decay=a["modal_decay"]), rec)
         return PxrAdamW(m, lr=a["learning_rate"], weight_decay=a["weight_decay"])
 
     # ---------------------------------------------------------------------------------------------- training

@@ -1,0 +1,102 @@
+"""Orchestration of the native image encoder (pixelrec_amd/model/vit_native.py) on CPU: with torch stand-ins for the HIP
+entry points (tests/emu_ops.py) its forward must equal the torch restatement of the tower (itself == HF CLIPVisionModel,
+tests/test_visual_cpu.py) and its hand-written backward must equal torch autograd -- operand offsets and strides of the
+batched attention GEMMs, the backward formulas, the flat packing and the VisualAdamW segments.  The kernels are
+checked on the GPU."""
+import pytest
+import torch
+
+from tests import emu_ops
+
+
+def _build(method, tune, monkeypatch):
+    from pixelrec_amd.model import visual
+
+    emu_ops.install(monkeypatch)
+    torch.manual_seed(3)
+    cfg = {"encoder_name": "clip-vit-tiny-test", "encoder_source": "transformers", "embedding_size": 24,
+           "pretrain_path": None,
+           "fine_tune_arg": {"tune_scale": tune, "pre_trained": False, "activation": "relu", "dnn_layers": [], "method": method}}
+    enc = visual.load_model(cfg)
+    for p in enc.parameters():                       # non-trivial LayerNorm / bias values
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    return enc
+
+
+@pytest.mark.parametrize("method,tune", [("mean", 5 + 16 * 2), ("mean", 5 + 16), ("mean", 0), ("cls", 5 + 16 * 2), ("mean", 57)])
+def test_native_tower_matches_autograd(method, tune, monkeypatch):
+    from pixelrec_amd.model import vit_native
+
+    enc = _build(method, tune, monkeypatch)
+    x = torch.randn(3, 3, 64, 64)
+    w = torch.randn(3, 24)
+    # reference: the torch restatement through autograd
+    ref_out = enc.forward(x) if False else (torch.mean(enc.rec_fc(enc.item_encoder(x)[0]), dim=1) if method == "mean"
+                                            else enc.rec_fc(enc.item_encoder(x)[0][:, 0, :]))
+    trainable = [(n, p) for n, p in enc.named_parameters() if p.requires_grad]
+    ref_grads = torch.autograd.grad((ref_out * w).sum(), [p for _, p in trainable], allow_unused=True)
+    # native orchestration
+    out = vit_native.run(enc, x)
+    assert (out - ref_out).abs().max().item() < 1e-5
+    (out * w).sum().backward()
+    checked = 0
+    for (n, p), g in zip(trainable, ref_grads):
+        if g is None:
+            assert "post_layernorm" in n
+            continue
+        err = (p.grad - g).abs().max().item()
+        assert err <= 1e-6 + 1e-4 * g.abs().max().item(), (n, err)
+        checked += 1
+    assert checked == len(trainable) - 2 * (tune <= 55)          # everything but the unused post_layernorm pair
+    # inference path (no_grad) gives the same vectors
+    with torch.no_grad():
+        assert (vit_native.run(enc, x) - ref_out).abs().max().item() < 1e-5
+
+
+def test_visual_adamw_matches_torch_adamw(monkeypatch):
+    """VisualAdamW over the flat segments == torch.optim.AdamW over the same parameters; its state_dict is torch's."""
+    from pixelrec_amd import ops
+    from pixelrec_amd.model import vit_native
+    from pixelrec_amd.optim import VisualAdamW
+
+    enc = _build("mean", 5 + 16 * 2, monkeypatch)
+
+    def adamw_flat(p, g, m, v, lr, b1, b2, eps, wd, step):
+        p.mul_(1 - lr * wd)
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
+
+    monkeypatch.setattr(ops, "adamw_flat", adamw_flat)
+    import copy
+
+    ref = copy.deepcopy(enc)
+    ref._native = vit_native.NativeTower(ref)
+    train_ref = [p for p in ref.parameters() if p.requires_grad]
+    # eps = 1e-3: the key-projection bias has a mathematically zero gradient (softmax is shift invariant), and Adam with
+    # the default eps turns its rounding noise into +-lr steps -- in torch and here alike, but not bit-alike
+    topt = torch.optim.AdamW(train_ref, lr=1e-2, weight_decay=0.05, eps=1e-2)
+    opt = VisualAdamW(enc, lr=1e-2, weight_decay=0.05, eps=1e-2)
+    for step in range(3):
+        x = torch.randn(2, 3, 64, 64)
+        w = torch.randn(2, 24) * 1e4          # gradients of O(1e-3) in this tiny random tower: well above eps-scale noise
+        (vit_native.run(enc, x) * w).sum().backward()
+        opt.step()
+        topt.zero_grad()
+        (torch.mean(ref.rec_fc(ref.item_encoder(x)[0]), dim=1) * w).sum().backward()
+        topt.step()
+    assert len(enc._native.segments) == 2            # [block 2 .. ln2] and [rec_fc] (post_layernorm sits between them)
+    for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert (p - q).abs().max().item() < 5e-5, n
+    sd, tsd = opt.state_dict(), topt.state_dict()
+    assert sd["param_groups"][0]["params"] == tsd["param_groups"][0]["params"]
+    assert set(sd["state"]) == set(tsd["state"])               # no state for the gradient-less post_layernorm pair
+    for i in sd["state"]:
+        ref_m = tsd["state"][i]["exp_avg"]
+        assert (sd["state"][i]["exp_avg"] - ref_m).abs().max().item() <= 1e-6 + 1e-5 * ref_m.abs().max().item()
+        assert float(sd["state"][i]["step"]) == float(tsd["state"][i]["step"]) == 3.0
+    opt2 = VisualAdamW(enc, lr=1.0)
+    opt2.load_state_dict(tsd)
+    assert opt2.step_count == 3 and opt2.param_groups[0]["lr"] == 1e-2
+    assert (opt2._m - opt._m).abs().max().item() <= 1e-5 * opt._m.abs().max().item()      # (torch's moments, loaded)
