@@ -1,0 +1,155 @@
+"""The kernels behind the native image encoder (csrc/vit.hip, the batched GEMM and the ViT epilogues of gemm_f32.hip),
+each against plain torch fp32/fp64 on the same inputs, and the whole encoder against the torch restatement of the tower
+(== HF CLIPVisionModel, tests/test_visual_cpu.py) incl. its hand-written backward and VisualAdamW."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _operand(t, off, ld, rows, cols, z, nb2, s12):
+    base = off + (z // nb2) * s12[0] + (z % nb2) * s12[1]
+    return torch.as_strided(t.reshape(-1), (rows, cols), (ld, 1), base)
+
+
+@pytest.mark.parametrize("T,heads,d,n", [(50, 12, 64, 3), (197, 4, 64, 2), (7, 2, 16, 5), (257, 2, 64, 1), (64, 3, 32, 2)])
+def test_batched_attention_contractions(T, heads, d, n):
+    """The six batched GEMMs of one attention layer with the strides vit_native uses (packed k|v|q projection)."""
+    from pixelrec_amd import ops
+
+    H, ld, Tp, bh = heads * d, 3 * heads * d, (T + 3) & ~3, n * heads
+    g = torch.Generator(device="cuda").manual_seed(T)
+    qkv = torch.randn(n, T, ld, device="cuda", generator=g)
+    S = torch.full((bh, T, Tp), 7.0, device="cuda")
+    sP, sQ, sC = (heads * T * Tp, T * Tp), (T * ld, d), (T * H, d)
+    ops.gemm_batched(True, True, T, T, d, qkv, 2 * H, ld, qkv, 0, ld, S, 0, Tp, bh, heads, sQ, sQ, sP)
+    q = qkv[..., 2 * H:].view(n, T, heads, d).transpose(1, 2).double()
+    k = qkv[..., :H].view(n, T, heads, d).transpose(1, 2).double()
+    v = qkv[..., H:2 * H].view(n, T, heads, d).transpose(1, 2).double()
+    ref_S = (q @ k.transpose(-1, -2)).reshape(bh, T, T)
+    assert (S[:, :, :T].double() - ref_S).abs().max().item() < 1e-4 * max(1.0, ref_S.abs().max().item())
+    ops.softmax_rows(S, bh * T, T, Tp, d ** -0.5)
+    ref_P = torch.softmax(ref_S * d ** -0.5, dim=-1)
+    assert (S[:, :, :T].double() - ref_P).abs().max().item() < 2e-6
+    assert float(S[:, :, T:].abs().max()) == 0.0 if Tp > T else True          # pad columns are zeros
+    ctx = torch.zeros(n, T, H, device="cuda")
+    ops.gemm_batched(True, False, T, d, T, S, 0, Tp, qkv, H, ld, ctx, 0, H, bh, heads, sP, sQ, sC)
+    ref_ctx = (ref_P.view(n, heads, T, T) @ v).transpose(1, 2).reshape(n, T, H)
+    assert (ctx.double() - ref_ctx).abs().max().item() < 1e-5
+    # backward contractions
+    dctx = torch.randn(n, T, H, device="cuda", generator=g)
+    dqkv = torch.zeros_like(qkv)
+    dP = torch.empty_like(S)
+    do = dctx.view(n, T, heads, d).transpose(1, 2).double()
+    ops.gemm_batched(False, False, T, d, T, S, 0, Tp, dctx, 0, H, dqkv, H, ld, bh, heads, sP, sC, sQ)
+    ref_dV = ref_P.view(n, heads, T, T).transpose(-1, -2) @ do
+    ops.gemm_batched(True, True, T, T, d, dctx, 0, H, qkv, H, ld, dP, 0, Tp, bh, heads, sC, sQ, sP)
+    ref_dP = do @ v.transpose(-1, -2)
+    assert (dP[:, :, :T].double().view(n, heads, T, T) - ref_dP).abs().max().item() < 1e-4 * max(1.0, ref_dP.abs().max().item())
+    ops.softmax_rows_bwd(S, dP, bh * T, T, Tp, d ** -0.5)
+    Pn = ref_P.view(n, heads, T, T)
+    ref_dS = d ** -0.5 * Pn * (ref_dP - (ref_dP * Pn).sum(-1, keepdim=True))
+    assert (dP[:, :, :T].double().view(n, heads, T, T) - ref_dS).abs().max().item() < 1e-5 * max(1.0, ref_dS.abs().max().item())
+    ops.gemm_batched(True, False, T, d, T, dP, 0, Tp, qkv, 0, ld, dqkv, 2 * H, ld, bh, heads, sP, sQ, sQ)
+    ops.gemm_batched(False, False, T, d, T, dP, 0, Tp, qkv, 2 * H, ld, dqkv, 0, ld, bh, heads, sP, sQ, sQ)
+    got = lambda off: dqkv[..., off:off + H].view(n, T, heads, d).transpose(1, 2).double()
+    for name, off, ref in (("dV", H, ref_dV), ("dQ", 2 * H, ref_dS @ k), ("dK", 0, ref_dS.transpose(-1, -2) @ q)):
+        assert (got(off) - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), name
+
+
+@pytest.mark.parametrize("T", [1, 5, 64, 65, 513, 700])
+def test_softmax_rows_long_and_short(T):
+    from pixelrec_amd import ops
+
+    rows, ld = 37, (T + 3) & ~3
+    g = torch.Generator(device="cuda").manual_seed(T)
+    S = torch.randn(rows, ld, device="cuda", generator=g) * 3
+    ref = torch.softmax(S[:, :T].double() * 0.3, dim=-1)
+    ops.softmax_rows(S, rows, T, ld, 0.3)
+    assert (S[:, :T].double() - ref).abs().max().item() < 2e-6
+    assert S[:, T:].abs().sum().item() == 0.0
+    dP = torch.randn(rows, ld, device="cuda", generator=g)
+    ref_ds = 0.3 * ref * (dP[:, :T].double() - (dP[:, :T].double() * ref).sum(-1, keepdim=True))
+    ops.softmax_rows_bwd(S, dP, rows, T, ld, 0.3)
+    assert (dP[:, :T].double() - ref_ds).abs().max().item() < 5e-6
+    assert dP[:, T:].abs().sum().item() == 0.0
+
+
+def test_vit_epilogues_and_small_kernels():
+    from pixelrec_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, K = 333, 200, 96
+    x = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.1
+    b = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    v = (x.double() @ W.double().t() + b.double())
+    y = ops.linear_epi(x, W, b, ops.EPI_BIAS_ADD, aux=res)
+    assert (y.double() - (v + res.double())).abs().max().item() < 1e-4
+    y, gq = ops.linear_epi(x, W, b, ops.EPI_BIAS_QGELU_GRAD)
+    s = torch.sigmoid(1.702 * v)
+    assert (y.double() - v * s).abs().max().item() < 1e-4
+    assert (gq.double() - (s + 1.702 * v * s * (1 - s))).abs().max().item() < 1e-4
+    y = ops.linear_epi(x, W, b, ops.EPI_BIAS_RELU)
+    assert (y.double() - torch.relu(v)).abs().max().item() < 1e-4
+    # embed / token mean / relu-mean backward / add
+    n, T, H = 5, 17, 64
+    patches = torch.randn(n, T - 1, H, device="cuda", generator=g)
+    cls, pos = torch.randn(H, device="cuda", generator=g), torch.randn(T, H, device="cuda", generator=g)
+    out = ops.vit_embed(patches, cls, pos)
+    assert torch.equal(out, torch.cat([cls.expand(n, 1, -1), patches], dim=1) + pos[None])
+    act = torch.randn(n, T, H, device="cuda", generator=g)
+    assert (ops.token_mean(act) - act.mean(1)).abs().max().item() < 1e-6
+    dout = torch.randn(n, H, device="cuda", generator=g)
+    ref = (act > 0).float() * dout[:, None, :] / T
+    assert (ops.token_mean_relu_bwd(dout, act) - ref).abs().max().item() < 1e-7
+    a2, b2 = torch.randn(1000, device="cuda", generator=g), torch.randn(1000, device="cuda", generator=g)
+    assert torch.equal(ops.add(a2, b2), a2 + b2)
+
+
+@pytest.mark.parametrize("method,tune", [("mean", 5 + 16 * 2), ("mean", 0), ("cls", 5 + 16)])
+def test_native_encoder_matches_torch_tower(method, tune):
+    """Forward, every trainable gradient and three VisualAdamW steps of the native encoder against the torch restatement
+    of the same tower under autograd + torch.optim.AdamW (tiny 3-block tower; full widths: tests/test_gpu_configs.py)."""
+    import copy
+
+    from pixelrec_amd.model import visual
+    from pixelrec_amd.optim import VisualAdamW
+
+    torch.manual_seed(5)
+    cfg = {"encoder_name": "clip-vit-tiny-test", "encoder_source": "transformers", "embedding_size": 24, "pretrain_path": None,
+           "fine_tune_arg": {"tune_scale": tune, "pre_trained": False, "activation": "relu", "dnn_layers": [], "method": method}}
+    enc = visual.load_model(cfg)
+    for p in enc.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    ref = copy.deepcopy(enc)                       # stays on the CPU: torch ops + autograd
+    enc = enc.cuda()
+    opt = VisualAdamW(enc, lr=1e-2, weight_decay=0.05, eps=1e-2)
+    topt = torch.optim.AdamW([p for p in ref.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-2)
+    for step in range(3):
+        x = torch.randn(4, 3, 64, 64)
+        w = torch.randn(4, 24) * 1e4
+        out = enc(x.cuda())
+        (out * w.cuda()).sum().backward()
+        tower = ref.item_encoder(x)[0]
+        ref_out = torch.mean(ref.rec_fc(tower), dim=1) if method == "mean" else ref.rec_fc(tower[:, 0, :])
+        assert (out.detach().cpu() - ref_out).abs().max().item() < 2e-5
+        topt.zero_grad()
+        (ref_out * w).sum().backward()
+        for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+            if q.grad is not None:
+                err = (p.grad.cpu() - q.grad).abs().max().item()
+                assert err <= 1e-6 + 3e-4 * q.grad.abs().max().item(), (step, n, err)
+            else:
+                assert (not p.requires_grad) or "post_layernorm" in n
+        opt.step()
+        topt.step()
+    for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert (p.detach().cpu() - q).abs().max().item() < 1e-4, n
+    with torch.no_grad():
+        x = torch.randn(2, 3, 64, 64)
+        tower = ref.item_encoder(x)[0]
+        ref_out = torch.mean(ref.rec_fc(tower), dim=1) if method == "mean" else ref.rec_fc(tower[:, 0, :])
+        assert (enc(x.cuda()).cpu() - ref_out).abs().max().item() < 1e-4

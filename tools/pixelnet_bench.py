@@ -10,7 +10,7 @@ import torch
 
 from pixelrec_amd.model import MOSASRec
 from pixelrec_amd.model.visual import ENCODER_SHAPES
-from pixelrec_amd.optim import OptimizerGroup, PxrAdamW
+from pixelrec_amd.optim import OptimizerGroup, PxrAdamW, VisualAdamW
 
 name = sys.argv[1] if len(sys.argv) > 1 else "clip-vit-base-patch32"
 hidden, n_layers, heads, inter, image, patch = ENCODER_SHAPES[name]
@@ -32,8 +32,7 @@ class DL:
 
 torch.manual_seed(0)
 m = MOSASRec(cfg, DL()).cuda().train()
-vis = [p for n, p in m.named_parameters() if "visual_encoder" in n and p.requires_grad]
-opt = OptimizerGroup(PxrAdamW(m, lr=1e-4, weight_decay=0.1), torch.optim.AdamW(vis, lr=1e-4, weight_decay=0.0))
+opt = OptimizerGroup(VisualAdamW(m.visual_encoder, lr=1e-4, weight_decay=0.0), PxrAdamW(m, lr=1e-4, weight_decay=0.1))
 images = torch.randn(B, 2 * (L + 1), 3, image, image, device="cuda")
 mask = torch.ones(B, L, dtype=torch.int64, device="cuda")
 
