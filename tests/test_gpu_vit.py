@@ -138,10 +138,13 @@ def test_native_encoder_matches_torch_tower(method, tune):
         assert (out.detach().cpu() - ref_out).abs().max().item() < 2e-5
         topt.zero_grad()
         (ref_out * w).sum().backward()
+        gmax = max(q.grad.abs().max().item() for q in ref.parameters() if q.grad is not None)
         for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
             if q.grad is not None:
                 err = (p.grad.cpu() - q.grad).abs().max().item()
-                assert err <= 1e-6 + 3e-4 * q.grad.abs().max().item(), (step, n, err)
+                # (the key-projection bias has a mathematically ZERO gradient -- softmax is shift invariant -- so its
+                # entries are rounding noise of the whole backward pass: the floor is relative to the largest gradient)
+                assert err <= 3e-4 * max(q.grad.abs().max().item(), 1e-5 * gmax), (step, n, err)
             else:
                 assert (not p.requires_grad) or "post_layernorm" in n
         opt.step()
