@@ -14,6 +14,8 @@
 // list only when fewer than K unmasked items exist.
 #include "gemm_f32.cuh"
 
+#include <cstdlib>
+
 namespace pxr {
 
 constexpr int ST_BM = 128, ST_BN = 128;
@@ -124,6 +126,90 @@ __global__ void __launch_bounds__(GEMM_THREADS) score_topk_kernel(ScoreTopkArgs 
   }
 }
 
+// ---- variant 2: selection in the accumulator registers --------------------------------------------------------------
+// The product is taken TRANSPOSED (A = the 128-item table tile, B = the 128 users), so in the 32x32 MFMA result layout
+// a lane holds ONE user (column = lane & 31) and 16 items of it in registers: the top-K list of (user, item sub-block) is
+// private to the lane and is fed straight from the accumulators -- no score tile in LDS, no scan.  8 waves per workgroup
+// (each owns a 64-item x 32-user block: FINE = 2) at <= 128 VGPRs, i.e. two workgroups per CU, so that one workgroup's
+// selection (VALU) runs under the other's MFMAs.  (16 waves of 32x32 -- the fastest cut of the plain GEMM -- would need
+// <= 64 VGPRs for two workgroups per CU: the 20 list registers then spill.)
+// History pairs become a [128 users] x [128 items] bitmap in LDS (2 KB) per tile; item 0 and the ragged edge are id tests.
+// Per user and workgroup there are 4 partial lists (2 item sub-blocks x 2 half-waves); the merge kernel is unchanged.
+// FINE = 1 (PXR_TOPK_VARIANT=3): 16 waves of 32x32, one workgroup per CU (the lists do not fit in the 64 VGPRs that two
+// 1024-thread workgroups per CU would leave).
+constexpr int ST2_BITMAP_WORDS = ST_BN * (ST_BM / 32);        // [user][4 words of 32 items]
+
+template <int KT, int FINE>
+__global__ void __launch_bounds__((FINE == 1 ? 1024 : 512), (FINE == 1 ? 4 : 4)) score_topk2_kernel(ScoreTopkArgs a) {
+  using St2Cfg = GemmCfg<ST_BM, ST_BN, true, true, 1, FINE>;
+  constexpr int ST2_THREADS = St2Cfg::NT;
+  constexpr int ST2_LISTS = St2Cfg::WGM * 2;                  // item sub-blocks of the wave grid x 2 half-waves
+  constexpr int ST2_SMEM_FLOATS = 2 * St2Cfg::STAGE + ST2_BITMAP_WORDS;
+  __shared__ __attribute__((aligned(16))) float smem[ST2_SMEM_FLOATS];
+  unsigned* bitmap = reinterpret_cast<unsigned*>(smem + 2 * St2Cfg::STAGE);
+  const int tid = threadIdx.x;
+  const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
+  const int rb = t % a.row_blocks, sp = t / a.row_blocks;   // row-block fastest: neighbours share the item tiles
+  const int u0 = rb * ST_BN;                                // first user of this workgroup
+  const int per = (a.tiles_n + a.n_split - 1) / a.n_split;
+  const int tn0 = sp * per, tn1 = min(a.tiles_n, tn0 + per);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave / St2Cfg::WGN, wu = wave % St2Cfg::WGN;   // item sub-block / user sub-block of this wave
+  const int h = lane >> 5, r = lane & 31;
+  const int ul = wu * 32 + r;                                // user (local) of this lane
+  TopList<KT> top;
+  top.init();
+  int hb = 0, he = 0;
+  if (a.hist_ptr) {
+    hb = a.hist_ptr[u0];
+    he = a.hist_ptr[min(a.B, u0 + ST_BN)];
+  }
+  for (int tn = tn0; tn < tn1; ++tn) {
+    const int i0 = tn * ST_BM;                               // first item of the tile
+    static_assert(ST2_BITMAP_WORDS <= ST2_THREADS, "one thread per bitmap word");
+    if (tid < ST2_BITMAP_WORDS) bitmap[tid] = 0u;
+    typename St2Cfg::Acc accs;
+    // rows (M) = items of the table tile, columns (N) = users
+    gemm_mainloop<ST_BM, ST_BN, true, true, false, 1, (FINE == 1 ? 2 : 1), 2, FINE>(accs, a.table, (int64_t)a.D, a.users, a.ld_users, a.N, a.B,
+                                                               0, a.D, i0, u0, smem);
+    // (the main loop starts and ends with barriers: the zeroed bitmap is visible, the staging buffers are not touched here)
+    for (int p = hb + tid; p < he; p += ST2_THREADS) {
+      const int64_t it = a.hist_items[p];
+      if (it >= i0 && it < i0 + ST_BM) {
+        int lo = u0, hi = min(a.B, u0 + ST_BN) - 1;          // owner of pair p: hist_ptr[u] <= p < hist_ptr[u+1]
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (a.hist_ptr[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        const int il = (int)(it - i0);
+        atomicOr(&bitmap[(lo - u0) * (ST_BM / 32) + (il >> 5)], 1u << (il & 31));
+      }
+    }
+    __syncthreads();
+    const bool user_ok = (u0 + ul) < a.B;
+#pragma unroll
+    for (int bi = 0; bi < St2Cfg::TM; ++bi) {
+      const unsigned bits = bitmap[ul * (ST_BM / 32) + wi * St2Cfg::TM + bi];   // this lane's user x 32 items
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int il = (e & 3) + 8 * (e >> 2) + 4 * h;       // item within the 32-item sub-block
+        const int item = i0 + wi * St2Cfg::WM + bi * 32 + il;
+        const float x = accs.v[bi][0][e];
+        const bool cand = user_ok && item != 0 && item < a.N && !((bits >> il) & 1u) && (x > top.v[KT - 1]);
+        if (__any(cand)) {
+          if (cand) top.insert(x, item);
+        }
+      }
+    }
+    __syncthreads();                                         // bitmap is re-zeroed at the top of the next tile
+  }
+  if ((u0 + ul) < a.B) {
+    const int64_t o = ((int64_t)(u0 + ul) * (a.n_split * ST2_LISTS) + (sp * ST2_LISTS + wi * 2 + h)) * KT;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { a.part_val[o + k] = top.v[k]; a.part_idx[o + k] = top.i[k]; }
+  }
+}
+
 // one wave per user: pick the K best of its n_cand partial candidates, descending
 __global__ void __launch_bounds__(256) topk_merge_kernel(const float* __restrict__ part_val,
                                                          const int* __restrict__ part_idx, int B, int n_cand, int K,
@@ -161,6 +247,12 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(const float* __restrict
 }
 
 static int pick_kt(int K) { return K <= 10 ? 10 : (K <= 16 ? 16 : (K <= 32 ? 32 : 0)); }
+// selection variant: 2 / 3 = in the accumulator registers (8 / 16 waves per workgroup), 1 = score tile through LDS
+static int topk_variant() {
+  static const int v = getenv("PXR_TOPK_VARIANT") ? atoi(getenv("PXR_TOPK_VARIANT")) : 2;
+  return (v == 1 || v == 3) ? v : 2;
+}
+static int lists_per_split() { return topk_variant() == 2 ? 4 : (topk_variant() == 3 ? 8 : 2); }
 static int pick_split(int B, int N) {
   const int row_blocks = (B + ST_BM - 1) / ST_BM;
   const int tiles_n = (N + ST_BN - 1) / ST_BN;
@@ -177,7 +269,7 @@ using namespace pxr;
 extern "C" int64_t pxr_score_topk_ws_bytes(int B, int N, int K) {
   const int kt = pick_kt(K);
   if (kt == 0) return -1;
-  const int64_t cand = (int64_t)pick_split(B, N) * 2 * kt;
+  const int64_t cand = (int64_t)pick_split(B, N) * lists_per_split() * kt;
   return (int64_t)B * cand * 8 + 256;
 }
 
@@ -197,16 +289,30 @@ extern "C" int pxr_score_topk_f32(const float* users, int64_t ld_users, int B, c
   a.row_blocks = (B + ST_BM - 1) / ST_BM;
   a.tiles_n = (N + ST_BN - 1) / ST_BN;
   a.n_split = pick_split(B, N);
-  const int64_t cand = (int64_t)a.n_split * 2 * kt;
+  const int64_t cand = (int64_t)a.n_split * lists_per_split() * kt;
   if ((int64_t)B * cand * 8 + 256 > ws_bytes) { pxr_set_error("pxr_score_topk_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
   a.part_val = (float*)ws;
   a.part_idx = (int*)((char*)ws + (((int64_t)B * cand * 4 + 255) & ~(int64_t)255));
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(a.row_blocks * a.n_split);
-  switch (kt) {
-    case 10: hipLaunchKernelGGL(score_topk_kernel<10>, grid, dim3(GEMM_THREADS), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(score_topk_kernel<16>, grid, dim3(GEMM_THREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL(score_topk_kernel<32>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+  if (topk_variant() == 2) {
+    switch (kt) {
+      case 10: hipLaunchKernelGGL((score_topk2_kernel<10, 2>), grid, dim3(512), 0, st, a); break;
+      case 16: hipLaunchKernelGGL((score_topk2_kernel<16, 2>), grid, dim3(512), 0, st, a); break;
+      default: hipLaunchKernelGGL((score_topk2_kernel<32, 2>), grid, dim3(512), 0, st, a); break;
+    }
+  } else if (topk_variant() == 3) {
+    switch (kt) {
+      case 10: hipLaunchKernelGGL((score_topk2_kernel<10, 1>), grid, dim3(1024), 0, st, a); break;
+      case 16: hipLaunchKernelGGL((score_topk2_kernel<16, 1>), grid, dim3(1024), 0, st, a); break;
+      default: hipLaunchKernelGGL((score_topk2_kernel<32, 1>), grid, dim3(1024), 0, st, a); break;
+    }
+  } else {
+    switch (kt) {
+      case 10: hipLaunchKernelGGL(score_topk_kernel<10>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+      case 16: hipLaunchKernelGGL(score_topk_kernel<16>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+      default: hipLaunchKernelGGL(score_topk_kernel<32>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+    }
   }
   int rc = pxr_check_launch("pxr_score_topk_f32");
   if (rc) return rc;
