@@ -93,6 +93,116 @@ def cpu_baseline(batch, budget_s=20.0):
                            "sample": f"1 step, {dt1:.2f} s (the reference's own launcher setting, OMP_NUM_THREADS=1)"}}
 
 
+def pixelnet_main(args):
+    """BASELINE configs[2] / [4]: one training step of MOSASRec (reference mosasrec.py:66-93) with the image encoder
+    trained end to end (blocks >= tune_scale; reference load.py:90-120), both optimizer groups (trainer.py:74-96).
+    Synthetic images already resident in HBM as fp32 pixel tensors; random-init weights of the named architecture."""
+    from pixelrec_amd import ops
+    from pixelrec_amd.model import MOSASRec
+    from pixelrec_amd.model.visual import ENCODER_SHAPES
+    from pixelrec_amd.optim import OptimizerGroup, PxrAdamW, VisualAdamW
+    from pixelrec_amd.parallel import DataParallel
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+    hidden, n_layers, heads, inter, image, patch = ENCODER_SHAPES[args.encoder]
+    B = 16 if args.batch == 64 else args.batch           # the reference's PixelNet batch (overall/ViT.yaml)
+    L, D = 10, 512
+    tune = 5 + 16 * (n_layers - 2) if args.encoder != "clip-vit-base-patch16" else 165      # ViT.yaml: tune_scale 165
+    cfg = {"n_layers": 2, "n_heads": 4, "embedding_size": D, "inner_size": 2, "hidden_dropout_prob": 0.1,
+           "attn_dropout_prob": 0.1, "hidden_act": "gelu", "layer_norm_eps": 1e-12, "initializer_range": 0.02,
+           "MAX_ITEM_LIST_LENGTH": L, "seed": 2020, "encoder_name": args.encoder, "encoder_source": "transformers",
+           "pretrain_path": None,
+           "fine_tune_arg": {"tune_scale": tune, "pre_trained": False, "activation": "relu", "dnn_layers": [],
+                             "method": "mean"}}
+
+    class DL:
+        item_num = 96_001
+
+    torch.manual_seed(2020)
+    m = MOSASRec(cfg, DL()).to(dev).train()
+    dp = DataParallel(m)
+    opt = OptimizerGroup(VisualAdamW(m.visual_encoder, lr=1e-4, weight_decay=0.0), PxrAdamW(m, lr=1e-4, weight_decay=0.1))
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    pool = [(torch.randn(B, 2 * (L + 1), 3, image, image, device=dev, generator=g),
+             torch.ones(B, L, dtype=torch.int64, device=dev)) for _ in range(2)]
+    one = torch.ones((), dtype=torch.float32, device=dev)
+
+    def step(i):
+        opt.zero_grad()
+        loss = dp(pool[i % 2])
+        loss.backward(one)
+        dp.sync_gradients(defer_flat=True)
+        opt.step()
+        return loss
+
+    for i in range(max(args.warmup, 2)):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # GEMM family of the step (ViT blocks + sequence block): HIP events around every launch of a few extra steps
+    ev = []
+    ops.GEMM_TIMING = ev
+    n_inst = min(args.steps, 3)
+    for i in range(n_inst):
+        step(i)
+    ops.GEMM_TIMING = None
+    torch.cuda.synchronize()
+    if rank != 0:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+    gem = [(s_.elapsed_time(e_) * 1e-3, w) for s_, e_, w, tag in ev if tag.startswith("gemm") or tag.startswith("grouped_dw")]
+    g_s, g_fl = sum(x for x, _ in gem) or float("nan"), sum(w for _, w in gem)
+    n_img = B * 2 * (L + 1)
+    T = (image // patch) ** 2 + 1
+    out = {"metric": f"user-sequences/sec, SASRec PixelNet + {args.encoder} end to end (training step: image encoder fwd, "
+                     "bwd of the trainable blocks, sequence block, both AdamW groups)",
+           "value": world * B * args.steps / dt, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+           "warmup": max(args.warmup, 2), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE.json configs[2]-shaped: SASRec PixelNet + {args.encoder}, train_batch_size {B}, "
+                                  f"MAX_ITEM_LIST_LENGTH {L} ({n_img} images of {image}x{image} = {n_img * T} tokens per step), "
+                                  f"emb {D}, tune_scale {tune} ({(391 if n_layers == 24 else 199) - tune} trainable encoder tensors)",
+                      "batch_per_gpu": B, "global_batch": world * B, "seq_len": L, "images_per_step": n_img,
+                      "parallelism": f"dp{world}", "hip_graph": False},
+           "images_per_s": world * n_img * args.steps / dt, "final_loss": float(loss.detach()),
+           "roofline": {"bound": "mfma", "kernel": "gemm_kernel / grouped_dw_kernel (v_mfma_f32_32x32x2_f32): ViT blocks, batched "
+                                                   "attention contractions, rec_fc, sequence block",
+                        "achieved": g_fl / g_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": g_fl / g_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                        "gemm_time_per_step_ms": g_s / max(n_inst, 1) * 1e3, "algorithmic_gflop_per_step": g_fl / max(n_inst, 1) / 1e9,
+                        "launches_per_step": len(gem) / max(n_inst, 1),
+                        "note": "HIP events around every GEMM launch of extra eager steps (sum of durations; one stream)"},
+           "cpu_baseline": None}
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,7 +235,13 @@ def main():
                     help="1-GPU validation knob: create a 1-rank RCCL group and run every gradient collective anyway")
     ap.add_argument("--graph-collectives", action="store_true",
                     help="capture the RCCL collectives inside the step hipGraph too (opt-in for world > 1)")
+    ap.add_argument("--model", choices=("idnet", "pixelnet"), default="idnet",
+                    help="idnet = the headline (BASELINE configs[1]); pixelnet = SASRec PixelNet + ViT end to end "
+                         "(BASELINE configs[2]: train_batch_size 16, MAX_ITEM_LIST_LENGTH 10, 352 images per step)")
+    ap.add_argument("--encoder", default="clip-vit-base-patch16", help="--model pixelnet: image encoder")
     args = ap.parse_args()
+    if args.model == "pixelnet":
+        return pixelnet_main(args)
     custom = (args.emb, args.heads, args.items, args.seq_len) != (NS["D"], NS["H"], NS["n_items"], NS["L"]) or args.table_sharding
     NS.update(D=args.emb, H=args.heads, n_items=args.items, L=args.seq_len)   # other BASELINE configs on request
 

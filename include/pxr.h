@@ -44,7 +44,8 @@ int pxr_dropout_keep_host(uint64_t seed, uint32_t stream_id, uint64_t first_inde
 /* Registers a caller-owned int32 in DEVICE memory as this process' status word (NULL unregisters).  Kernels that
  * gather table rows by id (pxr_embed_gather_f32, pxr_input_ln_fwd_f32) OR bit 0 into it when an id lies outside
  * [0, N) -- where the reference's nn.Embedding raises IndexError / a device-side assert (model/IDNet/sasrec.py:68) --
- * and clamp the id; the host reads the word at its next synchronisation point and raises.  One process per GPU. */
+ * and clamp the id; pxr_merge_split_rows_f32 ORs bit 1 when a rank's row count exceeded the exchanged capacity.  The
+ * host reads the word at its next synchronisation point and raises.  One process per GPU. */
 int pxr_set_status_word(int32_t* dev_word);
 
 /* ---- embedding table ---------------------------------------------------------------------------------------- */
@@ -78,6 +79,12 @@ int64_t pxr_packed_rows_bytes(int64_t cap, int D);
 int pxr_merge_packed_rows_f32(const void* packed_all, int W, int64_t cap, int D, int64_t n_table, float scale,
                               int64_t* out_idx, float* out_rows, int32_t* n_out_dev, void* ws, int64_t ws_bytes,
                               void* stream);
+/* The exchange with a REDUCED row capacity cap_x <= cap (two collectives): heads_all = W x pxr_packed_rows_offset(cap)
+ * bytes ({ids[cap], count, pad} of every rank), rows_all = [W, cap_x, D] (the first cap_x rows of every rank).  A rank
+ * whose count exceeds cap_x is cut there and bit 1 of the status word (pxr_set_status_word) is set.  out_*: W*cap_x slots. */
+int pxr_merge_split_rows_f32(const void* heads_all, const float* rows_all, int W, int64_t cap, int64_t cap_x, int D,
+                             int64_t n_table, float scale, int64_t* out_idx, float* out_rows, int32_t* n_out_dev,
+                             void* ws, int64_t ws_bytes, void* stream);
 /* On-device train-batch construction (data/dataset/trainset.py:40-63): pos int64 [B,W] left-padded windows (W = L+1)
  * -> items [B,2,W] (positives | one negative per target position, uniform over [1, n_items-1] minus the window's own
  * items) and masked_index [B,W-1].  Stateless: (seed, batch_counter) select the random stream. */

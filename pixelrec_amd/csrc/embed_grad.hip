@@ -625,6 +625,7 @@ struct MergeSrc {
   const char* ids;    int64_t ids_stride;      // byte stride between consecutive ranks' lists
   const char* rows;   int64_t rows_stride;
   const char* counts; int64_t counts_stride;   // int32 per rank, or nullptr
+  int32_t* status;                             // device status word: bit 1 is set when a list's count exceeds `cap`
 };
 __device__ __forceinline__ const int64_t* merge_ids(const MergeSrc& s, int q) {
   return reinterpret_cast<const int64_t*>(s.ids + (int64_t)q * s.ids_stride);
@@ -635,6 +636,7 @@ __device__ __forceinline__ const float* merge_rows(const MergeSrc& s, int q) {
 __device__ __forceinline__ int merge_count(const MergeSrc& s, int q, int cap) {
   if (!s.counts) return cap;
   const int n = *reinterpret_cast<const int*>(s.counts + (int64_t)q * s.counts_stride);
+  if (n > cap && s.status) atomicOr(s.status, PXR_STATUS_ROWS_OVERFLOW);   // rows beyond the exchanged capacity were cut off
   return n < 0 ? 0 : (n > cap ? cap : n);
 }
 
@@ -886,6 +888,28 @@ extern "C" int pxr_merge_packed_rows_f32(const void* packed_all, int W, int64_t 
   src.counts = (const char*)packed_all + cap * 8;                      src.counts_stride = block;
   return launch_merge(src, W, cap, D, n_table, scale, out_idx, out_rows, n_out_dev, ws, (hipStream_t)stream,
                       "pxr_merge_packed_rows_f32");
+}
+
+// The TWO-collective exchange with a reduced row capacity: every rank all-gathers the HEAD of its packed block ({ids[cap],
+// count, pad} = pxr_packed_rows_offset(cap) bytes) and only the first `cap_x` rows.  cap_x is a bound on the unique rows
+// of a batch that the caller knows (e.g. from the batcher); a count above it sets bit 1 of the status word
+// (pxr_set_status_word) -- the host raises -- and the list is cut at cap_x.  Output: W * cap_x slots.
+extern "C" int pxr_merge_split_rows_f32(const void* heads_all, const float* rows_all, int W, int64_t cap, int64_t cap_x,
+                                        int D, int64_t n_table, float scale, int64_t* out_idx, float* out_rows,
+                                        int32_t* n_out_dev, void* ws, int64_t ws_bytes, void* stream) {
+  PXR_REQUIRE(heads_all && rows_all && out_idx && out_rows && n_out_dev && ws, "pxr_merge_split_rows_f32: null pointer");
+  PXR_REQUIRE(W >= 1 && W <= 64 && cap > 0 && cap_x > 0 && cap_x <= cap && (int64_t)W * cap_x * W < (1ll << 31) && D > 0 &&
+              D % 4 == 0 && n_table > 0, "pxr_merge_split_rows_f32: bad shape");
+  PXR_REQUIRE((((uintptr_t)heads_all | (uintptr_t)rows_all) & 15) == 0, "pxr_merge_split_rows_f32: unaligned input");
+  if (pxr_merge_rows_ws_bytes(W, cap_x) > ws_bytes) { pxr_set_error("pxr_merge_split_rows_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
+  const int64_t head = pxr_packed_rows_offset(cap);
+  MergeSrc src{};
+  src.ids = (const char*)heads_all;               src.ids_stride = head;
+  src.counts = (const char*)heads_all + cap * 8;  src.counts_stride = head;
+  src.rows = (const char*)rows_all;               src.rows_stride = cap_x * (int64_t)D * 4;
+  src.status = pxr_status_word();
+  return launch_merge(src, W, cap_x, D, n_table, scale, out_idx, out_rows, n_out_dev, ws, (hipStream_t)stream,
+                      "pxr_merge_split_rows_f32");
 }
 
 // ---- row-sharded table helpers (BASELINE configs[3]; pixelrec_amd/model/sharded.py) ---------------------------------

@@ -91,9 +91,13 @@ def raise_on_bad_indices(device=None):
     PXR_CHECK_INDICES=1."""
     t = device_status(device)
     v = int(t.item())
-    if v & 1:
+    if v:
         t.zero_()
+    if v & 1:
         raise IndexError("index out of range in self (an item id outside [0, item_num) reached an embedding gather)")
+    if v & 2:
+        raise RuntimeError("data-parallel row exchange: a rank's batch touched more unique table rows than the configured "
+                           "exchange capacity (GradSync(exchange_rows=...)); gradient rows were dropped -- raise the bound")
 
 
 # ------------------------------------------------------------------------------------------------ K1 gather
@@ -523,6 +527,20 @@ def merge_packed_rows(packed_all, world, cap, D, n_table, scale=1.0, out: Sparse
     _l.check(Lb.pxr_merge_packed_rows_f32(_l.ptr(packed_all), world, cap, D, n_table, float(scale), _l.ptr(sp.idx),
                                           _l.ptr(sp.rows), _l.ptr(sp.n), _l.ptr(ws), ws_bytes, _l.stream_ptr()),
              "pxr_merge_packed_rows_f32")
+    return sp
+
+
+def merge_split_rows(heads_all, rows_all, world, cap, cap_x, D, n_table, scale=1.0, out: SparseRows | None = None):
+    """merge on the two-collective exchange with a reduced row capacity (see pxr.h)."""
+    Lb = _l.load()
+    _req(heads_all, torch.uint8, "heads_all"); _req(rows_all, torch.float32, "rows_all")
+    device_status(rows_all.device)
+    sp = out if out is not None else SparseRows(world * cap_x, D, rows_all.device)
+    ws_bytes = int(Lb.pxr_merge_rows_ws_bytes(world, cap_x))
+    ws = _ws.get(ws_bytes, rows_all.device)
+    _l.check(Lb.pxr_merge_split_rows_f32(_l.ptr(heads_all), _l.ptr(rows_all), world, cap, cap_x, D, n_table, float(scale),
+                                         _l.ptr(sp.idx), _l.ptr(sp.rows), _l.ptr(sp.n), _l.ptr(ws), ws_bytes,
+                                         _l.stream_ptr()), "pxr_merge_split_rows_f32")
     return sp
 
 

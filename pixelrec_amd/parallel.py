@@ -50,6 +50,18 @@ def gather_sparse(idx: torch.Tensor, rows: torch.Tensor, n: torch.Tensor, group=
     return idx_all, rows_all, ([x for x in h if x is not None], idx_masked, rows)
 
 
+def unpack_split(heads_all: torch.Tensor, rows_all: torch.Tensor, world: int, cap: int, cap_x: int):
+    """The two-collective exchange (heads = {ids[cap], count, pad} per rank; rows [world, cap_x, D]) as PAD-terminated
+    lists of cap_x slots per rank, for a merge function that is not the HIP kernel (tests).  Raises if a rank overflowed."""
+    heads = heads_all.view(world, -1)
+    idx = heads[:, :cap * 8].contiguous().view(torch.int64).view(world, cap)[:, :cap_x]
+    counts = heads[:, cap * 8:cap * 8 + 4].contiguous().view(torch.int32).view(world, 1)
+    if int(counts.max()) > cap_x:
+        raise RuntimeError("row exchange capacity exceeded")
+    ar = torch.arange(cap_x, device=heads_all.device, dtype=torch.int32).unsqueeze(0)
+    return torch.where(ar < counts, idx, PAD_ID).reshape(-1), rows_all
+
+
 def unpack_blocks(packed_all: torch.Tensor, world: int, cap: int, D: int):
     """`world` packed blocks (include/pxr.h: ids[cap] | int32 count | pad | rows[cap][D]) -> (idx_all [world*cap] with
     PAD_ID beyond each block's count, rows_all [world*cap, D]): the two-array form of the same lists, for a merge
@@ -76,9 +88,17 @@ def _arange(cap, device):
 class GradSync:
     """Synchronises the gradients of a pixelrec_amd SASRec across ranks after backward()."""
 
-    def __init__(self, model, merge_fn=None, group=None, force: bool = False):
+    def __init__(self, model, merge_fn=None, group=None, force: bool = False, exchange_rows: int | None = None):
         self.model = model
         self.group = group
+        # Row capacity of the sparse exchange.  None = the worst case a batch can touch, B*(2L+1) rows, in ONE collective
+        # (ids, count and rows packed).  An int = a bound on the UNIQUE rows of any rank's batch that the caller knows
+        # (bench.py computes it from its batch stream; a trainer can take it from the batcher): the exchange then moves
+        # the packed HEAD (ids + count, 8 B per slot) and only the first `exchange_rows` rows -- two collectives, ~1.4x
+        # fewer bytes at the Zipf workload (6 464 -> 4 608 rows of 2 KB per rank).  A batch that exceeds the bound sets
+        # the device status word and the next ops.raise_on_bad_indices() raises: never silent.
+        self.exchange_rows = int(exchange_rows) if exchange_rows else None
+        self.phase_events = None       # bench.py: list collecting (name, start_event, end_event) per phase
         self.rank, self.world = world_info()
         # force=True runs every collective even in a world of one (a 1-rank RCCL group on a single-GPU box
         # still goes through the same torch.distributed/RCCL entry points, streams and async handles)
@@ -88,14 +108,42 @@ class GradSync:
         self._merged = None
         self._pending = None
         self._packed_all = self._packed_key = None   # persistent receive buffer of the one-collective exchange
+        self._heads_all = self._rows_all = None      # ... and of the two-collective (reduced capacity) exchange
         if self.active:
             model.grad_scale = 1.0 / self.world
             # start the row exchange as soon as the sparse rows exist, i.e. BEFORE the grouped weight-gradient GEMM of
             # the same backward pass: the all-gather (xGMI) then runs under 0.25 ms of MFMA work
             model._sparse_ready_hook = self.start_sparse_exchange
 
+    def _mark(self, name):
+        """bench.py instrumentation: an event on the current stream, tagged."""
+        if self.phase_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.phase_events.append((name, ev))
+
     def start_sparse_exchange(self):
         sp = self.model.sparse_table_grad
+        self._mark("exchange_start")
+        if getattr(sp, "packed", None) is not None and self.exchange_rows and self.exchange_rows < sp.cap:
+            from . import ops as _ops
+
+            cap_x, D = self.exchange_rows, sp.rows.shape[1]
+            head = int(_ops._l.load().pxr_packed_rows_offset(sp.cap))
+            key = ("split", sp.cap, cap_x, D, str(sp.packed.device))
+            if self._packed_key != key:
+                self._heads_all = torch.empty(self.world * head, dtype=torch.uint8, device=sp.packed.device)
+                self._rows_all = torch.empty(self.world * cap_x, D, dtype=torch.float32, device=sp.packed.device)
+                self._packed_key = key
+            mine_head, mine_rows = sp.packed[:head], sp.rows[:cap_x]
+            if dist.get_backend(self.group) == "nccl":
+                h = [dist.all_gather_into_tensor(self._heads_all, mine_head, group=self.group, async_op=True),
+                     dist.all_gather_into_tensor(self._rows_all, mine_rows, group=self.group, async_op=True)]
+            else:   # gloo (tests)
+                h = [dist.all_gather(list(self._heads_all.chunk(self.world)), mine_head.contiguous(), group=self.group, async_op=True),
+                     dist.all_gather(list(self._rows_all.chunk(self.world)), mine_rows.contiguous(), group=self.group, async_op=True)]
+            self._pending = ("split", self._heads_all, self._rows_all, [x for x in h if x is not None], sp, cap_x)
+            return
         if getattr(sp, "packed", None) is not None:
             # one collective: ids, count and rows of a rank are one packed block (ops.SparseRows(packed=True)); the
             # merge kernel reads the counts from the blocks, so no PAD fill and no separate id all-gather
@@ -140,19 +188,44 @@ class GradSync:
         _, gflat = self.model.flat_parameters()
         flat_wait = dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         waits = []
-        for p in self._extra_params():      # trainable tail of the visual encoder (frozen parameters have no grads)
-            if p.grad is not None:
-                waits.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        tower = getattr(getattr(self.model, "visual_encoder", None), "_native", None)
+        if tower is not None and tower.gflat is not None:
+            # the image encoder's trainable gradients are contiguous segments of ONE flat buffer (model/vit_native.py):
+            # one all-reduce per segment (two for the shipped tune_scale) instead of one per tensor
+            for lo, hi in tower.segments:
+                waits.append(dist.all_reduce(tower.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for p in self._extra_params():      # (an encoder that has not run yet has no packed gradients)
+                if p.grad is not None:
+                    waits.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         if hasattr(self.model, "item_embedding"):
             if self._pending is None:
                 self.start_sparse_exchange()
             pending, self._pending = self._pending, None
-            if pending[0] == "packed":
+            if pending[0] == "split":
+                from . import ops
+
+                _, heads_all, rows_all, handles, sp, cap_x = pending
+                for h in handles:
+                    h.wait()
+                self._mark("exchange_done")
+                D = sp.rows.shape[1]
+                if self._merge is not None:     # injected merge (CPU tests): PAD-terminated lists of cap_x slots per rank
+                    idx_all, rows2 = unpack_split(heads_all, rows_all, self.world, sp.cap, cap_x)
+                    self.model.sparse_table_grad = self._merge(idx_all, rows2, self.model.item_num)
+                else:
+                    if self._merged is None or self._merged.cap != self.world * cap_x or self._merged.rows.shape[1] != D:
+                        self._merged = ops.SparseRows(self.world * cap_x, D, rows_all.device)
+                    self.model.sparse_table_grad = ops.merge_split_rows(heads_all, rows_all, self.world, sp.cap, cap_x, D,
+                                                                        self.model.item_num, 1.0, out=self._merged)
+                self._mark("merge_done")
+            elif pending[0] == "packed":
                 from . import ops
 
                 _, packed_all, handles, sp = pending
                 for h in handles:
                     h.wait()
+                self._mark("exchange_done")
                 D = sp.rows.shape[1]
                 if self._merge is not None:     # injected merge (CPU tests): hand it the blocks as PAD-terminated lists
                     idx_all, rows_all = unpack_blocks(packed_all, self.world, sp.cap, D)
@@ -162,6 +235,7 @@ class GradSync:
                         self._merged = ops.SparseRows(self.world * sp.cap, D, packed_all.device)
                     self.model.sparse_table_grad = ops.merge_packed_rows(packed_all, self.world, sp.cap, D,
                                                                          self.model.item_num, 1.0, out=self._merged)
+                self._mark("merge_done")
             else:
                 _, idx_all, rows_all, (handles, *_keepalive) = pending
                 for h in handles:
@@ -188,10 +262,10 @@ class GradSync:
 class DataParallel(torch.nn.Module):
     """Minimal DDP-shaped wrapper: the Trainer reaches the model through `.module` (trainer.py:332,349,358,374)."""
 
-    def __init__(self, module, merge_fn=None, force_collectives: bool = False):
+    def __init__(self, module, merge_fn=None, force_collectives: bool = False, exchange_rows: int | None = None):
         super().__init__()
         self.module = module
-        self.grad_sync = GradSync(module, merge_fn, force=force_collectives)
+        self.grad_sync = GradSync(module, merge_fn, force=force_collectives, exchange_rows=exchange_rows)
         self.grad_sync.broadcast_parameters(0)
 
     def forward(self, *args, **kwargs):

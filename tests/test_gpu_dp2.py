@@ -137,3 +137,37 @@ def test_merge_packed_rows_kernel(W, cap, D, n_table):
     assert torch.equal(got.rows[live], ref.rows[live])
     with pytest.raises(ValueError):
         ops.merge_packed_rows(torch.cat(blocks)[:-16], W, cap, D, n_table)
+
+
+@pytest.mark.parametrize("W,cap,cap_x,D,n_table", [(2, 100, 64, 128, 300), (8, 257, 200, 512, 900), (3, 40, 40, 64, 1000)])
+def test_merge_split_rows_kernel(W, cap, cap_x, D, n_table):
+    """pxr_merge_split_rows_f32 (reduced row capacity: heads of the packed blocks + the first cap_x rows of every rank)
+    == the dense sum when every count respects the bound; a count above it is cut AND flagged (the host raises)."""
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(W * 31 + cap)
+    head = int(ops._l.load().pxr_packed_rows_offset(cap))
+    heads, rows, dense = [], [], torch.zeros(n_table, D, dtype=torch.float64)
+    sps = []
+    for r in range(W):
+        n = int(torch.randint(0, min(cap_x, n_table - 1) + 1, (1,), generator=g))
+        ids = torch.sort(torch.randperm(n_table - 1, generator=g)[:n] + 1).values
+        sp = ops.SparseRows(cap, D, "cuda", packed=True)
+        sp.idx.copy_(torch.randint(1, n_table, (cap,), generator=g))       # stale ids beyond n: must be ignored
+        sp.idx[:n] = ids.cuda()
+        sp.rows.copy_(torch.randn(cap, D, generator=g))
+        sp.n.fill_(n)
+        dense.index_add_(0, ids, sp.rows[:n].cpu().double())
+        heads.append(sp.packed[:head]); rows.append(sp.rows[:cap_x]); sps.append(sp)
+    ops.raise_on_bad_indices()
+    got = ops.merge_split_rows(torch.cat(heads), torch.cat(rows).contiguous(), W, cap, cap_x, D, n_table, 0.5)
+    assert got.count() == W * cap_x
+    live = got.idx[got.idx > 0]
+    assert live.numel() == live.unique().numel()
+    assert torch.allclose(got.to_dense(n_table).cpu().double(), 0.5 * dense, atol=1e-5)
+    ops.raise_on_bad_indices()                                             # bound respected: nothing flagged
+    sps[0].n.fill_(cap_x + 1)                                              # rank 0 now claims more rows than were exchanged
+    if cap_x < cap:
+        ops.merge_split_rows(torch.cat([s.packed[:head] for s in sps]), torch.cat(rows).contiguous(), W, cap, cap_x, D, n_table)
+        with pytest.raises(RuntimeError, match="exchange capacity"):
+            ops.raise_on_bad_indices()

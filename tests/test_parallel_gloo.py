@@ -12,8 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-WORLD = 2
-D, N, CAP = 8, 50, 12
+D, N, CAP = 8, 50, 16
 
 
 def _free_port():
@@ -28,7 +27,7 @@ def _rank_data(rank):
     """Deterministic per-rank 'gradients' every rank can recompute for every other rank."""
     g = torch.Generator().manual_seed(100 + rank)
     gflat = torch.randn(40, generator=g)
-    n = 5 + 3 * rank
+    n = (5 + 3 * rank) if rank != 2 else 0          # ragged counts; one rank with an EMPTY list (world 4)
     idx = torch.sort(torch.randperm(N - 1, generator=g)[:n] + 1).values
     rows = torch.randn(n, D, generator=g)
     return gflat, idx, rows
@@ -81,7 +80,7 @@ def _cpu_merge(idx_all, rows_all, n_table):
     return dense
 
 
-def _worker(rank, port, results):
+def _worker(rank, port, results, WORLD):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
@@ -112,6 +111,26 @@ def _worker(rank, port, results):
         assert gs3._pending[0] == "packed" and gs3._pending[1].numel() == WORLD * m3.sparse_table_grad.packed.numel()
         gs3.sync()
         assert torch.allclose(m3.gflat, exp_flat) and torch.allclose(m3.sparse_table_grad, exp_dense, atol=1e-6)
+        # reduced row capacity (GradSync(exchange_rows=...)): heads (ids + count) and the first cap_x rows travel as TWO
+        # collectives; the bound holds (max count = 14), so nothing is lost
+        m4 = _PackedModel(rank)
+        gs4 = GradSync(m4, merge_fn=_cpu_merge, exchange_rows=14)
+        m4._sparse_ready_hook()
+        assert gs4._pending[0] == "split" and gs4._pending[2].shape == (WORLD * 14, D)
+        gs4.sync()
+        assert torch.allclose(m4.gflat, exp_flat) and torch.allclose(m4.sparse_table_grad, exp_dense, atol=1e-6)
+        # ... and a bound that does NOT hold is loud (here: the injected merge raises; on the GPU the merge kernel sets the
+        # device status word and ops.raise_on_bad_indices raises)
+        m5 = _PackedModel(rank)
+        gs5 = GradSync(m5, merge_fn=_cpu_merge, exchange_rows=6)
+        m5._sparse_ready_hook()
+        try:
+            gs5.sync()
+            overflowed = False
+        except RuntimeError as e:
+            overflowed = "capacity" in str(e)
+        assert overflowed == (max((5 + 3 * r) if r != 2 else 0 for r in range(WORLD)) > 6)
+        dist.barrier()
         # deferred flat wait: sync leaves the all-reduce handle with the model; the consumer completes it
         m2 = _DeferringModel(rank)
         gs2 = GradSync(m2, merge_fn=_cpu_merge)
@@ -127,15 +146,16 @@ def _worker(rank, port, results):
         t = Trainer.__new__(Trainer)
         t.world = WORLD
         got = t.distributed_concat(torch.tensor([float(rank + 1)], dtype=torch.float64), 10)
-        assert abs(float(got) - (1 + 2) / 10) < 1e-12
+        assert abs(float(got) - sum(range(1, WORLD + 1)) / 10) < 1e-12
         results[rank] = "ok"
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gradient_exchange_and_eval_sharding():
+@pytest.mark.parametrize("world", [2, 4])
+def test_gradient_exchange_and_eval_sharding(world):
     port = _free_port()
     with mp.Manager() as mgr:
         results = mgr.dict()
-        mp.spawn(_worker, args=(port, results), nprocs=WORLD, join=True)
-        assert dict(results) == {0: "ok", 1: "ok"}
+        mp.spawn(_worker, args=(port, results, world), nprocs=world, join=True)
+        assert dict(results) == {r: "ok" for r in range(world)}
