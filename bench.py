@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--table-update", choices=("lazy", "dense"), default="lazy",
                     help="table AdamW schedule (dense = sweep all rows every step; eager only)")
     ap.add_argument("--dw-mode", default=None, help="weight-gradient placement: grouped | fork_layer | fork_half")
+    ap.add_argument("--full-exchange", action="store_true",
+                    help="data parallel: exchange the worst-case B*(2L+1) row slots (one collective) instead of the bound "
+                         "computed from the batch stream (two collectives)")
     ap.add_argument("--lookahead", action="store_true",
                     help="hand the next batch's ids to the model (look-ahead catch-up of its table rows on a side stream; "
                          "measured slower on MI355X, off by default)")
@@ -279,9 +282,7 @@ def main():
     if args.dw_mode:
         model.weight_grad_mode = args.dw_mode
     model.defer_weight_grad_join = True      # every step below ends in opt.step(), which joins the side stream
-    dp = (ShardedDataParallel(model, force_collectives=args.force_collectives) if args.table_sharding
-          else DataParallel(model, force_collectives=args.force_collectives))
-    opt = PxrAdamW(model, lr=1e-4, weight_decay=0.1, table_update=args.table_update)
+    opt = None
 
     # synthetic batches, rank-distinct, resident in HBM before the timed region.  The stream does NOT repeat inside
     # ageing + warm-up + timed steps (+ the instrumented steps after them): a lazily updated table row returns after the
@@ -293,10 +294,22 @@ def main():
     n_stream = min(args.age_steps + args.warmup + args.steps + n_inst_plan + 40, 4096)
     t_gen = time.perf_counter()
     its, mks = zip(*(synth.train_batch(N, B, L, rng, zipf) for _ in range(n_stream)))
+    # a rigorous bound on the unique table rows any batch of THIS stream touches: the row capacity of the data-parallel
+    # exchange (GradSync(exchange_rows=...)); all ranks agree on the maximum once, before the first step
+    max_unique = max(int(np.count_nonzero(np.unique(it))) for it in its)
     items_all = torch.from_numpy(np.stack(its)).to(dev)
     mask_all = torch.from_numpy(np.stack(mks)).to(dev)
     t_gen = time.perf_counter() - t_gen
     del its, mks
+
+    exchange_rows = None
+    if (world > 1 or args.force_collectives) and not args.full_exchange and not args.table_sharding:
+        t_mx = torch.tensor([max_unique], dtype=torch.int64, device=dev)
+        dist.all_reduce(t_mx, op=dist.ReduceOp.MAX)
+        exchange_rows = min(B * (2 * L + 1), (int(t_mx.item()) + 255) // 256 * 256)
+    dp = (ShardedDataParallel(model, force_collectives=args.force_collectives) if args.table_sharding
+          else DataParallel(model, force_collectives=args.force_collectives, exchange_rows=exchange_rows))
+    opt = PxrAdamW(model, lr=1e-4, weight_decay=0.1, table_update=args.table_update)
 
     class _Pool:
         def __len__(self):
@@ -420,6 +433,30 @@ def main():
         for i in range(n_inst):
             instrumented_step(i)
         torch.cuda.synchronize()
+    # data parallel: where a step's device time goes (exchange wait, merge, optimizer), from events on the compute stream
+    phases = None
+    gsync = getattr(dp, "grad_sync", None)
+    if gsync is not None and gsync.active and not args.table_sharding:
+        acc, n_ph = {}, 10
+        for _ in range(n_ph):
+            marks = []
+            gsync.phase_events = marks
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            b = next_batch()
+            eager_step(b, peek_items())
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            gsync.phase_events = None
+            torch.cuda.synchronize()
+            names = ["step_start"] + [n for n, _ in marks] + ["step_end"]
+            evs = [e0] + [e for _, e in marks] + [e1]
+            for (na, ea), (nb, eb) in zip(zip(names, evs), zip(names[1:], evs[1:])):
+                acc[f"{na}->{nb}"] = acc.get(f"{na}->{nb}", 0.0) + ea.elapsed_time(eb) * 1e3 / n_ph
+        phases = {"us": acc, "rccl_ranks": world, "exchange_rows_per_rank": exchange_rows or B * (2 * L + 1),
+                  "exchange_collectives": 2 if exchange_rows else 1,
+                  "note": "eager steps; step_start->exchange_start = forward + input-gradient chain + segmented sum; "
+                          "exchange_start->exchange_done = grouped weight-gradient GEMM + whatever of the all-gather it did not "
+                          "hide; exchange_done->merge_done = rank merge; merge_done->step_end = row update, flat all-reduce "
+                          "wait, flat update"}
     # the same eager step without the event brackets (the host keeps up at B=64): reference point for the dense A/B
     t_eager = None
     if world == 1 and not args.no_extras:
@@ -528,6 +565,8 @@ def main():
                    "repeats_inside_run": bool(stream_repeats), "optimizer_steps_before_timed_region": args.age_steps + args.warmup,
                    "table_update": args.table_update},
     }
+    if phases is not None:
+        out["data_parallel_phases"] = phases
     if lazy_flush is not None:
         out["lazy_flush"] = lazy_flush
     if lazy_gaps is not None:

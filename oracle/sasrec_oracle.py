@@ -98,7 +98,13 @@ def _dropout(x, keep_mask, p):
     return x * keep_mask.to(x.dtype) / (1.0 - p)
 
 
-def encoder_layer(p: Params, i: int, h, mask, n_heads, eps, drop=None, p_attn=0.0, p_hidden=0.0, trace=None):
+def hidden_act_fn(name):
+    """FeedForward.get_hidden_act (layers.py:641-649; swish :662-663)."""
+    return {"gelu": gelu_erf, "relu": torch.relu, "swish": lambda x: x * torch.sigmoid(x), "tanh": torch.tanh,
+            "sigmoid": torch.sigmoid}[name]
+
+
+def encoder_layer(p: Params, i: int, h, mask, n_heads, eps, drop=None, p_attn=0.0, p_hidden=0.0, trace=None, act="gelu"):
     """One TransformerLayer = MultiHeadAttention (layers.py:585-617) + FeedForward (layers.py:665-673)."""
     pre = f"trm_encoder.layer.{i}."
     B, L, D = h.shape
@@ -116,7 +122,7 @@ def encoder_layer(p: Params, i: int, h, mask, n_heads, eps, drop=None, p_attn=0.
     h1 = layer_norm(a + h, p[pre + "multi_head_attention.LayerNorm.weight"],
                     p[pre + "multi_head_attention.LayerNorm.bias"], eps)               # :615
     u = lin(h1, "feed_forward.dense_1")                               # :666
-    f = gelu_erf(u)                                                   # :667
+    f = hidden_act_fn(act)(u)                                         # :667
     f2 = lin(f, "feed_forward.dense_2")                               # :669
     f2 = _dropout(f2, None if drop is None else drop.get((i, "ffn_out")), p_hidden)    # :670
     h2 = layer_norm(f2 + h1, p[pre + "feed_forward.LayerNorm.weight"], p[pre + "feed_forward.LayerNorm.bias"], eps)
@@ -140,7 +146,8 @@ def encode(p: Params, seq_ids, key_mask_src, cfg, drop=None, trace=None):
     for i in range(cfg["n_layers"]):
         h = encoder_layer(p, i, h, mask, cfg["n_heads"], cfg["layer_norm_eps"], drop,
                           cfg.get("attn_dropout_prob", 0.0) if drop is not None else 0.0,
-                          cfg.get("hidden_dropout_prob", 0.0) if drop is not None else 0.0, trace)
+                          cfg.get("hidden_dropout_prob", 0.0) if drop is not None else 0.0, trace,
+                          act=cfg.get("hidden_act", "gelu"))
     return h
 
 

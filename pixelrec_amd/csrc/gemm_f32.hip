@@ -15,13 +15,17 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD
        EPI_BIAS_ADD = 7,          // C = acc + bias + aux            (out_proj / fc2 + residual stream)
        EPI_BIAS_QGELU_GRAD = 8,   // C = quick_gelu(acc + bias), aux = quick_gelu'(acc + bias)   (CLIP MLP fc1)
        EPI_BIAS_RELU = 9,         // C = relu(acc + bias)            (rec_fc of MeanItemEncoder, layers.py:121-128)
-       EPI_LAST = 9 };
+       // the other hidden_act choices of the reference's FeedForward (layers.py:642-649: relu / swish / tanh / sigmoid):
+       EPI_BIAS_ACT_GRAD = 10,    // C = act(acc + bias), aux = act'(acc + bias); act = GemmBatch::act
+       EPI_LAST = 10 };
+enum { ACT_RELU = 3, ACT_SWISH = 4, ACT_TANH = 5, ACT_SIGMOID = 6 };
 
 // Batched launch: grid.z = batch index z; operand offsets (in floats) = (z / nb2) * x1 + (z % nb2) * x2 -- two levels, so
 // that "image n, head h" of a packed [n, T, 3, heads, d] projection is addressed without copies.
 struct GemmBatch {
   int nb2;
   int64_t a1, a2, b1, b2, c1, c2;
+  int act;      // EPI_BIAS_ACT_GRAD: which activation (ACT_*)
 };
 
 // erf-GELU exactly as the reference writes it: x * 0.5 * (1 + erf(x / sqrt(2)))  (layers.py:651-660)
@@ -94,7 +98,7 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
     if (col >= N) continue;
     float bv = 0.f;
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD || EPI == EPI_BIAS_ADD ||
-                  EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU)
+                  EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ACT_GRAD)
       bv = bias[col];
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) {
@@ -128,6 +132,22 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
           v = v * sg;
         } else if constexpr (EPI == EPI_BIAS_RELU) {
           v = fmaxf(v + bv, 0.f);
+        } else if constexpr (EPI == EPI_BIAS_ACT_GRAD) {
+          v += bv;
+          float dv;
+          if (bt.act == ACT_RELU) {                 // F.relu
+            dv = v > 0.f ? 1.f : 0.f; v = fmaxf(v, 0.f);
+          } else if (bt.act == ACT_SWISH) {         // x * sigmoid(x)   (layers.py:662-663)
+            const float sg = 1.0f / (1.0f + __expf(-v));
+            dv = sg + v * sg * (1.0f - sg); v = v * sg;
+          } else if (bt.act == ACT_TANH) {
+            const float th = tanhf(v);
+            dv = 1.0f - th * th; v = th;
+          } else {                                  // sigmoid
+            const float sg = 1.0f / (1.0f + __expf(-v));
+            dv = sg * (1.0f - sg); v = sg;
+          }
+          aux[(int64_t)row * ldaux + col] = dv;
         }
         C[(int64_t)row * ldc + col] = v;
       }
@@ -325,7 +345,8 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   PXR_REQUIRE(ext_b % 4 == 0 || ldb >= ((ext_b + 3) & ~3), "pxr_gemm_f32: B contiguous extent must be a multiple of 4 (or padded)");
   PXR_REQUIRE(epilogue >= 0 && epilogue <= EPI_LAST, "pxr_gemm_f32: bad epilogue %d", epilogue);
   PXR_REQUIRE(!(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_GELU_GRAD ||
-                epilogue == EPI_BIAS_ADD || epilogue == EPI_BIAS_QGELU_GRAD || epilogue == EPI_BIAS_RELU) || bias,
+                epilogue == EPI_BIAS_ADD || epilogue == EPI_BIAS_QGELU_GRAD || epilogue == EPI_BIAS_RELU ||
+                epilogue == EPI_BIAS_ACT_GRAD) || bias,
               "pxr_gemm_f32: epilogue needs bias");
   PXR_REQUIRE(!(epilogue >= EPI_BIAS_GELU && epilogue != EPI_BIAS_RELU) || aux, "pxr_gemm_f32: epilogue needs aux");
   hipStream_t st = (hipStream_t)stream;
@@ -388,6 +409,7 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
       case EPI_BIAS_ADD: PXR_GEMM_CASE(true, true, EPI_BIAS_ADD); break;
       case EPI_BIAS_QGELU_GRAD: PXR_GEMM_CASE(true, true, EPI_BIAS_QGELU_GRAD); break;
       case EPI_BIAS_RELU: PXR_GEMM_CASE(true, true, EPI_BIAS_RELU); break;
+      case EPI_BIAS_ACT_GRAD: PXR_GEMM_CASE(true, true, EPI_BIAS_ACT_GRAD); break;
       default: pxr_set_error("pxr_gemm_f32: epilogue %d unsupported for (KC,KC)", epilogue); return PXR_ERR_BAD_ARG;
     }
   } else if (a_kc && !b_kc) {
@@ -430,7 +452,7 @@ extern "C" int pxr_gemm_batched_f32(int a_kc, int b_kc, int M, int N, int K, con
   for (int z0 = 0; z0 < batch && rc == PXR_OK; z0 += 65535 / nb2 * nb2) {   // grid.z <= 65535: whole groups per launch
     const int nz = min(batch - z0, 65535 / nb2 * nb2);
     const int64_t g0 = z0 / nb2;
-    g_bt = GemmBatch{nb2, a1, a2, b1, b2, c1, c2};
+    g_bt = GemmBatch{nb2, a1, a2, b1, b2, c1, c2, 0};
     g_batch = nz;
     rc = pxr_gemm_f32(a_kc, b_kc, M, N, K, A + g0 * a1, lda, B + g0 * b1, ldb, C + g0 * c1, ldc, EPI_NONE, nullptr, nullptr,
                       0, nullptr, 0, tile_hint ? tile_hint : 64, 1, stream);
@@ -444,7 +466,14 @@ extern "C" int pxr_gemm_batched_f32(int a_kc, int b_kc, int M, int N, int K, con
 // gelu'(pre-activation) saved to `pre` instead -- the form the training step uses: the backward is one multiply)
 extern "C" int pxr_linear_fwd_f32(const float* x, const float* W, const float* b, float* y, float* pre, int M,
                                   int N, int K, int act, void* stream) {
-  PXR_REQUIRE(act >= 0 && act <= 2, "pxr_linear_fwd_f32: bad act %d", act);
+  PXR_REQUIRE(act >= 0 && act <= ACT_SIGMOID, "pxr_linear_fwd_f32: bad act %d", act);
+  if (act >= ACT_RELU) {   // relu / swish / tanh / sigmoid: act'(pre-activation) saved to `pre`
+    g_bt = GemmBatch{};
+    g_bt.act = act;
+    const int rc = pxr_gemm_f32(1, 1, M, N, K, x, K, W, K, y, N, EPI_BIAS_ACT_GRAD, b, pre, N, nullptr, 0, 0, 0, stream);
+    g_bt = GemmBatch{};
+    return rc;
+  }
   const int epi = act == 2 ? EPI_BIAS_GELU_GRAD : (act == 1 ? EPI_BIAS_GELU : (b ? EPI_BIAS : EPI_NONE));
   return pxr_gemm_f32(1, 1, M, N, K, x, K, W, K, y, N, epi, b, pre, N, nullptr, 0, 0, 0, stream);
 }

@@ -75,9 +75,8 @@ class SeqRecCore(BaseModel):
         self.layer_norm_eps = float(config["layer_norm_eps"])
         self.initializer_range = config["initializer_range"]
         self.max_seq_length = config["MAX_ITEM_LIST_LENGTH"]
-        if self.hidden_act != "gelu":
-            raise NotImplementedError("pixelrec_amd implements hidden_act='gelu' (the shipped configs); "
-                                      f"got {self.hidden_act!r}")
+        if self.hidden_act not in ("gelu", "relu", "swish", "tanh", "sigmoid"):     # ACT2FN, layers.py:642-649
+            raise ValueError(f"hidden_act must be one of gelu / relu / swish / tanh / sigmoid, got {self.hidden_act!r}")
         if self.hidden_size % self.n_heads != 0:
             raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
                              % (self.hidden_size, self.n_heads))
@@ -242,7 +241,8 @@ class SeqRecCore(BaseModel):
             a = ops.linear_fwd(ctx, self._p(f"{i}.o.w"), self._p(f"{i}.o.b"))
             h1, xhat1, rstd1 = ops.ln_residual_fwd(a, h, self._p(f"{i}.ln1.w"), self._p(f"{i}.ln1.b"), eps, ph, seed,
                                                    2 + 3 * i, save=train, step_dev=sdv)
-            f, u = ops.linear_fwd(h1, self._p(f"{i}.f1.w"), self._p(f"{i}.f1.b"), gelu=True, save_grad=train)
+            f, u = ops.linear_fwd(h1, self._p(f"{i}.f1.w"), self._p(f"{i}.f1.b"), gelu=True, save_grad=train,
+                                  act=self.hidden_act)
             f2 = ops.linear_fwd(f, self._p(f"{i}.f2.w"), self._p(f"{i}.f2.b"))
             h2, xhat2, rstd2 = ops.ln_residual_fwd(f2, h1, self._p(f"{i}.ln2.w"), self._p(f"{i}.ln2.b"), eps, ph, seed,
                                                    3 + 3 * i, save=train, step_dev=sdv)

@@ -138,9 +138,18 @@ def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc,
     return C
 
 
-def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: bool = False, save_grad: bool = False):
+ACT_CODES = {"relu": 3, "swish": 4, "tanh": 5, "sigmoid": 6}      # the reference's ACT2FN besides gelu (layers.py:642-649)
+
+
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: bool = False, save_grad: bool = False,
+               act: str | None = None):
     """y = x W^T + b (nn.Linear, layers.py:586-588,613,666,669).  gelu=True also returns the pre-activation, or with
-    save_grad=True gelu'(pre-activation) (what linear_bwd_input(mul=...) multiplies by)."""
+    save_grad=True gelu'(pre-activation) (what linear_bwd_input(mul=...) multiplies by).  act in ACT_CODES: that
+    activation instead of erf-GELU, always with its derivative returned second."""
+    if act is not None and act != "gelu":
+        gelu, code = True, ACT_CODES[act]
+    else:
+        code = None
     L = _l.load()
     _req(x, torch.float32, "x"); _req(W, torch.float32, "W")
     N, K = W.shape
@@ -150,7 +159,8 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: b
     with _gemm_timer(2.0 * M * N * K, "gemm_kernel<KC,KC,EPI_BIAS_GELU*> (fwd + erf-GELU)" if gelu else
                      "gemm_kernel<KC,KC,EPI_BIAS> (fwd)"):
         _l.check(L.pxr_linear_fwd_f32(_l.ptr(x), _l.ptr(W), _l.ptr(b), _l.ptr(y), _l.ptr(pre), M, N, K,
-                                      (2 if save_grad else 1) if gelu else 0, _l.stream_ptr()), "pxr_linear_fwd_f32")
+                                      code if code is not None else ((2 if save_grad else 1) if gelu else 0),
+                                      _l.stream_ptr()), "pxr_linear_fwd_f32")
     return (y, pre) if gelu else y
 
 

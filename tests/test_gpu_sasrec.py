@@ -204,3 +204,41 @@ def test_degenerate_inputs():
     loss = m((items, mask))
     loss.backward()
     assert float(loss.detach()) > 0.0 and m.sparse_table_grad.count() > 0
+
+
+@pytest.mark.parametrize("act", ["relu", "swish", "tanh", "sigmoid"])
+def test_hidden_act_variants_match_reference_golden(act):
+    """hidden_act other than gelu (reference layers.py:642-649): the FFN-1 GEMM epilogue applies the activation and
+    saves its derivative; loss / gradients / predict scores against the reference SASRec's own outputs."""
+    import os
+
+    import numpy as np
+
+    from pixelrec_amd.model import SASRec
+    from tests.golden_util import GOLDEN_DIR, META_KEYS
+
+    z = np.load(os.path.join(GOLDEN_DIR, "sasrec_act.npz"))
+    meta = dict(zip(META_KEYS, [int(x) for x in z["meta"]]))
+    p = O.synth_params(meta["n_items"], meta["D"], meta["L"], meta["n_layers"], meta["inner"], seed=meta["seed"])
+    cfg = {"n_layers": meta["n_layers"], "n_heads": meta["H"], "embedding_size": meta["D"], "inner_size": meta["inner"],
+           "hidden_dropout_prob": 0.0, "attn_dropout_prob": 0.0, "hidden_act": act, "layer_norm_eps": 1e-12,
+           "initializer_range": 0.02, "MAX_ITEM_LIST_LENGTH": meta["L"], "seed": 2020}
+
+    class DL:
+        item_num = meta["n_items"]
+
+    m = SASRec(cfg, DL())
+    m.load_state_dict(p, strict=True)
+    m = m.cuda().train()
+    loss = m((torch.from_numpy(z["items"]).cuda(), torch.from_numpy(z["masked_index"]).cuda()))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(z[f"{act}.loss"])) <= 2e-5 * max(1.0, abs(float(z[f"{act}.loss"])))
+    named = dict(m.named_parameters())
+    for k in z.files:
+        if k.startswith(f"{act}.grad."):
+            name = k[len(act) + 6:]
+            err = np.abs(named[name].grad.cpu().numpy() - z[k]).max()
+            assert err <= 5e-6 + 3e-4 * np.abs(z[k]).max(), (name, err)
+    m.eval()
+    scores = m.predict(torch.from_numpy(z["eval.item_seq"]).cuda(), m.compute_item_all()).cpu().numpy()
+    assert np.abs(scores - z[f"{act}.scores"]).max() <= 1e-4

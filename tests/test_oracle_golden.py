@@ -78,3 +78,26 @@ def test_predict_topk_metrics(case):
     res = O.recall_ndcg(rec.numpy(), [5, 10])
     for name, val in zip(z["eval.metric_names"], z["eval.metric_sums"]):
         assert abs(res[str(name)] - float(val)) < 1e-9, name
+
+
+@pytest.mark.parametrize("act", ["relu", "swish", "tanh", "sigmoid"])
+def test_oracle_hidden_act_matches_reference_golden(act):
+    """The reference's other FeedForward activations (layers.py:642-649): tests/golden/sasrec_act.npz holds the reference
+    SASRec's loss / gradients / scores per activation (oracle/make_golden_act.py)."""
+    import os
+
+    from tests.golden_util import GOLDEN_DIR, META_KEYS
+
+    z = np.load(os.path.join(GOLDEN_DIR, "sasrec_act.npz"))
+    meta = dict(zip(META_KEYS, [int(x) for x in z["meta"]]))
+    p = O.synth_params(meta["n_items"], meta["D"], meta["L"], meta["n_layers"], meta["inner"], seed=meta["seed"])
+    cfg = {"n_layers": meta["n_layers"], "n_heads": meta["H"], "layer_norm_eps": 1e-12, "hidden_act": act}
+    loss, g = O.loss_and_grads(p, torch.from_numpy(z["items"]), torch.from_numpy(z["masked_index"]), cfg)
+    assert abs(float(loss) - float(z[f"{act}.loss"])) < 1e-6
+    for k in z.files:
+        if k.startswith(f"{act}.grad."):
+            name = k[len(act) + 6:]
+            assert np.abs(g[name].numpy() - z[k]).max() < 2e-7 + 2e-6 * np.abs(z[k]).max(), name
+    seq = torch.from_numpy(z["eval.item_seq"])
+    scores = O.predict(p, seq, p["item_embedding.weight"], cfg)
+    assert np.abs(scores.numpy() - z[f"{act}.scores"]).max() < 1e-6
