@@ -168,6 +168,15 @@ int pxr_vit_embed_f32(const float* patches, const float* cls, const float* pos, 
 int pxr_token_mean_f32(const float* x, float* out, int64_t n, int T, int D, void* stream);
 /* dact[n,t,:] = act[n,t,:] > 0 ? dout[n,:] / T : 0                          (through the mean and rec_fc's ReLU) */
 int pxr_token_mean_relu_bwd_f32(const float* dout, const float* act, float* dact, int64_t n, int T, int D, void* stream);
+/* SASRec attention for MAX_ITEM_LIST_LENGTH > 128 (beyond the fused kernels behind pxr_attn_fwd_f32): the scores come
+ * from a batched GEMM (S = Q K^T, unscaled, [B*H, L, ld]); this turns them in place into softmax(S / sqrt(d) + mask) with
+ * the reference's additive -1e9 causal + key mask (model/layers.py:595-604, model/IDNet/sasrec.py:119-126) and writes
+ * the dropped probabilities (layers.py:608; same counter hash and element numbering as pxr_attn_fwd_f32) to PD. */
+int pxr_attn_rows_fwd_f32(float* S, float* PD, const int64_t* keymask, int64_t km_bstride, int B, int H, int L, int ld,
+                          float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, int d, void* stream);
+/* in place on dPD (gradient w.r.t. the dropped probabilities): gradient w.r.t. the unscaled scores */
+int pxr_attn_rows_bwd_f32(const float* P, float* dPD, int B, int H, int L, int ld, float p_drop, uint64_t seed,
+                          uint32_t stream_id, const int64_t* step_dev, int d, void* stream);
 /* out = a + b (n floats, n % 4 == 0): the two branches of a residual-stream gradient */
 int pxr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 

@@ -129,6 +129,71 @@ __global__ void __launch_bounds__(256) add_kernel(const float4* __restrict__ a, 
   }
 }
 
+// ---- SASRec attention rows for sequences longer than the fused kernels of attention.hip hold (L > 128) ---------------
+// The same arithmetic as there (reference layers.py:595-608 + sasrec.py:119-126): s = S / sqrt(d) + (key real and j <= i
+// ? 0 : -1e9) -- ADDITIVE, so a fully masked (left-padded) query row becomes uniform over all L keys --, p = softmax(s)
+// saved in place, pd = dropout(p) with the counter-hash mask of element ((b*H + h)*L + i)*L + j written to PD.
+struct AttnRowsArgs {
+  float* S; float* PD;                 // [B*H, L, ld]; PD may be null when p_drop == 0
+  const float* dPD_in;                 // backward: gradient w.r.t. the dropped probabilities (in place -> dS)
+  const int64_t* keymask; int64_t km_bstride;
+  int B, H, L, ld;
+  float sqrt_d, p_drop; uint32_t drop_thr, stream; uint64_t seed;
+  const int64_t* step_dev;
+};
+
+__global__ void __launch_bounds__(256) attn_rows_fwd_kernel(AttnRowsArgs a) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (b*H + h)*L + i
+  if (row >= (int64_t)a.B * a.H * a.L) return;
+  const int i = (int)(row % a.L);
+  const int b = (int)(row / ((int64_t)a.H * a.L));
+  float* s = a.S + row * a.ld;
+  const int64_t* km = a.keymask + (int64_t)b * a.km_bstride;
+  float m = -3.0e38f;
+  for (int j = lane; j < a.L; j += 64) {
+    const float v = s[j] / a.sqrt_d + ((km[j] != 0 && j <= i) ? 0.0f : -1e9f);
+    s[j] = v;
+    m = fmaxf(m, v);
+  }
+  m = wave_max(m);
+  float z = 0.f;
+  for (int j = lane; j < a.L; j += 64) z += __expf(s[j] - m);
+  const float inv = 1.0f / wave_sum(z);
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  for (int j = lane; j < a.ld; j += 64) {
+    const float p = j < a.L ? __expf(s[j] - m) * inv : 0.f;
+    s[j] = p;
+    if (a.PD) {
+      const uint64_t pi = (uint64_t)row * a.L + j;
+      a.PD[row * a.ld + j] = (j < a.L && (!drop || pxr_keep(a.seed, a.stream, pi, a.drop_thr))) ? (drop ? p * inv_keep : p) : 0.f;
+    }
+  }
+}
+
+// dS = P o (dP - rowsum(dP o P)) / sqrt(d)  with  dP = dPD * keep / (1 - p_drop); in place on dPD
+__global__ void __launch_bounds__(256) attn_rows_bwd_kernel(AttnRowsArgs a, float* dPD) {
+  if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)a.B * a.H * a.L) return;
+  const float* p = a.S + row * a.ld;
+  float* d = dPD + row * a.ld;
+  const bool drop = a.drop_thr != 0u;
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  float dot = 0.f;
+  for (int j = lane; j < a.L; j += 64) {
+    float g = d[j];
+    if (drop) g = pxr_keep(a.seed, a.stream, (uint64_t)row * a.L + j, a.drop_thr) ? g * inv_keep : 0.f;
+    d[j] = g;
+    dot += g * p[j];
+  }
+  dot = wave_sum(dot);
+  for (int j = lane; j < a.ld; j += 64) d[j] = j < a.L ? p[j] * (d[j] - dot) / a.sqrt_d : 0.f;
+}
+
 static inline unsigned grid_for(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -193,4 +258,36 @@ extern "C" int pxr_add_f32(const float* a, const float* b, float* out, int64_t n
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)a,
                      (const float4*)b, (float4*)out, n / 4);
   return pxr_check_launch("pxr_add_f32");
+}
+
+// S [B*H, L, ld] (= Q K^T, unscaled) -> in place the softmax probabilities of the SASRec attention (additive -1e9
+// causal + key mask, reference layers.py:595-604, sasrec.py:119-126); PD (may be NULL when p_drop == 0) receives the
+// dropped probabilities (layers.py:608).  For sequences beyond the fused kernels of attention.hip (L > 128).
+extern "C" int pxr_attn_rows_fwd_f32(float* S, float* PD, const int64_t* keymask, int64_t km_bstride, int B, int H, int L,
+                                     int ld, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                                     int d, void* stream) {
+  PXR_REQUIRE(S && keymask && B >= 0 && H > 0 && L > 0 && ld >= L && d > 0, "pxr_attn_rows_fwd_f32: bad args");
+  PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || PD), "pxr_attn_rows_fwd_f32: dropout needs PD");
+  if (B == 0) return PXR_OK;
+  AttnRowsArgs a{};
+  a.S = S; a.PD = PD; a.keymask = keymask; a.km_bstride = km_bstride; a.B = B; a.H = H; a.L = L; a.ld = ld;
+  a.sqrt_d = sqrtf((float)d); a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id;
+  a.seed = seed; a.step_dev = step_dev;
+  const int64_t rows = (int64_t)B * H * L;
+  hipLaunchKernelGGL(attn_rows_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return pxr_check_launch("pxr_attn_rows_fwd_f32");
+}
+
+// dPD [B*H, L, ld] (gradient w.r.t. the dropped probabilities) -> in place the gradient w.r.t. the unscaled scores S
+extern "C" int pxr_attn_rows_bwd_f32(const float* P, float* dPD, int B, int H, int L, int ld, float p_drop, uint64_t seed,
+                                     uint32_t stream_id, const int64_t* step_dev, int d, void* stream) {
+  PXR_REQUIRE(P && dPD && B >= 0 && H > 0 && L > 0 && ld >= L && d > 0, "pxr_attn_rows_bwd_f32: bad args");
+  if (B == 0) return PXR_OK;
+  AttnRowsArgs a{};
+  a.S = const_cast<float*>(P); a.B = B; a.H = H; a.L = L; a.ld = ld;
+  a.sqrt_d = sqrtf((float)d); a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id;
+  a.seed = seed; a.step_dev = step_dev;
+  const int64_t rows = (int64_t)B * H * L;
+  hipLaunchKernelGGL(attn_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, dPD);
+  return pxr_check_launch("pxr_attn_rows_bwd_f32");
 }

@@ -401,10 +401,54 @@ def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0
 
 
 # ------------------------------------------------------------------------------------------------ attention
+ATTN_FUSED_MAX_L = 128     # sequences beyond this take the batched-GEMM path below (any length)
+
+
+def _attn_takes_gemm_path(L, d):
+    """Beyond 128 positions -- or 65..128 with a head size that is not a multiple of 8, which the two-keys-per-lane fused
+    kernels need -- the attention runs as batched GEMMs + the row kernel (any length, head size % 4 == 0)."""
+    return L > ATTN_FUSED_MAX_L or (L > 64 and d % 8 != 0)
+
+
+def _attn_long_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop, seed, stream_id, step_dev):
+    """MAX_ITEM_LIST_LENGTH > 128: S = Q K^T and O = PD V as batched fp32-MFMA GEMMs (grid.z = batch x head) around the
+    row kernel pxr_attn_rows_fwd_f32 (mask + softmax + dropout).  Same arithmetic as the fused kernels."""
+    Lb = _l.load()
+    D, ld, Lp, bh = H * d, 3 * H * d, (L + 3) & ~3, B * H
+    P = torch.empty(bh, L, Lp, dtype=torch.float32, device=qkv.device)
+    sP, sQ, sC = (H * L * Lp, L * Lp), (L * ld, d), (L * D, d)
+    gemm_batched(True, True, L, L, d, qkv, 0, ld, qkv, D, ld, P, 0, Lp, bh, H, sQ, sQ, sP)            # q at 0, k at D
+    PD = torch.empty_like(P) if p_drop > 0 else None
+    _l.check(Lb.pxr_attn_rows_fwd_f32(_l.ptr(P), _l.ptr(PD), _l.ptr(keymask), km_bstride, B, H, L, Lp, p_drop, seed,
+                                      stream_id, _l.ptr(step_dev), d, _l.stream_ptr()), "pxr_attn_rows_fwd_f32")
+    ctx = torch.empty(B, L, D, dtype=torch.float32, device=qkv.device)
+    gemm_batched(True, False, L, d, L, PD if PD is not None else P, 0, Lp, qkv, 2 * D, ld, ctx, 0, D, bh, H, sP, sQ, sC)
+    return ctx, (P, PD)
+
+
+def _attn_long_bwd(dctx, qkv, saved, B, H, L, d, p_drop, seed, stream_id, step_dev):
+    Lb = _l.load()
+    P, PD = saved
+    D, ld, Lp, bh = H * d, 3 * H * d, (L + 3) & ~3, B * H
+    sP, sQ, sC = (H * L * Lp, L * Lp), (L * ld, d), (L * D, d)
+    dqkv = torch.empty_like(qkv)
+    gemm_batched(False, False, L, d, L, PD if PD is not None else P, 0, Lp, dctx, 0, D, dqkv, 2 * D, ld, bh, H, sP, sC, sQ)  # dV
+    dP = torch.empty_like(P)
+    gemm_batched(True, True, L, L, d, dctx, 0, D, qkv, 2 * D, ld, dP, 0, Lp, bh, H, sC, sQ, sP)                         # dPD
+    _l.check(Lb.pxr_attn_rows_bwd_f32(_l.ptr(P), _l.ptr(dP), B, H, L, Lp, p_drop, seed, stream_id, _l.ptr(step_dev), d,
+                                      _l.stream_ptr()), "pxr_attn_rows_bwd_f32")
+    gemm_batched(True, False, L, d, L, dP, 0, Lp, qkv, D, ld, dqkv, 0, ld, bh, H, sP, sQ, sQ)                           # dQ = dS K
+    gemm_batched(False, False, L, d, L, dP, 0, Lp, qkv, 0, ld, dqkv, D, ld, bh, H, sP, sQ, sQ)                          # dK = dS^T Q
+    return dqkv
+
+
 def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None):
     """qkv [B,L,3*H*d] fused projection output -> (ctx [B,L,H*d], probs [B,H,L,L] | None)."""
     Lb = _l.load()
     _req(qkv, torch.float32, "qkv"); _req(keymask, torch.int64, "keymask", contiguous=False)
+    if _attn_takes_gemm_path(L, d):
+        ctx, saved = _attn_long_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop, seed, stream_id, step_dev)
+        return ctx, (saved if save else None)
     D = H * d
     ctx = torch.empty(B, L, D, dtype=torch.float32, device=qkv.device)
     probs = torch.empty(B, H, L, L, dtype=torch.float32, device=qkv.device) if save else None
@@ -419,6 +463,8 @@ def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id
 def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, step_dev=None):
     """-> dqkv [B,L,3*H*d] laid out like qkv."""
     Lb = _l.load()
+    if _attn_takes_gemm_path(L, d):
+        return _attn_long_bwd(dctx, qkv, probs, B, H, L, d, p_drop, seed, stream_id, step_dev)
     _req(dctx, torch.float32, "dctx"); _req(qkv, torch.float32, "qkv"); _req(probs, torch.float32, "probs")
     D = H * d
     dqkv = torch.empty_like(qkv)

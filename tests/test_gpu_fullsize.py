@@ -131,10 +131,8 @@ def test_edge_cases_all_padding_and_min_length():
     assert torch.isfinite(loss) and abs(float(loss.detach()) - float(ref)) < 3e-5 * max(1.0, abs(float(ref)))
     dense = m.sparse_table_grad.to_dense(N).cpu()
     assert (dense - gr["item_embedding.weight"]).abs().max().item() < 5e-6 + 2e-4 * gr["item_embedding.weight"].abs().max().item()
-    with pytest.raises(Exception):      # beyond the 128-position kernels: a loud error, no fallback
-        _model(N, D, 129, H)((torch.zeros(1, 2, 130, dtype=torch.int64).cuda(), torch.zeros(1, 129, dtype=torch.int64).cuda()))
-    with pytest.raises(Exception):      # 65..128 positions need a head size that is a multiple of 8 (here 20)
-        _model(N, 40, 70, 2)((torch.zeros(1, 2, 71, dtype=torch.int64).cuda(), torch.zeros(1, 70, dtype=torch.int64).cuda()))
+    with pytest.raises(Exception):      # head size must be a multiple of 4 (16-byte rows per head): a loud error
+        _model(N, 36, 10, 6)((torch.zeros(1, 2, 11, dtype=torch.int64).cuda(), torch.zeros(1, 10, dtype=torch.int64).cuda()))
 
 
 def test_wide_embedding_4096_and_chunked_attention():
@@ -172,7 +170,10 @@ def test_wide_embedding_4096_and_chunked_attention():
 
 @pytest.mark.parametrize("N,D,L,H,B", [(97, 96, 7, 4, 5), (300, 80, 13, 4, 3), (150, 64, 64, 1, 2), (5000, 256, 64, 8, 9),
                                         (60, 32, 2, 2, 4), (1000, 1024, 33, 16, 2), (211, 192, 50, 3, 7),
-                                        (300, 64, 100, 2, 3), (500, 512, 128, 4, 2), (200, 96, 65, 3, 2), (400, 256, 127, 1, 2)])
+                                        (300, 64, 100, 2, 3), (500, 512, 128, 4, 2), (200, 96, 65, 3, 2), (400, 256, 127, 1, 2),
+                                        # beyond the fused attention kernels: batched-GEMM attention (any length; and
+                                        # 65..128 positions with a head size that is not a multiple of 8)
+                                        (300, 64, 129, 2, 2), (400, 128, 200, 4, 3), (200, 40, 70, 2, 2), (250, 64, 300, 1, 2)])
 def test_unusual_shapes_match_oracle(N, D, L, H, B):
     """Head sizes that are not powers of two (24, 20), one head, the longest single-wave sequence (64), the two-keys-per-lane kernels
     (65..128 positions), two positions, 16 heads: loss, every gradient, predict scores and one AdamW step against the oracle."""
@@ -210,7 +211,7 @@ def test_unusual_shapes_match_oracle(N, D, L, H, B):
         assert d.max().item() <= 2.1e-3, k
 
 
-@pytest.mark.parametrize("N,D,L,H,B", [(300, 64, 100, 2, 3), (500, 256, 128, 4, 2)])
+@pytest.mark.parametrize("N,D,L,H,B", [(300, 64, 100, 2, 3), (500, 256, 128, 4, 2), (300, 64, 150, 2, 2)])
 def test_long_sequence_dropout_parity(N, D, L, H, B):
     """65..128 positions with dropout ON: the long attention kernels regenerate the same counter-hash masks in forward
     and backward; the masks, restated in numpy, are injected into the oracle."""
