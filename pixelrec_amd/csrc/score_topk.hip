@@ -52,6 +52,9 @@ struct ScoreTopkArgs {
   const int64_t* hist_items;              // item ids to mask per user
   float* part_val; int* part_idx;         // [B, n_split*2, KT]
   int B, N, D, tiles_n, n_split, row_blocks;
+  int tile_stride;                        // 1 = every item tile; s > 1 = a SAMPLE (every s-th tile of each split's range)
+  // threshold variant (score_thresh_kernel): per-user admission threshold and append buffers
+  const float* tau; int* cand_cnt; float* cand_val; int* cand_idx; int cand_cap;
 };
 
 template <int KT>
@@ -77,7 +80,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) score_topk_kernel(ScoreTopkArgs 
     he = a.hist_ptr[min(a.B, m0 + ST_BM)];
   }
 
-  for (int tn = tn0; tn < tn1; ++tn) {
+  for (int tn = tn0; tn < tn1; tn += a.tile_stride) {
     const int n0 = tn * ST_BN;
     typename StCfg::Acc accs;
     gemm_mainloop<ST_BM, ST_BN, true, true, false, 1, 1>(accs, a.users, a.ld_users, a.table, (int64_t)a.D, a.B, a.N, 0, a.D, m0,
@@ -210,6 +213,130 @@ __global__ void __launch_bounds__((FINE == 1 ? 1024 : 512), (FINE == 1 ? 4 : 4))
   }
 }
 
+// ---- variant 4: two passes around a per-user threshold ------------------------------------------------------------
+// Keeping a top-K list per lane costs 2K registers, which the fastest cut of the GEMM (16 waves of 32x32 at <= 64 VGPRs,
+// two workgroups per CU) does not have.  So: (1) the list kernel above scores a SAMPLE of the item tiles (every 64th)
+// and its merged K-th best value becomes tau[user] -- the K-th best of a subset is a LOWER bound of the K-th best of the
+// catalogue, so no true top-K item scores below it; (2) this kernel scores EVERY tile at full GEMM speed and appends the
+// few survivors (score >= tau, not masked: ~64 K per user) to a per-user candidate buffer with one atomic each;
+// (3) the merge kernel picks the K best candidates (ties: lower item id first, so the result does not depend on the
+// order of the appends).
+template <int DUMMY>
+__global__ void __launch_bounds__(1024, 8) score_thresh_kernel(ScoreTopkArgs a) {
+  using Cfg = GemmCfg<ST_BM, ST_BN, true, true, 1, 1>;
+  constexpr int SMEM_FLOATS = 2 * Cfg::STAGE + ST2_BITMAP_WORDS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  unsigned* bitmap = reinterpret_cast<unsigned*>(smem + 2 * Cfg::STAGE);
+  const int tid = threadIdx.x;
+  const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
+  const int rb = t % a.row_blocks, sp = t / a.row_blocks;
+  const int u0 = rb * ST_BN;
+  const int per = (a.tiles_n + a.n_split - 1) / a.n_split;
+  const int tn0 = sp * per, tn1 = min(a.tiles_n, tn0 + per);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave / Cfg::WGN, wu = wave % Cfg::WGN;
+  const int h = lane >> 5, r = lane & 31;
+  const int ul = wu * 32 + r;
+  int hb = 0, he = 0;
+  if (a.hist_ptr) {
+    hb = a.hist_ptr[u0];
+    he = a.hist_ptr[min(a.B, u0 + ST_BN)];
+  }
+  for (int tn = tn0; tn < tn1; ++tn) {
+    const int i0 = tn * ST_BM;
+    if (tid < ST2_BITMAP_WORDS) bitmap[tid] = 0u;
+    typename Cfg::Acc accs;
+    gemm_mainloop<ST_BM, ST_BN, true, true, false, 1, 2, 2, 1>(accs, a.table, (int64_t)a.D, a.users, a.ld_users, a.N, a.B,
+                                                               0, a.D, i0, u0, smem);
+    for (int p = hb + tid; p < he; p += 1024) {
+      const int64_t it = a.hist_items[p];
+      if (it >= i0 && it < i0 + ST_BM) {
+        int lo = u0, hi = min(a.B, u0 + ST_BN) - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (a.hist_ptr[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        const int il = (int)(it - i0);
+        atomicOr(&bitmap[(lo - u0) * (ST_BM / 32) + (il >> 5)], 1u << (il & 31));
+      }
+    }
+    __syncthreads();
+    const int user = u0 + ul;
+    const bool user_ok = user < a.B;
+    const float thr = user_ok ? a.tau[user] : INFINITY;
+    const unsigned bits = bitmap[ul * (ST_BM / 32) + wi];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int il = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int item = i0 + wi * 32 + il;
+      const float x = accs.v[0][0][e];
+      const bool cand = user_ok && (x >= thr) && item != 0 && item < a.N && !((bits >> il) & 1u);
+      if (__any(cand)) {
+        if (cand) {
+          const int pos = atomicAdd(&a.cand_cnt[user], 1);
+          if (pos < a.cand_cap) {
+            a.cand_val[(int64_t)user * a.cand_cap + pos] = x;
+            a.cand_idx[(int64_t)user * a.cand_cap + pos] = item;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// tau[u] = K-th best value of the sample pass (-inf when the sample held fewer than K unmasked items); cnt[u] = 0
+__global__ void __launch_bounds__(256) topk_tau_kernel(const float* __restrict__ sample_val, int B, int K, float* __restrict__ tau,
+                                                       int* __restrict__ cnt) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= B) return;
+  tau[u] = sample_val[(int64_t)u * K + (K - 1)];
+  cnt[u] = 0;
+}
+
+// one wave per user: the K best of its cnt[u] appended candidates, descending by value, ties by ascending item id
+// (independent of the append order).  A count above the capacity sets the status word: candidates were dropped.
+__global__ void __launch_bounds__(256) topk_cand_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                              const int* __restrict__ cnt, int cap, int B, int K,
+                                                              int64_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                              int32_t* status) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + wave;
+  if (u >= B) return;
+  int n = cnt[u];
+  if (n > cap) {
+    if (status && lane == 0) atomicOr(status, PXR_STATUS_TOPK_OVERFLOW);
+    n = cap;
+  }
+  const float* pv = cand_val + (int64_t)u * cap;
+  const int* pi = cand_idx + (int64_t)u * cap;
+  float last_v = INFINITY;
+  int last_id = -1;
+  for (int k = 0; k < K; ++k) {
+    float bv = -INFINITY;
+    int bid = 0x7fffffff;
+    for (int c = lane; c < n; c += 64) {
+      const float v = pv[c];
+      const int id = pi[c];
+      const bool remaining = (v < last_v) || (v == last_v && id > last_id);
+      if (remaining && (v > bv || (v == bv && id < bid))) { bv = v; bid = id; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bid, off, 64);
+      if (ov > bv || (ov == bv && oi < bid)) { bv = ov; bid = oi; }
+    }
+    if (lane == 0) {
+      const bool ok = bid != 0x7fffffff;
+      out_val[(int64_t)u * K + k] = ok ? bv : -INFINITY;
+      out_idx[(int64_t)u * K + k] = ok ? (int64_t)bid : (int64_t)-1;
+    }
+    last_v = bv;
+    last_id = bid;
+  }
+}
+
 // one wave per user: pick the K best of its n_cand partial candidates, descending
 __global__ void __launch_bounds__(256) topk_merge_kernel(const float* __restrict__ part_val,
                                                          const int* __restrict__ part_idx, int B, int n_cand, int K,
@@ -248,6 +375,7 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(const float* __restrict
 
 static int pick_kt(int K) { return K <= 10 ? 10 : (K <= 16 ? 16 : (K <= 32 ? 32 : 0)); }
 // selection variant: 2 / 3 = in the accumulator registers (8 / 16 waves per workgroup), 1 = score tile through LDS
+// (0 / unset: variant 4 -- two passes around a per-user threshold -- on catalogues of >= 65 536 items, else variant 2)
 static int topk_variant() {
   static const int v = getenv("PXR_TOPK_VARIANT") ? atoi(getenv("PXR_TOPK_VARIANT")) : 2;
   return (v == 1 || v == 3) ? v : 2;
@@ -266,11 +394,59 @@ static int pick_split(int B, int N) {
 
 using namespace pxr;
 
+// variant 4 (two passes around a threshold) pays off on big catalogues; small ones keep the register lists
+constexpr int ST4_MIN_TILES = 512;       // >= 65 536 items
+constexpr int ST4_STRIDE = 64;           // sample = every 64th item tile
+constexpr int ST4_CAP = 4096;            // candidates per user (expected ~64 K: 640 at K = 10, 2 048 at K = 32)
+static bool use_thresh(int N) {
+  static const int env = getenv("PXR_TOPK_VARIANT") ? atoi(getenv("PXR_TOPK_VARIANT")) : 0;
+  const int tiles_n = (N + ST_BN - 1) / ST_BN;
+  return (env == 0 || env == 4) && tiles_n >= ST4_MIN_TILES;
+}
+static int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+static int64_t lists_bytes(int B, int N, int kt, int lists) { return a256((int64_t)B * pick_split(B, N) * lists * kt * 4) * 2; }
+
 extern "C" int64_t pxr_score_topk_ws_bytes(int B, int N, int K) {
   const int kt = pick_kt(K);
   if (kt == 0) return -1;
+  if (use_thresh(N))   // sample lists (variant-1 layout) | sample top-K (idx, val) | tau | cnt | candidate values | ids
+    return lists_bytes(B, N, kt, 2) + a256((int64_t)B * K * 8) + a256((int64_t)B * K * 4) + 2 * a256((int64_t)B * 4) +
+           2 * a256((int64_t)B * ST4_CAP * 4) + 256;
   const int64_t cand = (int64_t)pick_split(B, N) * lists_per_split() * kt;
   return (int64_t)B * cand * 8 + 256;
+}
+
+static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, float* topk_val, void* ws, hipStream_t st) {
+  char* w = (char*)ws;
+  const int64_t lb = lists_bytes(a.B, a.N, kt, 2) / 2;
+  a.part_val = (float*)w;              a.part_idx = (int*)(w + lb);         w += 2 * lb;
+  int64_t* s_idx = (int64_t*)w;        w += a256((int64_t)a.B * K * 8);
+  float* s_val = (float*)w;            w += a256((int64_t)a.B * K * 4);
+  float* tau = (float*)w;              w += a256((int64_t)a.B * 4);
+  int* cnt = (int*)w;                  w += a256((int64_t)a.B * 4);
+  float* cval = (float*)w;             w += a256((int64_t)a.B * ST4_CAP * 4);
+  int* cidx = (int*)w;
+  const dim3 grid(a.row_blocks * a.n_split);
+  // pass 1: register/LDS lists over a sample of the tiles -> K-th best value per user
+  a.tile_stride = ST4_STRIDE;
+  switch (kt) {
+    case 10: hipLaunchKernelGGL(score_topk_kernel<10>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(score_topk_kernel<16>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL(score_topk_kernel<32>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+  }
+  const int64_t cand = (int64_t)a.n_split * 2 * kt;
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, (const float*)a.part_val,
+                     (const int*)a.part_idx, a.B, (int)cand, K, s_idx, s_val);
+  hipLaunchKernelGGL(topk_tau_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, (const float*)s_val, a.B, K, tau, cnt);
+  // pass 2: every tile at full GEMM speed, survivors appended
+  a.tile_stride = 1; a.tau = tau; a.cand_cnt = cnt; a.cand_val = cval; a.cand_idx = cidx; a.cand_cap = ST4_CAP;
+  hipLaunchKernelGGL(score_thresh_kernel<0>, grid, dim3(1024), 0, st, a);
+  int rc = pxr_check_launch("pxr_score_topk_f32(threshold pass)");
+  if (rc) return rc;
+  // pass 3: K best candidates per user
+  hipLaunchKernelGGL(topk_cand_merge_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, (const float*)cval, (const int*)cidx,
+                     (const int*)cnt, ST4_CAP, a.B, K, topk_idx, topk_val, pxr_status_word());
+  return pxr_check_launch("pxr_score_topk_f32(candidate merge)");
 }
 
 // Top-K item ids / scores per user of  users[B,D] x table[N,D]^T  with item 0 and each user's history masked.
@@ -289,6 +465,9 @@ extern "C" int pxr_score_topk_f32(const float* users, int64_t ld_users, int B, c
   a.row_blocks = (B + ST_BM - 1) / ST_BM;
   a.tiles_n = (N + ST_BN - 1) / ST_BN;
   a.n_split = pick_split(B, N);
+  a.tile_stride = 1;
+  if (pxr_score_topk_ws_bytes(B, N, K) > ws_bytes) { pxr_set_error("pxr_score_topk_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
+  if (use_thresh(N)) return score_topk_thresh(a, K, kt, topk_idx, topk_val, ws, (hipStream_t)stream);
   const int64_t cand = (int64_t)a.n_split * lists_per_split() * kt;
   if ((int64_t)B * cand * 8 + 256 > ws_bytes) { pxr_set_error("pxr_score_topk_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
   a.part_val = (float*)ws;

@@ -95,6 +95,9 @@ def raise_on_bad_indices(device=None):
         t.zero_()
     if v & 1:
         raise IndexError("index out of range in self (an item id outside [0, item_num) reached an embedding gather)")
+    if v & 4:
+        raise RuntimeError("fused scoring + top-k: the per-user candidate buffer of the threshold pass overflowed "
+                           "(results may miss items); set PXR_TOPK_VARIANT=2")
     if v & 2:
         raise RuntimeError("data-parallel row exchange: a rank's batch touched more unique table rows than the configured "
                            "exchange capacity (GradSync(exchange_rows=...)); gradient rows were dropped -- raise the bound")
@@ -723,6 +726,7 @@ def score_topk(users: torch.Tensor, ld_users: int, B: int, table: torch.Tensor, 
     Lb = _l.load()
     _req(users, torch.float32, "users", contiguous=False); _req(table, torch.float32, "table")
     N, D = table.shape
+    device_status(table.device)
     idx = torch.empty(B, K, dtype=torch.int64, device=table.device)
     val = torch.empty(B, K, dtype=torch.float32, device=table.device)
     ws_bytes = int(Lb.pxr_score_topk_ws_bytes(B, N, K))
