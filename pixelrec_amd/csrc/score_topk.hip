@@ -221,46 +221,82 @@ __global__ void __launch_bounds__((FINE == 1 ? 1024 : 512), (FINE == 1 ? 4 : 4))
 // few survivors (score >= tau, not masked: ~64 K per user) to a per-user candidate buffer with one atomic each;
 // (3) the merge kernel picks the K best candidates (ties: lower item id first, so the result does not depend on the
 // order of the appends).
+constexpr int ST4_HIST_CAP = 2048;   // history pairs of the workgroup's (128 users x its item range) kept in LDS
+
 template <int DUMMY>
 __global__ void __launch_bounds__(1024, 8) score_thresh_kernel(ScoreTopkArgs a) {
   using Cfg = GemmCfg<ST_BM, ST_BN, true, true, 1, 1>;
-  constexpr int SMEM_FLOATS = 2 * Cfg::STAGE + ST2_BITMAP_WORDS;
+  constexpr int SMEM_FLOATS = 2 * Cfg::STAGE + ST2_BITMAP_WORDS + ST4_HIST_CAP + 4;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   unsigned* bitmap = reinterpret_cast<unsigned*>(smem + 2 * Cfg::STAGE);
+  unsigned* hlist = bitmap + ST2_BITMAP_WORDS;             // (user_local << 20) | (item - first item of the range)
+  int* hcount = reinterpret_cast<int*>(hlist + ST4_HIST_CAP);
   const int tid = threadIdx.x;
   const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
   const int rb = t % a.row_blocks, sp = t / a.row_blocks;
   const int u0 = rb * ST_BN;
   const int per = (a.tiles_n + a.n_split - 1) / a.n_split;
   const int tn0 = sp * per, tn1 = min(a.tiles_n, tn0 + per);
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wi = wave / Cfg::WGN, wu = wave % Cfg::WGN;
-  const int h = lane >> 5, r = lane & 31;
-  const int ul = wu * 32 + r;
   int hb = 0, he = 0;
   if (a.hist_ptr) {
     hb = a.hist_ptr[u0];
     he = a.hist_ptr[min(a.B, u0 + ST_BN)];
   }
+  // The workgroup's users have a few thousand history pairs, of which only those inside ITS item range (a 1/n_split
+  // slice of the catalogue) can ever hit one of its tiles: collect them once (owner resolved here), so that the per-tile
+  // mask pass walks a short LDS list instead of re-reading every pair from global memory for each of its ~50 tiles.
+  if (tid == 0) *hcount = 0;
+  __syncthreads();
+  const int64_t r_lo = (int64_t)tn0 * ST_BM, r_hi = (int64_t)tn1 * ST_BM;
+  for (int p = hb + tid; p < he; p += 1024) {
+    const int64_t it = a.hist_items[p];
+    if (it >= r_lo && it < r_hi) {
+      int lo = u0, hi = min(a.B, u0 + ST_BN) - 1;          // owner of pair p: hist_ptr[u] <= p < hist_ptr[u+1]
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.hist_ptr[mid] <= p) lo = mid; else hi = mid - 1;
+      }
+      const int pos = atomicAdd(hcount, 1);
+      if (pos < ST4_HIST_CAP) hlist[pos] = ((unsigned)(lo - u0) << 20) | (unsigned)(it - r_lo);
+    }
+  }
+  __syncthreads();
+  const int n_hist = *hcount;
+  const bool list_ok = n_hist <= ST4_HIST_CAP;             // (else: walk the global pairs per tile, as before)
   for (int tn = tn0; tn < tn1; ++tn) {
     const int i0 = tn * ST_BM;
     if (tid < ST2_BITMAP_WORDS) bitmap[tid] = 0u;
     typename Cfg::Acc accs;
     gemm_mainloop<ST_BM, ST_BN, true, true, false, 1, 2, 2, 1>(accs, a.table, (int64_t)a.D, a.users, a.ld_users, a.N, a.B,
                                                                0, a.D, i0, u0, smem);
-    for (int p = hb + tid; p < he; p += 1024) {
-      const int64_t it = a.hist_items[p];
-      if (it >= i0 && it < i0 + ST_BM) {
-        int lo = u0, hi = min(a.B, u0 + ST_BN) - 1;
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (a.hist_ptr[mid] <= p) lo = mid; else hi = mid - 1;
+    if (list_ok) {
+      const unsigned off0 = (unsigned)(i0 - (int)r_lo);
+      for (int q = tid; q < n_hist; q += 1024) {
+        const unsigned e = hlist[q], off = e & 0xFFFFFu;
+        if (off >= off0 && off < off0 + ST_BM) {
+          const int il = (int)(off - off0);
+          atomicOr(&bitmap[(e >> 20) * (ST_BM / 32) + (il >> 5)], 1u << (il & 31));
         }
-        const int il = (int)(it - i0);
-        atomicOr(&bitmap[(lo - u0) * (ST_BM / 32) + (il >> 5)], 1u << (il & 31));
+      }
+    } else {
+      for (int p = hb + tid; p < he; p += 1024) {
+        const int64_t it = a.hist_items[p];
+        if (it >= i0 && it < i0 + ST_BM) {
+          int lo = u0, hi = min(a.B, u0 + ST_BN) - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.hist_ptr[mid] <= p) lo = mid; else hi = mid - 1;
+          }
+          const int il = (int)(it - i0);
+          atomicOr(&bitmap[(lo - u0) * (ST_BM / 32) + (il >> 5)], 1u << (il & 31));
+        }
       }
     }
     __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wi = wave / Cfg::WGN, wu = wave % Cfg::WGN;
+    const int h = lane >> 5, r = lane & 31;
+    const int ul = wu * 32 + r;
     const int user = u0 + ul;
     const bool user_ok = user < a.B;
     const float thr = user_ok ? a.tau[user] : INFINITY;
