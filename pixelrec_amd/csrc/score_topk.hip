@@ -432,15 +432,17 @@ using namespace pxr;
 
 // variant 4 (two passes around a threshold) pays off on big catalogues; small ones keep the register lists
 constexpr int ST4_MIN_TILES = 512;       // >= 65 536 items
-constexpr int ST4_STRIDE = 64;           // sample = every 64th item tile
-constexpr int ST4_CAP = 4096;            // candidates per user (expected ~64 K: 640 at K = 10, 2 048 at K = 32)
+constexpr int ST4_CAP = 4096;            // candidates per user
+// sample = every s-th item tile; expected candidates per user ~ s * K (1 280 / 1 024 / 1 024 of the 4 096 slots)
+static int st4_stride(int kt) { return kt <= 10 ? 128 : (kt <= 16 ? 64 : 32); }
 static bool use_thresh(int N) {
   static const int env = getenv("PXR_TOPK_VARIANT") ? atoi(getenv("PXR_TOPK_VARIANT")) : 0;
   const int tiles_n = (N + ST_BN - 1) / ST_BN;
   return (env == 0 || env == 4) && tiles_n >= ST4_MIN_TILES;
 }
 static int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
-static int64_t lists_bytes(int B, int N, int kt, int lists) { return a256((int64_t)B * pick_split(B, N) * lists * kt * 4) * 2; }
+static int sample_splits(int N, int kt) { return (((N + ST_BN - 1) / ST_BN) + st4_stride(kt) - 1) / st4_stride(kt); }
+static int64_t lists_bytes(int B, int N, int kt, int lists) { return a256((int64_t)B * sample_splits(N, kt) * lists * kt * 4) * 2; }
 
 extern "C" int64_t pxr_score_topk_ws_bytes(int B, int N, int K) {
   const int kt = pick_kt(K);
@@ -463,18 +465,22 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
   float* cval = (float*)w;             w += a256((int64_t)a.B * ST4_CAP * 4);
   int* cidx = (int*)w;
   const dim3 grid(a.row_blocks * a.n_split);
-  // pass 1: register/LDS lists over a sample of the tiles -> K-th best value per user
-  a.tile_stride = ST4_STRIDE;
+  // pass 1: lists over a SAMPLE of the tiles (one workgroup per sampled tile and row block) -> K-th best value per user
+  const int n_split_full = a.n_split;
+  a.n_split = sample_splits(a.N, kt);
+  a.tile_stride = (a.tiles_n + a.n_split - 1) / a.n_split;     // == the kernel's tiles-per-split: exactly one tile each
+  const dim3 grid_s(a.row_blocks * a.n_split);
   switch (kt) {
-    case 10: hipLaunchKernelGGL(score_topk_kernel<10>, grid, dim3(GEMM_THREADS), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(score_topk_kernel<16>, grid, dim3(GEMM_THREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL(score_topk_kernel<32>, grid, dim3(GEMM_THREADS), 0, st, a); break;
+    case 10: hipLaunchKernelGGL(score_topk_kernel<10>, grid_s, dim3(GEMM_THREADS), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(score_topk_kernel<16>, grid_s, dim3(GEMM_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL(score_topk_kernel<32>, grid_s, dim3(GEMM_THREADS), 0, st, a); break;
   }
   const int64_t cand = (int64_t)a.n_split * 2 * kt;
   hipLaunchKernelGGL(topk_merge_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, (const float*)a.part_val,
                      (const int*)a.part_idx, a.B, (int)cand, K, s_idx, s_val);
   hipLaunchKernelGGL(topk_tau_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, (const float*)s_val, a.B, K, tau, cnt);
   // pass 2: every tile at full GEMM speed, survivors appended
+  a.n_split = n_split_full;
   a.tile_stride = 1; a.tau = tau; a.cand_cnt = cnt; a.cand_val = cval; a.cand_idx = cidx; a.cand_cap = ST4_CAP;
   hipLaunchKernelGGL(score_thresh_kernel<0>, grid, dim3(1024), 0, st, a);
   int rc = pxr_check_launch("pxr_score_topk_f32(threshold pass)");
