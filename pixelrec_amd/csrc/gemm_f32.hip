@@ -7,6 +7,8 @@
 #include "gemm_f32.cuh"
 
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 namespace pxr {
 
@@ -38,6 +40,112 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
+// ---- epilogue pieces shared by the tile-per-workgroup kernel and the stream-K kernel ---------------------------------
+template <int EPI>
+struct EpiTraits {
+  static constexpr bool READS_AUX = (EPI == EPI_MUL_DGELU || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_BIAS_ADD);
+  static constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD || EPI == EPI_BIAS_ADD ||
+                                    EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ACT_GRAD);
+};
+template <class Cfg, int EPI>
+struct AuxRegs {
+  static constexpr bool R = EpiTraits<EPI>::READS_AUX;
+  float v[R ? Cfg::TM : 1][R ? Cfg::TN : 1][R ? 16 : 1];
+};
+// where this lane's accumulator elements live in the output tile
+struct LanePos {
+  int wm, wn, h, r;
+};
+template <class Cfg>
+__device__ __forceinline__ LanePos lane_pos() {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return LanePos{(wave % Cfg::G) / Cfg::WGN, (wave % Cfg::G) % Cfg::WGN, lane >> 5, lane & 31};
+}
+// epilogue operands that are READ (residual-branch gradient / saved pre-activation) are fetched before the main
+// loop: the loads complete under the MFMAs instead of stalling every wave after its last one
+template <class Cfg, int EPI>
+__device__ __forceinline__ void epi_prefetch_aux(AuxRegs<Cfg, EPI>& ar, const float* __restrict__ aux, int64_t ldaux, int M,
+                                                 int N, int m0, int n0, const LanePos p) {
+  if constexpr (EpiTraits<EPI>::READS_AUX) {
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + p.wn * Cfg::WN + j * 32 + p.r;
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + p.wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * p.h;
+          ar.v[i][j][e] = (col < N && row < M) ? aux[(int64_t)row * ldaux + col] : 0.f;
+        }
+    }
+  }
+}
+template <class Cfg, int EPI>
+__device__ __forceinline__ void epi_store(const typename Cfg::Acc& accs, const AuxRegs<Cfg, EPI>& ar, float* __restrict__ C,
+                                          int64_t ldc, int M, int N, const float* __restrict__ bias,
+                                          float* __restrict__ aux, int64_t ldaux, int m0, int n0, const LanePos p, int act) {
+  const auto& acc = accs.v;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + p.wn * Cfg::WN + j * 32 + p.r;
+    if (col >= N) continue;
+    float bv = 0.f;
+    if constexpr (EpiTraits<EPI>::HAS_BIAS) bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + p.wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * p.h;
+        if (row >= M) continue;
+        float v = acc[i][j][e];
+        if constexpr (EPI == EPI_BIAS) {
+          v += bv;
+        } else if constexpr (EPI == EPI_BIAS_GELU) {
+          v += bv;
+          aux[(int64_t)row * ldaux + col] = v;  // pre-activation, kept for the backward pass
+          v = gelu_erf(v);
+        } else if constexpr (EPI == EPI_BIAS_GELU_GRAD) {
+          v += bv;
+          aux[(int64_t)row * ldaux + col] = dgelu_erf(v);  // gelu'(pre-activation): the backward is then one multiply
+          v = gelu_erf(v);
+        } else if constexpr (EPI == EPI_MUL) {
+          v *= ar.v[i][j][e];
+        } else if constexpr (EPI == EPI_MUL_DGELU) {
+          v *= dgelu_erf(ar.v[i][j][e]);
+        } else if constexpr (EPI == EPI_ADD) {
+          v += ar.v[i][j][e];  // residual-branch gradient joins here
+        } else if constexpr (EPI == EPI_BIAS_ADD) {
+          v = (v + bv) + ar.v[i][j][e];
+        } else if constexpr (EPI == EPI_BIAS_QGELU_GRAD) {
+          v += bv;
+          const float sg = sigmoid_1702(v);
+          aux[(int64_t)row * ldaux + col] = sg + 1.702f * v * sg * (1.0f - sg);
+          v = v * sg;
+        } else if constexpr (EPI == EPI_BIAS_RELU) {
+          v = fmaxf(v + bv, 0.f);
+        } else if constexpr (EPI == EPI_BIAS_ACT_GRAD) {
+          v += bv;
+          float dv;
+          if (act == ACT_RELU) {                    // F.relu
+            dv = v > 0.f ? 1.f : 0.f; v = fmaxf(v, 0.f);
+          } else if (act == ACT_SWISH) {            // x * sigmoid(x)   (layers.py:662-663)
+            const float sg = 1.0f / (1.0f + __expf(-v));
+            dv = sg + v * sg * (1.0f - sg); v = v * sg;
+          } else if (act == ACT_TANH) {
+            const float th = tanhf(v);
+            dv = 1.0f - th * th; v = th;
+          } else {                                  // sigmoid
+            const float sg = 1.0f / (1.0f + __expf(-v));
+            dv = sg * (1.0f - sg); v = sg;
+          }
+          aux[(int64_t)row * ldaux + col] = dv;
+        }
+        C[(int64_t)row * ldc + col] = v;
+      }
+    }
+  }
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int KW = 1, int PD = 1, int ST = 2, int FINE = 0, bool DUAL = false>
 __global__ void __launch_bounds__((GemmCfg<BM, BN, A_KC, B_KC, KW, FINE>::NT))
 gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
@@ -65,93 +173,110 @@ gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ 
   const int kend = min(K, kbeg + ksplit_len);
   C += (int64_t)blockIdx.y * split_stride;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave % Cfg::G) / Cfg::WGN, wn = (wave % Cfg::G) % Cfg::WGN, h = lane >> 5, r = lane & 31;
-  // epilogue operands that are READ (residual-branch gradient / saved pre-activation) are fetched before the main
-  // loop: the loads complete under the MFMAs instead of stalling every wave after its last one
-  constexpr bool READS_AUX = (EPI == EPI_MUL_DGELU || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_BIAS_ADD);
-  float auxv[READS_AUX ? Cfg::TM : 1][READS_AUX ? Cfg::TN : 1][READS_AUX ? 16 : 1];
-  if constexpr (READS_AUX) {
-    if (!(KW > 1 && wave >= Cfg::G)) {
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {
-        const int col = n0 + wn * Cfg::WN + j * 32 + r;
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            auxv[i][j][e] = (col < N && row < M) ? aux[(int64_t)row * ldaux + col] : 0.f;
-          }
-      }
-    }
-  }
+  const LanePos lp = lane_pos<Cfg>();
+  const bool second_group = KW > 1 && (int)(threadIdx.x >> 6) >= Cfg::G;
+  AuxRegs<Cfg, EPI> ar;
+  if (!second_group) epi_prefetch_aux<Cfg, EPI>(ar, aux, ldaux, M, N, m0, n0, lp);
 
   typename Cfg::Acc accs;
   gemm_mainloop<BM, BN, A_KC, B_KC, false, KW, PD, ST, FINE, DUAL>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
 
-  auto& acc = accs.v;
-  if (KW > 1 && wave >= Cfg::G) return;  // the second wave group handed its partial sums over in the main loop
+  if (second_group) return;  // the second wave group handed its partial sums over in the main loop
+  epi_store<Cfg, EPI>(accs, ar, C, ldc, M, N, bias, aux, ldaux, m0, n0, lp, bt.act);
+}
+
+// ---- stream-K: the K loops of ALL output tiles as ONE sequence of K-tile iterations, cut into equal pieces --------------
+// M = B*L = 3200 tokens gives 400 (N = 512) or 800 (N = 2048) 64x64 tiles on 256 CUs: 1-2 / 3-4 tiles per CU, and the
+// launch takes as long as the fullest CU (profiles/r02/gemm_timeline.json: the CUs with one tile are done at 12.8 us,
+// those with two at 20 us).  Here `gridDim.x` workers (2 per CU) each take total_iters / workers consecutive iterations
+// of the sequence [tile 0: k-tiles 0..nk) [tile 1: ...) ...; a worker's range starts inside a tile, covers whole tiles,
+// and ends inside one.  The worker that STARTS a tile owns it: it keeps its accumulators, waits for the partial sums of
+// the workers that continued the tile (each of those handles that piece FIRST and publishes it before doing anything
+// else, so the wait is short and cannot deadlock: the only thing a worker ever waits for is work a later worker does
+// unconditionally at its very start), adds them in worker order and runs the epilogue.  Deterministic: the summation
+// order of every output element is fixed by (shape, worker count).
+// Partials cross XCDs (private, mutually incoherent L2s): they are written and read with sc0 sc1 (system-coherent)
+// buffer accesses, and the flag is an agent-scope atomic set after the stores were acknowledged (s_waitcnt vmcnt(0)).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int SK_MAX_WORKERS = 1024;
+constexpr int SK_PART_FLOATS = 64 * 64;                   // one 64x64 tile of partial sums per worker
+constexpr int SK_COHERENT = (1 << 4) | 1;                 // gfx940+ buffer cache policy: sc1 | sc0
+constexpr int64_t SK_SCRATCH_BYTES = (int64_t)SK_MAX_WORKERS * SK_PART_FLOATS * 4 + SK_MAX_WORKERS * 4;
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_sk_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+               float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
+               float* __restrict__ aux, int64_t ldaux, int tiles_m, int tiles_n, int n_fastest, int act,
+               float* __restrict__ part, unsigned* __restrict__ flags, unsigned* __restrict__ status) {
+  using Cfg = GemmCfg<64, 64, A_KC, B_KC>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
+  const int nk = (K + GEMM_BK - 1) / GEMM_BK;
+  const int64_t total = (int64_t)tiles_m * tiles_n * nk;
+  const int G = gridDim.x;
+  const int w = xcd_remap(blockIdx.x, G);     // neighbouring workers (which share tiles) sit on the same XCD
+  int64_t it = total * w / G;
+  const int64_t it_end = total * (w + 1) / G;
+  const LanePos lp = lane_pos<Cfg>();
+  const int tid = threadIdx.x;
+  const bufrsrc rs_part = make_rsrc(part, (int64_t)SK_MAX_WORKERS * SK_PART_FLOATS * 4);
+
+  while (it < it_end) {     // block-uniform
+    const int tile = (int)(it / nk);
+    const int kf = (int)(it - (int64_t)tile * nk);
+    const int kl = (int)min((int64_t)nk, kf + (it_end - it));
+    const int tm = n_fastest ? tile / tiles_n : tile % tiles_m, tn = n_fastest ? tile % tiles_n : tile / tiles_m;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const bool owner = (kf == 0);
+    AuxRegs<Cfg, EPI> ar;
+    if (owner) epi_prefetch_aux<Cfg, EPI>(ar, aux, ldaux, M, N, m0, n0, lp);
+    typename Cfg::Acc accs;
+    gemm_mainloop<64, 64, A_KC, B_KC, false, 1, 2, 2>(accs, A, lda, B, ldb, M, N, kf * GEMM_BK, min(K, kl * GEMM_BK), m0, n0, smem);
+    auto& acc = accs.v[0][0];
+    if (!owner) {
+      // publish: [worker][4 x float4][thread]
 #pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
-    const int col = n0 + wn * Cfg::WN + j * 32 + r;
-    if (col >= N) continue;
-    float bv = 0.f;
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD || EPI == EPI_BIAS_ADD ||
-                  EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ACT_GRAD)
-      bv = bias[col];
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row >= M) continue;
-        float v = acc[i][j][e];
-        if constexpr (EPI == EPI_BIAS) {
-          v += bv;
-        } else if constexpr (EPI == EPI_BIAS_GELU) {
-          v += bv;
-          aux[(int64_t)row * ldaux + col] = v;  // pre-activation, kept for the backward pass
-          v = gelu_erf(v);
-        } else if constexpr (EPI == EPI_BIAS_GELU_GRAD) {
-          v += bv;
-          aux[(int64_t)row * ldaux + col] = dgelu_erf(v);  // gelu'(pre-activation): the backward is then one multiply
-          v = gelu_erf(v);
-        } else if constexpr (EPI == EPI_MUL) {
-          v *= auxv[i][j][e];
-        } else if constexpr (EPI == EPI_MUL_DGELU) {
-          v *= dgelu_erf(auxv[i][j][e]);
-        } else if constexpr (EPI == EPI_ADD) {
-          v += auxv[i][j][e];  // residual-branch gradient joins here
-        } else if constexpr (EPI == EPI_BIAS_ADD) {
-          v = (v + bv) + auxv[i][j][e];
-        } else if constexpr (EPI == EPI_BIAS_QGELU_GRAD) {
-          v += bv;
-          const float sg = sigmoid_1702(v);
-          aux[(int64_t)row * ldaux + col] = sg + 1.702f * v * sg * (1.0f - sg);
-          v = v * sg;
-        } else if constexpr (EPI == EPI_BIAS_RELU) {
-          v = fmaxf(v + bv, 0.f);
-        } else if constexpr (EPI == EPI_BIAS_ACT_GRAD) {
-          v += bv;
-          float dv;
-          if (bt.act == ACT_RELU) {                 // F.relu
-            dv = v > 0.f ? 1.f : 0.f; v = fmaxf(v, 0.f);
-          } else if (bt.act == ACT_SWISH) {         // x * sigmoid(x)   (layers.py:662-663)
-            const float sg = 1.0f / (1.0f + __expf(-v));
-            dv = sg + v * sg * (1.0f - sg); v = v * sg;
-          } else if (bt.act == ACT_TANH) {
-            const float th = tanhf(v);
-            dv = 1.0f - th * th; v = th;
-          } else {                                  // sigmoid
-            const float sg = 1.0f / (1.0f + __expf(-v));
-            dv = sg * (1.0f - sg); v = sg;
-          }
-          aux[(int64_t)row * ldaux + col] = dv;
-        }
-        C[(int64_t)row * ldc + col] = v;
+      for (int q = 0; q < 4; ++q) {
+        u32x4 v;
+        v[0] = __float_as_uint(acc[4 * q]); v[1] = __float_as_uint(acc[4 * q + 1]);
+        v[2] = __float_as_uint(acc[4 * q + 2]); v[3] = __float_as_uint(acc[4 * q + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_part, (unsigned)(((w * 4 + q) * GEMM_THREADS + tid) * 16), 0, SK_COHERENT);
       }
+      __builtin_amdgcn_s_waitcnt(0);          // every lane's stores acknowledged at the coherence point
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&flags[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      int covered = kl;
+      int u = w + 1;
+      while (covered < nk) {                   // block-uniform: the workers that continued this tile, in order
+        const int64_t u0 = total * u / G, u1 = total * (u + 1) / G;
+        if (tid == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(&flags[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) {        // ~seconds: never in a healthy launch; flag it instead of hanging the GPU
+              if (status) atomicOr(status, (unsigned)PXR_STATUS_GEMM_TIMEOUT);
+              break;
+            }
+          }
+          __hip_atomic_store(&flags[u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs_part, (unsigned)(((u * 4 + q) * GEMM_THREADS + tid) * 16), 0, SK_COHERENT);
+          acc[4 * q + 0] += __uint_as_float(raw[0]);
+          acc[4 * q + 1] += __uint_as_float(raw[1]);
+          acc[4 * q + 2] += __uint_as_float(raw[2]);
+          acc[4 * q + 3] += __uint_as_float(raw[3]);
+        }
+        covered += (int)min((int64_t)(nk - covered), u1 - u0);
+        ++u;
+      }
+      epi_store<Cfg, EPI>(accs, ar, C, ldc, M, N, bias, aux, ldaux, m0, n0, lp, act);
     }
+    it += kl - kf;
+    __syncthreads();     // the staging LDS is reused by the next piece
   }
 }
 
@@ -317,6 +442,71 @@ static int dispatch_tile(int tile, const float* A, int64_t lda, const float* B, 
 #undef PXR_TILE
 }
 
+
+// Scratch of the stream-K kernel (partials + flags), one per stream: two stream-K launches may only run concurrently
+// if they do not share it.  Allocated and zeroed on a stream's first use -- which must not happen inside a stream
+// capture (every capture in this package is preceded by eager warm-up steps on the same streams).
+struct SkScratch { float* part; unsigned* flags; };
+static std::mutex g_sk_mu;
+static std::unordered_map<hipStream_t, SkScratch> g_sk_scratch;
+static int sk_scratch_for(hipStream_t st, SkScratch* out) {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  auto f = g_sk_scratch.find(st);
+  if (f != g_sk_scratch.end()) { *out = f->second; return PXR_OK; }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    pxr_set_error("pxr_gemm_f32: first stream-K GEMM on this stream happens inside a stream capture; run one eager step "
+                  "on the same streams first (or PXR_GEMM_SK=0)");
+    return PXR_ERR_WORKSPACE;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, SK_SCRATCH_BYTES) != hipSuccess || hipMemset(p, 0, SK_SCRATCH_BYTES) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
+    pxr_set_error("pxr_gemm_f32: cannot allocate the stream-K scratch (%lld bytes): %s", (long long)SK_SCRATCH_BYTES,
+                  hipGetErrorString(hipGetLastError()));
+    return PXR_ERR_WORKSPACE;
+  }
+  SkScratch s{(float*)p, (unsigned*)((char*)p + (int64_t)SK_MAX_WORKERS * SK_PART_FLOATS * 4)};
+  g_sk_scratch[st] = s;
+  *out = s;
+  return PXR_OK;
+}
+
+// Where stream-K pays (tools/sk_sweep.py, M = 3200 tokens, us per launch, tile-per-workgroup -> stream-K with 768 workers):
+//   N=512 K=1536 (dX of the QKV projection) 58.0 -> 52.9;  N=512 K=1024 40.7 -> 38.5 / 37.3 -> 38.8;
+//   N=512 K=512 21.3 -> 24.9;  N=1024 K=512 45.6 -> 48.3;  N=1536 K=512 46.3 -> 51.8.
+// Publishing and fetching a partial tile through coherent memory costs ~3-4 us per launch, more than the 22 % idle
+// tail of a 400-tile launch is worth unless the K loop is long: the heuristic takes it for one to two tiles per CU
+// and K >= 1536 only.
+static int sk_workers(int64_t tiles, int nk, int batch, int splits, int forced_workers) {
+  static const int mode = getenv("PXR_GEMM_SK") ? atoi(getenv("PXR_GEMM_SK")) : 1;      // 0 off, 1 heuristic, 2 always
+  static const int wg_env = getenv("PXR_GEMM_SK_WGS") ? atoi(getenv("PXR_GEMM_SK_WGS")) : 768;
+  const int wg = forced_workers > 0 ? forced_workers : wg_env;
+  if (batch != 1 || splits != 1 || nk < 4) return 0;
+  if (forced_workers == 0 && mode == 0) return 0;
+  if (forced_workers == 0 && mode == 1) {
+    if (tiles <= 256 || tiles > 512 || nk < 48) return 0;
+  }
+  int64_t g = wg < 16 ? 16 : (wg > SK_MAX_WORKERS ? SK_MAX_WORKERS : wg);
+  const int64_t total = tiles * nk;
+  if (g > total / 4) g = total / 4;       // at least 4 K tiles per worker
+  return g < 1 ? 0 : (int)g;
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm_sk(int workers, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                          int N, int K, const float* bias, float* aux, int64_t ldaux, hipStream_t st) {
+  SkScratch sc;
+  const int rc = sk_scratch_for(st, &sc);
+  if (rc != PXR_OK) return rc;
+  const int tiles_m = (M + 63) / 64, tiles_n = (N + 63) / 64;
+  static const int xcd_env = getenv("PXR_GEMM_XCD") ? atoi(getenv("PXR_GEMM_XCD")) : -1;
+  const int n_fastest = xcd_env >= 0 ? xcd_env : (M > N ? 1 : 0);
+  hipLaunchKernelGGL((gemm_sk_kernel<A_KC, B_KC, EPI>), dim3(workers), dim3(GEMM_THREADS), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                     bias, aux, ldaux, tiles_m, tiles_n, n_fastest, g_bt.act, sc.part, sc.flags, (unsigned*)pxr_status_word());
+  return pxr_check_launch("pxr_gemm_f32(stream-K)");
+}
+
 }  // namespace pxr
 
 using namespace pxr;
@@ -363,6 +553,10 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   static const int small_tile = getenv("PXR_GEMM_SMALL_TILE") ? atoi(getenv("PXR_GEMM_SMALL_TILE")) : 64;
   if (tile == 64) tile = small_tile;
   if (tile_hint == 641 || tile_hint == 128611 || tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861 || tile_hint == 1282) tile = tile_hint;
+  // tile_hint 6464: force the stream-K kernel (64x64 tiles) with split_hint workers (0 = default) -- tests and sweeps
+  const int sk_force = tile_hint == 6464 ? (split_hint > 0 ? split_hint : 768) : 0;
+  if (sk_force) { tile = 64; split_hint = 1; }
+  const int64_t t64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
   const int bm = (tile == 128 || tile == 12864 || tile == 1281 || tile == 12861 || tile == 128611 || tile == 1282) ? 128 : (tile == 3264 ? 32 : 64);
   const int bn = (tile == 128 || tile == 64128 || tile == 1281 || tile == 1282) ? 128 : 64;
   const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
@@ -397,9 +591,12 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   }
 
   int rc;
+  const int skw = sk_force ? sk_workers(tiles, nk, g_batch, 1, sk_force)
+                           : ((tile_hint == 0 && split_hint == 0) ? sk_workers(t64, nk, g_batch, splits, 0) : 0);
 #define PXR_GEMM_CASE(AK, BK_, E)                                                                            \
-  rc = dispatch_tile<AK, BK_, E>(tile, A, lda, B, ldb, Cw, ldcw, M, N, K, bias, aux, ldaux, splits, ksplit_len, \
-                                 split_stride, st)
+  rc = skw > 0 ? launch_gemm_sk<AK, BK_, E>(skw, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, st)        \
+               : dispatch_tile<AK, BK_, E>(tile, A, lda, B, ldb, Cw, ldcw, M, N, K, bias, aux, ldaux, splits, ksplit_len, \
+                                           split_stride, st)
   if (a_kc && b_kc) {
     switch (epilogue) {
       case EPI_NONE: PXR_GEMM_CASE(true, true, EPI_NONE); break;

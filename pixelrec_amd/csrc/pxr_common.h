@@ -28,6 +28,7 @@ void pxr_set_error(const char* fmt, ...);
 int32_t* pxr_status_word(void);
 #define PXR_STATUS_BAD_INDEX 1
 #define PXR_STATUS_TOPK_OVERFLOW 4   /* the candidate buffer of the two-pass top-k overflowed (results may miss items) */
+#define PXR_STATUS_GEMM_TIMEOUT 8    /* a stream-K GEMM worker gave up waiting for a partial tile (results are wrong) */
 #define PXR_STATUS_ROWS_OVERFLOW 2   /* a rank's unique-row count exceeded the capacity of a reduced row exchange */
 
 static inline int pxr_check_launch(const char* what) {

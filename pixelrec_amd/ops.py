@@ -93,6 +93,9 @@ def raise_on_bad_indices(device=None):
     v = int(t.item())
     if v:
         t.zero_()
+    if v & 8:
+        raise RuntimeError("stream-K GEMM: a worker timed out waiting for a partial tile (results are wrong); "
+                           "set PXR_GEMM_SK=0 and report")
     if v & 1:
         raise IndexError("index out of range in self (an item id outside [0, item_num) reached an embedding gather)")
     if v & 4:

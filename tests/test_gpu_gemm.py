@@ -74,3 +74,57 @@ def test_gelu_epilogues_save_activation_or_its_derivative():
     d2 = ops.linear_bwd_input(dy, W2, mul=dg)
     assert torch.equal(d1, d2)
     assert (d1.cpu().double() - (dy.double().cpu() @ W2.double().cpu()) * ref_dg).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("workers", [0, 16, 301, 1000])
+@pytest.mark.parametrize("M,N,K", [(3200, 512, 512), (3200, 512, 2048), (3200, 2048, 512), (777, 132, 1024), (129, 196, 260),
+                                   (64, 64, 128), (5, 8, 4096)])
+def test_stream_k_forward_and_input_grad(workers, M, N, K):
+    """The stream-K kernel (tile_hint 6464; split_hint = workers) for both operand flavours the step uses it with: right
+    against fp64, and bit-identical from launch to launch (fixed summation order; the flags clean themselves)."""
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    xs, Ws, bs = x.cuda(), W.cuda(), b.cuda()
+    outs = []
+    for _ in range(3):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        pre = torch.empty(M, N, device="cuda")
+        ops.gemm(True, True, M, N, K, xs, K, Ws, K, y, N, ops.EPI_BIAS_GELU, bias=bs, aux=pre, ldaux=N, use_ws=False,
+                 tile_hint=6464, split_hint=workers)
+        outs.append((y, pre))
+    ref = x.double() @ W.double().t() + b.double()
+    _check(outs[0][1], ref, K)
+    _check(outs[0][0], torch.nn.functional.gelu(ref), K)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    # dX = dY W + residual-branch gradient  (KC, XC)
+    Wt, add = torch.randn(K, N, generator=g), torch.randn(M, N, generator=g)
+    dx = [torch.full((M, N), float("nan"), device="cuda") for _ in range(2)]
+    for d in dx:
+        ops.gemm(True, False, M, N, K, xs, K, Wt.cuda(), N, d, N, ops.EPI_ADD, aux=add.cuda(), ldaux=N, use_ws=False,
+                 tile_hint=6464, split_hint=workers)
+    _check(dx[0], x.double() @ Wt.double() + add.double(), K)
+    assert torch.equal(dx[0], dx[1])
+    assert int(ops.device_status("cuda").item()) & 8 == 0
+
+
+def test_stream_k_on_two_streams_at_once():
+    """Each stream has its own partial-tile scratch: launches on two streams may overlap."""
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 3200, 512, 1024
+    x, W = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda()
+    ref = torch.empty(M, N, device="cuda")
+    ops.gemm(True, True, M, N, K, x, K, W, K, ref, N, ops.EPI_NONE, use_ws=False, tile_hint=6464)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [[torch.empty(M, N, device="cuda") for _ in range(8)] for _ in range(2)]
+    for i in range(8):
+        for s, o in ((s1, outs[0][i]), (s2, outs[1][i])):
+            with torch.cuda.stream(s):
+                ops.gemm(True, True, M, N, K, x, K, W, K, o, N, ops.EPI_NONE, use_ws=False, tile_hint=6464)
+    torch.cuda.synchronize()
+    for o in outs[0] + outs[1]:
+        assert torch.equal(o, ref)
