@@ -357,4 +357,139 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
+// ---- epilogues (shared by gemm_f32.hip, gemm_b3.hip and score_topk.hip) ------------------------------------------
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD = 4, EPI_BIAS_GELU_GRAD = 5, EPI_MUL = 6,
+       // the ViT blocks of the PixelNet image encoder (HF CLIPEncoderLayer; reference load.py:90-120):
+       EPI_BIAS_ADD = 7,          // C = acc + bias + aux            (out_proj / fc2 + residual stream)
+       EPI_BIAS_QGELU_GRAD = 8,   // C = quick_gelu(acc + bias), aux = quick_gelu'(acc + bias)   (CLIP MLP fc1)
+       EPI_BIAS_RELU = 9,         // C = relu(acc + bias)            (rec_fc of MeanItemEncoder, layers.py:121-128)
+       // the other hidden_act choices of the reference's FeedForward (layers.py:642-649: relu / swish / tanh / sigmoid):
+       EPI_BIAS_ACT_GRAD = 10,    // C = act(acc + bias), aux = act'(acc + bias); act = GemmBatch::act
+       EPI_LAST = 10 };
+enum { ACT_RELU = 3, ACT_SWISH = 4, ACT_TANH = 5, ACT_SIGMOID = 6 };
+
+// Batched launch: grid.z = batch index z; operand offsets (in floats) = (z / nb2) * x1 + (z % nb2) * x2 -- two levels, so
+// that "image n, head h" of a packed [n, T, 3, heads, d] projection is addressed without copies.
+struct GemmBatch {
+  int nb2;
+  int64_t a1, a2, b1, b2, c1, c2;
+  int act;      // EPI_BIAS_ACT_GRAD: which activation (ACT_*)
+};
+
+// erf-GELU exactly as the reference writes it: x * 0.5 * (1 + erf(x / sqrt(2)))  (layers.py:651-660)
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
+// CLIP's quick_gelu: x * sigmoid(1.702 x), and its derivative s + 1.702 x s (1 - s)
+__device__ __forceinline__ float sigmoid_1702(float x) { return 1.0f / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x / 1.41421356237309504880f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- epilogue pieces shared by the tile-per-workgroup kernel and the stream-K kernel ---------------------------------
+template <int EPI>
+struct EpiTraits {
+  static constexpr bool READS_AUX = (EPI == EPI_MUL_DGELU || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_BIAS_ADD);
+  static constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD || EPI == EPI_BIAS_ADD ||
+                                    EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ACT_GRAD);
+};
+template <class Cfg, int EPI>
+struct AuxRegs {
+  static constexpr bool R = EpiTraits<EPI>::READS_AUX;
+  float v[R ? Cfg::TM : 1][R ? Cfg::TN : 1][R ? 16 : 1];
+};
+// where this lane's accumulator elements live in the output tile
+struct LanePos {
+  int wm, wn, h, r;
+};
+template <class Cfg>
+__device__ __forceinline__ LanePos lane_pos() {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return LanePos{(wave % Cfg::G) / Cfg::WGN, (wave % Cfg::G) % Cfg::WGN, lane >> 5, lane & 31};
+}
+// epilogue operands that are READ (residual-branch gradient / saved pre-activation) are fetched before the main
+// loop: the loads complete under the MFMAs instead of stalling every wave after its last one
+template <class Cfg, int EPI>
+__device__ __forceinline__ void epi_prefetch_aux(AuxRegs<Cfg, EPI>& ar, const float* __restrict__ aux, int64_t ldaux, int M,
+                                                 int N, int m0, int n0, const LanePos p) {
+  if constexpr (EpiTraits<EPI>::READS_AUX) {
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + p.wn * Cfg::WN + j * 32 + p.r;
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + p.wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * p.h;
+          ar.v[i][j][e] = (col < N && row < M) ? aux[(int64_t)row * ldaux + col] : 0.f;
+        }
+    }
+  }
+}
+template <class Cfg, int EPI>
+__device__ __forceinline__ void epi_store(const typename Cfg::Acc& accs, const AuxRegs<Cfg, EPI>& ar, float* __restrict__ C,
+                                          int64_t ldc, int M, int N, const float* __restrict__ bias,
+                                          float* __restrict__ aux, int64_t ldaux, int m0, int n0, const LanePos p, int act) {
+  const auto& acc = accs.v;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + p.wn * Cfg::WN + j * 32 + p.r;
+    if (col >= N) continue;
+    float bv = 0.f;
+    if constexpr (EpiTraits<EPI>::HAS_BIAS) bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + p.wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * p.h;
+        if (row >= M) continue;
+        float v = acc[i][j][e];
+        if constexpr (EPI == EPI_BIAS) {
+          v += bv;
+        } else if constexpr (EPI == EPI_BIAS_GELU) {
+          v += bv;
+          aux[(int64_t)row * ldaux + col] = v;  // pre-activation, kept for the backward pass
+          v = gelu_erf(v);
+        } else if constexpr (EPI == EPI_BIAS_GELU_GRAD) {
+          v += bv;
+          aux[(int64_t)row * ldaux + col] = dgelu_erf(v);  // gelu'(pre-activation): the backward is then one multiply
+          v = gelu_erf(v);
+        } else if constexpr (EPI == EPI_MUL) {
+          v *= ar.v[i][j][e];
+        } else if constexpr (EPI == EPI_MUL_DGELU) {
+          v *= dgelu_erf(ar.v[i][j][e]);
+        } else if constexpr (EPI == EPI_ADD) {
+          v += ar.v[i][j][e];  // residual-branch gradient joins here
+        } else if constexpr (EPI == EPI_BIAS_ADD) {
+          v = (v + bv) + ar.v[i][j][e];
+        } else if constexpr (EPI == EPI_BIAS_QGELU_GRAD) {
+          v += bv;
+          const float sg = sigmoid_1702(v);
+          aux[(int64_t)row * ldaux + col] = sg + 1.702f * v * sg * (1.0f - sg);
+          v = v * sg;
+        } else if constexpr (EPI == EPI_BIAS_RELU) {
+          v = fmaxf(v + bv, 0.f);
+        } else if constexpr (EPI == EPI_BIAS_ACT_GRAD) {
+          v += bv;
+          float dv;
+          if (act == ACT_RELU) {                    // F.relu
+            dv = v > 0.f ? 1.f : 0.f; v = fmaxf(v, 0.f);
+          } else if (act == ACT_SWISH) {            // x * sigmoid(x)   (layers.py:662-663)
+            const float sg = 1.0f / (1.0f + __expf(-v));
+            dv = sg + v * sg * (1.0f - sg); v = v * sg;
+          } else if (act == ACT_TANH) {
+            const float th = tanhf(v);
+            dv = 1.0f - th * th; v = th;
+          } else {                                  // sigmoid
+            const float sg = 1.0f / (1.0f + __expf(-v));
+            dv = sg * (1.0f - sg); v = sg;
+          }
+          aux[(int64_t)row * ldaux + col] = dv;
+        }
+        C[(int64_t)row * ldc + col] = v;
+      }
+    }
+  }
+}
+
 }  // namespace pxr
