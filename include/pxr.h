@@ -156,20 +156,14 @@ int pxr_gemm_batched_f32(int a_kc, int b_kc, int M, int N, int K, const float* A
                          int64_t ldb, float* C, int64_t ldc, int batch, int nb2, int64_t a1, int64_t a2, int64_t b1,
                          int64_t b2, int64_t c1, int64_t c2, int tile_hint, void* stream);
 
-/* ---- fp32 GEMM on the bf16 matrix pipe (csrc/gemm_b3.cuh/.hip): exact 3 x bf16 operand split, 6 products, fp32
- * accumulate -- the same nn.Linear forwards / input gradients (layers.py:586-588,613,666,669 + autograd) and the
- * full-catalog scoring product (sasrec.py:112) as pxr_gemm_f32, fp32-accurate (see gemm_b3.cuh for the error bound). */
-/* bf16x3 planes of up to 32 matrices in one launch: dst[i] = 3 planes (hi, mid, lo; plane[i] elements apart) of R[i] rows
- * x ldd[i] bf16 (ldd % 8 == 0, >= C rounded up to 8; pad columns zero) holding src[i] (R x C floats, row stride ld[i]) or,
- * with transpose[i] != 0, its transpose (src is then C x R). */
-int pxr_split_bf16x3_f32(int n, const float* const* src, const int64_t* ld, const int* R, const int* C,
-                         const int* transpose, void* const* dst, const int64_t* ldd, const int64_t* plane, void* stream);
-/* C[M,N] = epilogue(A[M,K] * B^T): A fp32 row-major (lda), B as planes [3][N][ldb] from pxr_split_bf16x3_f32 (bplane
- * elements between planes).  Epilogues and `aux` as pxr_gemm_f32; act = activation code for epilogue 10.
- * tile_hint 0 = heuristic, 64 / 1281 = 64x64 (4 waves) / 128x128 (16 waves) tile. */
-int pxr_gemm_b3_f32(int M, int N, int K, const float* A, int64_t lda, const void* Bp, int64_t ldb, int64_t bplane, float* C,
-                    int64_t ldc, int epilogue, int act, const float* bias, float* aux, int64_t ldaux, int tile_hint,
-                    void* stream);
+/* GEMM mode of the process (also PXR_GEMM_MODE=bf16x3|f32, default bf16x3): with bf16x3 every product pxr_gemm_f32 /
+ * pxr_gemm_batched_f32 / pxr_linear_* / pxr_grouped_linear_bwd_weight_f32 would run with its heuristic tile is computed
+ * on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) after an EXACT split of each fp32 operand into three bf16 terms,
+ * six cross products, fp32 accumulation (csrc/gemm_b3.cuh: error bound ~2^-25 |a||b| per product, i.e. fp32-class;
+ * tests/test_gpu_gemm_b3.py).  f32 = the f32-input MFMA kernels (v_mfma_f32_32x32x2_f32).  An explicit f32 tile_hint
+ * always takes the f32 kernels; tile_hint 9064 / 91281 force the bf16x3 64x64 / 128x128 tile. */
+int pxr_set_gemm_mode(int bf16x3);
+int pxr_get_gemm_mode(void);
 
 /* ---- ViT image encoder, non-GEMM pieces (csrc/vit.hip) ------------------------------------------------------ */
 /* in place: S[row, :T] = softmax(scale * S[row, :T]), S[row, T:ld] = 0      (HF CLIPAttention, no mask / dropout) */

@@ -393,9 +393,11 @@ struct EpiTraits {
   static constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD || EPI == EPI_BIAS_ADD ||
                                     EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ACT_GRAD);
 };
-template <class Cfg, int EPI>
+// DIRECT: the epilogue reads `aux` from memory itself instead of from registers filled before the main loop (kernels
+// that have no registers to spare)
+template <class Cfg, int EPI, bool DIRECT = false>
 struct AuxRegs {
-  static constexpr bool R = EpiTraits<EPI>::READS_AUX;
+  static constexpr bool R = EpiTraits<EPI>::READS_AUX && !DIRECT;
   float v[R ? Cfg::TM : 1][R ? Cfg::TN : 1][R ? 16 : 1];
 };
 // where this lane's accumulator elements live in the output tile
@@ -409,10 +411,10 @@ __device__ __forceinline__ LanePos lane_pos() {
 }
 // epilogue operands that are READ (residual-branch gradient / saved pre-activation) are fetched before the main
 // loop: the loads complete under the MFMAs instead of stalling every wave after its last one
-template <class Cfg, int EPI>
-__device__ __forceinline__ void epi_prefetch_aux(AuxRegs<Cfg, EPI>& ar, const float* __restrict__ aux, int64_t ldaux, int M,
+template <class Cfg, int EPI, bool DIRECT = false>
+__device__ __forceinline__ void epi_prefetch_aux(AuxRegs<Cfg, EPI, DIRECT>& ar, const float* __restrict__ aux, int64_t ldaux, int M,
                                                  int N, int m0, int n0, const LanePos p) {
-  if constexpr (EpiTraits<EPI>::READS_AUX) {
+  if constexpr (EpiTraits<EPI>::READS_AUX && !DIRECT) {
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
       const int col = n0 + p.wn * Cfg::WN + j * 32 + p.r;
@@ -426,8 +428,8 @@ __device__ __forceinline__ void epi_prefetch_aux(AuxRegs<Cfg, EPI>& ar, const fl
     }
   }
 }
-template <class Cfg, int EPI>
-__device__ __forceinline__ void epi_store(const typename Cfg::Acc& accs, const AuxRegs<Cfg, EPI>& ar, float* __restrict__ C,
+template <class Cfg, int EPI, bool DIRECT = false>
+__device__ __forceinline__ void epi_store(const typename Cfg::Acc& accs, const AuxRegs<Cfg, EPI, DIRECT>& ar, float* __restrict__ C,
                                           int64_t ldc, int M, int N, const float* __restrict__ bias,
                                           float* __restrict__ aux, int64_t ldaux, int m0, int n0, const LanePos p, int act) {
   const auto& acc = accs.v;
@@ -444,6 +446,8 @@ __device__ __forceinline__ void epi_store(const typename Cfg::Acc& accs, const A
         const int row = m0 + p.wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * p.h;
         if (row >= M) continue;
         float v = acc[i][j][e];
+        float av = 0.f;
+        if constexpr (EpiTraits<EPI>::READS_AUX) av = DIRECT ? aux[(int64_t)row * ldaux + col] : ar.v[DIRECT ? 0 : i][DIRECT ? 0 : j][DIRECT ? 0 : e];
         if constexpr (EPI == EPI_BIAS) {
           v += bv;
         } else if constexpr (EPI == EPI_BIAS_GELU) {
@@ -455,13 +459,13 @@ __device__ __forceinline__ void epi_store(const typename Cfg::Acc& accs, const A
           aux[(int64_t)row * ldaux + col] = dgelu_erf(v);  // gelu'(pre-activation): the backward is then one multiply
           v = gelu_erf(v);
         } else if constexpr (EPI == EPI_MUL) {
-          v *= ar.v[i][j][e];
+          v *= av;
         } else if constexpr (EPI == EPI_MUL_DGELU) {
-          v *= dgelu_erf(ar.v[i][j][e]);
+          v *= dgelu_erf(av);
         } else if constexpr (EPI == EPI_ADD) {
-          v += ar.v[i][j][e];  // residual-branch gradient joins here
+          v += av;  // residual-branch gradient joins here
         } else if constexpr (EPI == EPI_BIAS_ADD) {
-          v = (v + bv) + ar.v[i][j][e];
+          v = (v + bv) + av;
         } else if constexpr (EPI == EPI_BIAS_QGELU_GRAD) {
           v += bv;
           const float sg = sigmoid_1702(v);
@@ -492,4 +496,22 @@ __device__ __forceinline__ void epi_store(const typename Cfg::Acc& accs, const A
   }
 }
 
+constexpr int DW_MAX = 16;
+struct DwProblem {
+  const float* dy; const float* x; float* dW; float* db;
+  int M, N, K;        // tokens, out features, in features
+  int tile_begin, tiles_m;
+};
+struct DwGroup {
+  DwProblem p[DW_MAX];
+  int n, total_tiles;
+};
+
+
+// ---- entry points of gemm_b3.hip (the same products on the bf16 matrix pipe, gemm_b3.cuh) used by gemm_f32.hip ---------
+// tile: 64 (64x64, 4 waves) or 1281 (128x128, 16 waves).  Same argument meaning as gemm_kernel's launch.
+int gemm_b3_launch(int a_kc, int b_kc, int epilogue, int tile, const float* A, int64_t lda, const float* B, int64_t ldb,
+                   float* C, int64_t ldc, int M, int N, int K, const float* bias, float* aux, int64_t ldaux, int splits,
+                   int ksplit_len, int64_t split_stride, const GemmBatch& bt, int batch, hipStream_t st);
+int grouped_dw_b3_launch(const DwGroup& g, hipStream_t st);
 }  // namespace pxr

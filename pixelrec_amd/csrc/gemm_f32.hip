@@ -179,17 +179,6 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
 // the long token reduction (M = B*L) as its K loop, so with all problems' 64x64 output tiles in one grid (1024 tiles
 // for the two SASRec layers at D=512) the chip is full without split-K: no partial buffers, no reduce launches, no
 // separate bias-gradient reductions.  Deterministic: each output element is one fixed-order MFMA chain.
-constexpr int DW_MAX = 16;
-struct DwProblem {
-  const float* dy; const float* x; float* dW; float* db;
-  int M, N, K;        // tokens, out features, in features
-  int tile_begin, tiles_m;
-};
-struct DwGroup {
-  DwProblem p[DW_MAX];
-  int n, total_tiles;
-};
-
 __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_kernel(DwGroup g) {
   using Cfg = GemmCfg<64, 64, false, false>;
   __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
@@ -392,6 +381,22 @@ static int launch_gemm_sk(int workers, const float* A, int64_t lda, const float*
 
 using namespace pxr;
 
+// GEMM mode of the process: "bf16x3" (default) = exact 3 x bf16 operand split on the bf16 matrix pipe (gemm_b3.cuh),
+// "f32" = the f32-input MFMA kernels.  PXR_GEMM_MODE, or pxr_set_gemm_mode (tests, A/B runs).
+static int g_gemm_mode = -1;
+static bool gemm_mode_b3() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("PXR_GEMM_MODE");
+    g_gemm_mode = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+  }
+  return g_gemm_mode == 1;
+}
+extern "C" int pxr_set_gemm_mode(int bf16x3) {
+  g_gemm_mode = bf16x3 ? 1 : 0;
+  return PXR_OK;
+}
+extern "C" int pxr_get_gemm_mode(void) { return gemm_mode_b3() ? 1 : 0; }
+
 // Bytes of workspace pxr_gemm_f32 may use for split-K partials (0 => never splits).
 extern "C" int64_t pxr_gemm_ws_bytes(int a_kc, int b_kc, int M, int N, int K) {
   (void)a_kc; (void)b_kc; (void)K;
@@ -434,6 +439,8 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   static const int small_tile = getenv("PXR_GEMM_SMALL_TILE") ? atoi(getenv("PXR_GEMM_SMALL_TILE")) : 64;
   if (tile == 64) tile = small_tile;
   if (tile_hint == 641 || tile_hint == 128611 || tile_hint == 128 || tile_hint == 64 || tile_hint == 12864 || tile_hint == 64128 || tile_hint == 642 || tile_hint == 3264 || tile_hint == 1281 || tile_hint == 12861 || tile_hint == 1282) tile = tile_hint;
+  const int b3_hint = (tile_hint == 9064 || tile_hint == 91281) ? tile_hint : 0;
+  if (b3_hint) tile = b3_hint == 9064 ? 64 : 1281;
   // tile_hint 6464: force the stream-K kernel (64x64 tiles) with split_hint workers (0 = default) -- tests and sweeps
   const int sk_force = tile_hint == 6464 ? (split_hint > 0 ? split_hint : 768) : 0;
   if (sk_force) { tile = 64; split_hint = 1; }
@@ -472,6 +479,22 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
   }
 
   int rc;
+  // bf16x3 mode (default): the heuristic's choices run on the bf16 matrix pipe (gemm_b3.cuh); an explicit f32 tile_hint
+  // keeps the f32-input MFMA kernel (tests / sweeps), 9064 / 91281 force the bf16x3 64x64 / 128x128 tile.
+  const bool b3 = b3_hint ? true : (gemm_mode_b3() && tile_hint == 0);
+  if (b3) {
+    const int t3 = b3_hint == 91281 ? 1281 : (b3_hint == 9064 ? 64 : ((t128 >= 384 || (t128 >= 192 && t128 <= 256)) ? 1281 : 64));
+    rc = gemm_b3_launch(a_kc, b_kc, epilogue, t3, A, lda, B, ldb, Cw, ldcw, M, N, K, bias, aux, ldaux, splits, ksplit_len,
+                        split_stride, g_bt, g_batch, st);
+    if (rc != PXR_OK) return rc;
+    if (splits > 1) {
+      const int64_t n4 = (int64_t)M * N / 4;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                         (const float4*)ws, (float4*)C, n4, n4, splits);
+      return pxr_check_launch("pxr_gemm_f32(split-K reduce)");
+    }
+    return PXR_OK;
+  }
   const int skw = sk_force ? sk_workers(tiles, nk, g_batch, 1, sk_force)
                            : ((tile_hint == 0 && split_hint == 0) ? sk_workers(t64, nk, g_batch, splits, 0) : 0);
 #define PXR_GEMM_CASE(AK, BK_, E)                                                                            \
@@ -533,7 +556,7 @@ extern "C" int pxr_gemm_batched_f32(int a_kc, int b_kc, int M, int N, int K, con
     g_bt = GemmBatch{nb2, a1, a2, b1, b2, c1, c2, 0};
     g_batch = nz;
     rc = pxr_gemm_f32(a_kc, b_kc, M, N, K, A + g0 * a1, lda, B + g0 * b1, ldb, C + g0 * c1, ldc, EPI_NONE, nullptr, nullptr,
-                      0, nullptr, 0, tile_hint ? tile_hint : 64, 1, stream);
+                      0, nullptr, 0, tile_hint ? tile_hint : (gemm_mode_b3() ? 9064 : 64), 1, stream);
     g_bt = GemmBatch{};
     g_batch = 1;
   }
@@ -630,6 +653,7 @@ extern "C" int pxr_grouped_linear_bwd_weight_f32(int n, const float* const* dy, 
     tiles += P.tiles_m * ((K[i] + 63) / 64);
   }
   g.total_tiles = tiles;
+  if (gemm_mode_b3()) return grouped_dw_b3_launch(g, (hipStream_t)stream);
   hipLaunchKernelGGL(grouped_dw_kernel, dim3(tiles), dim3(GEMM_THREADS), 0, (hipStream_t)stream, g);
   return pxr_check_launch("pxr_grouped_linear_bwd_weight_f32");
 }

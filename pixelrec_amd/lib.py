@@ -80,8 +80,8 @@ _SIGNATURES = {
     "pxr_set_status_word": (_I, [_P]),
     "pxr_gemm_batched_f32": (_I, [_I, _I, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I64, _I64, _I64, _I64, _I64,
                                   _I64, _I, _P]),
-    "pxr_split_bf16x3_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "pxr_gemm_b3_f32": (_I, [_I, _I, _I, _P, _I64, _P, _I64, _I64, _P, _I64, _I, _I, _P, _P, _I64, _I, _P]),
+    "pxr_set_gemm_mode": (_I, [_I]),
+    "pxr_get_gemm_mode": (_I, []),
     "pxr_softmax_rows_f32": (_I, [_P, _I64, _I, _I, _F, _P]),
     "pxr_softmax_rows_bwd_f32": (_I, [_P, _P, _I64, _I, _I, _F, _P]),
     "pxr_vit_embed_f32": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P]),

@@ -115,13 +115,6 @@ class SeqRecCore(BaseModel):
         self.defer_weight_grad_join = False
         self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
         self._step_counter = 0
-        # how the nn.Linear forwards / input gradients multiply: "bf16x3" = on the bf16 matrix pipe through the exact
-        # 3 x bf16 operand split (csrc/gemm_b3.cuh; fp32-accurate, 1.2-1.4x faster at these shapes), "f32" = the
-        # f32-input MFMA kernels.  Weight gradients and attention stay on the f32-input MFMA either way.
-        self.gemm_mode = os.environ.get("PXR_GEMM_MODE", config["gemm_mode"] if "gemm_mode" in config else "bf16x3")
-        if self.gemm_mode not in ("bf16x3", "f32"):
-            raise ValueError(f"gemm_mode must be 'bf16x3' or 'f32', got {self.gemm_mode!r}")
-        self._planes = None
 
     def _init_weights(self, module):
         """N(0, initializer_range) for every Linear/Embedding weight; LayerNorm (1, 0); biases 0 (sasrec.py:51-61)."""
@@ -171,7 +164,6 @@ class SeqRecCore(BaseModel):
             views[name] = (off, n, tuple(p.shape))
             off += n
         self._flat, self._gflat, self._views = flat, gflat, views
-        self._planes = None
         self._anchor = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
         self._drop_dev = torch.full((1,), self._step_counter, dtype=torch.int64, device=dev)
 
@@ -182,33 +174,6 @@ class SeqRecCore(BaseModel):
         if span == 1:
             return buf[off:off + n].view(shape)
         return buf[off:off + span * n].view((span * shape[0],) + tuple(shape[1:]))
-
-    # ---- bf16x3 operand planes of the weights (gemm_mode "bf16x3") ---------------------------------------------------
-    def _weight_names(self):
-        return [(f"{i}.{n}.w", 3 if n == "q" else 1) for i in range(self.n_layers) for n in ("q", "o", "f1", "f2")]
-
-    def _refresh_planes(self):
-        """Split every weight matrix (and its transpose, for the input gradients) into bf16x3 planes: ONE launch at the
-        start of each forward, so the planes can never be stale (optimizer steps, load_state_dict, manual edits)."""
-        if self._planes is None:
-            items, planes = [], {}
-            shapes = [(name, span, self._p(name, span=span)) for name, span in self._weight_names()]
-            total = sum(2 * ops.Planes.numel(*w.shape) + 32 for _, _, w in shapes)     # (+ alignment slack)
-            buf = torch.empty(total, dtype=torch.bfloat16, device=self._flat.device)
-            off = 0
-            for name, span, w in shapes:
-                for tr in (False, True):
-                    R, C = (w.shape[1], w.shape[0]) if tr else w.shape
-                    n = ops.Planes.numel(R, C)
-                    pl = ops.Planes(R, C, buf.device, buf[off:off + n])
-                    off += (n + 7) & ~7
-                    planes[(name, tr)] = pl
-                    items.append((w, tr, pl))
-            self._planes, self._plane_items = planes, items
-        ops.split_planes(self._plane_items)
-
-    def _pl(self, name, transposed=False):
-        return self._planes[(name, transposed)] if self.gemm_mode == "bf16x3" else None
 
     # ---- the dropout "RNG state": masks are a stateless hash of (seed, site, element, step), so the only state is
     # the number of completed backward passes (host mirror + device counter).  Saved / restored with checkpoints.
@@ -266,21 +231,19 @@ class SeqRecCore(BaseModel):
         seed = (self._drop_seed * 1000003) & 0xFFFFFFFFFFFFFFFF
         sdv = self._drop_dev if train else None
         saved = {"seed": seed, "ph": ph, "pa": pa, "layers": []} if train else None
-        if self.gemm_mode == "bf16x3":
-            self._refresh_planes()
         h, xhat0, rstd0 = ops.input_ln_fwd(table, idx, idx_bstride, B, L, self._p("pos"), self._p("ln0.w"),
                                            self._p("ln0.b"), eps, ph, seed, 0, save=train, step_dev=sdv)
         if train:
             saved["xhat0"], saved["rstd0"] = xhat0, rstd0
         for i in range(self.n_layers):
-            qkv = ops.linear_fwd(h, self._p(f"{i}.q.w", span=3), self._p(f"{i}.q.b", span=3), planes=self._pl(f"{i}.q.w"))
+            qkv = ops.linear_fwd(h, self._p(f"{i}.q.w", span=3), self._p(f"{i}.q.b", span=3))
             ctx, probs = ops.attn_fwd(qkv, keymask, km_bstride, B, H, L, d, pa, seed, 1 + 3 * i, save=train, step_dev=sdv)
-            a = ops.linear_fwd(ctx, self._p(f"{i}.o.w"), self._p(f"{i}.o.b"), planes=self._pl(f"{i}.o.w"))
+            a = ops.linear_fwd(ctx, self._p(f"{i}.o.w"), self._p(f"{i}.o.b"))
             h1, xhat1, rstd1 = ops.ln_residual_fwd(a, h, self._p(f"{i}.ln1.w"), self._p(f"{i}.ln1.b"), eps, ph, seed,
                                                    2 + 3 * i, save=train, step_dev=sdv)
             f, u = ops.linear_fwd(h1, self._p(f"{i}.f1.w"), self._p(f"{i}.f1.b"), gelu=True, save_grad=train,
-                                  act=self.hidden_act, planes=self._pl(f"{i}.f1.w"))
-            f2 = ops.linear_fwd(f, self._p(f"{i}.f2.w"), self._p(f"{i}.f2.b"), planes=self._pl(f"{i}.f2.w"))
+                                  act=self.hidden_act)
+            f2 = ops.linear_fwd(f, self._p(f"{i}.f2.w"), self._p(f"{i}.f2.b"))
             h2, xhat2, rstd2 = ops.ln_residual_fwd(f2, h1, self._p(f"{i}.ln2.w"), self._p(f"{i}.ln2.b"), eps, ph, seed,
                                                    3 + 3 * i, save=train, step_dev=sdv)
             if train:
@@ -371,24 +334,23 @@ class SeqRecCore(BaseModel):
             if dxf2 is None:
                 dxf2 = dz2
             weight_grads(dxf2.view(T, D), a["f"].view(T, -1), f"{i}.f2.w", f"{i}.f2.b")
-            du = ops.linear_bwd_input(dxf2, self._p(f"{i}.f2.w"), mul=a["u"],      # a["u"] holds gelu'(pre-activation)
-                                      planes_t=self._pl(f"{i}.f2.w", True))
+            du = ops.linear_bwd_input(dxf2, self._p(f"{i}.f2.w"), mul=a["u"])      # a["u"] holds gelu'(pre-activation)
             weight_grads(du.view(T, -1), a["h1"].view(T, D), f"{i}.f1.w", f"{i}.f1.b")
             if fork and self.weight_grad_mode == "fork_half":
                 fork_pending()
-            dh1 = ops.linear_bwd_input(du, self._p(f"{i}.f1.w"), add=dz2, planes_t=self._pl(f"{i}.f1.w", True))
+            dh1 = ops.linear_bwd_input(du, self._p(f"{i}.f1.w"), add=dz2)
             # attention block: h1 = LN(dropout(a) + h)
             dz1, dxa = ops.ln_bwd(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
                                   g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer)
             if dxa is None:
                 dxa = dz1
             weight_grads(dxa.view(T, D), a["ctx"].view(T, D), f"{i}.o.w", f"{i}.o.b")
-            dctx = ops.linear_bwd_input(dxa, self._p(f"{i}.o.w"), planes_t=self._pl(f"{i}.o.w", True))
+            dctx = ops.linear_bwd_input(dxa, self._p(f"{i}.o.w"))
             dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv)
             weight_grads(dqkv.view(T, 3 * D), a["h_in"].view(T, D), f"{i}.q.w", f"{i}.q.b", 3)
             if fork:
                 fork_pending()
-            dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1, planes_t=self._pl(f"{i}.q.w", True))
+            dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1)
         dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,
                             step_dev=sdv, defer=defer)
         ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1), defer=defer)

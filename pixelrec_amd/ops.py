@@ -77,6 +77,8 @@ _status = {}
 def device_status(device=None) -> torch.Tensor:
     """The int32 device status word of this process' GPU (created and registered with the library on first use)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:            # "cuda" without an index names the current device, not a second status word
+        dev = torch.device("cuda", torch.cuda.current_device())
     t = _status.get(dev.index)
     if t is None:
         t = _status[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -144,15 +146,29 @@ def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc,
     return C
 
 
+def set_gemm_mode(mode: str):
+    """"bf16x3" (default; PXR_GEMM_MODE) = the heuristic's GEMM choices run on the bf16 matrix pipe through the exact
+    3 x bf16 operand split (csrc/gemm_b3.cuh), "f32" = on the f32-input MFMA.  Process-wide; returns the previous mode."""
+    L = _l.load()
+    prev = "bf16x3" if L.pxr_get_gemm_mode() else "f32"
+    if mode not in ("bf16x3", "f32"):
+        raise ValueError(f"gemm mode must be 'bf16x3' or 'f32', got {mode!r}")
+    _l.check(L.pxr_set_gemm_mode(1 if mode == "bf16x3" else 0), "pxr_set_gemm_mode")
+    return prev
+
+
+def gemm_mode() -> str:
+    return "bf16x3" if _l.load().pxr_get_gemm_mode() else "f32"
+
+
 ACT_CODES = {"relu": 3, "swish": 4, "tanh": 5, "sigmoid": 6}      # the reference's ACT2FN besides gelu (layers.py:642-649)
 
 
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: bool = False, save_grad: bool = False,
-               act: str | None = None, planes: "Planes | None" = None):
+               act: str | None = None):
     """y = x W^T + b (nn.Linear, layers.py:586-588,613,666,669).  gelu=True also returns the pre-activation, or with
     save_grad=True gelu'(pre-activation) (what linear_bwd_input(mul=...) multiplies by).  act in ACT_CODES: that
-    activation instead of erf-GELU, always with its derivative returned second.  planes: the bf16x3 split of W
-    (split_planes) -- the product then runs on the bf16 matrix pipe (gemm_b3), same results to fp32 accuracy."""
+    activation instead of erf-GELU, always with its derivative returned second."""
     if act is not None and act != "gelu":
         gelu, code = True, ACT_CODES[act]
     else:
@@ -163,12 +179,6 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor | None, gelu: b
     M = x.numel() // K
     y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if gelu else None
-    if planes is not None:
-        epi = (EPI_BIAS_ACT_GRAD if code is not None else (EPI_BIAS_GELU_GRAD if save_grad else EPI_BIAS_GELU)) if gelu else \
-            (EPI_BIAS if b is not None else EPI_NONE)
-        gemm_b3(M, N, K, x, K, planes, y, N, epi, bias=b, aux=pre, ldaux=N, act=code or 0,
-                tag="gemm_b3_kernel<EPI_BIAS_GELU*> (fwd + erf-GELU)" if gelu else "gemm_b3_kernel<EPI_BIAS> (fwd)")
-        return (y, pre) if gelu else y
     with _gemm_timer(2.0 * M * N * K, "gemm_kernel<KC,KC,EPI_BIAS_GELU*> (fwd + erf-GELU)" if gelu else
                      "gemm_kernel<KC,KC,EPI_BIAS> (fwd)"):
         _l.check(L.pxr_linear_fwd_f32(_l.ptr(x), _l.ptr(W), _l.ptr(b), _l.ptr(y), _l.ptr(pre), M, N, K,
@@ -208,53 +218,6 @@ def gemm_batched(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, a_off, lda, 
                                         cp(B.data_ptr() + 4 * b_off), ldb, cp(C.data_ptr() + 4 * c_off), ldc, batch, nb2,
                                         a12[0], a12[1], b12[0], b12[1], c12[0], c12[1], 0, _l.stream_ptr()),
                  "pxr_gemm_batched_f32")
-
-
-class Planes:
-    """bf16x3 planes (hi, mid, lo) of a matrix [R, C] for the B operand of gemm_b3: one bf16 tensor [3, R, ldd], ldd = C
-    rounded up to 8 (csrc/gemm_b3.cuh)."""
-
-    __slots__ = ("buf", "R", "C", "ldd")
-
-    def __init__(self, R: int, C: int, device, buf: torch.Tensor | None = None):
-        self.R, self.C, self.ldd = int(R), int(C), (int(C) + 7) & ~7
-        self.buf = buf if buf is not None else torch.empty(3 * self.R * self.ldd, dtype=torch.bfloat16, device=device)
-
-    @staticmethod
-    def numel(R: int, C: int) -> int:
-        return 3 * int(R) * ((int(C) + 7) & ~7)
-
-
-def split_planes(items):
-    """items: list of (src fp32 2-D tensor or view with unit column stride, transpose: bool, Planes).  One launch (up to
-    32 matrices): Planes = the split of src (transpose False) or of src^T (transpose True)."""
-    import ctypes
-
-    L = _l.load()
-    for i0 in range(0, len(items), 32):
-        part = items[i0:i0 + 32]
-        n = len(part)
-        P, I, I64 = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
-        for src, tr, pl in part:
-            _req(src, torch.float32, "src")
-            assert src.dim() == 2 and src.stride(1) == 1, "split_planes: src must be 2-D with unit column stride"
-            assert (pl.R, pl.C) == ((src.shape[1], src.shape[0]) if tr else tuple(src.shape)), "split_planes: Planes shape"
-        _l.check(L.pxr_split_bf16x3_f32(n, P(*[s.data_ptr() for s, _, _ in part]), I64(*[s.stride(0) for s, _, _ in part]),
-                                        I(*[p.R for _, _, p in part]), I(*[p.C for _, _, p in part]),
-                                        I(*[int(t) for _, t, _ in part]), P(*[p.buf.data_ptr() for _, _, p in part]),
-                                        I64(*[p.ldd for _, _, p in part]), I64(*[p.R * p.ldd for _, _, p in part]),
-                                        _l.stream_ptr()), "pxr_split_bf16x3_f32")
-
-
-def gemm_b3(M: int, N: int, K: int, A, lda, planes: Planes, C, ldc, epilogue=EPI_NONE, bias=None, aux=None, ldaux=0, act=0,
-            tile_hint=0, tag=None):
-    """C[M,N] = epilogue(A[M,K] planes^T) on the bf16 matrix pipe with the exact 3 x bf16 split (pxr_gemm_b3_f32)."""
-    assert planes.R == N and planes.C == K, f"gemm_b3: planes are {planes.R}x{planes.C}, GEMM wants {N}x{K}"
-    with _gemm_timer(2.0 * M * N * K, tag or "gemm_b3_kernel (3 x bf16 split)"):
-        _l.check(_l.load().pxr_gemm_b3_f32(M, N, K, _l.ptr(A), lda, _l.ptr(planes.buf), planes.ldd, planes.R * planes.ldd,
-                                           _l.ptr(C), ldc, epilogue, act, _l.ptr(bias), _l.ptr(aux), ldaux, tile_hint,
-                                           _l.stream_ptr()), "pxr_gemm_b3_f32")
-    return C
 
 
 def softmax_rows(S: torch.Tensor, rows: int, T: int, ld: int, scale: float):
@@ -301,22 +264,18 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def linear_bwd_input(dy: torch.Tensor, W: torch.Tensor, dgelu_pre: torch.Tensor | None = None,
-                     add: torch.Tensor | None = None, mul: torch.Tensor | None = None, planes_t: "Planes | None" = None):
+                     add: torch.Tensor | None = None, mul: torch.Tensor | None = None):
     """dx = dy W, optionally times gelu'(pre) (from the saved pre-activation), times `mul` (gelu' saved by the forward),
-    or plus `add` (residual gradient).  planes_t: the bf16x3 split of W^T (split_planes(transpose=True)) -> gemm_b3."""
+    or plus `add` (residual gradient)."""
     L = _l.load()
     _req(dy, torch.float32, "dy"); _req(W, torch.float32, "W")
     N, K = W.shape
     M = dy.numel() // N
     dx = torch.empty(*dy.shape[:-1], K, dtype=torch.float32, device=dy.device)
-    kind = ("EPI_MUL_DGELU> (dX through GELU)" if dgelu_pre is not None else "EPI_MUL> (dX x saved gelu')" if mul is not None else
-            "EPI_ADD> (dX + residual grad)" if add is not None else "EPI_NONE> (dX)")
-    if planes_t is not None:
-        aux = dgelu_pre if dgelu_pre is not None else (add if add is not None else mul)
-        epi = EPI_MUL_DGELU if dgelu_pre is not None else (EPI_ADD if add is not None else (EPI_MUL if mul is not None else EPI_NONE))
-        gemm_b3(M, K, N, dy, N, planes_t, dx, K, epi, aux=aux, ldaux=K, tag="gemm_b3_kernel<" + kind)
-        return dx
-    with _gemm_timer(2.0 * M * N * K, "gemm_kernel<KC,XC," + kind):
+    tag = ("gemm_kernel<KC,XC,EPI_MUL_DGELU> (dX through GELU)" if dgelu_pre is not None else
+           "gemm_kernel<KC,XC,EPI_MUL> (dX x saved gelu')" if mul is not None else
+           "gemm_kernel<KC,XC,EPI_ADD> (dX + residual grad)" if add is not None else "gemm_kernel<KC,XC,EPI_NONE> (dX)")
+    with _gemm_timer(2.0 * M * N * K, tag):
         _l.check(L.pxr_linear_bwd_input_f32(_l.ptr(dy), _l.ptr(W), _l.ptr(dx), _l.ptr(dgelu_pre), _l.ptr(add),
                                             _l.ptr(mul), M, N, K, _l.stream_ptr()), "pxr_linear_bwd_input_f32")
     return dx

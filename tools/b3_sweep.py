@@ -36,26 +36,26 @@ def main():
         W = torch.randn(N, K, device=dev) * 0.05
         b = torch.randn(N, device=dev)
         big = name == "scoring"
-        aux = None if big else torch.randn(M, N, device=dev)
         y = torch.empty(M, N, device=dev)
-        pl = ops.Planes(N, K, dev)
-        ops.split_planes([(W, False, pl)])
-        epi = ops.EPI_BIAS            # (the issue-order variants 641 / 643 / 12811 are built for this epilogue only)
-        mk = lambda th: (lambda: ops.gemm_b3(M, N, K, x, K, pl, y, N, epi, bias=b, tile_hint=th))
-        cfgs = {"f32_default": lambda: ops.gemm(True, True, M, N, K, x, K, W, K, y, N, epi, bias=b, use_ws=False),
-                "b3_64": mk(64), "b3_641": mk(641), "b3_642": mk(642), "b3_643": mk(643), "b3_1281": mk(1281), "b3_12811": mk(12811),
-                "split_planes": lambda: ops.split_planes([(W, False, pl)])}
+        epi = ops.EPI_BIAS
+        dy = None if big else torch.randn(M, N, device=dev)
+        dx = None if big else torch.empty(M, K, device=dev)
+        mk = lambda th: (lambda: ops.gemm(True, True, M, N, K, x, K, W, K, y, N, epi, bias=b, use_ws=False, tile_hint=th))
+        mkx = lambda th: (lambda: ops.gemm(True, False, M, K, N, dy, N, W, K, dx, K, ops.EPI_NONE, use_ws=False, tile_hint=th))
+        cfgs = {"f32_64": mk(64), "f32_1281": mk(1281), "b3_64": mk(9064), "b3_1281": mk(91281), "default": mk(0)}
+        if not big:
+            cfgs.update({"dx_f32_64": mkx(64), "dx_b3_64": mkx(9064), "dx_b3_1281": mkx(91281)})
         samples = {k: [] for k in cfgs}
         for rnd in range(3 if big else 5):
             for k, fn in cfgs.items():
                 samples[k].append(timeit(fn, 6 if big else 60))
         row = {k: round(sorted(v)[len(v) // 2], 2) for k, v in samples.items()}
         fl = 2.0 * M * N * K
-        row["tflops_f32"] = round(fl / (row["f32_default"] * 1e-6) / 1e12, 1)
-        row["tflops_b3_best"] = round(fl / (min(v for k, v in row.items() if k.startswith("b3_")) * 1e-6) / 1e12, 1)
+        row["tflops_f32"] = round(fl / (min(row["f32_64"], row["f32_1281"]) * 1e-6) / 1e12, 1)
+        row["tflops_b3_best"] = round(fl / (min(row["b3_64"], row["b3_1281"]) * 1e-6) / 1e12, 1)
         res[name] = row
         print(name, row, flush=True)
-        del x, W, y, aux, pl
+        del x, W, y, dy, dx
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "b3_sweep.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)

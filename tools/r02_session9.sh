@@ -1,7 +1,7 @@
 #!/bin/bash
 # full GPU suite + default bench with the bf16x3 GEMM mode, and the same bench in f32 mode (A/B)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/r02i
+OUT=$REPO/gpurun_out/r02j
 mkdir -p $OUT
 cd $REPO
 export PYTHONUNBUFFERED=1
@@ -13,7 +13,7 @@ python - <<'PY'
 import json
 for f in ("bench_b3", "bench_f32"):
     try:
-        d = json.loads(open(f"/root/repo/gpurun_out/r02i/{f}.json").read().strip().splitlines()[-1])
+        d = json.loads(open(f"/root/repo/gpurun_out/r02j/{f}.json").read().strip().splitlines()[-1])
         r = d["roofline"]
         print(f, round(d["value"]), round(d["ms_per_step"], 4), "gemm us/step", round(r["gemm_time_per_step_us"], 1), "frac", round(r["frac"], 3), "launches", r["launches_per_step"])
         for k, v in r["kernels"].items():
