@@ -12,9 +12,11 @@
 //
 // Ties: scores are continuous fp32 dot products, so ties only occur among -inf entries, which can reach the
 // list only when fewer than K unmasked items exist.
-#include "gemm_f32.cuh"
+#include "gemm_b3.cuh"
 
 #include <cstdlib>
+
+extern "C" int pxr_get_gemm_mode(void);
 
 namespace pxr {
 
@@ -223,12 +225,15 @@ __global__ void __launch_bounds__((FINE == 1 ? 1024 : 512), (FINE == 1 ? 4 : 4))
 // order of the appends).
 constexpr int ST4_HIST_CAP = 2048;   // history pairs of the workgroup's (128 users x its item range) kept in LDS
 
-template <int DUMMY>
-__global__ void __launch_bounds__(1024, 8) score_thresh_kernel(ScoreTopkArgs a) {
+// B3 = 1: the product runs on the bf16 matrix pipe through the exact 3 x bf16 split (gemm_b3.cuh; GEMM mode bf16x3): 96 KB
+// of staging LDS, one 16-wave workgroup per CU at 128 VGPRs instead of two at 64.
+template <int B3>
+__global__ void __launch_bounds__(1024, (B3 ? 4 : 8)) score_thresh_kernel(ScoreTopkArgs a) {
   using Cfg = GemmCfg<ST_BM, ST_BN, true, true, 1, 1>;
-  constexpr int SMEM_FLOATS = 2 * Cfg::STAGE + ST2_BITMAP_WORDS + ST4_HIST_CAP + 4;
+  constexpr int MAIN_FLOATS = B3 ? B3Cfg<ST_BM, ST_BN, 1>::LDS_BYTES / 4 : 2 * Cfg::STAGE;
+  constexpr int SMEM_FLOATS = MAIN_FLOATS + ST2_BITMAP_WORDS + ST4_HIST_CAP + 4;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-  unsigned* bitmap = reinterpret_cast<unsigned*>(smem + 2 * Cfg::STAGE);
+  unsigned* bitmap = reinterpret_cast<unsigned*>(smem + MAIN_FLOATS);
   unsigned* hlist = bitmap + ST2_BITMAP_WORDS;             // (user_local << 20) | (item - first item of the range)
   int* hcount = reinterpret_cast<int*>(hlist + ST4_HIST_CAP);
   const int tid = threadIdx.x;
@@ -267,8 +272,12 @@ __global__ void __launch_bounds__(1024, 8) score_thresh_kernel(ScoreTopkArgs a) 
     const int i0 = tn * ST_BM;
     if (tid < ST2_BITMAP_WORDS) bitmap[tid] = 0u;
     typename Cfg::Acc accs;
-    gemm_mainloop<ST_BM, ST_BN, true, true, false, 1, 2, 2, 1>(accs, a.table, (int64_t)a.D, a.users, a.ld_users, a.N, a.B,
-                                                               0, a.D, i0, u0, smem);
+    if constexpr (B3)
+      gemm_b3_mainloop<ST_BM, ST_BN, true, true, 1>(accs, a.table, (int64_t)a.D, a.users, a.ld_users, a.N, a.B, 0, a.D, i0, u0,
+                                                    reinterpret_cast<char*>(smem));
+    else
+      gemm_mainloop<ST_BM, ST_BN, true, true, false, 1, 2, 2, 1>(accs, a.table, (int64_t)a.D, a.users, a.ld_users, a.N, a.B,
+                                                                 0, a.D, i0, u0, smem);
     if (list_ok) {
       const unsigned off0 = (unsigned)(i0 - (int)r_lo);
       for (int q = tid; q < n_hist; q += 1024) {
@@ -482,7 +491,10 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
   // pass 2: every tile at full GEMM speed, survivors appended
   a.n_split = n_split_full;
   a.tile_stride = 1; a.tau = tau; a.cand_cnt = cnt; a.cand_val = cval; a.cand_idx = cidx; a.cand_cap = ST4_CAP;
-  hipLaunchKernelGGL(score_thresh_kernel<0>, grid, dim3(1024), 0, st, a);
+  if (pxr_get_gemm_mode() && a.D % 4 == 0)
+    hipLaunchKernelGGL(score_thresh_kernel<1>, grid, dim3(1024), 0, st, a);
+  else
+    hipLaunchKernelGGL(score_thresh_kernel<0>, grid, dim3(1024), 0, st, a);
   int rc = pxr_check_launch("pxr_score_topk_f32(threshold pass)");
   if (rc) return rc;
   // pass 3: K best candidates per user
