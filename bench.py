@@ -188,7 +188,9 @@ def pixelnet_main(args):
                       "batch_per_gpu": B, "global_batch": world * B, "seq_len": L, "images_per_step": n_img,
                       "parallelism": f"dp{world}", "hip_graph": False},
            "images_per_s": world * n_img * args.steps / dt, "final_loss": float(loss.detach()),
-           "roofline": {"bound": "mfma", "kernel": "gemm_kernel / grouped_dw_kernel (v_mfma_f32_32x32x2_f32): ViT blocks, batched "
+           "roofline": {"bound": "mfma", "gemm_mode": ops.gemm_mode(),
+                        "kernel": "gemm_b3_kernel / gemm_kernel + grouped dW (bf16x3: v_mfma_f32_32x32x16_bf16 on the exact 3 x bf16 "
+                                  "split; f32: v_mfma_f32_32x32x2_f32 -- see gemm_mode): ViT blocks, batched "
                                                    "attention contractions, rec_fc, sequence block",
                         "achieved": g_fl / g_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": g_fl / g_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
@@ -533,10 +535,17 @@ def main():
             traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roof = {"bound": "mfma", "kernel": "gemm_kernel / grouped_dw_kernel (v_mfma_f32_32x32x2_f32; every nn.Linear "
-                                       "fwd/bwd of the step)",
+    b3 = ops.gemm_mode() == "bf16x3"
+    roof = {"bound": "mfma",
+            "kernel": ("gemm_b3_kernel / grouped_dw_b3_kernel (v_mfma_f32_32x32x16_bf16 on an exact 3 x bf16 split of the fp32 "
+                       "operands, 6 products per multiply, fp32 accumulate; every nn.Linear fwd/bwd of the step)" if b3 else
+                       "gemm_kernel / grouped_dw_kernel (v_mfma_f32_32x32x2_f32; every nn.Linear fwd/bwd of the step)"),
+            "gemm_mode": ops.gemm_mode(),
             "achieved": g_fl / g_union / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": g_fl / g_union / 1e12 / MFMA_F32_PEAK_TF, "traffic": traffic,
+            "matrix_pipe": ({"executed_tflops": 6.0 * g_fl / g_union / 1e12, "peak": 2500.0, "frac": 6.0 * g_fl / g_union / 1e12 / 2500.0,
+                             "note": "the bf16 products actually issued (6 per fp32 multiply) against the dense bf16 MFMA peak"}
+                            if b3 else None),
             "launches_per_step": n_launch / max(n_inst, 1), "avg_kernel_us": g_union / max(n_launch, 1) * 1e6,
             "algorithmic_flops_per_step": g_fl / max(n_inst, 1),
             "gemm_time_per_step_us": g_union / max(n_inst, 1) * 1e6,
@@ -546,9 +555,11 @@ def main():
             "kernels": per_kernel,
             "note": f"HIP events (each on the stream its kernel runs on) around every GEMM launch of {n_inst} extra "
                     "eager steps issued right after the timed region (bracketing launches inside it would make the step "
-                    "host-bound); achieved = algorithmic flops / UNION of the launches' [start,end] intervals, because "
-                    "the weight-gradient launches co-run with the input-gradient chain on a second stream; `traffic` = "
-                    "HBM bytes per launch from the separate rocprofv3 --pmc pass of this command (profiles/r02/pmc)"}
+                    "host-bound); achieved = ALGORITHMIC fp32 flops / union of the launches' [start,end] intervals (= the sum "
+                    "of durations in the default one-stream schedule); peak = the fp32-input MFMA peak, i.e. what the same "
+                    "arithmetic costs on v_mfma_f32_32x32x2_f32 -- in bf16x3 mode the products run on the bf16 pipe "
+                    "(`matrix_pipe`), so `frac` may exceed what that instruction could reach; `traffic` = HBM bytes per "
+                    "launch from the separate rocprofv3 --pmc pass of this command (profiles/r02/pmc)"}
     hbm_kernels = per_tag(other_events, 1e9, "gbs")
 
     out = {
@@ -557,6 +568,10 @@ def main():
         "value": world * B * args.steps / dt, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "arithmetic": ("fp32 storage and accumulation everywhere; GEMM products on the bf16 matrix pipe after an exact split of "
+                       "each fp32 operand into 3 bf16 terms (6 of 9 cross products: error ~2^-25 |a||b| per product, fp32-class; "
+                       "tests/test_gpu_gemm_b3.py); attention, LayerNorm, loss, optimizer in fp32" if b3 else
+                       "fp32 end to end (f32-input MFMA)"),
         "config": {"workload": (f"custom shape (NOT the headline config): SASRec IDNet emb={D} seq_len={L}, {N} items, "
                                 f"{NS['H']} heads, inner 2x, 2 layers" if custom else
                                 "BASELINE.json configs[1]: SASRec IDNet emb=512 seq_len=50, 400001 items, 4 heads, "
@@ -663,9 +678,11 @@ def main():
         t_s = time_kernel(lambda: ops.gemm(True, True, 1024, N, D, last, L * D, table, D, scores, N, ops.EPI_NONE,
                                            use_ws=False), iters=10)
         fl = 2.0 * 1024 * N * D
-        out["roofline_scoring"] = {"bound": "mfma", "kernel": "gemm_kernel<128,128,KC,KC>", "achieved": fl / t_s / 1e12,
+        out["roofline_scoring"] = {"bound": "mfma", "kernel": "gemm_b3_kernel<128,128,KC,KC>" if b3 else "gemm_kernel<128,128,KC,KC>",
+                                   "achieved": fl / t_s / 1e12,
                                    "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl / t_s / 1e12 / MFMA_F32_PEAK_TF,
-                                   "avg_kernel_us": t_s * 1e6, "note": "409.6 MFLOP/user x 1024 users, exact fp32 MFMA"}
+                                   "avg_kernel_us": t_s * 1e6,
+                                   "note": "409.6 MFLOP/user x 1024 users (algorithmic fp32 flops; gemm_mode " + ops.gemm_mode() + ")"}
         del scores
         # (3) the dense AdamW table sweep (what `table_update="dense"` runs every step; the default lazy optimizer
         # replays untouched rows on demand instead): pure HBM streaming of p, m, v

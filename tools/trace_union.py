@@ -16,7 +16,7 @@ def main():
         key = n.replace("void ", "").split("(")[0][:100]
         p = per.setdefault(key, [0, 0])
         p[0] += 1; p[1] += e - s
-        if "gemm_kernel" in n or "grouped_dw_kernel" in n:
+        if "gemm_kernel" in n or "grouped_dw" in n or "gemm_b3_kernel" in n or "gemm_sk_kernel" in n:
             iv.append((s, e))
     iv.sort()
     union, cs, ce = 0, None, None
