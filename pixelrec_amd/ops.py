@@ -58,6 +58,9 @@ class _gemm_timer:
         self.flops = flops
         self.tag = tag          # names the kernel instantiation the launch resolves to (see bench.py's roofline)
         self.on = GEMM_TIMING is not None
+        if self.on and tag.startswith(("gemm_kernel", "grouped_dw_kernel")) and _l.load().pxr_get_gemm_mode():
+            # bf16x3 GEMM mode: the same launch sites resolve to the bf16-pipe kernels (csrc/gemm_b3.hip)
+            self.tag = tag.replace("gemm_kernel", "gemm_b3_kernel", 1).replace("grouped_dw_kernel", "grouped_dw_b3_kernel", 1)
 
     def __enter__(self):
         if self.on:

@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the line the last GPU run committed (profiles/r01/bench_default_line.json):
+"""The bench.py output contract, checked on the line the last GPU run committed (profiles/r02/bench_default_line_final.json):
 every key the driver parses is there with the right type, the metric/config are BASELINE.json's, and the derived
 fields are consistent with each other.  (bench.py itself needs an MI355X: this guards the schema on CPU.)"""
 import json
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    text = open(os.path.join(ROOT, "profiles", "r01", "bench_default_line.json")).read().strip().splitlines()
+    text = open(os.path.join(ROOT, "profiles", "r02", "bench_default_line_final.json")).read().strip().splitlines()
     assert len(text) == 1, "bench.py prints ONE JSON line"
     return json.loads(text[0])
 
@@ -42,6 +42,10 @@ def test_roofline_and_cpu_baseline_objects():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert r["peak"] > 0 and 0 < r["frac"] <= 1 and math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-6)
     assert r["traffic"] is None or r["traffic"] > 0
+    assert r["gemm_mode"] in ("bf16x3", "f32") and (r["matrix_pipe"] is None) == (r["gemm_mode"] == "f32")
+    # round 2: the stream does not repeat inside the run and the line says what the lazy table update costs
+    assert d["stream"]["repeats_inside_run"] is False and d["stream"]["age_steps"] >= 256
+    assert d["roofline_adamw_rows"]["us_per_step"] > 0 and d["lazy_flush"]["amortised_us_per_step"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert c["unit"] == d["unit"]
