@@ -223,7 +223,7 @@ def main():
                          "to the steady-state distribution of gaps an epoch presents (and ramp the clocks)")
     ap.add_argument("--table-update", choices=("lazy", "dense"), default="lazy",
                     help="table AdamW schedule (dense = sweep all rows every step; eager only)")
-    ap.add_argument("--dw-mode", default=None, help="weight-gradient placement: grouped | fork_layer | fork_half")
+    ap.add_argument("--dw-mode", default=None, help="weight-gradient placement: grouped | fork_tail | fork_layer | fork_half")
     ap.add_argument("--split-exchange", action="store_true",
                     help="data parallel: force the reduced-capacity two-collective row exchange (default from 4 ranks up)")
     ap.add_argument("--full-exchange", action="store_true",

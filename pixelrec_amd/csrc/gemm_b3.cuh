@@ -54,13 +54,16 @@ __device__ __forceinline__ void b3_split8(const float (&x)[8], u32x4v (&p)[3]) {
   }
 }
 
-template <int BM, int BN, int FINE = 0>
+// STAGES = 3: a third LDS stage, so that the first fragments of the NEXT K tile are read before the barrier that ends the
+// current one (they were written an iteration earlier) -- the matrix pipe does not wait for an LDS round trip after
+// every barrier.
+template <int BM, int BN, int FINE = 0, int STAGES = 2>
 struct B3Cfg {
   using F = GemmCfg<BM, BN, true, true, 1, FINE>;     // same wave grid, accumulators and epilogues as the f32 kernels
   static constexpr int NT = F::NT;
   static constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;       // bytes per plane per stage
   static constexpr int STAGE = 3 * (A_PLANE + B_PLANE);            // bytes
-  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int LDS_BYTES = STAGES * STAGE;
   static constexpr int A_ITEMS = BM * 4, B_ITEMS = BN * 4;         // (row, 8-k chunk) staging items per K tile
   // every thread stages A_PT items of A and B_PT of B, or (16-wave tiles) the first half of the workgroup stages A
   // and the second half B
@@ -113,13 +116,14 @@ struct B3Operand {
 // acc tile (m0, n0) = A_op x B_op over k in [kbeg, kend); operand flavours as gemm_f32.cuh (KC: [X][K], XC: [K][X]).
 // CS (XC A operand only): cs[q] += the sum over k of the values this thread staged for its q-th item (a column of the
 // stored matrix); the caller adds the 4 chunk owners of each column (items x, x + BM, x + 2 BM, x + 3 BM).
-template <int BM, int BN, bool A_KC, bool B_KC, int FINE = 0, bool CS = false, int PD = 2>
-__device__ __forceinline__ void gemm_b3_mainloop(typename B3Cfg<BM, BN, FINE>::F::Acc& accs, const float* __restrict__ A,
+template <int BM, int BN, bool A_KC, bool B_KC, int FINE = 0, bool CS = false, int STAGES = 2, int PD = 2>
+__device__ __forceinline__ void gemm_b3_mainloop(typename B3Cfg<BM, BN, FINE, STAGES>::F::Acc& accs, const float* __restrict__ A,
                                                  int64_t lda, const float* __restrict__ B, int64_t ldb, int M, int N,
                                                  int kbeg, int kend, int m0, int n0, char* smem, float* cs = nullptr) {
-  using Cfg = B3Cfg<BM, BN, FINE>;
+  using Cfg = B3Cfg<BM, BN, FINE, STAGES>;
   using F = typename Cfg::F;
   constexpr int NT = Cfg::NT;
+  static_assert(PD == 2, "the register ring is two tiles deep");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / F::WGN, wn = wave % F::WGN;
@@ -234,42 +238,82 @@ __device__ __forceinline__ void gemm_b3_mainloop(typename B3Cfg<BM, BN, FINE>::F
     accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[1], accl, 0, 0, 0);   // mid * mid
   };
 
-#pragma unroll
-  for (int s = 0; s < PD; ++s) fetch(s, ring[s]);
   Staged st;
-  split(ring[0], st);
-  put(0, st, ring[0]);
-  __syncthreads();
   Frag fr[2];
-  read_frag(fr[0], 0, 0);
-  for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+  auto hints = [&]() {
+    if constexpr (!LATE_SPLIT) {
+      // issue order: the split's VALU work and the LDS writes in the shadow of the MFMAs (a wave issues in order;
+      // 32 cycles of matrix pipe per MFMA cover ~7 other instructions)
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
-      const int kt = kt0 + s;
-      if (kt < nk) {   // block-uniform
-        const int buf = kt & 1, nxt = buf ^ 1;
-        fetch(kt + PD, ring[s]);          // slot s held tile kt, which already sits in LDS
-        read_frag(fr[1], buf, 1);
-        split(ring[(s + 1) % PD], st);    // (zeros after the last tile)
-        mfma(fr[0]);
-        put(nxt, st, ring[(s + 1) % PD]);
-        mfma(fr[1]);
-        if constexpr (!LATE_SPLIT) {
-          // issue order: the split's VALU work and the LDS writes in the shadow of the MFMAs (a wave issues in order;
-          // 32 cycles of matrix pipe per MFMA cover ~7 other instructions)
+      for (int q = 0; q < 6; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7 * SLOTS / 2 + 1, 0);
+      }
 #pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 7 * SLOTS / 2 + 1, 0);
-          }
+      for (int q = 0; q < 6; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+  };
+  if constexpr (STAGES == 2) {
+    fetch(0, ring[0]);
+    fetch(1, ring[1]);
+    split(ring[0], st);
+    put(0, st, ring[0]);
+    __syncthreads();
+    read_frag(fr[0], 0, 0);
+    for (int kt0 = 0; kt0 < nk; kt0 += 2) {
 #pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          }
+      for (int s = 0; s < 2; ++s) {
+        const int kt = kt0 + s;
+        if (kt < nk) {   // block-uniform
+          const int buf = kt & 1, nxt = buf ^ 1;
+          fetch(kt + 2, ring[s]);           // slot s held tile kt, which already sits in LDS
+          read_frag(fr[1], buf, 1);
+          split(ring[s ^ 1], st);           // (zeros after the last tile)
+          mfma(fr[0]);
+          put(nxt, st, ring[s ^ 1]);
+          mfma(fr[1]);
+          hints();
+          __syncthreads();
+          read_frag(fr[0], nxt, 0);
         }
-        __syncthreads();
-        read_frag(fr[0], nxt, 0);
+      }
+    }
+  } else {
+    // tiles 0 and 1 into stages 0 and 1, tiles 2 and 3 into the ring; iteration kt multiplies tile kt, writes tile kt + 2
+    // into the stage tile kt - 1 left, fetches tile kt + 4 and -- before its closing barrier -- reads the first fragments
+    // of tile kt + 1 (complete since the previous barrier)
+    static_assert(STAGES == 3, "2 or 3 LDS stages");
+    fetch(0, ring[0]);
+    fetch(1, ring[1]);
+    split(ring[0], st);
+    put(0, st, ring[0]);
+    fetch(2, ring[0]);
+    split(ring[1], st);
+    put(1, st, ring[1]);
+    fetch(3, ring[1]);
+    __syncthreads();
+    read_frag(fr[0], 0, 0);
+    int cur = 0;                            // stage of tile kt
+    for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int kt = kt0 + s;
+        if (kt < nk) {   // block-uniform
+          const int nx1 = cur == 2 ? 0 : cur + 1, nx2 = nx1 == 2 ? 0 : nx1 + 1;
+          read_frag(fr[1], cur, 1);
+          split(ring[s], st);               // tile kt + 2 (zeros after the last tile)
+          mfma(fr[0]);
+          read_frag(fr[0], nx1, 0);         // tile kt + 1
+          put(nx2, st, ring[s]);
+          fetch(kt + 4, ring[s]);
+          mfma(fr[1]);
+          hints();
+          __syncthreads();
+          cur = nx1;
+        }
       }
     }
   }

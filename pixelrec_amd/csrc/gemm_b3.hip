@@ -7,15 +7,17 @@
 // autograd transposes of all of them).
 #include "gemm_b3.cuh"
 
+#include <cstdlib>
+
 namespace pxr {
 
-template <int BM, int BN, bool A_KC, bool B_KC, int FINE, int EPI>
+template <int BM, int BN, bool A_KC, bool B_KC, int FINE, int EPI, int STAGES = 2>
 __global__ void __launch_bounds__((B3Cfg<BM, BN, FINE>::NT))
 gemm_b3_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
                float* __restrict__ aux, int64_t ldaux, int tiles_m, int tiles_n, int ksplit_len,
                int64_t split_stride, int n_fastest, GemmBatch bt) {
-  using Cfg = B3Cfg<BM, BN, FINE>;
+  using Cfg = B3Cfg<BM, BN, FINE, STAGES>;
   using F = typename Cfg::F;
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
   if (bt.nb2 > 0) {   // batched launch (block-uniform)
@@ -35,13 +37,14 @@ gemm_b3_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict
   AuxRegs<F, EPI, DIRECT> ar;
   epi_prefetch_aux<F, EPI, DIRECT>(ar, aux, ldaux, M, N, m0, n0, lp);
   typename F::Acc accs;
-  gemm_b3_mainloop<BM, BN, A_KC, B_KC, FINE>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
+  gemm_b3_mainloop<BM, BN, A_KC, B_KC, FINE, false, STAGES>(accs, A, lda, B, ldb, M, N, kbeg, kend, m0, n0, smem);
   epi_store<F, EPI, DIRECT>(accs, ar, C, ldc, M, N, bias, aux, ldaux, m0, n0, lp, bt.act);
 }
 
 // All dW[N,K] = dY[M,N]^T X[M,K] (+ db[N] = column sums of dY) of a backward pass in ONE launch: see grouped_dw_kernel.
+template <int STAGES>
 __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_b3_kernel(DwGroup g) {
-  using Cfg = B3Cfg<64, 64, 0>;
+  using Cfg = B3Cfg<64, 64, 0, STAGES>;
   using F = typename Cfg::F;
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
   const int t = xcd_remap(blockIdx.x, g.total_tiles);
@@ -57,9 +60,9 @@ __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_b3_kernel(DwGroup g) 
   float cs[1] = {0.f};
   const bool do_bias = (P.db != nullptr) && (tn == 0);
   if (do_bias)
-    gemm_b3_mainloop<64, 64, false, false, 0, true>(accs, P.dy, P.N, P.x, P.K, P.N, P.K, 0, P.M, m0, n0, smem, cs);
+    gemm_b3_mainloop<64, 64, false, false, 0, true, STAGES>(accs, P.dy, P.N, P.x, P.K, P.N, P.K, 0, P.M, m0, n0, smem, cs);
   else
-    gemm_b3_mainloop<64, 64, false, false, 0, false>(accs, P.dy, P.N, P.x, P.K, P.N, P.K, 0, P.M, m0, n0, smem);
+    gemm_b3_mainloop<64, 64, false, false, 0, false, STAGES>(accs, P.dy, P.N, P.x, P.K, P.N, P.K, 0, P.M, m0, n0, smem);
   auto& acc = accs.v[0][0];
   const LanePos lp = lane_pos<F>();
   const int col = n0 + lp.wn * 32 + lp.r;
@@ -84,14 +87,19 @@ __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_b3_kernel(DwGroup g) 
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int FINE, int EPI>
+static int b3_stages() {
+  static const int st = getenv("PXR_B3_STAGES") ? atoi(getenv("PXR_B3_STAGES")) : 2;    // LDS stages of the 64x64 tile
+  return st == 3 ? 3 : 2;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int FINE, int EPI, int STAGES = 2>
 static int launch_b3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
                      const float* bias, float* aux, int64_t ldaux, int splits, int ksplit_len, int64_t split_stride,
                      const GemmBatch& bt, int batch, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   static const int xcd_env = getenv("PXR_GEMM_XCD") ? atoi(getenv("PXR_GEMM_XCD")) : -1;
   const int n_fastest = xcd_env >= 0 ? xcd_env : (M > N ? 1 : 0);
-  hipLaunchKernelGGL((gemm_b3_kernel<BM, BN, A_KC, B_KC, FINE, EPI>), dim3(tiles_m * tiles_n, splits, batch),
+  hipLaunchKernelGGL((gemm_b3_kernel<BM, BN, A_KC, B_KC, FINE, EPI, STAGES>), dim3(tiles_m * tiles_n, splits, batch),
                      dim3(B3Cfg<BM, BN, FINE>::NT), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, tiles_m, tiles_n,
                      ksplit_len, split_stride, n_fastest, bt);
   return pxr_check_launch("pxr_gemm_f32(bf16x3)");
@@ -104,6 +112,9 @@ static int tile_b3(int tile, const float* A, int64_t lda, const float* B, int64_
   if (tile == 1281)
     return launch_b3<128, 128, A_KC, B_KC, 1, EPI>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits, ksplit_len,
                                                    split_stride, bt, batch, st);
+  if (b3_stages() == 3)
+    return launch_b3<64, 64, A_KC, B_KC, 0, EPI, 3>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits, ksplit_len,
+                                                    split_stride, bt, batch, st);
   return launch_b3<64, 64, A_KC, B_KC, 0, EPI>(A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, splits, ksplit_len,
                                                split_stride, bt, batch, st);
 }
@@ -134,7 +145,8 @@ int gemm_b3_launch(int a_kc, int b_kc, int epilogue, int tile, const float* A, i
 }
 
 int grouped_dw_b3_launch(const DwGroup& g, hipStream_t st) {
-  hipLaunchKernelGGL(grouped_dw_b3_kernel, dim3(g.total_tiles), dim3(GEMM_THREADS), 0, st, g);
+  if (b3_stages() == 3) hipLaunchKernelGGL(grouped_dw_b3_kernel<3>, dim3(g.total_tiles), dim3(GEMM_THREADS), 0, st, g);
+  else hipLaunchKernelGGL(grouped_dw_b3_kernel<2>, dim3(g.total_tiles), dim3(GEMM_THREADS), 0, st, g);
   return pxr_check_launch("pxr_grouped_linear_bwd_weight_f32(bf16x3)");
 }
 

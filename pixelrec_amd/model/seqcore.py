@@ -102,7 +102,9 @@ class SeqRecCore(BaseModel):
         #   "grouped"    one launch on the main stream after the input-gradient chain (default);
         #   "fork_layer" one launch per layer on a side stream as soon as the layer's dqkv exists, so that its tiles
         #                co-run with the input-gradient chain of the layers below (a parallel branch of a captured graph);
-        #   "fork_half"  two launches per layer (FFN pair after du, attention pair after dqkv): starts earlier.
+        #   "fork_half"  two launches per layer (FFN pair after du, attention pair after dqkv): starts earlier;
+        #   "fork_tail"  the one grouped launch on a side stream BESIDE the tail of the step (reductions, segmented sum of
+        #                the table gradient, the optimizer's row update).
         # Measured on MI355X (profiles/r02/README.md): the kernels DO overlap (sum of durations 1190 us vs 935 us of
         # union per step) but the aggregate rate does not rise -- both sides slow down, the step gets 2-8 % LONGER
         # (1.199 -> 1.250 / 1.319 ms).  The chip is not short of idle MFMA slots to fill: under sustained fp32-MFMA
@@ -292,7 +294,7 @@ class SeqRecCore(BaseModel):
             if side is None or side.device != main.device:
                 side = self._side_stream = torch.cuda.Stream(device=main.device)
         pending = []
-        fork = self.group_weight_grads and self.weight_grad_mode in ("fork_layer", "fork_half")
+        fork = self.group_weight_grads and self.weight_grad_mode in ("fork_layer", "fork_half", "fork_tail")
         if fork:
             side = self._side_stream
             if side is None or side.device != main.device:
@@ -348,11 +350,16 @@ class SeqRecCore(BaseModel):
             dctx = ops.linear_bwd_input(dxa, self._p(f"{i}.o.w"))
             dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv)
             weight_grads(dqkv.view(T, 3 * D), a["h_in"].view(T, D), f"{i}.q.w", f"{i}.q.b", 3)
-            if fork:
+            if fork and self.weight_grad_mode != "fork_tail":
                 fork_pending()
             dh = ops.linear_bwd_input(dqkv, self._p(f"{i}.q.w", span=3), add=dz1)
         dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,
                             step_dev=sdv, defer=defer)
+        if fork and self.weight_grad_mode == "fork_tail":
+            # the ONE grouped weight-gradient launch goes to the side stream here; the main stream carries on with the
+            # small reductions, the segmented sum of the table gradient and (defer_weight_grad_join) the optimizer's
+            # row update -- memory/latency-bound kernels beside an MFMA-bound one
+            fork_pending()
         ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1), defer=defer)
         # every dropout-mask consumer of this pass has been issued: the reduction launch also advances the dropout
         # step counter (saves a 1-thread launch per step)

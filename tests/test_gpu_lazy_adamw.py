@@ -138,6 +138,41 @@ def test_graph_replay_equals_eager_steps():
         assert torch.equal(se[k], sg[k]), k
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_weight_gradients_beside_the_tail_of_the_step(graph):
+    """weight_grad_mode "fork_tail" (the grouped weight-gradient launch on a side stream beside the reductions, the
+    segmented sum and the row update) == the one-stream schedule, bit for bit, eagerly and replayed from a hipGraph."""
+    from pixelrec_amd.graph import GraphedTrainStep
+    from pixelrec_amd.optim import PxrAdamW
+
+    make, rng, zipf, synth = _setup(n_items=3000)
+    batches = [tuple(torch.from_numpy(x).cuda() for x in synth.train_batch(3000, 4, 10, rng, zipf)) for _ in range(8)]
+
+    def run(mode):
+        m = make()
+        m.weight_grad_mode = mode
+        m.defer_weight_grad_join = True
+        m.hidden_dropout_prob = m.attn_dropout_prob = 0.1
+        opt = PxrAdamW(m, lr=1e-3, weight_decay=0.1)
+        losses, g = [], None
+        for i, (it, mk) in enumerate(batches):
+            if graph and i >= 2:
+                if g is None:
+                    g = GraphedTrainStep(m, opt, it, mk, warmup=0)
+                losses.append(float(g(it, mk)))
+            else:
+                loss = m((it, mk)); loss.backward(); opt.step()
+                losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    l0, s0 = run("grouped")
+    l1, s1 = run("fork_tail")
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_checkpoint_round_trip_resumes_bit_identically():
     """k steps -> state_dict (model + optimizer, lazy table flushed) -> fresh model / optimizer -> k more steps must equal
     2k uninterrupted steps bit for bit (dropout on: the seed offset is part of the resumed state through step_count)."""
