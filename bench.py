@@ -301,8 +301,12 @@ def main():
     # a rigorous bound on the unique table rows any batch of THIS stream touches: the row capacity of the data-parallel
     # exchange (GradSync(exchange_rows=...)); all ranks agree on the maximum once, before the first step
     max_unique = max(int(np.count_nonzero(np.unique(it))) for it in its)
-    items_all = torch.from_numpy(np.stack(its)).to(dev)
-    mask_all = torch.from_numpy(np.stack(mks)).to(dev)
+    # every batch is ONE packed int64 row (ids | mask), the two tensors are views of it: the graphed step copies a batch
+    # into its static buffer with one copy (pixelrec_amd/graph.py)
+    n_it = its[0].size
+    packed_all = torch.from_numpy(np.concatenate([np.stack(its).reshape(n_stream, -1),
+                                                  np.stack(mks).reshape(n_stream, -1).astype(np.int64)], axis=1)).to(dev)
+    items_shape, mask_shape = its[0].shape, mks[0].shape
     t_gen = time.perf_counter() - t_gen
     del its, mks
 
@@ -323,7 +327,8 @@ def main():
             return n_stream
 
         def __getitem__(self, i):
-            return items_all[i], mask_all[i]
+            row = packed_all[i]
+            return row[:n_it].view(items_shape), row[n_it:].view(mask_shape)
 
     pool = _Pool()
 

@@ -24,8 +24,14 @@ class GraphedTrainStep:
         # every step goes through optimizer.step(): the join with the weight-gradient side stream can wait until the
         # flat gradient is consumed (seqcore.SeqRecCore.wait_flat_grads) -- inside the capture, so the graph is closed
         self.model.defer_weight_grad_join = True
-        self.items = items.clone()
-        self.mask = masked_index.clone()
+        # the batch lives in ONE buffer (ids | mask): a caller that hands over two views of one packed tensor (bench.py,
+        # the trainer's batcher) pays one copy per step instead of two
+        n_i = items.numel()
+        self._packed = torch.empty(n_i + masked_index.numel(), dtype=torch.int64, device=items.device)
+        self.items = self._packed[:n_i].view(items.shape)
+        self.mask = self._packed[n_i:].view(masked_index.shape)
+        self.items.copy_(items)
+        self.mask.copy_(masked_index)
         # look-ahead: the NEXT batch's ids (SASRec.set_next_batch) -- its table rows are caught up beside this step's
         # GEMMs.  Without a next batch the buffer holds this batch again (nothing left to replay: two light launches).
         self.items_next = items.clone() if (lookahead and hasattr(self.model, "set_next_batch")) else None
@@ -95,9 +101,23 @@ class GraphedTrainStep:
     def matches(self, items, masked_index) -> bool:
         return items.shape == self.items.shape and masked_index.shape == self.mask.shape
 
+    @staticmethod
+    def pack(items, masked_index):
+        """(items, masked_index) as two views of one packed int64 tensor (what __call__ copies in one go)."""
+        pk = torch.cat([items.reshape(-1), masked_index.reshape(-1).to(torch.int64)])
+        n_i = items.numel()
+        return pk[:n_i].view(items.shape), pk[n_i:].view(masked_index.shape)
+
     def __call__(self, items, masked_index, next_items=None):
-        self.items.copy_(items, non_blocking=True)
-        self.mask.copy_(masked_index, non_blocking=True)
+        if (items.dtype == torch.int64 and masked_index.dtype == torch.int64 and items.is_contiguous()
+                and masked_index.is_contiguous() and items.device == masked_index.device
+                and masked_index.data_ptr() == items.data_ptr() + 8 * items.numel()
+                and items.untyped_storage().data_ptr() == masked_index.untyped_storage().data_ptr()):
+            src = torch.as_strided(items, (self._packed.numel(),), (1,))      # the packed range, one copy
+            self._packed.copy_(src, non_blocking=True)
+        else:
+            self.items.copy_(items, non_blocking=True)
+            self.mask.copy_(masked_index, non_blocking=True)
         if self.items_next is not None:
             nxt = next_items if (next_items is not None and next_items.shape == self.items.shape) else items
             self.items_next.copy_(nxt, non_blocking=True)

@@ -48,7 +48,12 @@ class _Prefetcher:
         try:
             pin = self.device.type == "cuda"
             for batch in self.loader:   # pinned staging (in this thread) makes the consumer's H2D copies asynchronous
-                if pin:
+                if (len(batch) == 2 and all(isinstance(x, torch.Tensor) and x.dtype == torch.int64 for x in batch)):
+                    # (items, masked_index): ONE packed host tensor -> one H2D copy, and the graphed step copies the two
+                    # device views into its static buffer in one go (graph.GraphedTrainStep.__call__)
+                    pk = torch.cat([batch[0].reshape(-1), batch[1].reshape(-1)])
+                    batch = ("packed", pk.pin_memory() if pin else pk, batch[0].shape, batch[1].shape)
+                elif pin:
                     batch = tuple(x.pin_memory() if isinstance(x, torch.Tensor) else x for x in batch)
                 self.q.put(batch)
         except BaseException as e:  # surfaced in the consumer
@@ -62,6 +67,11 @@ class _Prefetcher:
                 return
             if isinstance(b, BaseException):
                 raise b
+            if isinstance(b[0], str):        # packed (items | masked_index)
+                d = b[1].to(self.device, non_blocking=True)
+                n_i = int(torch.Size(b[2]).numel())
+                yield d[:n_i].view(b[2]), d[n_i:].view(b[3])
+                continue
             if isinstance(b[1], tuple):      # device sampler: (positive windows, (seed, batch counter))
                 pos = b[0].to(self.device, non_blocking=True)
                 yield ops.sample_negatives(pos, self.loader.item_num, *b[1])
