@@ -257,12 +257,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # PXR_BENCH_SHARE_GPU=1 (development only): all ranks on GPU 0 over gloo -- exercises the N > 1 control flow of this
+    # script on a 1-GPU box; its numbers mean nothing
+    share = os.environ.get("PXR_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        if share:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from pixelrec_amd import ops, synth
     from pixelrec_amd.model import SASRec
