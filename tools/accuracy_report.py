@@ -1,0 +1,91 @@
+"""Accuracy of the two GEMM modes against fp64, on the GEMM shapes of the training step and on a whole training step
+(loss, gradients, parameters after AdamW steps against the CPU oracle).   usage: python tools/accuracy_report.py
+Writes gpurun_out/accuracy_report.json (copied to profiles/)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+import torch
+
+from pixelrec_amd import ops
+
+
+def gemm_rows():
+    rows = []
+    g = torch.Generator().manual_seed(0)
+    for name, M, N, K in (("qkv", 3200, 1536, 512), ("out-proj", 3200, 512, 512), ("ffn-1", 3200, 1024, 512),
+                          ("ffn-2", 3200, 512, 1024), ("scoring (8 K items)", 1024, 8192, 512), ("vit fc2", 3200, 768, 3072)):
+        x, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+        ref = x.double() @ W.double().t()
+        scale = (x.double().abs() @ W.double().abs().t())
+        out = {}
+        for mode in ("f32", "bf16x3"):
+            ops.set_gemm_mode(mode)
+            y = torch.empty(M, N, device="cuda")
+            ops.gemm(True, True, M, N, K, x.cuda(), K, W.cuda(), K, y, N, use_ws=False)
+            e = (y.double().cpu() - ref).abs()
+            out[mode] = {"max_abs_err": float(e.max()), "max_err_over_sum_abs_products": float((e / scale).max()),
+                         "rms_err_over_rms_ref": float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())}
+        rows.append({"gemm": name, "M": M, "N": N, "K": K, **{f"{m}_{k}": v for m, d in out.items() for k, v in d.items()}})
+        print(rows[-1], flush=True)
+    return rows
+
+
+def step_rows():
+    from oracle import sasrec_oracle as O
+    from pixelrec_amd import synth
+    from pixelrec_amd.model import SASRec
+    from pixelrec_amd.optim import PxrAdamW
+
+    N, D, L, H, B = 5000, 512, 50, 4, 16
+    cfg = {"n_layers": 2, "n_heads": H, "embedding_size": D, "inner_size": 2, "hidden_dropout_prob": 0.0,
+           "attn_dropout_prob": 0.0, "hidden_act": "gelu", "layer_norm_eps": 1e-12, "initializer_range": 0.02,
+           "MAX_ITEM_LIST_LENGTH": L, "seed": 2020}
+
+    class DL:
+        item_num = N
+
+    params = O.synth_params(N, D, L, 2, 2, seed=7)
+    rng = np.random.default_rng(3)
+    z = synth.ZipfItems(N, seed=3)
+    batches = [tuple(torch.from_numpy(a) for a in synth.train_batch(N, B, L, rng, z)) for _ in range(3)]
+    # oracle: 3 AdamW steps on the CPU in fp64-free plain fp32 torch (what the reference computes)
+    om = O.SASRecOracle(cfg, N) if hasattr(O, "SASRecOracle") else None
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        ops.set_gemm_mode(mode)
+        m = SASRec(cfg, DL())
+        m.load_state_dict(params, strict=True)
+        m = m.cuda().train()
+        it, mk = batches[0]
+        loss = m((it.cuda(), mk.cuda()))
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if k != "item_embedding.weight"}
+        grads["item_embedding.weight"] = m.sparse_table_grad.to_dense(N).cpu()
+        res[mode] = (float(loss.detach()), grads)
+    lf, gf = res["f32"]
+    lb, gb = res["bf16x3"]
+    rel = sorted(((float((gf[k] - gb[k]).abs().max()) / max(float(gf[k].abs().max()), 1e-30), k) for k in gf
+                  if ".key.bias" not in k), reverse=True)
+    out = {"loss_f32_mode": lf, "loss_bf16x3_mode": lb,
+           "largest_gradient_differences_between_modes_relative_to_the_tensor_max": rel[:4],
+           "note": "one forward + backward of N=5000 items, emb 512, seq 50, B=16 from the same parameters in both modes "
+                   "(each mode is held to the reference goldens by tests/test_gpu_sasrec.py).  Key-projection biases are "
+                   "left out: their gradient is mathematically zero (softmax shift invariance), what is computed is rounding "
+                   "noise in either mode."}
+    print(out, flush=True)
+    return out
+
+
+def main():
+    rep = {"gemm_vs_fp64": gemm_rows(), "training_steps": step_rows()}
+    ops.set_gemm_mode("bf16x3")
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "accuracy_report.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(rep, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
