@@ -103,8 +103,11 @@ class SeqRecCore(BaseModel):
         #   "fork_layer" one launch per layer on a side stream as soon as the layer's dqkv exists, so that its tiles
         #                co-run with the input-gradient chain of the layers below (a parallel branch of a captured graph);
         #   "fork_half"  two launches per layer (FFN pair after du, attention pair after dqkv): starts earlier;
-        #   "fork_tail"  the one grouped launch on a side stream BESIDE the tail of the step (reductions, segmented sum of
-        #                the table gradient, the optimizer's row update).
+        #   "fork_tail"  the one grouped launch on a side stream BESIDE the tail of the step (reductions, segmented sum of the
+        #                table gradient, the optimizer's row update): memory / latency-bound kernels next to an MFMA-bound
+        #                one -- 1.083 -> 1.069 ms replayed from a hipGraph in bf16x3 mode, but +0.14 ms of HOST time per
+        #                eagerly issued step (stream waits), which is what a multi-rank step is bound by: not the default.
+        #                The per-layer forks below lose outright (1.13 / 1.18 ms).
         # Measured on MI355X (profiles/r02/README.md): the kernels DO overlap (sum of durations 1190 us vs 935 us of
         # union per step) but the aggregate rate does not rise -- both sides slow down, the step gets 2-8 % LONGER
         # (1.199 -> 1.250 / 1.319 ms).  The chip is not short of idle MFMA slots to fill: under sustained fp32-MFMA
