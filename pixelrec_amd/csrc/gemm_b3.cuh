@@ -116,14 +116,17 @@ struct B3Operand {
 // acc tile (m0, n0) = A_op x B_op over k in [kbeg, kend); operand flavours as gemm_f32.cuh (KC: [X][K], XC: [K][X]).
 // CS (XC A operand only): cs[q] += the sum over k of the values this thread staged for its q-th item (a column of the
 // stored matrix); the caller adds the 4 chunk owners of each column (items x, x + BM, x + 2 BM, x + 3 BM).
-template <int BM, int BN, bool A_KC, bool B_KC, int FINE = 0, bool CS = false, int STAGES = 2, int PD = 2>
+#ifndef PXR_B3_PD
+#define PXR_B3_PD 2      // register-ring depth of the global prefetch (tiles in flight); 4 was measured, see DESIGN.md
+#endif
+template <int BM, int BN, bool A_KC, bool B_KC, int FINE = 0, bool CS = false, int STAGES = 2, int PD = (STAGES == 2 ? PXR_B3_PD : 2)>
 __device__ __forceinline__ void gemm_b3_mainloop(typename B3Cfg<BM, BN, FINE, STAGES>::F::Acc& accs, const float* __restrict__ A,
                                                  int64_t lda, const float* __restrict__ B, int64_t ldb, int M, int N,
                                                  int kbeg, int kend, int m0, int n0, char* smem, float* cs = nullptr) {
   using Cfg = B3Cfg<BM, BN, FINE, STAGES>;
   using F = typename Cfg::F;
   constexpr int NT = Cfg::NT;
-  static_assert(PD == 2, "the register ring is two tiles deep");
+  static_assert(PD == 2 || (PD == 4 && STAGES == 2), "register ring: two tiles deep (four: 2-stage loop only)");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / F::WGN, wn = wave % F::WGN;
@@ -257,23 +260,23 @@ __device__ __forceinline__ void gemm_b3_mainloop(typename B3Cfg<BM, BN, FINE, ST
     }
   };
   if constexpr (STAGES == 2) {
-    fetch(0, ring[0]);
-    fetch(1, ring[1]);
+#pragma unroll
+    for (int s = 0; s < PD; ++s) fetch(s, ring[s]);
     split(ring[0], st);
     put(0, st, ring[0]);
     __syncthreads();
     read_frag(fr[0], 0, 0);
-    for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+    for (int kt0 = 0; kt0 < nk; kt0 += PD) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < PD; ++s) {
         const int kt = kt0 + s;
         if (kt < nk) {   // block-uniform
           const int buf = kt & 1, nxt = buf ^ 1;
-          fetch(kt + 2, ring[s]);           // slot s held tile kt, which already sits in LDS
+          fetch(kt + PD, ring[s]);          // slot s held tile kt, which already sits in LDS
           read_frag(fr[1], buf, 1);
-          split(ring[s ^ 1], st);           // (zeros after the last tile)
+          split(ring[(s + 1) % PD], st);    // (zeros after the last tile)
           mfma(fr[0]);
-          put(nxt, st, ring[s ^ 1]);
+          put(nxt, st, ring[(s + 1) % PD]);
           mfma(fr[1]);
           hints();
           __syncthreads();
