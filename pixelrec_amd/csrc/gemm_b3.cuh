@@ -8,7 +8,10 @@
 //
 // Arithmetic.  x = hi + mid + lo with hi = bf16_rne(x), mid = bf16_rne(x - hi), lo = x - hi - mid.  Both remainders
 // are exact in fp32 and lo has at most 8 significant bits, so the three terms carry all 24 bits of x (exponents of
-// normal fp32 values are preserved; values below 2^-110 lose low bits, irrelevant here).  bf16 x bf16 products are
+// normal fp32 values are preserved; values below 2^-110 lose low bits, irrelevant here; an infinite operand -- or one
+// above bf16's largest finite value, 3.39e38 -- turns into NaN through inf - inf in the remainder, where the f32-input
+// kernel would propagate the infinity: non-finite activations are an error state in this path either way, the trainer
+// raises on a NaN loss like the reference's trainer.py:192-194).  bf16 x bf16 products are
 // exact in the fp32 accumulator.  Kept: hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi.  Dropped: mid*lo, lo*mid, lo*lo
 // <= (2^-9 * 2^-17) * 2 + 2^-34 ~ 2^-25 |a||b| per product -- half an fp32 ulp of the product, the same order as the
 // rounding of an fp32 multiply, random in sign.  The small terms are accumulated apart from hi*hi and added at the end,
