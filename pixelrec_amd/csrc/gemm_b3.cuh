@@ -109,16 +109,20 @@ struct B3Operand {
       // becomes a divergent branch)
       const bufrsrc r = make_rsrc(base + (int64_t)k0 * ld, (int64_t)(kend - k0) * ld * 4);
       const unsigned ox = (row < x_left) ? 0u : 0x80000000u;
+      // one per-lane offset (row 8c of the chunk); the 8 k rows are reached through the instruction's SCALAR offset, which
+      // the raw-buffer range check includes -- no per-row offset registers (they spilled in the 16-wave kernels)
+      const unsigned vo = ((unsigned)(c * 8 * (int)ld + row) * 4u) | ox;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ((unsigned)((c * 8 + j) * (int)ld + row) * 4u) | ox, 0, 0));
+        v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, (unsigned)(j * (int)ld) * 4u, 0));
     }
   }
 };
 
 // acc tile (m0, n0) = A_op x B_op over k in [kbeg, kend); operand flavours as gemm_f32.cuh (KC: [X][K], XC: [K][X]).
-// CS (XC A operand only): cs[q] += the sum over k of the values this thread staged for its q-th item (a column of the
-// stored matrix); the caller adds the 4 chunk owners of each column (items x, x + BM, x + 2 BM, x + 3 BM).
+// CS (XC A operand only): cs[q] += the sum over k of the values this thread staged for its q-th A item (a column of the
+// stored matrix; 16-wave tiles: threads 0 .. 4 BM - 1 stage A, one item each); the caller adds the 4 chunk owners of each
+// column (items x, x + BM, x + 2 BM, x + 3 BM).
 #ifndef PXR_B3_PD
 #define PXR_B3_PD 2      // register-ring depth of the global prefetch (tiles in flight); 4 was measured, see DESIGN.md
 #endif
@@ -178,10 +182,14 @@ __device__ __forceinline__ void gemm_b3_mainloop(typename B3Cfg<BM, BN, FINE, ST
       for (int q = 0; q < SLOTS; ++q) b3_split8(g.v[q], st.p[q]);
     }
     if constexpr (CS) {
-      static_assert(!A_KC && !Cfg::ROLES, "column sums are taken over an x-contiguous A operand of a 4-wave tile");
+      static_assert(!A_KC, "column sums are taken over an x-contiguous A operand");
+      if (stage_a) {
 #pragma unroll
-      for (int q = 0; q < Cfg::A_PT; ++q)
-        cs[q] += ((g.v[q][0] + g.v[q][1]) + (g.v[q][2] + g.v[q][3])) + ((g.v[q][4] + g.v[q][5]) + (g.v[q][6] + g.v[q][7]));
+        for (int q = 0; q < Cfg::A_PT; ++q) {
+          const float (&v)[8] = g.v[Cfg::ROLES ? 0 : q];
+          cs[q] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+      }
     }
   };
   auto put = [&](int buf, const Staged& st, const Ring& g) {   // LDS writes only

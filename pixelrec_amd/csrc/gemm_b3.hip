@@ -87,6 +87,56 @@ __global__ void __launch_bounds__(GEMM_THREADS) grouped_dw_b3_kernel(DwGroup g) 
   }
 }
 
+// The same with 128x128 tiles (16 waves): the two layers of the step at D = 512 give exactly 256 tiles -- one per CU, four
+// waves per SIMD -- and the tile runs the long token reduction 33 % faster than the 64x64 one (tools/diag/dw_tile_test.py:
+// 180 vs 133 TFLOP/s at 256 tiles).  `tile_begin` / `tiles_m` of the group are in 128-tiles here.  Every tile takes the
+// column sums (8 adds per staged chunk); the tn == 0 tiles store them: one copy of the main loop in the kernel.
+__global__ void __launch_bounds__(1024) grouped_dw_b3_kernel128(DwGroup g) {
+  using Cfg = B3Cfg<128, 128, 1>;
+  using F = typename Cfg::F;
+  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
+  const int t = xcd_remap(blockIdx.x, g.total_tiles);
+  int pi = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.n; ++i)
+    if (t >= g.p[i].tile_begin) pi = i;
+  // block-uniform problem fields, pinned into scalar registers (the kernel has 128 VGPRs per lane)
+  const DwProblem& P = g.p[pi];
+  const float* dy = P.dy;
+  const float* x = P.x;
+  float* dW = P.dW;
+  float* db = P.db;
+  const int PM = __builtin_amdgcn_readfirstlane(P.M), PN = __builtin_amdgcn_readfirstlane(P.N);
+  const int PK = __builtin_amdgcn_readfirstlane(P.K), ptm = __builtin_amdgcn_readfirstlane(P.tiles_m);
+  const int local = t - __builtin_amdgcn_readfirstlane(P.tile_begin);
+  const int tm = local % ptm, tn = local / ptm;
+  const int m0 = tm * 128, n0 = tn * 128;
+  typename F::Acc accs;
+  float cs[1] = {0.f};
+  gemm_b3_mainloop<128, 128, false, false, 1, true>(accs, dy, PN, x, PK, PN, PK, 0, PM, m0, n0, smem, cs);
+  auto& acc = accs.v[0][0];
+  const LanePos lp = lane_pos<F>();
+  const int col = n0 + lp.wn * 32 + lp.r;
+  if (col < PK) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + lp.wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lp.h;
+      if (row < PN) dW[(int64_t)row * PK + col] = acc[e];
+    }
+  }
+  if (db != nullptr && tn == 0) {
+    // threads 0..511 staged A: thread tid held column tid % 128 for the k rows of chunk tid / 128 (fixed-order add)
+    float* red = reinterpret_cast<float*>(smem);
+    if (threadIdx.x < 512) red[threadIdx.x] = cs[0];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const float s = (red[threadIdx.x] + red[threadIdx.x + 128]) + (red[threadIdx.x + 256] + red[threadIdx.x + 384]);
+      const int c = m0 + threadIdx.x;
+      if (c < PN) db[c] = s;
+    }
+  }
+}
+
 static int b3_stages() {
   static const int st = getenv("PXR_B3_STAGES") ? atoi(getenv("PXR_B3_STAGES")) : 2;    // LDS stages of the 64x64 tile
   return st == 3 ? 3 : 2;
@@ -145,6 +195,20 @@ int gemm_b3_launch(int a_kc, int b_kc, int epilogue, int tile, const float* A, i
 }
 
 int grouped_dw_b3_launch(const DwGroup& g, hipStream_t st) {
+  // 128x128 tiles when they fill (most of) the chip at least once
+  int64_t t128 = 0;
+  DwGroup g2 = g;
+  for (int i = 0; i < g.n; ++i) {
+    g2.p[i].tile_begin = (int)t128;
+    g2.p[i].tiles_m = (g.p[i].N + 127) / 128;
+    t128 += (int64_t)g2.p[i].tiles_m * ((g.p[i].K + 127) / 128);
+  }
+  static const int dw128 = getenv("PXR_B3_DW128") ? atoi(getenv("PXR_B3_DW128")) : 1;
+  if (dw128 && t128 >= 192 && t128 < (1ll << 30)) {
+    g2.total_tiles = (int)t128;
+    hipLaunchKernelGGL(grouped_dw_b3_kernel128, dim3((unsigned)t128), dim3(1024), 0, st, g2);
+    return pxr_check_launch("pxr_grouped_linear_bwd_weight_f32(bf16x3, 128x128)");
+  }
   if (b3_stages() == 3) hipLaunchKernelGGL(grouped_dw_b3_kernel<3>, dim3(g.total_tiles), dim3(GEMM_THREADS), 0, st, g);
   else hipLaunchKernelGGL(grouped_dw_b3_kernel<2>, dim3(g.total_tiles), dim3(GEMM_THREADS), 0, st, g);
   return pxr_check_launch("pxr_grouped_linear_bwd_weight_f32(bf16x3)");
