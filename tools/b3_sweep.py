@@ -31,7 +31,10 @@ def main():
               ("dx_f2", 3200, 1024, 512, ops.EPI_MUL), ("dx_f1", 3200, 512, 1024, ops.EPI_ADD),
               ("dx_o", 3200, 512, 512, ops.EPI_NONE), ("dx_qkv", 3200, 512, 1536, ops.EPI_ADD),
               ("B512_fwd_qkv", 25600, 1536, 512, ops.EPI_BIAS), ("scoring", 1024, 400001, 512, ops.EPI_NONE)]
+    only = os.environ.get("SHAPES")
     for name, M, N, K, epi in shapes:
+        if only and name not in only.split(","):
+            continue
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) * 0.05
         b = torch.randn(N, device=dev)
