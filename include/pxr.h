@@ -165,6 +165,35 @@ int pxr_gemm_batched_f32(int a_kc, int b_kc, int M, int N, int K, const float* A
 int pxr_set_gemm_mode(int bf16x3);
 int pxr_get_gemm_mode(void);
 
+/* ---- pre-split operands ("planes"): the same fp32 products on the bf16 matrix pipe, operands split ONCE ---------- */
+/* An fp32 matrix X[rows, cols] (cols % 32 == 0) as three bf16 planes hi | mid | lo with X = hi + mid + lo exactly
+ * (hi = bf16(X), mid = bf16(X - hi), lo = X - hi - mid).  Plane q starts q * plane_stride ELEMENTS after `planes`; inside
+ * a plane the matrix is stored as cols / 32 PANELS of panel_rows (>= rows, multiple of 16) rows x 32 columns:
+ *     element (r, c) at ((c / 32) * panel_rows + r) * 32 + ((((c / 8) % 4) ^ ((r / 4) % 4)) * 8 + c % 8
+ * (64-byte row segments, 16-byte chunks XOR-swizzled by the row: a GEMM tile is a byte copy of 1 KiB runs, csrc/gemm_p3.cuh).
+ * A row range [r0, r1) with r0 % 16 == 0 is the same layout at planes + 32 r0; a column range with c0 % 32 == 0 at
+ * planes + (c0 / 32) * panel_rows * 32.  pxr_split_planes_f32 writes the planes of an operand whose producer does not
+ * (weights after an optimizer step, the item table before a full-sort evaluation -- model/IDNet/sasrec.py:112,115-117). */
+int pxr_split_planes_f32(const float* x, int64_t rows, int64_t cols, int64_t ldx, void* planes, int64_t plane_stride,
+                         int64_t panel_rows, void* stream);
+/* C[M,N] = A[M,K] x B (+ epilogue as pxr_gemm_f32) with both operands given as planes: b_kc = 1: B is [N][K] (nn.Linear
+ * forward model/layers.py:586-588,613,666,669; scoring model/IDNet/sasrec.py:112), b_kc = 0: B is [K][N] (the input
+ * gradient dX = dY W of the same layers).  What pxr_gemm_f32 computes in mode bf16x3, bit for bit.  K % 32 == 0.
+ * C may be NULL when only the output planes (c_planes: panel layout of C, N % 32 == 0) are wanted; c_planes may be NULL. */
+int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows,
+                        const void* B, int64_t b_plane_stride, int64_t b_panel_rows, float* C, int64_t ldc, int epilogue,
+                        const float* bias, float* aux, int64_t ldaux, void* c_planes, int64_t c_plane_stride,
+                        int64_t c_panel_rows, int act, int tile_hint, void* stream);
+
+/* pxr_grouped_linear_bwd_weight_f32 from planes: dW[i][N_i,K_i] = dy[i][T_i,N_i]^T x[i][T_i,K_i], db[i][N_i] = column sums
+ * of dy[i] (db[i] may be NULL), all problems in one launch.  dy[i] / x[i] are planes of the [T_i, .] matrices whose panel
+ * rows (multiples of 32) T_i .. panel_rows-1 are ZERO.  N_i, K_i multiples of 32.  Autograd of model/layers.py:586-588,613,
+ * 666,669. */
+int pxr_grouped_dw_planes_f32(int n, const void* const* dy, const int64_t* dy_plane_stride, const int64_t* dy_panel_rows,
+                              const void* const* x, const int64_t* x_plane_stride, const int64_t* x_panel_rows,
+                              float* const* dW, float* const* db, const int* T, const int* N, const int* K, int tile_hint,
+                              void* stream);
+
 /* ---- ViT image encoder, non-GEMM pieces (csrc/vit.hip) ------------------------------------------------------ */
 /* in place: S[row, :T] = softmax(scale * S[row, :T]), S[row, T:ld] = 0      (HF CLIPAttention, no mask / dropout) */
 int pxr_softmax_rows_f32(float* S, int64_t rows, int T, int ld, float scale, void* stream);

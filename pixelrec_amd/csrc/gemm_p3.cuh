@@ -1,0 +1,388 @@
+// gemm_p3.cuh -- fp32 GEMM on the bf16 matrix pipe from PRE-SPLIT operands ("planes").
+//
+// gemm_b3.cuh splits every fp32 operand into its three bf16 terms inside the main loop: every one of the 8-24 tiles that
+// read an activation tile repeats that VALU work, the staging registers cap the occupancy, and the loads are 64-byte row
+// segments (half of every cache line per request: measured 29 B/clk/CU from L2, which bounds the 64x64 tiles of the
+// training step, not the matrix pipe).  Here the producers (LayerNorm / attention / GEMM epilogues / the optimizer) have
+// already written each operand as three bf16 planes  hi | mid | lo  (x = hi + mid + lo exactly, p3_split2), in a PANEL
+// layout that makes every global -> LDS transfer a linear 1 KiB LDS-DMA piece: the main loop is LDS-DMA + ds_read +
+// v_mfma_f32_32x32x16_bf16 only -- no VALU on the operands, no staging registers.
+//
+// Arithmetic: identical to gemm_b3.cuh (six of the nine cross products, fp32 accumulation, the small terms in their own
+// accumulators, same k order) -- the planes ARE the terms that kernel computes on the fly: results are bit-identical to it.
+//
+// Panel layout of a matrix X[R][C] (C % 32 == 0; `pr` >= R rows allocated per panel, pr % 16 == 0): plane q starts
+// q * ps elements after the base; inside a plane, panel cb = c / 32 holds columns 32 cb .. 32 cb + 31 of ALL rows:
+//     element (r, c)  at  ((cb * pr + r) * 32 + (((c >> 3) & 3) ^ ((r >> 2) & 3)) * 8 + (c & 7))      [elements]
+// i.e. a 64-byte row segment per (row, panel) whose four 16-byte chunks are XOR-swizzled by the row -- the LDS image of a
+// tile IS a byte copy of 1 KiB runs of a panel (16 rows): conflict-free ds_read_b128 / ds_read_b64_tr_b16 without any
+// address arithmetic on the DMA source.  Rows beyond R inside a panel may hold anything finite or not: they only ever
+// reach accumulator rows / columns the epilogues do not store.
+//
+// Operand flavours (as gemm_f32.cuh):  "KC"  k runs along the panel's 32 columns (A[M][K] / B[N][K]): fragment = one
+// ds_read_b128;  "XC"  k runs along the ROWS (A stored [K][M], B stored [K][N]): the tile is 32 k-rows of BX/32 panels,
+// fragments come from two ds_read_b64_tr_b16 (hardware 4x4 transpose: a 16-lane group reads a [4 k][16 x] block).
+//   Y = X W^T (KC,KC) forward;  dX = dY W (KC,XC);  dW = dY^T X (XC,XC) -- all from the same panels.
+//
+// The DMA is issued from inline asm: hipcc orders every ds_read behind ALL outstanding LDS-DMA it knows of (vmcnt(0)),
+// which would serialise the pipeline; the asm loads are invisible to it and are counted by hand (s_waitcnt vmcnt(N) +
+// s_barrier before a stage is read) -- cdna_hip_programming.md §5.7.
+#pragma once
+#include "gemm_f32.cuh"
+
+namespace pxr {
+
+typedef __bf16 p3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 p3_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned p3_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 p3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float p3_f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- the exact 3-term split (same arithmetic as gemm_b3.cuh::b3_split2: hi = bf16_rne(x), mid = bf16_rne(x - hi),
+// lo = x - hi - mid; both remainders are exact in fp32 and lo has <= 8 significant bits) -----------------------------
+__device__ __forceinline__ void p3_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const p3_f32x2 v = {a, b};
+  const p3_bf16x2 h = __builtin_convertvector(v, p3_bf16x2);
+  const p3_f32x2 r1 = v - __builtin_convertvector(h, p3_f32x2);
+  const p3_bf16x2 m = __builtin_convertvector(r1, p3_bf16x2);
+  const p3_f32x2 r2 = r1 - __builtin_convertvector(m, p3_f32x2);
+  const p3_bf16x2 l = __builtin_convertvector(r2, p3_bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  mid = __builtin_bit_cast(unsigned, m);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// A planes matrix as a kernel argument.
+struct P3Mat {
+  __bf16* p;       // plane 0
+  int64_t ps;      // plane stride, elements
+  int64_t pr;      // rows per panel (allocated), multiple of 16
+};
+// element offset of (row r, 8-column chunk starting at column c, c % 8 == 0) inside a plane
+__device__ __forceinline__ int64_t p3_chunk_index(int64_t pr, int64_t r, int c) {
+  return (((int64_t)(c >> 5) * pr + r) << 5) + ((((c >> 3) & 3) ^ ((int)(r >> 2) & 3)) << 3);
+}
+// store 8 consecutive values x[r][c .. c+7] (c % 8 == 0) into the three planes: one 16-byte store per plane
+__device__ __forceinline__ void p3_store8(const P3Mat& m, int64_t r, int c, const float (&v)[8]) {
+  p3_u32x4 p[3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h, mi, l;
+    p3_split2(v[2 * j], v[2 * j + 1], h, mi, l);
+    p[0][j] = h; p[1][j] = mi; p[2][j] = l;
+  }
+  __bf16* dst = m.p + p3_chunk_index(m.pr, r, c);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<p3_u32x4*>(dst + q * m.ps) = p[q];
+}
+
+template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_>
+struct P3Cfg {
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, STAGES = STAGES_;
+  static constexpr int G = WGM * WGN, NT = 64 * G, BK = 32;
+  static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+  static constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;          // bytes per plane per stage
+  static constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  static constexpr int LDS_BYTES = STAGES * STAGE;
+  static constexpr int A_PIECES = 3 * BM / 16, B_PIECES = 3 * BN / 16;   // 1 KiB DMA pieces per K tile
+  static constexpr int A_PPW = A_PIECES / G, B_PPW = B_PIECES / G, PPW = A_PPW + B_PPW;
+  static constexpr int EPI_LD = BN + 4;                               // floats per row of the epilogue's LDS tile
+  static_assert(A_PIECES % G == 0 && B_PIECES % G == 0, "DMA pieces must divide evenly among the waves");
+  static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile = 32x32 blocks");
+  static_assert(STAGES >= 2 && STAGES <= 6, "2..6 LDS stages");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(BM * EPI_LD * 4 <= LDS_BYTES, "the epilogue's fp32 tile must fit in the staging LDS");
+  struct Acc {
+    f32x16 v[TM][TN];
+  };
+};
+
+// one LDS-DMA piece: lane l's 16 bytes from rs[voff + soff] land at LDS byte address lds_dst + 16 * l (lds_dst
+// wave-uniform).  M0 carries the destination and is written in the statement that reads it (the compiler reserves M0 but
+// keeps nothing live in it around an asm statement that names it as clobbered; it warns about the clobber).  s_mov, not
+// s_add: an asm statement must not touch SCC, the compiler may hold a condition in it across the statement.  The s_nop
+// pads the SALU-write -> VMEM-read hazard of the descriptor / soffset registers the compiler may have written just before
+// the statement (5 wait states; hipcc pads nothing inside an asm string) and the M0 write -> LDS-DMA one.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void p3_dma16(bufrsrc rs, unsigned voff, unsigned soff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+               :
+               : "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff)
+               : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int N>
+__device__ __forceinline__ void p3_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+// wait until at most `tiles` K tiles (PPW pieces each) of this wave's DMA are still in flight
+template <int PPW>
+__device__ __forceinline__ void p3_wait_tiles(int tiles) {
+  static_assert(PPW <= 63, "vmcnt is a 6-bit counter");
+  if constexpr (4 * PPW <= 63) {
+    if (tiles >= 4) { p3_wait_vm<4 * PPW>(); return; }
+  }
+  if constexpr (3 * PPW <= 63) {
+    if (tiles >= 3) { p3_wait_vm<3 * PPW>(); return; }
+  }
+  if constexpr (2 * PPW <= 63) {
+    if (tiles >= 2) { p3_wait_vm<2 * PPW>(); return; }
+  }
+  if (tiles >= 1) p3_wait_vm<PPW>();
+  else p3_wait_vm<0>();
+}
+
+// One operand's DMA plan.  BX = tile extent along the operand's x (BM or BN), PPWX = pieces this wave issues per K tile,
+// KC = flavour.
+template <int BX, int PPWX, bool KC>
+struct P3Operand {
+  bufrsrc rs;
+  unsigned voff[PPWX];     // per-lane byte offset of each piece (loop-invariant)
+  unsigned dst[PPWX];      // LDS byte offset of each piece inside a stage (wave-uniform)
+  unsigned soff, sstep;    // byte offset of the next K tile to issue / its step
+  // m: the matrix; x0: tile origin along x; area: byte offset of this operand's planes inside a stage
+  __device__ __forceinline__ void init(const P3Mat& m, int x0, int wave, int lane, unsigned area) {
+    rs = make_rsrc(reinterpret_cast<const float*>(m.p), m.ps * 3 * 2);
+#pragma unroll
+    for (int j = 0; j < PPWX; ++j) {
+      const int q = wave * PPWX + j;                    // piece id: plane-major, then 1 KiB run
+      const int pl = q / (BX / 16), run = q % (BX / 16);
+      dst[j] = __builtin_amdgcn_readfirstlane(area + (unsigned)(pl * BX * 64 + run * 1024));
+      if constexpr (KC) {
+        // runs are 16-row groups of the tile's rows inside panel kt
+        voff[j] = (unsigned)(pl * m.ps * 2) + (unsigned)((x0 + run * 16) * 64 + lane * 16);
+      } else {
+        // runs are (panel run / 2, 16-k-row half run % 2) of the 32 k-rows of tile kt
+        voff[j] = (unsigned)(pl * m.ps * 2) + (unsigned)((((int64_t)(x0 / 32 + run / 2) * m.pr + (run & 1) * 16) * 64) + lane * 16);
+      }
+    }
+    soff = 0;
+    sstep = KC ? (unsigned)(m.pr * 64) : 32u * 64u;
+  }
+  __device__ __forceinline__ void issue(unsigned stage_base) {
+#pragma unroll
+    for (int j = 0; j < PPWX; ++j) p3_dma16(rs, voff[j], soff, __builtin_amdgcn_readfirstlane(stage_base + dst[j]));
+    soff += sstep;
+  }
+};
+
+// fragment addressing of one 32-row block: lane (r = lane & 31, h = lane >> 5) gets x = row r, k = 16 kb + 8 h .. + 7 of the
+// stage's 32-wide K tile.
+template <bool KC>
+struct P3Frag {
+  int off[2];     // KC: off[0] = row byte offset (the chunk is XORed in per kb); XC: the two transposed reads at kb = 0
+  int swz;
+  __device__ __forceinline__ void init(int blk_row0, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    if constexpr (KC) {
+      off[0] = (blk_row0 + r) * 64;
+      off[1] = h;
+      swz = (r >> 2) & 3;
+    } else {
+      // 16-lane group g: x block (g & 1) of 16 columns, k half h = g >> 1; lane li of the group addresses k row
+      // 8 h + (li >> 2) (+ 4 for the second read), 4 columns starting at 16 (g & 1) + 4 (li & 3)
+      const int li = lane & 15, x16 = (lane >> 4) & 1;
+      const int chunk = 2 * x16 + ((li & 3) >> 1), inner = (li & 1) * 8;
+      const int panel = blk_row0 / 32;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = 8 * h + 4 * t + (li >> 2);               // k row inside the 16-wide block (kb adds 16: same swizzle phase)
+        off[t] = panel * 2048 + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4) + inner;
+      }
+      swz = 0;
+    }
+  }
+  __device__ __forceinline__ p3_bf16x8 read(const char* plane_base, int kb) const {
+    if constexpr (KC) {
+      return *reinterpret_cast<const p3_bf16x8*>(plane_base + off[0] + ((((kb << 1) + off[1]) ^ swz) << 4));
+    } else {
+      typedef __attribute__((address_space(3))) p3_bf16x4 lds_v4;
+      // rows 16 kb + ...: (row >> 2) & 3 gains (4 kb) & 3 = 0 -> the kb = 0 offsets + 1024 kb
+      const p3_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(plane_base + off[0] + kb * 1024));
+      const p3_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(plane_base + off[1] + kb * 1024));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
+};
+
+// acc tile (m0, n0) = A_op x B_op over k in [0, K) (K % 32 == 0), operands as planes (see the header).
+// ONES (dW only): additionally accumulate in `ones_acc[i]` the products of the A fragments with an all-ones B fragment:
+// every column of that 32x32 block is the sum over k of the A rows (= the bias gradient when A = dY^T).
+// dbg (timing experiments only, results are wrong): 2 = no DMA, 4 = no fragment reads / MFMAs, 8 = no barriers
+template <class Cfg, bool A_KC, bool B_KC, bool EARLY, bool ONES = false>
+__device__ __forceinline__ void gemm_p3_mainloop(typename Cfg::Acc& accs, const P3Mat& A, const P3Mat& B, int K, int m0, int n0,
+                                                 char* smem, f32x16* ones_acc = nullptr, int dbg = 0) {
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, S = Cfg::STAGES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  f32x16 accm[TM][TN], accl[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { accs.v[i][j][e] = 0.f; accm[i][j][e] = 0.f; accl[i][j][e] = 0.f; }
+  if constexpr (ONES) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ones_acc[i][e] = 0.f;
+  }
+  const int nk = K / 32;
+  if (nk <= 0) return;
+
+  P3Operand<Cfg::BM, Cfg::A_PPW, A_KC> opA;
+  P3Operand<Cfg::BN, Cfg::B_PPW, B_KC> opB;
+  opA.init(A, m0, wave, lane, 0u);
+  opB.init(B, n0, wave, lane, (unsigned)(3 * Cfg::A_PLANE));
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  unsigned i_stage = 0;                                       // stage of the next tile to issue
+  auto issue = [&]() {
+    const unsigned sb = smem_base + i_stage * (unsigned)Cfg::STAGE;
+    if (!(dbg & 2)) {
+      opA.issue(sb);
+      opB.issue(sb);
+    }
+    i_stage = (i_stage + 1 == (unsigned)S) ? 0u : i_stage + 1;
+  };
+
+  P3Frag<A_KC> fa[TM];
+  P3Frag<B_KC> fb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[i].init(wm * Cfg::WM + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb[j].init(wn * Cfg::WN + j * 32, lane);
+  struct Frag {
+    p3_bf16x8 a[TM][3], b[TN][3];
+  };
+  auto read_frag = [&](Frag& f, int stage, int kb) {
+    const char* sa = smem + stage * Cfg::STAGE;
+    const char* sb = sa + 3 * Cfg::A_PLANE;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f.a[i][p] = fa[i].read(sa + p * Cfg::A_PLANE, kb);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f.b[j][p] = fb[j].read(sb + p * Cfg::B_PLANE, kb);
+    }
+  };
+  p3_bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  // six products per (block, 16-wide k block); consecutive MFMAs never share an accumulator
+  auto mfma = [&](const Frag& f) {
+#define PXR_P3_PROD(ACC, PA, PB)                                                                                \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA], f.b[j][PB], ACC[i][j], 0, 0, 0);
+    PXR_P3_PROD(accl, 2, 0)        // lo  * hi
+    PXR_P3_PROD(accm, 1, 0)        // mid * hi
+    PXR_P3_PROD(accs.v, 0, 0)      // hi  * hi
+    PXR_P3_PROD(accl, 0, 2)        // hi  * lo
+    PXR_P3_PROD(accm, 0, 1)        // hi  * mid
+    PXR_P3_PROD(accl, 1, 1)        // mid * mid
+#undef PXR_P3_PROD
+    if constexpr (ONES) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ones_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][p], ones, ones_acc[i], 0, 0, 0);
+    }
+  };
+
+  Frag f0, f1;
+  int st = 0;                                               // stage of tile kt
+  if constexpr (!EARLY) {
+    // ---- tiles kt+1 .. kt+S-2 stay in flight across the barrier of tile kt; fragments are read after it ---------------
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+      if (s < nk) issue();
+    for (int kt = 0; kt < nk; ++kt) {
+      p3_wait_tiles<Cfg::PPW>(min(nk - 1 - kt, S - 2));    // this wave's pieces of tile kt have landed
+      if (!(dbg & 8)) __builtin_amdgcn_s_barrier();         // ... and everybody's; everybody is done reading tile kt-1
+      if (kt + S - 1 < nk) issue();                         // into the stage tile kt-1 occupied
+      if (!(dbg & 4)) {
+        read_frag(f0, st, 0);
+        read_frag(f1, st, 1);
+        mfma(f0);
+        mfma(f1);
+      }
+      st = (st + 1 == S) ? 0 : st + 1;
+    }
+  } else {
+    // ---- the barrier of tile kt certifies tile kt+1: its first fragments are read under the MFMAs of tile kt, so no wave
+    // waits for an LDS round trip after a barrier (one LDS stage more for the same DMA lead) -----------------------------
+    static_assert(!EARLY || S >= 3, "early fragment reads need 3 stages");
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+      if (s < nk) issue();
+    p3_wait_tiles<Cfg::PPW>(min(nk - 1, S - 2));
+    __builtin_amdgcn_s_barrier();                           // tile 0 has landed
+    read_frag(f0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nx = (st + 1 == S) ? 0 : st + 1;
+      p3_wait_tiles<Cfg::PPW>(min(max(nk - 2 - kt, 0), S - 3));   // this wave's pieces of tile kt+1 have landed
+      if (!(dbg & 8)) __builtin_amdgcn_s_barrier();         // ... everybody's; everybody is done reading tile kt-1
+      if (kt + S - 1 < nk) issue();                         // into the stage tile kt-1 occupied
+      if (!(dbg & 4)) {
+        read_frag(f1, st, 1);
+        mfma(f0);
+        if (kt + 1 < nk) read_frag(f0, nx, 0);
+        mfma(f1);
+      }
+      st = nx;
+    }
+  }
+  __syncthreads();   // the staging LDS is reused by the epilogues
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accs.v[i][j][e] += (accm[i][j][e] + accl[i][j][e]);
+}
+
+// ---- row epilogue: the accumulators go through LDS ([BM][BN + 4] fp32, the staging buffers are free) so that every thread
+// owns 8 CONSECUTIVE columns of a row: 16-byte loads of bias / aux, 16-byte stores of C, one 16-byte store per output
+// plane.  `fn(it, row, col, nv, v)` is called once per (row, 8-column chunk) that starts inside the matrix (it = the thread's
+// chunk counter, see P3ChunkMap); nv = min(8, N - col) of its columns exist. --------------------------------------------------------------------------------------------------
+template <class Cfg, class Fn>
+__device__ __forceinline__ void p3_row_epilogue(const typename Cfg::Acc& accs, char* smem, int M, int N, int m0, int n0, Fn&& fn) {
+  float* t = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN, h = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        t[row * Cfg::EPI_LD + wn * Cfg::WN + j * 32 + r] = accs.v[i][j][e];
+      }
+  __syncthreads();
+  constexpr int CPR = Cfg::BN / 8;                       // chunks per row
+  constexpr int CPT = Cfg::BM * CPR / Cfg::NT;           // chunks per thread: chunk it of thread t is (row it * NT / CPR + t / CPR, t % CPR)
+  static_assert(Cfg::NT % CPR == 0 && (Cfg::BM * CPR) % Cfg::NT == 0, "chunk map");
+  const int c8 = (threadIdx.x % CPR) * 8;
+#pragma unroll
+  for (int it = 0; it < CPT; ++it) {
+    const int row = it * (Cfg::NT / CPR) + threadIdx.x / CPR;
+    if (m0 + row >= M || n0 + c8 >= N) continue;
+    const float4 a = *reinterpret_cast<const float4*>(t + row * Cfg::EPI_LD + c8);
+    const float4 b = *reinterpret_cast<const float4*>(t + row * Cfg::EPI_LD + c8 + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    fn(it, m0 + row, n0 + c8, min(8, N - n0 - c8), v);
+  }
+}
+// the same chunk map, for operands the epilogue READS (bias, residual gradient, saved activation derivative): fetched before
+// the main loop, they arrive under the MFMAs instead of stalling every thread after its last one
+template <class Cfg>
+struct P3ChunkMap {
+  static constexpr int CPR = Cfg::BN / 8, CPT = Cfg::BM * CPR / Cfg::NT;
+  static __device__ __forceinline__ int col8() { return (threadIdx.x % CPR) * 8; }
+  static __device__ __forceinline__ int row(int it) { return it * (Cfg::NT / CPR) + threadIdx.x / CPR; }
+};
+
+}  // namespace pxr

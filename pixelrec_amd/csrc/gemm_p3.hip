@@ -1,0 +1,393 @@
+// gemm_p3.hip -- fp32 GEMMs on the bf16 matrix pipe from pre-split operands ("planes" in panel layout, gemm_p3.cuh) + the
+// plane producer for operands nobody has split yet (pxr_split_planes_f32: weights after an optimizer step, the item table
+// before an evaluation).
+//
+// Reference call sites replaced: the nn.Linear forwards of the sequence block (layers.py:586-588,613,666,669), their
+// autograd input / weight gradients, the full-catalogue scoring product (sasrec.py:112) -- the same products pxr_gemm_f32
+// computes, from operands that were split once by their producer instead of once per reading tile.
+#include "gemm_p3.cuh"
+
+#include <cstdlib>
+
+namespace pxr {
+
+// one element of the epilogues of gemm_f32.cuh::epi_store (same formulas, same order of operations)
+template <int EPI>
+__device__ __forceinline__ float p3_epi_elem(float v, float bv, float av, float& aux_out, int act) {
+  if constexpr (EPI == EPI_BIAS) {
+    v += bv;
+  } else if constexpr (EPI == EPI_BIAS_GELU) {
+    v += bv;
+    aux_out = v;
+    v = gelu_erf(v);
+  } else if constexpr (EPI == EPI_BIAS_GELU_GRAD) {
+    v += bv;
+    aux_out = dgelu_erf(v);
+    v = gelu_erf(v);
+  } else if constexpr (EPI == EPI_MUL) {
+    v *= av;
+  } else if constexpr (EPI == EPI_MUL_DGELU) {
+    v *= dgelu_erf(av);
+  } else if constexpr (EPI == EPI_ADD) {
+    v += av;
+  } else if constexpr (EPI == EPI_BIAS_ADD) {
+    v = (v + bv) + av;
+  } else if constexpr (EPI == EPI_BIAS_QGELU_GRAD) {
+    v += bv;
+    const float sg = sigmoid_1702(v);
+    aux_out = sg + 1.702f * v * sg * (1.0f - sg);
+    v = v * sg;
+  } else if constexpr (EPI == EPI_BIAS_RELU) {
+    v = fmaxf(v + bv, 0.f);
+  } else if constexpr (EPI == EPI_BIAS_ACT_GRAD) {
+    v += bv;
+    float dv;
+    if (act == ACT_RELU) {
+      dv = v > 0.f ? 1.f : 0.f; v = fmaxf(v, 0.f);
+    } else if (act == ACT_SWISH) {
+      const float sg = 1.0f / (1.0f + __expf(-v));
+      dv = sg + v * sg * (1.0f - sg); v = v * sg;
+    } else if (act == ACT_TANH) {
+      const float th = tanhf(v);
+      dv = 1.0f - th * th; v = th;
+    } else {
+      const float sg = 1.0f / (1.0f + __expf(-v));
+      dv = sg * (1.0f - sg); v = sg;
+    }
+    aux_out = dv;
+  }
+  return v;
+}
+template <int EPI>
+struct P3EpiTraits {
+  static constexpr bool WRITES_AUX = (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD || EPI == EPI_BIAS_QGELU_GRAD ||
+                                      EPI == EPI_BIAS_ACT_GRAD);
+};
+
+struct P3Args {
+  P3Mat A, B, Cp;          // Cp.p == nullptr: no output planes
+  float* C;                // nullptr: the fp32 output is not stored (the consumer reads the planes)
+  int64_t ldc;
+  int M, N, K;
+  const float* bias;
+  float* aux;
+  int64_t ldaux;
+  int tiles_m, tiles_n, n_fastest, act, dbg;
+};
+
+template <class Cfg, bool B_KC, int EPI, bool EARLY>
+__global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = g.n_fastest ? t / g.tiles_n : t % g.tiles_m, tn = g.n_fastest ? t % g.tiles_n : t / g.tiles_m;
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+  // 16-byte accesses when every row of C / aux starts 16-byte aligned and the chunk is whole; scalar otherwise (ragged N)
+  const bool vec_ok = (g.N % 8 == 0) && (g.ldc % 4 == 0) && (g.ldaux % 4 == 0);
+  using Map = P3ChunkMap<Cfg>;
+  constexpr bool PRE_AUX = EpiTraits<EPI>::READS_AUX && Map::CPT <= 4;
+  float bpre[8], apre[PRE_AUX ? Map::CPT : 1][8];
+  const int pc = n0 + Map::col8();
+  const bool pre_ok = vec_ok && pc + 8 <= g.N;
+  if constexpr (EpiTraits<EPI>::HAS_BIAS) {
+    if (pre_ok) {
+      const float4 b0 = *reinterpret_cast<const float4*>(g.bias + pc), b1 = *reinterpret_cast<const float4*>(g.bias + pc + 4);
+      bpre[0] = b0.x; bpre[1] = b0.y; bpre[2] = b0.z; bpre[3] = b0.w; bpre[4] = b1.x; bpre[5] = b1.y; bpre[6] = b1.z; bpre[7] = b1.w;
+    }
+  }
+  if constexpr (PRE_AUX) {
+#pragma unroll
+    for (int it = 0; it < Map::CPT; ++it) {
+      const int row = m0 + Map::row(it);
+      if (pre_ok && row < g.M) {
+        const float* ap = g.aux + (int64_t)row * g.ldaux + pc;
+        const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+        apre[it][0] = a0.x; apre[it][1] = a0.y; apre[it][2] = a0.z; apre[it][3] = a0.w;
+        apre[it][4] = a1.x; apre[it][5] = a1.y; apre[it][6] = a1.z; apre[it][7] = a1.w;
+      }
+    }
+  }
+  typename Cfg::Acc accs;
+  gemm_p3_mainloop<Cfg, true, B_KC, EARLY>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
+  p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, [&](int it, int row, int col, int nv, float (&v)[8]) {
+    float bv[8], av[8], ao[8];
+    const bool vec = vec_ok && nv == 8;
+    if constexpr (EpiTraits<EPI>::HAS_BIAS) {
+      if (vec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = bpre[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = e < nv ? g.bias[col + e] : 0.f;
+      }
+    }
+    if constexpr (EpiTraits<EPI>::READS_AUX) {
+      const float* ap = g.aux + (int64_t)row * g.ldaux + col;
+      if (vec) {
+        if constexpr (PRE_AUX) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) av[e] = apre[it][e];
+        } else {
+          const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+          av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = e < nv ? ap[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      v[e] = p3_epi_elem<EPI>(v[e], EpiTraits<EPI>::HAS_BIAS ? bv[e] : 0.f, EpiTraits<EPI>::READS_AUX ? av[e] : 0.f, ao[e], g.act);
+    if constexpr (P3EpiTraits<EPI>::WRITES_AUX) {
+      float* ap = g.aux + (int64_t)row * g.ldaux + col;
+      if (vec) {
+        *reinterpret_cast<float4*>(ap) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+        *reinterpret_cast<float4*>(ap + 4) = make_float4(ao[4], ao[5], ao[6], ao[7]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nv) ap[e] = ao[e];
+      }
+    }
+    if (g.C != nullptr) {
+      float* cp = g.C + (int64_t)row * g.ldc + col;
+      if (vec) {
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nv) cp[e] = v[e];
+      }
+    }
+    if (g.Cp.p != nullptr) p3_store8(g.Cp, row, col, v);      // (output planes: N % 32 == 0, chunks are whole)
+  });
+}
+
+// x[rows, cols] (row stride ldx floats) -> planes (panel layout); a thread converts 8 consecutive values of a row
+__global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols8, P3Mat out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols8) return;
+  const int64_t row = i / cols8;
+  const int c = (int)(i % cols8) * 8;
+  const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
+  const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  p3_store8(out, row, c, v);
+}
+
+// All dW[N,K] = dY[T,N]^T X[T,K] (+ db[N] = column sums of dY) of a backward pass in ONE launch, from the planes of dY and X
+// (both x-contiguous operands: the token reduction runs along the panels' rows, fragments come from transposing LDS reads).
+// The planes' rows T .. round_up(T, 32) - 1 must be zero.  db: the A fragments are also multiplied by an all-ones B fragment
+// (3 extra MFMAs per 16 tokens in the wn == 0 waves of the tn == 0 tiles): every column of that block is the column sum.
+struct P3DwProblem {
+  P3Mat dy, x;
+  float* dW;
+  float* db;
+  int T, N, K;              // tokens, out features, in features
+  int tile_begin, tiles_m;
+};
+struct P3DwGroup {
+  P3DwProblem p[DW_MAX];
+  int n, total_tiles;
+};
+template <class Cfg, bool EARLY>
+__global__ void __launch_bounds__(Cfg::NT) grouped_dw_p3_kernel(const P3DwGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = xcd_remap(blockIdx.x, g.total_tiles);
+  int pi = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.n; ++i)
+    if (t >= g.p[i].tile_begin) pi = i;
+  const P3DwProblem& P = g.p[pi];
+  const int local = t - P.tile_begin;
+  const int tm = local % P.tiles_m, tn = local / P.tiles_m;
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+  const int kpad = (P.T + 31) & ~31;
+  typename Cfg::Acc accs;
+  f32x16 ones_acc[Cfg::TM];
+  const bool do_bias = (P.db != nullptr) && (tn == 0);      // block-uniform
+  if (do_bias) gemm_p3_mainloop<Cfg, false, false, EARLY, true>(accs, P.dy, P.x, kpad, m0, n0, smem, ones_acc);
+  else gemm_p3_mainloop<Cfg, false, false, EARLY, false>(accs, P.dy, P.x, kpad, m0, n0, smem);
+  float* dW = P.dW;
+  const int64_t ldw = P.K;
+  const bool vec_ok = (P.K % 8 == 0);
+  p3_row_epilogue<Cfg>(accs, smem, P.N, P.K, m0, n0, [&](int, int row, int col, int nv, float (&v)[8]) {
+    float* cp = dW + (int64_t)row * ldw + col;
+    if (vec_ok && nv == 8) {
+      *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nv) cp[e] = v[e];
+    }
+  });
+  if (do_bias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN, h = lane >> 5, r = lane & 31;
+    if (wn == 0 && r == 0) {
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < P.N) P.db[row] = ones_acc[i][e];
+        }
+    }
+  }
+}
+
+template <class Cfg, bool EARLY>
+static int launch_dw_p3(P3DwGroup& g, hipStream_t st) {
+  int tiles = 0;
+  for (int i = 0; i < g.n; ++i) {
+    g.p[i].tile_begin = tiles;
+    g.p[i].tiles_m = (g.p[i].N + Cfg::BM - 1) / Cfg::BM;
+    tiles += g.p[i].tiles_m * ((g.p[i].K + Cfg::BN - 1) / Cfg::BN);
+  }
+  g.total_tiles = tiles;
+  auto kern = grouped_dw_p3_kernel<Cfg, EARLY>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      pxr_set_error("pxr_grouped_dw_planes_f32: cannot reserve %d bytes of LDS", Cfg::LDS_BYTES);
+      return PXR_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, st, g);
+  return pxr_check_launch("pxr_grouped_dw_planes_f32");
+}
+
+template <class Cfg, bool B_KC, int EPI, bool EARLY>
+static int launch_p3(P3Args& g, hipStream_t st) {
+  g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+  g.tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
+  static const int xcd_env = getenv("PXR_GEMM_XCD") ? atoi(getenv("PXR_GEMM_XCD")) : -1;
+  g.n_fastest = xcd_env >= 0 ? xcd_env : (g.M > g.N ? 1 : 0);
+  g.dbg = getenv("PXR_P3_DBG") ? atoi(getenv("PXR_P3_DBG")) : 0;   // timing experiments only (gemm_p3.cuh)
+  auto kern = gemm_p3_kernel<Cfg, B_KC, EPI, EARLY>;
+  static bool attr_set = false;     // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      pxr_set_error("pxr_gemm_planes_f32: cannot reserve %d bytes of LDS", Cfg::LDS_BYTES);
+      return PXR_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, g);
+  return pxr_check_launch("pxr_gemm_planes_f32");
+}
+
+template <class Cfg, bool EARLY>
+static int epi_p3(int b_kc, int epilogue, P3Args& g, hipStream_t st) {
+#define PXR_P3(BK_, E) \
+  case E: return launch_p3<Cfg, BK_, E, EARLY>(g, st)
+  if (b_kc) {
+    switch (epilogue) {
+      PXR_P3(true, EPI_NONE); PXR_P3(true, EPI_BIAS); PXR_P3(true, EPI_BIAS_GELU_GRAD);
+    }
+  } else {
+    switch (epilogue) {
+      PXR_P3(false, EPI_NONE); PXR_P3(false, EPI_ADD); PXR_P3(false, EPI_MUL);
+    }
+  }
+#undef PXR_P3
+  pxr_set_error("pxr_gemm_planes_f32: flavour b_kc=%d / epilogue %d is not instantiated", b_kc, epilogue);
+  return PXR_ERR_BAD_ARG;
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+extern "C" int pxr_split_planes_f32(const float* x, int64_t rows, int64_t cols, int64_t ldx, void* planes, int64_t plane_stride,
+                                    int64_t panel_rows, void* stream) {
+  PXR_REQUIRE(x && planes, "pxr_split_planes_f32: null operand");
+  PXR_REQUIRE(rows >= 0 && cols >= 0 && cols % 32 == 0 && ldx % 4 == 0, "pxr_split_planes_f32: cols must be a multiple of 32, ldx of 4");
+  PXR_REQUIRE(panel_rows >= rows && panel_rows % 16 == 0 && plane_stride >= panel_rows * cols && plane_stride % 8 == 0,
+              "pxr_split_planes_f32: panel_rows must be a multiple of 16 >= rows, plane_stride >= panel_rows * cols");
+  PXR_REQUIRE((((uintptr_t)x | (uintptr_t)planes) & 15) == 0, "pxr_split_planes_f32: operands must be 16-byte aligned");
+  const int64_t n = rows * (cols / 8);
+  if (n == 0) return PXR_OK;
+  PXR_REQUIRE((n + 255) / 256 < (1ll << 31), "pxr_split_planes_f32: too large");
+  const P3Mat out{reinterpret_cast<__bf16*>(planes), plane_stride, panel_rows};
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
+                     (int)(cols / 8), out);
+  return pxr_check_launch("pxr_split_planes_f32");
+}
+
+extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows,
+                                   const void* B, int64_t b_plane_stride, int64_t b_panel_rows, float* C, int64_t ldc,
+                                   int epilogue, const float* bias, float* aux, int64_t ldaux, void* c_planes,
+                                   int64_t c_plane_stride, int64_t c_panel_rows, int act, int tile_hint, void* stream) {
+  PXR_REQUIRE(A && B && (C || c_planes), "pxr_gemm_planes_f32: null operand");
+  PXR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && K % 32 == 0, "pxr_gemm_planes_f32: K must be a multiple of 32");
+  PXR_REQUIRE(b_kc || N % 32 == 0, "pxr_gemm_planes_f32: an x-contiguous B needs N %% 32 == 0");
+  PXR_REQUIRE(a_panel_rows % 16 == 0 && b_panel_rows % 16 == 0 && a_plane_stride % 8 == 0 && b_plane_stride % 8 == 0,
+              "pxr_gemm_planes_f32: panel rows must be multiples of 16, plane strides of 8 elements");
+  PXR_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)c_planes | (uintptr_t)aux | (uintptr_t)bias) & 15) == 0,
+              "pxr_gemm_planes_f32: operands must be 16-byte aligned");
+  PXR_REQUIRE(a_plane_stride * 6 < 0x7FFFFFF0ll && b_plane_stride * 6 < 0x7FFFFFF0ll,
+              "pxr_gemm_planes_f32: an operand's three planes must span less than 2 GiB");
+  PXR_REQUIRE(!c_planes || (N % 32 == 0 && c_panel_rows % 16 == 0 && c_panel_rows >= M), "pxr_gemm_planes_f32: output planes need N %% 32 == 0");
+  if (M == 0 || N == 0) return PXR_OK;
+  P3Args g;
+  g.A = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(A)), a_plane_stride, a_panel_rows};
+  g.B = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(B)), b_plane_stride, b_panel_rows};
+  g.Cp = P3Mat{reinterpret_cast<__bf16*>(c_planes), c_plane_stride, c_panel_rows};
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.act = act;
+  hipStream_t st = (hipStream_t)stream;
+  // tile_hint digits: waves | BM (3) | BN (3) | stages | early fragment reads
+#define PXR_P3_TILE(CODE, EARLY, ...) \
+  if (tile_hint == CODE) return epi_p3<P3Cfg<__VA_ARGS__>, EARLY>(b_kc, epilogue, g, st)
+  PXR_P3_TILE(406406430, false, 64, 64, 2, 2, 3);
+  PXR_P3_TILE(406406431, true, 64, 64, 2, 2, 3);
+  PXR_P3_TILE(412806420, false, 128, 64, 2, 2, 2);
+  PXR_P3_TILE(412806430, false, 128, 64, 2, 2, 3);
+  PXR_P3_TILE(406412820, false, 64, 128, 2, 2, 2);
+  PXR_P3_TILE(412812830, false, 128, 128, 2, 2, 3);
+  PXR_P3_TILE(412812831, true, 128, 128, 2, 2, 3);
+  PXR_P3_TILE(812812830, false, 128, 128, 2, 4, 3);
+  PXR_P3_TILE(812812831, true, 128, 128, 2, 4, 3);
+  PXR_P3_TILE(825612820, false, 256, 128, 4, 2, 2);
+#undef PXR_P3_TILE
+  pxr_set_error("pxr_gemm_planes_f32: tile %d is not instantiated", tile_hint);
+  return PXR_ERR_BAD_ARG;
+}
+
+extern "C" int pxr_grouped_dw_planes_f32(int n, const void* const* dy, const int64_t* dy_plane_stride, const int64_t* dy_panel_rows,
+                                         const void* const* x, const int64_t* x_plane_stride, const int64_t* x_panel_rows,
+                                         float* const* dW, float* const* db, const int* T, const int* N, const int* K,
+                                         int tile_hint, void* stream) {
+  PXR_REQUIRE(n >= 1 && n <= DW_MAX && dy && x && dW && db && T && N && K && dy_plane_stride && dy_panel_rows && x_plane_stride &&
+                  x_panel_rows, "pxr_grouped_dw_planes_f32: bad args (n=%d, max %d)", n, DW_MAX);
+  P3DwGroup g{};
+  g.n = n;
+  int64_t t128 = 0;
+  for (int i = 0; i < n; ++i) {
+    PXR_REQUIRE(dy[i] && x[i] && dW[i] && T[i] > 0 && N[i] > 0 && K[i] > 0 && N[i] % 32 == 0 && K[i] % 32 == 0,
+                "pxr_grouped_dw_planes_f32: problem %d has a bad shape (N and K must be multiples of 32)", i);
+    PXR_REQUIRE(dy_panel_rows[i] % 32 == 0 && x_panel_rows[i] % 32 == 0 && dy_panel_rows[i] >= T[i] && x_panel_rows[i] >= T[i],
+                "pxr_grouped_dw_planes_f32: problem %d: panel rows must be multiples of 32 >= T", i);
+    PXR_REQUIRE((((uintptr_t)dy[i] | (uintptr_t)x[i] | (uintptr_t)dW[i]) & 15) == 0, "pxr_grouped_dw_planes_f32: unaligned operand");
+    PXR_REQUIRE(dy_plane_stride[i] * 6 < 0x7FFFFFF0ll && x_plane_stride[i] * 6 < 0x7FFFFFF0ll, "pxr_grouped_dw_planes_f32: planes too large");
+    P3DwProblem& P = g.p[i];
+    P.dy = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(dy[i])), dy_plane_stride[i], dy_panel_rows[i]};
+    P.x = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(x[i])), x_plane_stride[i], x_panel_rows[i]};
+    P.dW = dW[i]; P.db = db[i]; P.T = T[i]; P.N = N[i]; P.K = K[i];
+    t128 += (int64_t)((N[i] + 127) / 128) * ((K[i] + 127) / 128);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (tile_hint == 0) tile_hint = t128 >= 192 ? 812812830 : 406406431;
+  if (tile_hint == 812812830) return launch_dw_p3<P3Cfg<128, 128, 2, 4, 3>, false>(g, st);
+  if (tile_hint == 812812831) return launch_dw_p3<P3Cfg<128, 128, 2, 4, 3>, true>(g, st);
+  if (tile_hint == 412812831) return launch_dw_p3<P3Cfg<128, 128, 2, 2, 3>, true>(g, st);
+  if (tile_hint == 406406431) return launch_dw_p3<P3Cfg<64, 64, 2, 2, 3>, true>(g, st);
+  if (tile_hint == 412806420) return launch_dw_p3<P3Cfg<128, 64, 2, 2, 2>, false>(g, st);
+  pxr_set_error("pxr_grouped_dw_planes_f32: tile %d is not instantiated", tile_hint);
+  return PXR_ERR_BAD_ARG;
+}

@@ -5,6 +5,7 @@ no CPU path.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -146,6 +147,80 @@ def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc,
         _l.check(L.pxr_gemm_f32(int(a_kc), int(b_kc), M, N, K, _l.ptr(A), lda, _l.ptr(B), ldb, _l.ptr(C), ldc,
                                 epilogue, _l.ptr(bias), _l.ptr(aux), ldaux, _l.ptr(ws), ws_bytes, tile_hint,
                                 split_hint, _l.stream_ptr()), "pxr_gemm_f32")
+    return C
+
+
+class Planes:
+    """An fp32 matrix [rows, cols] pre-split into three bf16 planes in PANEL layout (include/pxr.h, csrc/gemm_p3.cuh): the
+    operand format of gemm_planes.  `buf` is a flat bf16 tensor; `off` / `pr` / `ps` are the element offset of plane 0, the
+    rows per panel and the plane stride, so row / column ranges are views of the same buffer."""
+    __slots__ = ("buf", "rows", "cols", "pr", "ps", "off")
+
+    def __init__(self, buf, rows, cols, pr, ps, off=0):
+        self.buf, self.rows, self.cols, self.pr, self.ps, self.off = buf, rows, cols, pr, ps, off
+
+    @staticmethod
+    def alloc(rows: int, cols: int, device) -> "Planes":
+        if cols % 32:
+            raise _l.PxrError(f"planes need a multiple of 32 columns, got {cols}")
+        pr = (rows + 31) // 32 * 32
+        ps = pr * cols
+        # rows past `rows` of a panel are read by edge tiles and, when the rows are a GEMM's reduction dimension (weight
+        # gradients), multiplied in: they must be zero.  Producers never write them, so one fill at allocation is enough.
+        mk = torch.empty if pr == rows else torch.zeros
+        return Planes(mk(3 * ps, dtype=torch.bfloat16, device=device), rows, cols, pr, ps)
+
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr() + 2 * self.off)
+
+    def row_range(self, r0: int, r1: int) -> "Planes":
+        assert r0 % 16 == 0 and r0 <= r1 <= self.rows
+        return Planes(self.buf, r1 - r0, self.cols, self.pr, self.ps, self.off + 32 * r0)
+
+    def col_range(self, c0: int, c1: int) -> "Planes":
+        assert c0 % 32 == 0 and c1 % 32 == 0 and c0 <= c1 <= self.cols
+        return Planes(self.buf, self.rows, c1 - c0, self.pr, self.ps, self.off + (c0 // 32) * self.pr * 32)
+
+    def to_dense(self) -> torch.Tensor:
+        """fp32 [rows, cols] = hi + mid + lo (exact).  For tests; not on the product path."""
+        dev = self.buf.device
+        r = torch.arange(self.rows, device=dev).view(-1, 1)
+        c = torch.arange(self.cols, device=dev).view(1, -1)
+        idx = ((c // 32) * self.pr + r) * 32 + ((((c // 8) % 4) ^ ((r // 4) % 4)) * 8) + c % 8 + self.off
+        out = None
+        for q in range(3):
+            t = self.buf[(idx + q * self.ps).reshape(-1)].view(self.rows, self.cols).float()
+            out = t if out is None else out + t
+        return out
+
+
+def split_planes(x: torch.Tensor, out: Planes | None = None) -> Planes:
+    """fp32 [rows, cols] -> Planes with x = hi + mid + lo exactly (pxr_split_planes_f32)."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    rows, cols = x.shape
+    if out is None:
+        out = Planes.alloc(rows, cols, x.device)
+    assert (out.rows, out.cols) == (rows, cols)
+    _l.check(_l.load().pxr_split_planes_f32(_l.ptr(x), rows, cols, x.stride(0), out.ptr(), out.ps, out.pr,
+                                            _l.stream_ptr()), "pxr_split_planes_f32")
+    return out
+
+
+def gemm_planes(Ap: Planes, Bp: Planes, C: torch.Tensor | None, epilogue=EPI_NONE, bias=None, aux=None, act=0, tile_hint=0,
+                b_kc=True, Cp: Planes | None = None):
+    """C[M,N] = A[M,K] x B from planes (pxr_gemm_planes_f32): Bp is [N,K] (b_kc) or [K,N]; C (fp32) and / or Cp (planes of
+    the result) are written."""
+    M, K = Ap.rows, Ap.cols
+    N = Bp.rows if b_kc else Bp.cols
+    assert (Bp.cols if b_kc else Bp.rows) == K
+    assert C is None or C.shape == (M, N)
+    with _gemm_timer(2.0 * M * N * K):
+        _l.check(_l.load().pxr_gemm_planes_f32(int(b_kc), M, N, K, Ap.ptr(), Ap.ps, Ap.pr, Bp.ptr(), Bp.ps, Bp.pr, _l.ptr(C),
+                                               C.stride(0) if C is not None else 0, epilogue, _l.ptr(bias), _l.ptr(aux),
+                                               aux.stride(0) if aux is not None else 0,
+                                               Cp.ptr() if Cp is not None else None, Cp.ps if Cp is not None else 0,
+                                               Cp.pr if Cp is not None else 0, act, tile_hint, _l.stream_ptr()),
+                 "pxr_gemm_planes_f32")
     return C
 
 
@@ -317,6 +392,23 @@ def grouped_linear_bwd_weight(problems):
     with _gemm_timer(flops, "grouped_dw_kernel (all dW + db of the step)"):
         _l.check(L.pxr_grouped_linear_bwd_weight_f32(n, dy, x, dW, db, M, N, K, _l.stream_ptr()),
                  "pxr_grouped_linear_bwd_weight_f32")
+
+
+def grouped_dw_planes(problems, tile_hint=0):
+    """problems: list of (dy Planes [T,N], x Planes [T,K], dW [N,K] out, db [N] out | None).  One launch for all of them
+    (pxr_grouped_dw_planes_f32)."""
+    L = _l.load()
+    n = len(problems)
+    P, I, I64 = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
+    for dy, x, _, _ in problems:
+        assert dy.rows == x.rows
+    args = (P(*[p[0].ptr().value for p in problems]), I64(*[p[0].ps for p in problems]), I64(*[p[0].pr for p in problems]),
+            P(*[p[1].ptr().value for p in problems]), I64(*[p[1].ps for p in problems]), I64(*[p[1].pr for p in problems]),
+            P(*[p[2].data_ptr() for p in problems]), P(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems]),
+            I(*[p[0].rows for p in problems]), I(*[p[0].cols for p in problems]), I(*[p[1].cols for p in problems]))
+    flops = sum(2.0 * p[0].rows * p[0].cols * p[1].cols for p in problems)
+    with _gemm_timer(flops, "grouped_dw_p3_kernel (all dW + db of the step, from planes)"):
+        _l.check(L.pxr_grouped_dw_planes_f32(n, *args, tile_hint, _l.stream_ptr()), "pxr_grouped_dw_planes_f32")
 
 
 def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None, defer=None):
