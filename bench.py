@@ -309,6 +309,7 @@ def main():
     if args.dw_mode:
         model.weight_grad_mode = args.dw_mode
     model.defer_weight_grad_join = True      # every step below ends in opt.step(), which joins the side stream
+    model.trust_optimizer_planes = True      # ... and nothing but the optimizer rewrites the weights between forwards
     opt = None
 
     # synthetic batches, rank-distinct, resident in HBM before the timed region.  The stream does NOT repeat inside

@@ -168,7 +168,7 @@ int pxr_get_gemm_mode(void);
 /* ---- pre-split operands ("planes"): the same fp32 products on the bf16 matrix pipe, operands split ONCE ---------- */
 /* An fp32 matrix X[rows, cols] (cols % 32 == 0) as three bf16 planes hi | mid | lo with X = hi + mid + lo exactly
  * (hi = bf16(X), mid = bf16(X - hi), lo = X - hi - mid).  Plane q starts q * plane_stride ELEMENTS after `planes`; inside
- * a plane the matrix is stored as cols / 32 PANELS of panel_rows (>= rows, multiple of 16) rows x 32 columns:
+ * a plane the matrix is stored as cols / 32 PANELS of panel_rows (>= rows, multiple of 32; rows past `rows` must be ZERO when the rows are a GEMM's reduction dimension) rows x 32 columns:
  *     element (r, c) at ((c / 32) * panel_rows + r) * 32 + ((((c / 8) % 4) ^ ((r / 4) % 4)) * 8 + c % 8
  * (64-byte row segments, 16-byte chunks XOR-swizzled by the row: a GEMM tile is a byte copy of 1 KiB runs, csrc/gemm_p3.cuh).
  * A row range [r0, r1) with r0 % 16 == 0 is the same layout at planes + 32 r0; a column range with c0 % 32 == 0 at
@@ -185,6 +185,37 @@ int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A, int64_t a_
                         const float* bias, float* aux, int64_t ldaux, void* c_planes, int64_t c_plane_stride,
                         int64_t c_panel_rows, int act, int tile_hint, void* stream);
 
+/* up to 16 matrices in one launch (host arrays of n entries): the weight matrices of the block after an optimizer step */
+int pxr_split_planes_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
+                               void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows, void* stream);
+/* Producers that write their output straight as planes (same arguments as the functions they extend + the planes matrix;
+ * planes == NULL: exactly the plain function).  LayerNorm sites: y as planes; LayerNorm backward (residual sites): the
+ * gradient the next GEMMs read (dx when given, else dz); attention: ctx as the [B*L, H*d] matrix (ctx may then be NULL),
+ * dq | dk | dv as column ranges starting at col_q / col_k / col_v of one [B*L, g_cols] matrix (dq, dk, dv may then all be
+ * NULL).  pxr_attn_planes_supported(L, d): whether the fused attention kernels that can do so serve the shape. */
+int pxr_input_ln_fwd_planes_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
+                                const float* pos, const float* gamma, const float* beta, float eps, int B, int L, int D,
+                                float* y, float* xhat, float* rstd, float p_drop, uint64_t seed, uint32_t stream_id,
+                                const int64_t* step_dev, void* y_planes, int64_t y_plane_stride, int64_t y_panel_rows,
+                                void* stream);
+int pxr_ln_residual_fwd_planes_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                                   int rows, int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
+                                   uint32_t stream_id, const int64_t* step_dev, void* y_planes, int64_t y_plane_stride,
+                                   int64_t y_panel_rows, void* stream);
+int pxr_ln_bwd_planes_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                          int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed,
+                          uint32_t stream_id, const int64_t* step_dev, void* ws, int64_t ws_bytes, void* g_planes,
+                          int64_t g_plane_stride, int64_t g_panel_rows, void* stream);
+int pxr_attn_planes_supported(int L, int d);
+int pxr_attn_fwd_planes_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
+                            int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx, float* probs,
+                            float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ctx_planes,
+                            int64_t ctx_plane_stride, int64_t ctx_panel_rows, void* stream);
+int pxr_attn_bwd_planes_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
+                            const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d,
+                            float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* g_planes,
+                            int64_t g_plane_stride, int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v,
+                            void* stream);
 /* pxr_grouped_linear_bwd_weight_f32 from planes: dW[i][N_i,K_i] = dy[i][T_i,N_i]^T x[i][T_i,K_i], db[i][N_i] = column sums
  * of dy[i] (db[i] may be NULL), all problems in one launch.  dy[i] / x[i] are planes of the [T_i, .] matrices whose panel
  * rows (multiples of 32) T_i .. panel_rows-1 are ZERO.  N_i, K_i multiples of 32.  Autograd of model/layers.py:586-588,613,
@@ -316,6 +347,14 @@ int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t 
 /* pxr_adamw_flat_f32 with the step's scalars read from hyper[step] (or hyper[*step_dev + 1]). */
 int pxr_adamw_flat_tab_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper, int64_t step,
                            const int64_t* step_dev, double beta1, double beta2, double eps, void* stream);
+/* pxr_adamw_flat_tab_f32 that also writes the UPDATED values of n_seg (<= 16) weight matrices inside the flat buffer
+ * ([seg_rows, seg_cols] row-major at element seg_off) as bf16x3 planes (see "pre-split operands"): the operands of the next
+ * step's GEMMs come out of the optimizer (trainer.py:125) with no split launch. */
+int pxr_adamw_flat_tab_planes_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper, int64_t step,
+                                  const int64_t* step_dev, double beta1, double beta2, double eps, int n_seg,
+                                  const int64_t* seg_off, const int64_t* seg_rows, const int64_t* seg_cols,
+                                  void* const* seg_planes, const int64_t* seg_plane_stride, const int64_t* seg_panel_rows,
+                                  void* stream);
 /* *counter += delta on the device. */
 int pxr_counter_add_i64(int64_t* counter, int64_t delta, void* stream);
 

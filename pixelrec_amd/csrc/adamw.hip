@@ -15,7 +15,7 @@
 //     gradient this step).  HBM traffic per step = 6 x 4 B x N x D (read+write p, m, v) instead of the
 //     reference's 7 x 4 B plus the 2 x dense-gradient zero-fill/scatter; no 819 MB dense gradient exists.
 //     The kernel clears the slots it consumes, so the map is all -1 again afterwards.
-#include "pxr_common.h"
+#include "planes.cuh"
 
 #include <cstdlib>
 
@@ -285,12 +285,35 @@ __global__ void hyper_append_kernel(float4* hyper, double* cumlog, int64_t capac
   cumlog[step] = cumlog[step - 1] + log((double)decay);
 }
 
+// Weight matrices inside the flat buffer whose updated values are ALSO written as bf16x3 planes (the operand format of the
+// planes GEMMs, planes.cuh): the next forward then needs no split launch.  Segment i covers flat elements
+// [off, off + rows * cols) as a row-major [rows][cols] matrix; offsets are multiples of 4 and cols of 32, so a thread's
+// float4 never straddles a row or a 8-column chunk half.
+struct FlatPlanes {
+  int64_t off[16];
+  int rows[16], cols[16];
+  P3Mat out[16];
+  int n;
+};
+__device__ __forceinline__ void flat_planes_store(const FlatPlanes& fp, int64_t e, const float4& pp) {
+#pragma unroll 1
+  for (int i = 0; i < fp.n; ++i) {
+    const int64_t r = e - fp.off[i];
+    if (r >= 0 && r < (int64_t)fp.rows[i] * fp.cols[i]) {
+      const int row = (int)(r / fp.cols[i]);
+      p3_store4(fp.out[i], row, (int)(r - (int64_t)row * fp.cols[i]), pp);
+      return;
+    }
+  }
+}
+
 // flat AdamW reading the step's scalars from the hyper table (graph-replayable form of adamw_flat_kernel)
+template <bool PLANES>
 __global__ void __launch_bounds__(256) adamw_flat_tab_kernel(float4* __restrict__ p, const float4* __restrict__ g,
                                                              float4* __restrict__ m, float4* __restrict__ v,
                                                              int64_t n4, const float4* __restrict__ hyper, int64_t step,
                                                              const int64_t* step_dev, float one_m_b1, float b2,
-                                                             float one_m_b2, float eps) {
+                                                             float one_m_b2, float eps, const FlatPlanes fp) {
   if (step_dev) step = step_dev[0] + 1;
   const float4 hs = hyper[step];
   AdamHyper h;
@@ -302,6 +325,7 @@ __global__ void __launch_bounds__(256) adamw_flat_tab_kernel(float4* __restrict_
     adam_elem(pp.x, mm.x, vv.x, gg.x, h); adam_elem(pp.y, mm.y, vv.y, gg.y, h);
     adam_elem(pp.z, mm.z, vv.z, gg.z, h); adam_elem(pp.w, mm.w, vv.w, gg.w, h);
     p[i] = pp; m[i] = mm; v[i] = vv;
+    if constexpr (PLANES) flat_planes_store(fp, i * 4, pp);
   }
 }
 
@@ -395,18 +419,50 @@ extern "C" int pxr_adamw_hyper_append(void* hyper, void* cumlog, int64_t capacit
 }
 
 // Flat AdamW with the step's scalars taken from the hyper table entry `step` (or *step_dev + 1).
+extern "C" int pxr_adamw_flat_tab_planes_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper,
+                                             int64_t step, const int64_t* step_dev, double beta1, double beta2, double eps,
+                                             int n_seg, const int64_t* seg_off, const int64_t* seg_rows, const int64_t* seg_cols,
+                                             void* const* seg_planes, const int64_t* seg_plane_stride,
+                                             const int64_t* seg_panel_rows, void* stream);
 extern "C" int pxr_adamw_flat_tab_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper,
                                       int64_t step, const int64_t* step_dev, double beta1, double beta2, double eps,
                                       void* stream) {
+  return pxr_adamw_flat_tab_planes_f32(p, g, m, v, n, hyper, step, step_dev, beta1, beta2, eps, 0, nullptr, nullptr, nullptr,
+                                       nullptr, nullptr, nullptr, stream);
+}
+// the same; the updated values of n_seg (<= 16) weight matrices inside the flat buffer ([seg_rows, seg_cols] row-major at
+// element seg_off) are additionally written as bf16x3 planes (pxr.h: planes) -- the operands of the next step's GEMMs
+extern "C" int pxr_adamw_flat_tab_planes_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper,
+                                             int64_t step, const int64_t* step_dev, double beta1, double beta2, double eps,
+                                             int n_seg, const int64_t* seg_off, const int64_t* seg_rows, const int64_t* seg_cols,
+                                             void* const* seg_planes, const int64_t* seg_plane_stride,
+                                             const int64_t* seg_panel_rows, void* stream) {
   PXR_REQUIRE(p && g && m && v && hyper, "pxr_adamw_flat_tab_f32: null pointer");
   PXR_REQUIRE(n >= 0 && n % 4 == 0 && (step_dev || step >= 1), "pxr_adamw_flat_tab_f32: bad n / step");
+  PXR_REQUIRE(n_seg >= 0 && n_seg <= 16 && (n_seg == 0 || (seg_off && seg_rows && seg_cols && seg_planes && seg_plane_stride && seg_panel_rows)),
+              "pxr_adamw_flat_tab_planes_f32: bad segment table");
   if (n == 0) return PXR_OK;
+  FlatPlanes fp{};
+  fp.n = n_seg;
+  for (int i = 0; i < n_seg; ++i) {
+    PXR_REQUIRE(seg_off[i] >= 0 && seg_off[i] % 4 == 0 && seg_rows[i] > 0 && seg_rows[i] < (1ll << 31) && seg_cols[i] > 0 &&
+                    seg_off[i] + seg_rows[i] * seg_cols[i] <= n && seg_planes[i] &&
+                    p3_mat_ok(seg_planes[i], seg_plane_stride[i], seg_panel_rows[i], seg_rows[i], seg_cols[i]),
+                "pxr_adamw_flat_tab_planes_f32: segment %d is bad", i);
+    fp.off[i] = seg_off[i]; fp.rows[i] = (int)seg_rows[i]; fp.cols[i] = (int)seg_cols[i];
+    fp.out[i] = P3Mat{reinterpret_cast<__bf16*>(seg_planes[i]), seg_plane_stride[i], seg_panel_rows[i]};
+  }
   const int64_t n4 = n / 4;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adamw_flat_tab_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p,
-                     (const float4*)g, (float4*)m, (float4*)v, n4, (const float4*)hyper, step, step_dev,
-                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
+  if (n_seg > 0)
+    hipLaunchKernelGGL(adamw_flat_tab_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p,
+                       (const float4*)g, (float4*)m, (float4*)v, n4, (const float4*)hyper, step, step_dev,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, fp);
+  else
+    hipLaunchKernelGGL(adamw_flat_tab_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p,
+                       (const float4*)g, (float4*)m, (float4*)v, n4, (const float4*)hyper, step, step_dev,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, fp);
   return pxr_check_launch("pxr_adamw_flat_tab_f32");
 }
 

@@ -22,7 +22,7 @@
 //     the un-dropped probabilities are saved ([B,H,L,L]) for the backward pass.
 #include <stdlib.h>
 
-#include "pxr_common.h"
+#include "planes.cuh"
 
 namespace pxr {
 
@@ -42,6 +42,10 @@ struct AttnArgs {
   float sqrt_d;
   float p_drop; uint32_t drop_thr; uint32_t stream; uint64_t seed;
   const int64_t* step_dev;  // optional device counter added to the seed
+  // optional outputs as bf16x3 planes (planes.cuh), attn_*_mfma1_kernel only: ctx as the [B*L, H*d] matrix; dq | dk | dv as
+  // column ranges (starting at pcol[0..2]) of one [B*L, .] matrix.  With planes the fp32 outputs may be null.
+  P3Mat op;
+  int pcol[3];
 };
 
 // stage tile[row][0..w) <- src[(row)*ld + 0..w) for row < L; all threads of the block, float4 accesses
@@ -319,6 +323,31 @@ __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TN], float* out, i
   }
 }
 
+// the same block(s) as bf16x3 planes: through an LDS tile ([64][ATT_KLD], free at the call site) so that every thread owns 8
+// consecutive columns of a row = one 16-byte store per plane.  ALL threads of the workgroup must call it (two barriers).
+template <int TN, int NT>
+__device__ __forceinline__ void store_acc_planes(const f32x16 (&acc)[TN], bool mine, float* tile, int m_base, int n_base, int L,
+                                                 int w, int lane, const P3Mat& P, int64_t row0, int col0) {
+  const int h = lane >> 5, r = lane & 31;
+  if (mine) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        tile[(m_base + (e & 3) + 8 * (e >> 2) + 4 * h) * ATT_KLD + n_base + j * 32 + r] = acc[j][e];
+  }
+  __syncthreads();
+  const int cpr = w >> 3;
+  for (int q = threadIdx.x; q < L * cpr; q += NT) {
+    const int row = q / cpr, c8 = (q - row * cpr) * 8;
+    const float4 x0 = *reinterpret_cast<const float4*>(tile + row * ATT_KLD + c8);
+    const float4 x1 = *reinterpret_cast<const float4*>(tile + row * ATT_KLD + c8 + 4);
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    p3_store8(P, row0 + row, col0 + c8, v);
+  }
+  __syncthreads();
+}
+
 // stage rows < L of a [L][w] global tile into LDS with the given stride; rows L..63 are zero-filled.
 // All of a thread's global loads are issued BEFORE its first LDS store: with one workgroup per CU a
 // load -> wait -> ds_write loop would serialise ~8 HBM round trips per tile (measured: 20 of the kernel's 25 us).
@@ -555,13 +584,15 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_mfma1_kernel(AttnArgs a) {
     f32x16 accO[2];
     zero_acc<2>(accO);
     if (wn * 64 < d) lds_mma<true, false, 2>(accO, sS, ATT_SLD, sV, ATT_KLD, wm * 32, wn * 64, 64, lane);
-    store_acc<2>(accO, ctx, a.ld_ctx, wm * 32, wn * 64, L, d, lane);
+    if (a.ctx) store_acc<2>(accO, ctx, a.ld_ctx, wm * 32, wn * 64, L, d, lane);
+    if (a.op.p) store_acc_planes<2, NT>(accO, wn * 64 < d, sQ, wm * 32, wn * 64, L, d, lane, a.op, (int64_t)b * L, h * d);
   } else {
     const int wm = wave >> 2, wn = wave & 3;
     f32x16 accO[1];
     zero_acc<1>(accO);
     if (wn * 32 < d) lds_mma<true, false, 1>(accO, sS, ATT_SLD, sV, ATT_KLD, wm * 32, wn * 32, 64, lane);
-    store_acc<1>(accO, ctx, a.ld_ctx, wm * 32, wn * 32, L, d, lane);
+    if (a.ctx) store_acc<1>(accO, ctx, a.ld_ctx, wm * 32, wn * 32, L, d, lane);
+    if (a.op.p) store_acc_planes<1, NT>(accO, wn * 32 < d, sQ, wm * 32, wn * 32, L, d, lane, a.op, (int64_t)b * L, h * d);
   }
 }
 
@@ -636,7 +667,9 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   f32x16 acc[TN];
   zero_acc<TN>(acc);
   if (mine) lds_mma<false, false, TN>(acc, sS, ATT_SLD, sO, ATT_KLD, wm * 32, n_base, 64, lane);   // dV = Pd^T dctx
-  store_acc<TN>(acc, a.dv + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
+  if (a.dv) store_acc<TN>(acc, a.dv + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
+  // (sV was last read by the dPd product, two barriers ago: free for the plane staging)
+  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[2] + h * d);
   __syncthreads();
 #pragma unroll
   for (int g = 0; g < ROWS; ++g) {
@@ -646,10 +679,12 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   __syncthreads();
   zero_acc<TN>(acc);
   if (mine) lds_mma<true, false, TN>(acc, sS, ATT_SLD, sK, ATT_KLD, wm * 32, n_base, 64, lane);    // dQ = dS K
-  store_acc<TN>(acc, a.dq + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
+  if (a.dq) store_acc<TN>(acc, a.dq + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
+  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[0] + h * d);
   zero_acc<TN>(acc);
   if (mine) lds_mma<false, false, TN>(acc, sS, ATT_SLD, sQ, ATT_KLD, wm * 32, n_base, 64, lane);   // dK = dS^T Q
-  store_acc<TN>(acc, a.dk + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
+  if (a.dk) store_acc<TN>(acc, a.dk + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
+  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[1] + h * d);
 }
 
 // ---- sequences of 65..128 positions ------------------------------------------------------------------------------
@@ -898,11 +933,30 @@ static int attn_check(int B, int H, int L, int d, int64_t ld, const char* who) {
 }
 
 // ctx[b,t,h*d:(h+1)*d] = softmax(q k^T / sqrt(d) + mask) v       (eval: p_drop = 0)
+// 1 when the fused kernels that can write their outputs as planes serve this shape (pxr_attn_*_planes_f32)
+extern "C" int pxr_attn_planes_supported(int L, int d) { return (L <= ATT_MAXL && attn_use_mfma(d) && d <= ATT_DC && d % 8 == 0) ? 1 : 0; }
+
+extern "C" int pxr_attn_fwd_planes_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
+                                       int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx,
+                                       float* probs, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                                       void* ctx_planes, int64_t ctx_plane_stride, int64_t ctx_panel_rows, void* stream);
 extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
                                 int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx,
                                 float* probs, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
                                 void* stream) {
-  PXR_REQUIRE(q && k && v && keymask && ctx, "pxr_attn_fwd_f32: null pointer");
+  PXR_REQUIRE(ctx, "pxr_attn_fwd_f32: null pointer");
+  return pxr_attn_fwd_planes_f32(q, k, v, ld, keymask, km_bstride, B, H, L, d, ctx, ld_ctx, probs, p_drop, seed, stream_id,
+                                 step_dev, nullptr, 0, 0, stream);
+}
+// the same with ctx (the [B*L, H*d] matrix) additionally -- or, ctx == NULL, only -- written as bf16x3 planes: the operand
+// format of the output projection that follows (layers.py:613).  Shapes: pxr_attn_planes_supported.
+extern "C" int pxr_attn_fwd_planes_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
+                                       int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx,
+                                       float* probs, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                                       void* ctx_planes, int64_t ctx_plane_stride, int64_t ctx_panel_rows, void* stream) {
+  PXR_REQUIRE(q && k && v && keymask && (ctx || ctx_planes), "pxr_attn_fwd_f32: null pointer");
+  PXR_REQUIRE(!ctx_planes || (pxr_attn_planes_supported(L, d) && p3_mat_ok(ctx_planes, ctx_plane_stride, ctx_panel_rows, (int64_t)B * L, (int64_t)H * d)),
+              "pxr_attn_fwd_planes_f32: planes are not available for this shape (L=%d, d=%d)", L, d);
   int rc = attn_check(B, H, L, d, ld, "pxr_attn_fwd_f32");
   if (rc) return rc;
   PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_attn_fwd_f32: bad dropout p");
@@ -910,6 +964,7 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.keymask = keymask; a.km_bstride = km_bstride;
   a.ctx = ctx; a.ld_ctx = ld_ctx; a.probs = probs; a.B = B; a.H = H; a.L = L; a.d = d;
+  a.op = P3Mat{reinterpret_cast<__bf16*>(ctx_planes), ctx_plane_stride, ctx_panel_rows};
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
@@ -934,11 +989,31 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
 }
 
 // Gradients w.r.t. q, k, v (written with row stride ld_d, head h at column h*d) from dctx and the saved probs.
+extern "C" int pxr_attn_bwd_planes_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v,
+                                       int64_t ld, const float* probs, int B, int H, int L, int d, float* dq, float* dk,
+                                       float* dv, int64_t ld_d, float p_drop, uint64_t seed, uint32_t stream_id,
+                                       const int64_t* step_dev, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows,
+                                       int g_cols, int col_q, int col_k, int col_v, void* stream);
 extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v,
                                 int64_t ld, const float* probs, int B, int H, int L, int d, float* dq, float* dk,
                                 float* dv, int64_t ld_d, float p_drop, uint64_t seed, uint32_t stream_id,
                                 const int64_t* step_dev, void* stream) {
-  PXR_REQUIRE(dctx && q && k && v && probs && dq && dk && dv, "pxr_attn_bwd_f32: null pointer");
+  PXR_REQUIRE(dq && dk && dv, "pxr_attn_bwd_f32: null pointer");
+  return pxr_attn_bwd_planes_f32(dctx, ld_ctx, q, k, v, ld, probs, B, H, L, d, dq, dk, dv, ld_d, p_drop, seed, stream_id,
+                                 step_dev, nullptr, 0, 0, 0, 0, 0, 0, stream);
+}
+// the same with dq | dk | dv additionally -- or, all three NULL, only -- written as bf16x3 planes: column ranges starting at
+// col_q / col_k / col_v of one [B*L, g_cols] planes matrix (the gradient of the fused QKV projection's output).
+extern "C" int pxr_attn_bwd_planes_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v,
+                                       int64_t ld, const float* probs, int B, int H, int L, int d, float* dq, float* dk,
+                                       float* dv, int64_t ld_d, float p_drop, uint64_t seed, uint32_t stream_id,
+                                       const int64_t* step_dev, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows,
+                                       int g_cols, int col_q, int col_k, int col_v, void* stream) {
+  PXR_REQUIRE(dctx && q && k && v && probs && ((dq && dk && dv) || (g_planes && !dq && !dk && !dv)), "pxr_attn_bwd_f32: null pointer");
+  PXR_REQUIRE(!g_planes || (pxr_attn_planes_supported(L, d) && p3_mat_ok(g_planes, g_plane_stride, g_panel_rows, (int64_t)B * L, g_cols) &&
+                            col_q % 8 == 0 && col_k % 8 == 0 && col_v % 8 == 0 && col_q >= 0 && col_k >= 0 && col_v >= 0 &&
+                            (int64_t)H * d + (col_q > col_k ? (col_q > col_v ? col_q : col_v) : (col_k > col_v ? col_k : col_v)) <= g_cols),
+              "pxr_attn_bwd_planes_f32: planes are not available for this shape (L=%d, d=%d) or bad column ranges", L, d);
   int rc = attn_check(B, H, L, d, ld, "pxr_attn_bwd_f32");
   if (rc) return rc;
   PXR_REQUIRE(ld_d % 4 == 0 && ld_ctx % 4 == 0, "pxr_attn_bwd_f32: strides must be multiples of 4");
@@ -946,6 +1021,8 @@ extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* 
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.ld_ctx = ld_ctx; a.probs = const_cast<float*>(probs);
   a.dctx = dctx; a.dq = dq; a.dk = dk; a.dv = dv; a.ld_d = ld_d; a.B = B; a.H = H; a.L = L; a.d = d;
+  a.op = P3Mat{reinterpret_cast<__bf16*>(g_planes), g_plane_stride, g_panel_rows};
+  a.pcol[0] = col_q; a.pcol[1] = col_k; a.pcol[2] = col_v;
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;

@@ -11,7 +11,7 @@
 // Arithmetic: identical to gemm_b3.cuh (six of the nine cross products, fp32 accumulation, the small terms in their own
 // accumulators, same k order) -- the planes ARE the terms that kernel computes on the fly: results are bit-identical to it.
 //
-// Panel layout of a matrix X[R][C] (C % 32 == 0; `pr` >= R rows allocated per panel, pr % 16 == 0): plane q starts
+// Panel layout of a matrix X[R][C] (C % 32 == 0; `pr` >= R rows allocated per panel, pr % 32 == 0): plane q starts
 // q * ps elements after the base; inside a plane, panel cb = c / 32 holds columns 32 cb .. 32 cb + 31 of ALL rows:
 //     element (r, c)  at  ((cb * pr + r) * 32 + (((c >> 3) & 3) ^ ((r >> 2) & 3)) * 8 + (c & 7))      [elements]
 // i.e. a 64-byte row segment per (row, panel) whose four 16-byte chunks are XOR-swizzled by the row -- the LDS image of a
@@ -29,51 +29,12 @@
 // s_barrier before a stage is read) -- cdna_hip_programming.md §5.7.
 #pragma once
 #include "gemm_f32.cuh"
+#include "planes.cuh"
 
 namespace pxr {
 
 typedef __bf16 p3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 p3_bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned p3_u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 p3_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float p3_f32x2 __attribute__((ext_vector_type(2)));
-
-// ---- the exact 3-term split (same arithmetic as gemm_b3.cuh::b3_split2: hi = bf16_rne(x), mid = bf16_rne(x - hi),
-// lo = x - hi - mid; both remainders are exact in fp32 and lo has <= 8 significant bits) -----------------------------
-__device__ __forceinline__ void p3_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  const p3_f32x2 v = {a, b};
-  const p3_bf16x2 h = __builtin_convertvector(v, p3_bf16x2);
-  const p3_f32x2 r1 = v - __builtin_convertvector(h, p3_f32x2);
-  const p3_bf16x2 m = __builtin_convertvector(r1, p3_bf16x2);
-  const p3_f32x2 r2 = r1 - __builtin_convertvector(m, p3_f32x2);
-  const p3_bf16x2 l = __builtin_convertvector(r2, p3_bf16x2);
-  hi = __builtin_bit_cast(unsigned, h);
-  mid = __builtin_bit_cast(unsigned, m);
-  lo = __builtin_bit_cast(unsigned, l);
-}
-// A planes matrix as a kernel argument.
-struct P3Mat {
-  __bf16* p;       // plane 0
-  int64_t ps;      // plane stride, elements
-  int64_t pr;      // rows per panel (allocated), multiple of 16
-};
-// element offset of (row r, 8-column chunk starting at column c, c % 8 == 0) inside a plane
-__device__ __forceinline__ int64_t p3_chunk_index(int64_t pr, int64_t r, int c) {
-  return (((int64_t)(c >> 5) * pr + r) << 5) + ((((c >> 3) & 3) ^ ((int)(r >> 2) & 3)) << 3);
-}
-// store 8 consecutive values x[r][c .. c+7] (c % 8 == 0) into the three planes: one 16-byte store per plane
-__device__ __forceinline__ void p3_store8(const P3Mat& m, int64_t r, int c, const float (&v)[8]) {
-  p3_u32x4 p[3];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned h, mi, l;
-    p3_split2(v[2 * j], v[2 * j + 1], h, mi, l);
-    p[0][j] = h; p[1][j] = mi; p[2][j] = l;
-  }
-  __bf16* dst = m.p + p3_chunk_index(m.pr, r, c);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) *reinterpret_cast<p3_u32x4*>(dst + q * m.ps) = p[q];
-}
 
 template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_>
 struct P3Cfg {

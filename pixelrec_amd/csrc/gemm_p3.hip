@@ -261,6 +261,29 @@ static int launch_dw_p3(P3DwGroup& g, hipStream_t st) {
   return pxr_check_launch("pxr_grouped_dw_planes_f32");
 }
 
+// up to 16 matrices in one launch (the weight matrices of the sequence block after an optimizer step)
+struct SplitMulti {
+  const float* x[16]; int64_t ldx[16]; int rows[16], cols8[16]; P3Mat out[16];
+  int64_t begin[17];
+  int n;
+};
+__global__ void __launch_bounds__(256) split_planes_multi_kernel(const SplitMulti m) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m.begin[m.n]) return;
+  int pi = 0;
+#pragma unroll 1
+  for (int k = 1; k < m.n; ++k)
+    if (i >= m.begin[k]) pi = k;
+  const int64_t li = i - m.begin[pi];
+  const int64_t row = li / m.cols8[pi];
+  const int c = (int)(li % m.cols8[pi]) * 8;
+  const float* src = m.x[pi] + row * m.ldx[pi] + c;
+  const float4 a = *reinterpret_cast<const float4*>(src);
+  const float4 b = *reinterpret_cast<const float4*>(src + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  p3_store8(m.out[pi], row, c, v);
+}
+
 template <class Cfg, bool B_KC, int EPI, bool EARLY>
 static int launch_p3(P3Args& g, hipStream_t st) {
   g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
@@ -288,7 +311,8 @@ static int epi_p3(int b_kc, int epilogue, P3Args& g, hipStream_t st) {
   case E: return launch_p3<Cfg, BK_, E, EARLY>(g, st)
   if (b_kc) {
     switch (epilogue) {
-      PXR_P3(true, EPI_NONE); PXR_P3(true, EPI_BIAS); PXR_P3(true, EPI_BIAS_GELU_GRAD);
+      PXR_P3(true, EPI_NONE); PXR_P3(true, EPI_BIAS); PXR_P3(true, EPI_BIAS_GELU); PXR_P3(true, EPI_BIAS_GELU_GRAD);
+      PXR_P3(true, EPI_BIAS_ACT_GRAD);
     }
   } else {
     switch (epilogue) {
@@ -320,6 +344,28 @@ extern "C" int pxr_split_planes_f32(const float* x, int64_t rows, int64_t cols, 
   return pxr_check_launch("pxr_split_planes_f32");
 }
 
+extern "C" int pxr_split_planes_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
+                                          void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows,
+                                          void* stream) {
+  PXR_REQUIRE(n >= 1 && n <= 16 && x && rows && cols && ldx && planes && plane_stride && panel_rows, "pxr_split_planes_multi_f32: bad args");
+  SplitMulti m{};
+  m.n = n;
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    PXR_REQUIRE(x[i] && planes[i] && rows[i] > 0 && rows[i] < (1ll << 31) && cols[i] > 0 && cols[i] % 32 == 0 && ldx[i] % 4 == 0 &&
+                    (((uintptr_t)x[i]) & 15) == 0 && p3_mat_ok(planes[i], plane_stride[i], panel_rows[i], rows[i], cols[i]),
+                "pxr_split_planes_multi_f32: matrix %d is bad", i);
+    m.x[i] = x[i]; m.ldx[i] = ldx[i]; m.rows[i] = (int)rows[i]; m.cols8[i] = (int)(cols[i] / 8);
+    m.out[i] = P3Mat{reinterpret_cast<__bf16*>(planes[i]), plane_stride[i], panel_rows[i]};
+    m.begin[i] = total;
+    total += rows[i] * (cols[i] / 8);
+  }
+  m.begin[n] = total;
+  PXR_REQUIRE((total + 255) / 256 < (1ll << 31), "pxr_split_planes_multi_f32: too large");
+  hipLaunchKernelGGL(split_planes_multi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m);
+  return pxr_check_launch("pxr_split_planes_multi_f32");
+}
+
 extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows,
                                    const void* B, int64_t b_plane_stride, int64_t b_panel_rows, float* C, int64_t ldc,
                                    int epilogue, const float* bias, float* aux, int64_t ldaux, void* c_planes,
@@ -341,18 +387,24 @@ extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A,
   g.Cp = P3Mat{reinterpret_cast<__bf16*>(c_planes), c_plane_stride, c_panel_rows};
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.act = act;
   hipStream_t st = (hipStream_t)stream;
-  // tile_hint digits: waves | BM (3) | BN (3) | stages | early fragment reads
+  // tile_hint digits: waves | BM (3) | BN (3) | stages | early fragment reads.  Heuristic (tools/p3_sweep.py on MI355X):
+  // 256x128 tiles when they fill the chip more than twice; at M = B*L ~ 3200 tokens 128x64 (two workgroups per CU) for wide
+  // outputs and 64x64 with early fragment reads otherwise
+  if (tile_hint == 0) {
+    const int64_t t256 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
+    static const int env_small = getenv("PXR_P3_TILE_SMALL") ? atoi(getenv("PXR_P3_TILE_SMALL")) : 406406430;   // A/B knobs
+    static const int env_wide = getenv("PXR_P3_TILE_WIDE") ? atoi(getenv("PXR_P3_TILE_WIDE")) : 412806420;
+    tile_hint = t256 >= 512 ? 825612820 : (N >= 1024 ? env_wide : env_small);
+  }
 #define PXR_P3_TILE(CODE, EARLY, ...) \
   if (tile_hint == CODE) return epi_p3<P3Cfg<__VA_ARGS__>, EARLY>(b_kc, epilogue, g, st)
-  PXR_P3_TILE(406406430, false, 64, 64, 2, 2, 3);
   PXR_P3_TILE(406406431, true, 64, 64, 2, 2, 3);
+  PXR_P3_TILE(406406461, true, 64, 64, 2, 2, 6);
+  PXR_P3_TILE(406406430, false, 64, 64, 2, 2, 3);
+  PXR_P3_TILE(412806441, true, 128, 64, 2, 2, 4);
   PXR_P3_TILE(412806420, false, 128, 64, 2, 2, 2);
-  PXR_P3_TILE(412806430, false, 128, 64, 2, 2, 3);
   PXR_P3_TILE(406412820, false, 64, 128, 2, 2, 2);
-  PXR_P3_TILE(412812830, false, 128, 128, 2, 2, 3);
-  PXR_P3_TILE(412812831, true, 128, 128, 2, 2, 3);
   PXR_P3_TILE(812812830, false, 128, 128, 2, 4, 3);
-  PXR_P3_TILE(812812831, true, 128, 128, 2, 4, 3);
   PXR_P3_TILE(825612820, false, 256, 128, 4, 2, 2);
 #undef PXR_P3_TILE
   pxr_set_error("pxr_gemm_planes_f32: tile %d is not instantiated", tile_hint);
@@ -382,12 +434,10 @@ extern "C" int pxr_grouped_dw_planes_f32(int n, const void* const* dy, const int
     t128 += (int64_t)((N[i] + 127) / 128) * ((K[i] + 127) / 128);
   }
   hipStream_t st = (hipStream_t)stream;
-  if (tile_hint == 0) tile_hint = t128 >= 192 ? 812812830 : 406406431;
+  if (tile_hint == 0) tile_hint = t128 >= 192 ? 412812831 : 406406431;
   if (tile_hint == 812812830) return launch_dw_p3<P3Cfg<128, 128, 2, 4, 3>, false>(g, st);
-  if (tile_hint == 812812831) return launch_dw_p3<P3Cfg<128, 128, 2, 4, 3>, true>(g, st);
   if (tile_hint == 412812831) return launch_dw_p3<P3Cfg<128, 128, 2, 2, 3>, true>(g, st);
   if (tile_hint == 406406431) return launch_dw_p3<P3Cfg<64, 64, 2, 2, 3>, true>(g, st);
-  if (tile_hint == 412806420) return launch_dw_p3<P3Cfg<128, 64, 2, 2, 2>, false>(g, st);
   pxr_set_error("pxr_grouped_dw_planes_f32: tile %d is not instantiated", tile_hint);
   return PXR_ERR_BAD_ARG;
 }

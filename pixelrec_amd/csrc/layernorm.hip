@@ -12,7 +12,7 @@
 // Backward (autograd of the above):   a = dy*gamma;  dz = rstd*(a - mean(a) - xhat*mean(a*xhat))
 //   dgamma = sum_rows dy*xhat, dbeta = sum_rows dy  -> per-block partials, summed in fixed order by
 //   pxr_colsum-style stage 2 (deterministic, no float atomics).
-#include "pxr_common.h"
+#include "planes.cuh"
 
 #include <cstdlib>
 
@@ -39,6 +39,7 @@ struct LnFwdArgs {
   uint64_t seed;
   const int64_t* step_dev;  // optional device counter added to the seed (hipGraph replays advance it on the device)
   int32_t* status;          // GATHER: device status word (bad-index flag) or null
+  P3Mat yp;                 // optional: y also as bf16x3 planes (the next GEMM's operand format, planes.cuh); p == null: none
 };
 
 // RPW = rows per wave.  RPW = 2 (large batches): both rows' ids and table rows are requested before either is reduced,
@@ -146,6 +147,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
           }
         }
         *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
+        if (a.yp.p) p3_store4(a.yp, row, c, y);
       }
     }
   }
@@ -165,6 +167,7 @@ struct LnBwdArgs {
   uint32_t stream;
   uint64_t seed;
   const int64_t* step_dev;
+  P3Mat gp;             // optional: planes of the gradient the next GEMMs read (dx when it is written, else dz)
 };
 
 template <int VEC, bool GATHER>
@@ -228,6 +231,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
         z.z = rs * (g4[k].z - c1 - xh[k].z * c2); z.w = rs * (g4[k].w - c1 - xh[k].w * c2);
         *reinterpret_cast<float4*>(a.dz + (int64_t)row * D + c) = z;
         if constexpr (!GATHER) {
+          if (a.gp.p && !a.dx) p3_store4(a.gp, row, c, z);
           if (a.dx) {
             float4 o = z;
             if (drop) {
@@ -238,6 +242,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
               o.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? z.w * inv_keep : 0.f;
             }
             *reinterpret_cast<float4*>(a.dx + (int64_t)row * D + c) = o;
+            if (a.gp.p) p3_store4(a.gp, row, c, o);
           }
         }
       }
@@ -335,11 +340,26 @@ using namespace pxr;
 
 // y = dropout(LN(table[idx] + pos))   rows = B*L; idx element (b,t) at idx[b*idx_bstride + t].
 // xhat / rstd may be null (inference).  (sasrec.py:68,77-82 train; :99-104 predict)
+extern "C" int pxr_input_ln_fwd_planes_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
+                                           const float* pos, const float* gamma, const float* beta, float eps, int B, int L,
+                                           int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
+                                           uint32_t stream_id, const int64_t* step_dev, void* y_planes,
+                                           int64_t y_plane_stride, int64_t y_panel_rows, void* stream);
 extern "C" int pxr_input_ln_fwd_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
                                     const float* pos, const float* gamma, const float* beta, float eps, int B, int L,
                                     int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
                                     uint32_t stream_id, const int64_t* step_dev, void* stream) {
+  return pxr_input_ln_fwd_planes_f32(table, n_table, idx, idx_bstride, pos, gamma, beta, eps, B, L, D, y, xhat, rstd, p_drop,
+                                     seed, stream_id, step_dev, nullptr, 0, 0, stream);
+}
+// the same, y additionally written as bf16x3 planes (y_planes may be NULL): the QKV GEMM's operand
+extern "C" int pxr_input_ln_fwd_planes_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
+                                           const float* pos, const float* gamma, const float* beta, float eps, int B, int L,
+                                           int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
+                                           uint32_t stream_id, const int64_t* step_dev, void* y_planes,
+                                           int64_t y_plane_stride, int64_t y_panel_rows, void* stream) {
   PXR_REQUIRE(table && idx && pos && gamma && beta && y, "pxr_input_ln_fwd_f32: null pointer");
+  PXR_REQUIRE(p3_mat_ok(y_planes, y_plane_stride, y_panel_rows, (int64_t)B * L, D), "pxr_input_ln_fwd_planes_f32: bad planes");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && B >= 0 && L > 0, "pxr_input_ln_fwd_f32: bad shape");
   PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_input_ln_fwd_f32: bad dropout p");
   if (B == 0) return PXR_OK;
@@ -349,14 +369,27 @@ extern "C" int pxr_input_ln_fwd_f32(const float* table, int64_t n_table, const i
   a.status = pxr_status_word();
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
+  a.yp = P3Mat{reinterpret_cast<__bf16*>(y_planes), y_plane_stride, y_panel_rows};
   return launch_ln_fwd<true>(a, (hipStream_t)stream);
 }
 
 // y = LN(dropout(x) + res)   (layers.py:614-615, :670-671).  res may be null.
+extern "C" int pxr_ln_residual_fwd_planes_f32(const float* x, const float* res, const float* gamma, const float* beta,
+                                              float eps, int rows, int D, float* y, float* xhat, float* rstd, float p_drop,
+                                              uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* y_planes,
+                                              int64_t y_plane_stride, int64_t y_panel_rows, void* stream);
 extern "C" int pxr_ln_residual_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta,
                                        float eps, int rows, int D, float* y, float* xhat, float* rstd, float p_drop,
                                        uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* stream) {
+  return pxr_ln_residual_fwd_planes_f32(x, res, gamma, beta, eps, rows, D, y, xhat, rstd, p_drop, seed, stream_id, step_dev,
+                                        nullptr, 0, 0, stream);
+}
+extern "C" int pxr_ln_residual_fwd_planes_f32(const float* x, const float* res, const float* gamma, const float* beta,
+                                              float eps, int rows, int D, float* y, float* xhat, float* rstd, float p_drop,
+                                              uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* y_planes,
+                                              int64_t y_plane_stride, int64_t y_panel_rows, void* stream) {
   PXR_REQUIRE(x && gamma && beta && y, "pxr_ln_residual_fwd_f32: null pointer");
+  PXR_REQUIRE(p3_mat_ok(y_planes, y_plane_stride, y_panel_rows, rows, D), "pxr_ln_residual_fwd_planes_f32: bad planes");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && rows >= 0, "pxr_ln_residual_fwd_f32: bad shape");
   PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_ln_residual_fwd_f32: bad dropout p");
   if (rows == 0) return PXR_OK;
@@ -365,6 +398,7 @@ extern "C" int pxr_ln_residual_fwd_f32(const float* x, const float* res, const f
   a.rows = rows; a.D = D; a.L = 1; a.eps = eps;
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
+  a.yp = P3Mat{reinterpret_cast<__bf16*>(y_planes), y_plane_stride, y_panel_rows};
   return launch_ln_fwd<false>(a, (hipStream_t)stream);
 }
 
@@ -382,11 +416,27 @@ extern "C" int64_t pxr_ln_bwd_ws_bytes(int rows, int D) {
 // Backward of either LN site.  gather_mode=1: dy is w.r.t. dropout(LN(z)) and the mask is re-applied to dy;
 // gather_mode=0: dx (optional) = dropout-mask(dz)/(1-p) is the gradient w.r.t. the sub-layer output x and dz
 // the gradient w.r.t. the residual.  dgamma/dbeta are OVERWRITTEN (not accumulated).
+extern "C" int pxr_ln_bwd_planes_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd,
+                                     const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
+                                     float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ws,
+                                     int64_t ws_bytes, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows,
+                                     void* stream);
 extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd,
                               const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
                               float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ws,
                               int64_t ws_bytes, void* stream) {
+  return pxr_ln_bwd_planes_f32(gather_mode, dy, xhat, rstd, gamma, rows, D, dz, dx, dgamma, dbeta, p_drop, seed, stream_id,
+                               step_dev, ws, ws_bytes, nullptr, 0, 0, stream);
+}
+// the same (gather_mode = 0), the gradient the next GEMMs read (dx when given, else dz) additionally written as planes
+extern "C" int pxr_ln_bwd_planes_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd,
+                                     const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
+                                     float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ws,
+                                     int64_t ws_bytes, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows,
+                                     void* stream) {
   PXR_REQUIRE(dy && xhat && rstd && gamma && dz && ws, "pxr_ln_bwd_f32: null pointer");
+  PXR_REQUIRE(p3_mat_ok(g_planes, g_plane_stride, g_panel_rows, rows, D) && !(g_planes && gather_mode),
+              "pxr_ln_bwd_planes_f32: bad planes (residual sites only)");
   PXR_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "pxr_ln_bwd_f32: dgamma and dbeta must both be given or both NULL");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && rows > 0, "pxr_ln_bwd_f32: bad shape");
   LnBwdArgs a{};
@@ -399,6 +449,7 @@ extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xha
   }
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
+  a.gp = P3Mat{reinterpret_cast<__bf16*>(g_planes), g_plane_stride, g_panel_rows};
   hipStream_t st = (hipStream_t)stream;
   int rc = gather_mode ? launch_ln_bwd<true>(a, nblk, st) : launch_ln_bwd<false>(a, nblk, st);
   if (rc) return rc;

@@ -1,0 +1,70 @@
+// planes.cuh -- the pre-split operand format of the planes GEMMs (gemm_p3.cuh): an fp32 matrix as three bf16 planes
+// hi | mid | lo (x = hi + mid + lo exactly) in PANEL layout.  Shared by the GEMM kernels and by every producer that writes
+// its output straight in this format (LayerNorm, attention, GEMM epilogues, the optimizer).
+//
+// Panel layout of a matrix X[R][C] (C % 32 == 0; `pr` >= R rows allocated per panel, pr % 32 == 0): plane q starts
+// q * ps elements after the base; inside a plane, panel cb = c / 32 holds columns 32 cb .. 32 cb + 31 of ALL rows:
+//     element (r, c)  at  ((cb * pr + r) * 32 + (((c >> 3) & 3) ^ ((r >> 2) & 3)) * 8 + (c & 7))      [elements]
+// i.e. a 64-byte row segment per (row, panel) whose four 16-byte chunks are XOR-swizzled by the row: the LDS image of a GEMM
+// tile is a byte copy of 1 KiB runs of a panel (16 rows), conflict-free for ds_read_b128 and ds_read_b64_tr_b16.
+#pragma once
+#include "pxr_common.h"
+
+namespace pxr {
+
+typedef unsigned p3_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned p3_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 p3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float p3_f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- the exact 3-term split (same arithmetic as gemm_b3.cuh::b3_split2: hi = bf16_rne(x), mid = bf16_rne(x - hi),
+// lo = x - hi - mid; both remainders are exact in fp32 and lo has <= 8 significant bits) -----------------------------
+__device__ __forceinline__ void p3_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const p3_f32x2 v = {a, b};
+  const p3_bf16x2 h = __builtin_convertvector(v, p3_bf16x2);
+  const p3_f32x2 r1 = v - __builtin_convertvector(h, p3_f32x2);
+  const p3_bf16x2 m = __builtin_convertvector(r1, p3_bf16x2);
+  const p3_f32x2 r2 = r1 - __builtin_convertvector(m, p3_f32x2);
+  const p3_bf16x2 l = __builtin_convertvector(r2, p3_bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  mid = __builtin_bit_cast(unsigned, m);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// A planes matrix as a kernel argument.
+struct P3Mat {
+  __bf16* p;       // plane 0 (nullptr: "no planes wanted" for optional outputs)
+  int64_t ps;      // plane stride, elements
+  int64_t pr;      // rows per panel (allocated), multiple of 32
+};
+// element offset of (row r, 8-column chunk starting at column c, c % 8 == 0) inside a plane
+__device__ __forceinline__ int64_t p3_chunk_index(int64_t pr, int64_t r, int c) {
+  return (((int64_t)(c >> 5) * pr + r) << 5) + ((((c >> 3) & 3) ^ ((int)(r >> 2) & 3)) << 3);
+}
+// store 8 consecutive values x[r][c .. c+7] (c % 8 == 0) into the three planes: one 16-byte store per plane
+__device__ __forceinline__ void p3_store8(const P3Mat& m, int64_t r, int c, const float (&v)[8]) {
+  p3_u32x4 p[3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h, mi, l;
+    p3_split2(v[2 * j], v[2 * j + 1], h, mi, l);
+    p[0][j] = h; p[1][j] = mi; p[2][j] = l;
+  }
+  __bf16* dst = m.p + p3_chunk_index(m.pr, r, c);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<p3_u32x4*>(dst + q * m.ps) = p[q];
+}
+// store 4 consecutive values x[r][c .. c+3] (c % 4 == 0): one 8-byte store per plane (row-per-wave kernels, float4 per lane)
+__device__ __forceinline__ void p3_store4(const P3Mat& m, int64_t r, int c, const float4& v) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  p3_split2(v.x, v.y, h0, m0, l0);
+  p3_split2(v.z, v.w, h1, m1, l1);
+  __bf16* dst = m.p + p3_chunk_index(m.pr, r, c & ~7) + (c & 4);
+  *reinterpret_cast<p3_u32x2*>(dst) = p3_u32x2{h0, h1};
+  *reinterpret_cast<p3_u32x2*>(dst + m.ps) = p3_u32x2{m0, m1};
+  *reinterpret_cast<p3_u32x2*>(dst + 2 * m.ps) = p3_u32x2{l0, l1};
+}
+static inline bool p3_mat_ok(const void* p, int64_t ps, int64_t pr, int64_t rows, int64_t cols) {
+  return p == nullptr || (cols % 32 == 0 && pr % 32 == 0 && pr >= rows && ps >= pr * cols && ps % 8 == 0 && ((uintptr_t)p & 15) == 0);
+}
+
+}  // namespace pxr

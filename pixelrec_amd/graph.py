@@ -24,6 +24,8 @@ class GraphedTrainStep:
         # every step goes through optimizer.step(): the join with the weight-gradient side stream can wait until the
         # flat gradient is consumed (seqcore.SeqRecCore.wait_flat_grads) -- inside the capture, so the graph is closed
         self.model.defer_weight_grad_join = True
+        if hasattr(self.model, "trust_optimizer_planes"):
+            self.model.trust_optimizer_planes = True     # the captured forward has no split launch (seqcore._weight_planes)
         # the batch lives in ONE buffer (ids | mask): a caller that hands over two views of one packed tensor (bench.py,
         # the trainer's batcher) pays one copy per step instead of two
         n_i = items.numel()
@@ -80,6 +82,8 @@ class GraphedTrainStep:
         o.step_count, m._step_counter, o._dirty = counters[:3]
         o._step_dev.copy_(counters[3])
         m._drop_dev.copy_(counters[4])
+        if hasattr(m, "refresh_weight_planes"):
+            m.refresh_weight_planes()     # the weights were restored behind the optimizer's back: its planes are stale
 
     def _eager(self):
         self.opt.zero_grad()

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "pxr_adamw_hyper_append": (_I, [_P, _P, _I64, _I64, _P, _D, _D, _D, _D, _D, _I, _P]),
     "pxr_adamw_rows_f32": (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _D, _D, _D, _P]),
     "pxr_adamw_flat_tab_f32": (_I, [_P, _P, _P, _P, _I64, _P, _I64, _P, _D, _D, _D, _P]),
+    "pxr_adamw_flat_tab_planes_f32": (_I, [_P, _P, _P, _P, _I64, _P, _I64, _P, _D, _D, _D, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pxr_counter_add_i64": (_I, [_P, _I64, _P]),
     "pxr_set_status_word": (_I, [_P]),
     "pxr_gemm_batched_f32": (_I, [_I, _I, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I64, _I64, _I64, _I64, _I64,
@@ -93,6 +94,16 @@ _SIGNATURES = {
     "pxr_split_planes_f32": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _P]),
     "pxr_gemm_planes_f32": (_I, [_I, _I, _I, _I, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I, _P, _P, _I64, _P, _I64, _I64,
                                  _I, _I, _P]),
+    "pxr_split_planes_multi_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pxr_input_ln_fwd_planes_f32": (_I, [_P, _I64, _P, _I64, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64,
+                                         _I64, _P]),
+    "pxr_ln_residual_fwd_planes_f32": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64, _I64, _P]),
+    "pxr_ln_bwd_planes_f32": (_I, [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64, _P, _I64, _I64, _P]),
+    "pxr_attn_planes_supported": (_I, [_I, _I]),
+    "pxr_attn_fwd_planes_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _I, _I, _I, _I, _P, _I64, _P, _F, _U64, _U32, _P, _P, _I64, _I64,
+                                     _P]),
+    "pxr_attn_bwd_planes_f32": (_I, [_P, _I64, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _P, _I64, _F, _U64, _U32, _P, _P, _I64,
+                                     _I64, _I, _I, _I, _I, _P]),
     "pxr_grouped_dw_planes_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "pxr_merge_split_rows_f32": (_I, [_P, _P, _I, _I64, _I64, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
 }

@@ -120,6 +120,13 @@ class SeqRecCore(BaseModel):
         self.defer_weight_grad_join = False
         self._drop_seed = int(config["seed"]) if config["seed"] is not None else 2020
         self._step_counter = 0
+        # GEMM operands as pre-split bf16x3 planes (csrc/gemm_p3.cuh): every producer of a GEMM operand (LayerNorm, attention,
+        # GEMM epilogues) writes the three bf16 terms once, in the panel layout the GEMM tiles copy linearly, instead of every
+        # reading tile splitting fp32 values again.  Same arithmetic as GEMM mode bf16x3 (bit-identical products).  Needs
+        # the feature sizes to be multiples of 32; PXR_PLANES=0 turns it off.
+        self.use_planes = os.environ.get("PXR_PLANES", "1") != "0"
+        self._wplanes = None
+        self.register_load_state_dict_post_hook(lambda mod, _keys: mod.refresh_weight_planes())
 
     def _init_weights(self, module):
         """N(0, initializer_range) for every Linear/Embedding weight; LayerNorm (1, 0); biases 0 (sasrec.py:51-61)."""
@@ -169,6 +176,7 @@ class SeqRecCore(BaseModel):
             views[name] = (off, n, tuple(p.shape))
             off += n
         self._flat, self._gflat, self._views = flat, gflat, views
+        self._wplanes, self._wplanes_fresh = None, False
         self._anchor = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
         self._drop_dev = torch.full((1,), self._step_counter, dtype=torch.int64, device=dev)
 
@@ -222,10 +230,100 @@ class SeqRecCore(BaseModel):
         grouped weight-gradient GEMM (so whatever it launches -- e.g. a data-parallel row exchange -- overlaps it)."""
         return None
 
+    # ------------------------------------------------------------------------------------------ planes mode
+    def _planes_on(self) -> bool:
+        return (self.use_planes and ops.gemm_mode() == "bf16x3" and self.hidden_size % 32 == 0
+                and self.inner_size % 32 == 0)
+
+    _W_NAMES = (("q.w", 3, "qkv"), ("o.w", 1, "o"), ("f1.w", 1, "f1"), ("f2.w", 1, "f2"))
+
+    _wplanes_fresh = False
+    # opt-in (GraphedTrainStep, Trainer, bench.py -- loops in which nothing but the optimizer and load_state_dict touches the
+    # weights): trust the planes the optimizer's flat kernel wrote and skip the split launch of the next training forward
+    trust_optimizer_planes = False
+
+    def _weight_mats(self):
+        return [self._p(f"{i}.{n}", span=sp) for i in range(self.n_layers) for n, sp, _ in self._W_NAMES]
+
+    def _weight_planes(self, train: bool = False):
+        """The block's weight matrices as planes.  Re-split from the flat parameter buffer (ONE launch) at the start of every
+        forward -- whoever changed the weights since (load_state_dict, a broadcast, a test poking .data) needs no hook --
+        EXCEPT a training-mode forward that directly follows an optimizer step of PxrAdamW, whose flat kernel wrote the
+        planes itself (mark_weight_planes_fresh)."""
+        mats = self._weight_mats()
+        if self._wplanes is None:
+            self._wplanes = [ops.Planes.alloc(m.shape[0], m.shape[1], m.device) for m in mats]
+            self._wplanes_fresh = False
+        if not (train and self._wplanes_fresh and self.trust_optimizer_planes):
+            ops.split_planes_multi(mats, self._wplanes)
+        self._wplanes_fresh = False
+        keys = [f"{i}.{k}" for i in range(self.n_layers) for _, _, k in self._W_NAMES]
+        return dict(zip(keys, self._wplanes))
+
+    def weight_plane_segments(self):
+        """(flat element offset, rows, cols, Planes) of every weight matrix, for the optimizer's fused plane output; None when
+        the planes mode is off."""
+        if not self._planes_on() or self._flat is None:
+            return None
+        mats = self._weight_mats()
+        if self._wplanes is None:
+            self._wplanes = [ops.Planes.alloc(m.shape[0], m.shape[1], m.device) for m in mats]
+        base = self._flat.data_ptr()
+        return [((m.data_ptr() - base) // 4, m.shape[0], m.shape[1], pl) for m, pl in zip(mats, self._wplanes)]
+
+    def mark_weight_planes_fresh(self):
+        self._wplanes_fresh = True
+
+    def refresh_weight_planes(self):
+        """Re-split now (after anything but the optimizer rewrote the weights: load_state_dict, a parameter broadcast, a
+        restored snapshot), so that a captured step that trusts the optimizer's planes finds them valid."""
+        if self._planes_on() and self._flat is not None and self._wplanes is not None:
+            ops.split_planes_multi(self._weight_mats(), self._wplanes)
+            self._wplanes_fresh = True
+
+    def _encode_planes(self, table, idx, idx_bstride, B, keymask, km_bstride, train: bool):
+        """_encode with every GEMM operand as planes (same kernels' results, bit for bit: the products are those of GEMM mode
+        bf16x3).  fp32 copies exist only where a non-GEMM kernel reads them (residual streams, the attention's qkv)."""
+        L, D, H = self.max_seq_length, self.hidden_size, self.n_heads
+        d = D // H
+        eps = self.layer_norm_eps
+        ph = self.hidden_dropout_prob if train else 0.0
+        pa = self.attn_dropout_prob if train else 0.0
+        seed = (self._drop_seed * 1000003) & 0xFFFFFFFFFFFFFFFF
+        sdv = self._drop_dev if train else None
+        saved = {"seed": seed, "ph": ph, "pa": pa, "layers": [], "planes": True} if train else None
+        wp = self._weight_planes(train)
+        h, xhat0, rstd0, hp = ops.input_ln_fwd(table, idx, idx_bstride, B, L, self._p("pos"), self._p("ln0.w"),
+                                               self._p("ln0.b"), eps, ph, seed, 0, save=train, step_dev=sdv, planes=True)
+        if train:
+            saved["xhat0"], saved["rstd0"], saved["wp"] = xhat0, rstd0, wp
+        for i in range(self.n_layers):
+            qkv, _, _ = ops.linear_fwd_planes(hp, wp[f"{i}.qkv"], self._p(f"{i}.q.b", span=3), lead_shape=(B, L))
+            ctxp, probs = ops.attn_fwd(qkv, keymask, km_bstride, B, H, L, d, pa, seed, 1 + 3 * i, save=train, step_dev=sdv,
+                                       planes=True)
+            a, _, _ = ops.linear_fwd_planes(ctxp, wp[f"{i}.o"], self._p(f"{i}.o.b"), lead_shape=(B, L))
+            h1, xhat1, rstd1, h1p = ops.ln_residual_fwd(a, h, self._p(f"{i}.ln1.w"), self._p(f"{i}.ln1.b"), eps, ph, seed,
+                                                        2 + 3 * i, save=train, step_dev=sdv, planes=True)
+            _, fp, u = ops.linear_fwd_planes(h1p, wp[f"{i}.f1"], self._p(f"{i}.f1.b"), gelu=True, save_grad=train,
+                                             act=self.hidden_act, want_fp32=False, want_planes=True, lead_shape=(B, L))
+            f2, _, _ = ops.linear_fwd_planes(fp, wp[f"{i}.f2"], self._p(f"{i}.f2.b"), lead_shape=(B, L))
+            last = i == self.n_layers - 1
+            r = ops.ln_residual_fwd(f2, h1, self._p(f"{i}.ln2.w"), self._p(f"{i}.ln2.b"), eps, ph, seed, 3 + 3 * i,
+                                    save=train, step_dev=sdv, planes=not last)
+            h2, xhat2, rstd2 = r[0], r[1], r[2]
+            if train:
+                saved["layers"].append(dict(h_in=hp, qkv=qkv, probs=probs, ctx=ctxp, xhat1=xhat1, rstd1=rstd1, h1=h1p,
+                                            u=u, f=fp, xhat2=xhat2, rstd2=rstd2))
+            h = h2
+            hp = r[3] if not last else None
+        return h, saved
+
     # ------------------------------------------------------------------------------------------ forward
     def _encode(self, table, idx, idx_bstride, B, keymask, km_bstride, train: bool):
         """row ids into `table` -> last-layer states [B, L, D] (sasrec.py:68-86 / :97-109); saves activations when
         train."""
+        if self._planes_on():
+            return self._encode_planes(table, idx, idx_bstride, B, keymask, km_bstride, train)
         L, D, H = self.max_seq_length, self.hidden_size, self.n_heads
         d = D // H
         eps = self.layer_norm_eps
@@ -331,6 +429,39 @@ class SeqRecCore(BaseModel):
                 ops.colsum(dy2d, out=g(b_name, span))
 
         dh, coef = ops.bpr_loss_bwd(s["pos"], s["neg"], table, s["items"], s["mask"], D, self.grad_scale, gsd)
+        if s.get("planes"):
+            # every GEMM operand as planes: the gradients that only GEMMs read (du, dqkv) exist as planes only
+            wp = s["wp"]
+            pend = []
+            for i in reversed(range(self.n_layers)):
+                a = s["layers"][i]
+                dz2, _, dxf2p = ops.ln_bwd(0, dh, a["xhat2"], a["rstd2"], self._p(f"{i}.ln2.w"), g(f"{i}.ln2.w"),
+                                           g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer,
+                                           planes=True)
+                pend.append((dxf2p, a["f"], g(f"{i}.f2.w"), g(f"{i}.f2.b")))
+                _, dup = ops.linear_bwd_input_planes(dxf2p, wp[f"{i}.f2"], mul=a["u"].view(T, -1), want_fp32=False,
+                                                     want_planes=True)
+                pend.append((dup, a["h1"], g(f"{i}.f1.w"), g(f"{i}.f1.b")))
+                dh1, _ = ops.linear_bwd_input_planes(dup, wp[f"{i}.f1"], add=dz2.view(T, D), lead_shape=(B, L))
+                dz1, _, dxap = ops.ln_bwd(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
+                                          g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer,
+                                          planes=True)
+                pend.append((dxap, a["ctx"], g(f"{i}.o.w"), g(f"{i}.o.b")))
+                dctx, _ = ops.linear_bwd_input_planes(dxap, wp[f"{i}.o"], lead_shape=(B, L))
+                dqkvp = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv, planes=True)
+                pend.append((dqkvp, a["h_in"], g(f"{i}.q.w", 3), g(f"{i}.q.b", 3)))
+                dh, _ = ops.linear_bwd_input_planes(dqkvp, wp[f"{i}.qkv"], add=dz1.view(T, D), lead_shape=(B, L))
+            dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,
+                                step_dev=sdv, defer=defer)
+            ops.colsum(dx0.view(B, L * D), out=g("pos").view(-1), defer=defer)
+            bumped = defer.flush(bump=self._drop_dev)
+            self._after_input_grads(dx0, coef, s)
+            ops.grouped_dw_planes(pend)
+            self._saved = None
+            if not bumped:
+                ops.counter_add(self._drop_dev, 1)
+            self._step_counter += 1
+            return dx0, coef, s
         for i in reversed(range(self.n_layers)):
             a = s["layers"][i]
             # FFN: h2 = LN(dropout(f2) + h1)

@@ -394,6 +394,65 @@ def grouped_linear_bwd_weight(problems):
                  "pxr_grouped_linear_bwd_weight_f32")
 
 
+def split_planes_multi(mats, outs=None):
+    """Several fp32 matrices -> Planes in ONE launch (pxr_split_planes_multi_f32); `outs`: existing Planes to overwrite."""
+    n = len(mats)
+    if outs is None:
+        outs = [Planes.alloc(m.shape[0], m.shape[1], m.device) for m in mats]
+    P, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+    for m in mats:
+        assert m.dim() == 2 and m.stride(1) == 1 and m.dtype == torch.float32
+    _l.check(_l.load().pxr_split_planes_multi_f32(
+        n, P(*[m.data_ptr() for m in mats]), I64(*[m.shape[0] for m in mats]), I64(*[m.shape[1] for m in mats]),
+        I64(*[m.stride(0) for m in mats]), P(*[o.ptr().value for o in outs]), I64(*[o.ps for o in outs]),
+        I64(*[o.pr for o in outs]), _l.stream_ptr()), "pxr_split_planes_multi_f32")
+    return outs
+
+
+def linear_fwd_planes(xp: Planes, Wp: Planes, b, gelu: bool = False, save_grad: bool = False, act: str | None = None,
+                      want_fp32: bool = True, want_planes: bool = False, lead_shape=None):
+    """linear_fwd from planes: y = x W^T + b (xp [M,K], Wp [N,K]).  Returns (y | None, y Planes | None, aux | None) where aux
+    is the saved pre-activation / activation derivative of the gelu / act variants (as linear_fwd's second value)."""
+    M, K, N = xp.rows, xp.cols, Wp.rows
+    dev = xp.buf.device
+    shape = tuple(lead_shape) + (N,) if lead_shape is not None else (M, N)
+    y = torch.empty(shape, dtype=torch.float32, device=dev) if want_fp32 else None
+    yp = Planes.alloc(M, N, dev) if want_planes else None
+    aux, epi, code = None, EPI_BIAS, 0
+    if act is not None and act != "gelu":
+        epi, code = EPI_BIAS_ACT_GRAD, ACT_CODES[act]
+    elif gelu:
+        epi = EPI_BIAS_GELU_GRAD if save_grad else EPI_BIAS_GELU
+    if epi != EPI_BIAS:
+        aux = torch.empty(shape, dtype=torch.float32, device=dev)
+    tag = "gemm_p3_kernel<KC,KC,EPI_BIAS_GELU*> (fwd + activation)" if epi != EPI_BIAS else "gemm_p3_kernel<KC,KC,EPI_BIAS> (fwd)"
+    with _gemm_timer(2.0 * M * N * K, tag):
+        _l.check(_l.load().pxr_gemm_planes_f32(1, M, N, K, xp.ptr(), xp.ps, xp.pr, Wp.ptr(), Wp.ps, Wp.pr, _l.ptr(y), N, epi,
+                                               _l.ptr(b), _l.ptr(aux), N, *_pl(yp), code, 0, _l.stream_ptr()),
+                 "pxr_gemm_planes_f32")
+    return y, yp, aux
+
+
+def linear_bwd_input_planes(dyp: Planes, Wp: Planes, add: torch.Tensor | None = None, mul: torch.Tensor | None = None,
+                            want_fp32: bool = True, want_planes: bool = False, lead_shape=None):
+    """linear_bwd_input from planes: dx = dy W (dyp [M,N], Wp [N,K]) (+ add | * mul).  Returns (dx | None, dx Planes | None)."""
+    M, N, K = dyp.rows, dyp.cols, Wp.cols
+    assert Wp.rows == N
+    dev = dyp.buf.device
+    shape = tuple(lead_shape) + (K,) if lead_shape is not None else (M, K)
+    dx = torch.empty(shape, dtype=torch.float32, device=dev) if want_fp32 else None
+    dxp = Planes.alloc(M, K, dev) if want_planes else None
+    aux = mul if mul is not None else add
+    epi = EPI_MUL if mul is not None else (EPI_ADD if add is not None else EPI_NONE)
+    tag = ("gemm_p3_kernel<KC,XC,EPI_MUL> (dX x saved gelu')" if mul is not None else
+           "gemm_p3_kernel<KC,XC,EPI_ADD> (dX + residual grad)" if add is not None else "gemm_p3_kernel<KC,XC,EPI_NONE> (dX)")
+    with _gemm_timer(2.0 * M * N * K, tag):
+        _l.check(_l.load().pxr_gemm_planes_f32(0, M, K, N, dyp.ptr(), dyp.ps, dyp.pr, Wp.ptr(), Wp.ps, Wp.pr, _l.ptr(dx), K,
+                                               epi, None, _l.ptr(aux), K, *_pl(dxp), 0, 0, _l.stream_ptr()),
+                 "pxr_gemm_planes_f32")
+    return dx, dxp
+
+
 def grouped_dw_planes(problems, tile_hint=0):
     """problems: list of (dy Planes [T,N], x Planes [T,K], dW [N,K] out, db [N] out | None).  One launch for all of them
     (pxr_grouped_dw_planes_f32)."""
@@ -407,6 +466,8 @@ def grouped_dw_planes(problems, tile_hint=0):
             P(*[p[2].data_ptr() for p in problems]), P(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems]),
             I(*[p[0].rows for p in problems]), I(*[p[0].cols for p in problems]), I(*[p[1].cols for p in problems]))
     flops = sum(2.0 * p[0].rows * p[0].cols * p[1].cols for p in problems)
+    if tile_hint == 0 and os.environ.get("PXR_P3_DW_TILE"):
+        tile_hint = int(os.environ["PXR_P3_DW_TILE"])        # A/B knob (tools/p3_sweep.py)
     with _gemm_timer(flops, "grouped_dw_p3_kernel (all dW + db of the step, from planes)"):
         _l.check(L.pxr_grouped_dw_planes_f32(n, *args, tile_hint, _l.stream_ptr()), "pxr_grouped_dw_planes_f32")
 
@@ -429,9 +490,15 @@ def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None, defer=None):
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm sites
+def _pl(p):
+    """(ptr, plane stride, panel rows) of an optional Planes"""
+    return (p.ptr(), p.ps, p.pr) if p is not None else (None, 0, 0)
+
+
 def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True,
-                 step_dev=None):
-    """y = dropout(LN(table[idx[b,t]] + pos[t]))  (sasrec.py:68,77-82 / :99-104).  Returns (y, xhat, rstd)."""
+                 step_dev=None, planes: bool = False):
+    """y = dropout(LN(table[idx[b,t]] + pos[t]))  (sasrec.py:68,77-82 / :99-104).  Returns (y, xhat, rstd); with
+    planes=True a 4th value: y as Planes [B*L, D] (written by the same kernel)."""
     Lb = _l.load()
     _req(table, torch.float32, "table"); _req(idx, torch.int64, "idx", contiguous=False)
     N, D = table.shape
@@ -441,15 +508,17 @@ def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.
     rstd = torch.empty(B * L, dtype=torch.float32, device=table.device) if save else None
     # algorithmic bytes: B*L table rows read once + y (+ xhat when saved) written; the [B,2,L+1,D] gather of the
     # reference never exists (SURVEY.md §8d "fused" rule)
+    yp = Planes.alloc(B * L, D, table.device) if planes else None
     with _gemm_timer(4.0 * B * L * D * (3 if save else 2), "ln_fwd_kernel<GATHER> (gather + pos + LN + dropout)"):
-        _l.check(Lb.pxr_input_ln_fwd_f32(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
-                                         _l.ptr(beta), eps, B, L, D, _l.ptr(y), _l.ptr(xhat), _l.ptr(rstd), p_drop,
-                                         seed, stream_id, _l.ptr(step_dev), _l.stream_ptr()), "pxr_input_ln_fwd_f32")
-    return y, xhat, rstd
+        _l.check(Lb.pxr_input_ln_fwd_planes_f32(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
+                                                _l.ptr(beta), eps, B, L, D, _l.ptr(y), _l.ptr(xhat), _l.ptr(rstd), p_drop,
+                                                seed, stream_id, _l.ptr(step_dev), *_pl(yp), _l.stream_ptr()),
+                 "pxr_input_ln_fwd_f32")
+    return (y, xhat, rstd, yp) if planes else (y, xhat, rstd)
 
 
-def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None):
-    """y = LN(dropout(x) + res)  (layers.py:614-615, :670-671).  Returns (y, xhat, rstd)."""
+def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None, planes: bool = False):
+    """y = LN(dropout(x) + res)  (layers.py:614-615, :670-671).  Returns (y, xhat, rstd) (+ y as Planes with planes=True)."""
     Lb = _l.load()
     _req(x, torch.float32, "x")
     D = x.shape[-1]
@@ -457,10 +526,11 @@ def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, s
     y = torch.empty_like(x)
     xhat = torch.empty_like(x) if save else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
-    _l.check(Lb.pxr_ln_residual_fwd_f32(_l.ptr(x), _l.ptr(res), _l.ptr(gamma), _l.ptr(beta), eps, rows, D, _l.ptr(y),
-                                        _l.ptr(xhat), _l.ptr(rstd), p_drop, seed, stream_id, _l.ptr(step_dev),
-                                        _l.stream_ptr()), "pxr_ln_residual_fwd_f32")
-    return y, xhat, rstd
+    yp = Planes.alloc(rows, D, x.device) if planes else None
+    _l.check(Lb.pxr_ln_residual_fwd_planes_f32(_l.ptr(x), _l.ptr(res), _l.ptr(gamma), _l.ptr(beta), eps, rows, D, _l.ptr(y),
+                                               _l.ptr(xhat), _l.ptr(rstd), p_drop, seed, stream_id, _l.ptr(step_dev),
+                                               *_pl(yp), _l.stream_ptr()), "pxr_ln_residual_fwd_f32")
+    return (y, xhat, rstd, yp) if planes else (y, xhat, rstd)
 
 
 class DeferredReductions:
@@ -496,9 +566,10 @@ class DeferredReductions:
 
 
 def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0, stream_id=0, need_dx=False,
-           step_dev=None, defer: DeferredReductions | None = None):
+           step_dev=None, defer: DeferredReductions | None = None, planes: bool = False):
     """Backward of either LN site; dgamma/dbeta ([D] tensors) are overwritten (by `defer.flush()` when a
-    DeferredReductions collector is given).  Returns (dz, dx|None)."""
+    DeferredReductions collector is given).  Returns (dz, dx|None) (+ with planes=True the Planes of dx when it exists,
+    else of dz: what the following GEMMs read)."""
     Lb = _l.load()
     _req(dy, torch.float32, "dy")
     D = dy.shape[-1]
@@ -512,10 +583,11 @@ def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0
         dgamma = dbeta = None
     else:
         ws = _ws.get(ws_bytes, dy.device)
-    _l.check(Lb.pxr_ln_bwd_f32(int(gather_mode), _l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), rows, D,
-                               _l.ptr(dz), _l.ptr(dx), _l.ptr(dgamma), _l.ptr(dbeta), p_drop, seed, stream_id,
-                               _l.ptr(step_dev), _l.ptr(ws), ws_bytes, _l.stream_ptr()), "pxr_ln_bwd_f32")
-    return dz, dx
+    gp = Planes.alloc(rows, D, dy.device) if planes else None
+    _l.check(Lb.pxr_ln_bwd_planes_f32(int(gather_mode), _l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), rows, D,
+                                      _l.ptr(dz), _l.ptr(dx), _l.ptr(dgamma), _l.ptr(dbeta), p_drop, seed, stream_id,
+                                      _l.ptr(step_dev), _l.ptr(ws), ws_bytes, *_pl(gp), _l.stream_ptr()), "pxr_ln_bwd_f32")
+    return (dz, dx, gp) if planes else (dz, dx)
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -560,38 +632,56 @@ def _attn_long_bwd(dctx, qkv, saved, B, H, L, d, p_drop, seed, stream_id, step_d
     return dqkv
 
 
-def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None):
-    """qkv [B,L,3*H*d] fused projection output -> (ctx [B,L,H*d], probs [B,H,L,L] | None)."""
+def attn_planes_supported(L: int, d: int) -> bool:
+    return bool(_l.load().pxr_attn_planes_supported(L, d))
+
+
+def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None,
+             planes: bool = False):
+    """qkv [B,L,3*H*d] fused projection output -> (ctx [B,L,H*d], probs [B,H,L,L] | None).  planes=True: ctx is returned
+    as Planes [B*L, H*d] INSTEAD of the fp32 tensor (written by the fused kernel where it serves the shape, by a split
+    launch otherwise)."""
     Lb = _l.load()
     _req(qkv, torch.float32, "qkv"); _req(keymask, torch.int64, "keymask", contiguous=False)
+    D = H * d
     if _attn_takes_gemm_path(L, d):
         ctx, saved = _attn_long_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop, seed, stream_id, step_dev)
-        return ctx, (saved if save else None)
-    D = H * d
-    ctx = torch.empty(B, L, D, dtype=torch.float32, device=qkv.device)
+        return (split_planes(ctx.view(B * L, D)) if planes else ctx), (saved if save else None)
+    fused_p = planes and attn_planes_supported(L, d)
+    ctx = None if fused_p else torch.empty(B, L, D, dtype=torch.float32, device=qkv.device)
+    cp_ = Planes.alloc(B * L, D, qkv.device) if fused_p else None
     probs = torch.empty(B, H, L, L, dtype=torch.float32, device=qkv.device) if save else None
     base = qkv.data_ptr()
     q, k, v = _l.c_void_p(base), _l.c_void_p(base + 4 * D), _l.c_void_p(base + 8 * D)
-    _l.check(Lb.pxr_attn_fwd_f32(q, k, v, 3 * D, _l.ptr(keymask), km_bstride, B, H, L, d, _l.ptr(ctx), D,
-                                 _l.ptr(probs), p_drop, seed, stream_id, _l.ptr(step_dev), _l.stream_ptr()),
+    _l.check(Lb.pxr_attn_fwd_planes_f32(q, k, v, 3 * D, _l.ptr(keymask), km_bstride, B, H, L, d, _l.ptr(ctx), D,
+                                        _l.ptr(probs), p_drop, seed, stream_id, _l.ptr(step_dev), *_pl(cp_), _l.stream_ptr()),
              "pxr_attn_fwd_f32")
-    return ctx, probs
+    if planes and not fused_p:
+        cp_ = split_planes(ctx.view(B * L, D))
+    return (cp_ if planes else ctx), probs
 
 
-def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, step_dev=None):
-    """-> dqkv [B,L,3*H*d] laid out like qkv."""
+def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, step_dev=None, planes: bool = False):
+    """-> dqkv [B,L,3*H*d] laid out like qkv; planes=True: as Planes [B*L, 3*H*d] INSTEAD of the fp32 tensor."""
     Lb = _l.load()
-    if _attn_takes_gemm_path(L, d):
-        return _attn_long_bwd(dctx, qkv, probs, B, H, L, d, p_drop, seed, stream_id, step_dev)
-    _req(dctx, torch.float32, "dctx"); _req(qkv, torch.float32, "qkv"); _req(probs, torch.float32, "probs")
     D = H * d
-    dqkv = torch.empty_like(qkv)
-    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    if _attn_takes_gemm_path(L, d):
+        dqkv = _attn_long_bwd(dctx, qkv, probs, B, H, L, d, p_drop, seed, stream_id, step_dev)
+        return split_planes(dqkv.view(B * L, 3 * D)) if planes else dqkv
+    _req(dctx, torch.float32, "dctx"); _req(qkv, torch.float32, "qkv"); _req(probs, torch.float32, "probs")
+    fused_p = planes and attn_planes_supported(L, d) and (3 * D) % 32 == 0
+    dqkv = None if fused_p else torch.empty_like(qkv)
+    gp = Planes.alloc(B * L, 3 * D, qkv.device) if fused_p else None
+    base = qkv.data_ptr()
     cp = _l.c_void_p
-    _l.check(Lb.pxr_attn_bwd_f32(_l.ptr(dctx), D, cp(base), cp(base + 4 * D), cp(base + 8 * D), 3 * D, _l.ptr(probs),
-                                 B, H, L, d, cp(dbase), cp(dbase + 4 * D), cp(dbase + 8 * D), 3 * D, p_drop, seed,
-                                 stream_id, _l.ptr(step_dev), _l.stream_ptr()), "pxr_attn_bwd_f32")
-    return dqkv
+    dptr = (lambda o: None) if fused_p else (lambda o: cp(dqkv.data_ptr() + o))
+    _l.check(Lb.pxr_attn_bwd_planes_f32(_l.ptr(dctx), D, cp(base), cp(base + 4 * D), cp(base + 8 * D), 3 * D, _l.ptr(probs),
+                                        B, H, L, d, dptr(0), dptr(4 * D), dptr(8 * D), 3 * D, p_drop, seed,
+                                        stream_id, _l.ptr(step_dev), *_pl(gp), 3 * D, 0, D, 2 * D, _l.stream_ptr()),
+             "pxr_attn_bwd_f32")
+    if planes and not fused_p:
+        gp = split_planes(dqkv.view(B * L, 3 * D))
+    return gp if planes else dqkv
 
 
 # ------------------------------------------------------------------------------------------------ loss head
@@ -908,10 +998,21 @@ def adamw_rows(table, m, v, last, hyper, cumlog, t_prev, t_apply, beta1, beta2, 
                  "pxr_adamw_rows_f32")
 
 
-def adamw_flat_tab(p, g, m, v, hyper, step, beta1, beta2, eps, step_dev=None):
+def adamw_flat_tab(p, g, m, v, hyper, step, beta1, beta2, eps, step_dev=None, plane_segments=None):
+    """Flat AdamW with the step's scalars from the hyper table.  plane_segments: list of (flat element offset, rows, cols,
+    Planes): weight matrices whose updated values are also written as planes by the same launch."""
     Lb = _l.load()
-    _l.check(Lb.pxr_adamw_flat_tab_f32(_l.ptr(p), _l.ptr(g), _l.ptr(m), _l.ptr(v), p.numel(), _l.ptr(hyper), step,
-                                       _l.ptr(step_dev), beta1, beta2, eps, _l.stream_ptr()), "pxr_adamw_flat_tab_f32")
+    segs = plane_segments or []
+    n = len(segs)
+    if n:
+        P, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+        sa = (n, I64(*[s_[0] for s_ in segs]), I64(*[s_[1] for s_ in segs]), I64(*[s_[2] for s_ in segs]),
+              P(*[s_[3].ptr().value for s_ in segs]), I64(*[s_[3].ps for s_ in segs]), I64(*[s_[3].pr for s_ in segs]))
+    else:
+        sa = (0, None, None, None, None, None, None)
+    _l.check(Lb.pxr_adamw_flat_tab_planes_f32(_l.ptr(p), _l.ptr(g), _l.ptr(m), _l.ptr(v), p.numel(), _l.ptr(hyper), step,
+                                              _l.ptr(step_dev), beta1, beta2, eps, *sa, _l.stream_ptr()),
+             "pxr_adamw_flat_tab_f32")
 
 
 def counter_add(counter, delta=1):

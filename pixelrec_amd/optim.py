@@ -232,7 +232,12 @@ class PxrAdamW:
         wait = getattr(self.model, "wait_flat_grads", None)
         if wait is not None:
             wait()
-        ops.adamw_flat_tab(flat, gflat, self._m, self._v, self._hyper, self.step_count + 1, b1, b2, g["eps"], step_dev=sd)
+        # planes mode: the updated weight matrices leave this launch already split (the next forward skips its split launch)
+        segs = self.model.weight_plane_segments() if hasattr(self.model, "weight_plane_segments") else None
+        ops.adamw_flat_tab(flat, gflat, self._m, self._v, self._hyper, self.step_count + 1, b1, b2, g["eps"], step_dev=sd,
+                           plane_segments=segs)
+        if segs:
+            self.model.mark_weight_planes_fresh()
         # close the step: count it on the device and prepare the next step's scalars -- one 1-thread launch
         ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 2, *cfg, step_dev=sd, advance=True)
         self.step_count += 1

@@ -169,6 +169,8 @@ class GradSync:
             dist.broadcast(self.model.item_embedding.weight.data, src=src, group=self.group)
         for p in self._extra_params():
             dist.broadcast(p.data, src=src, group=self.group)
+        if hasattr(self.model, "refresh_weight_planes"):
+            self.model.refresh_weight_planes()
 
     def _extra_params(self):
         """Parameters outside the flat buffer and the table: the visual encoder of the PixelNet models."""

@@ -119,6 +119,8 @@ class Trainer:
         # every training step ends in optimizer.step(), which joins the weight-gradient side stream itself
         if hasattr(model.module, "defer_weight_grad_join"):
             model.module.defer_weight_grad_join = True
+            if hasattr(model.module, "trust_optimizer_planes"):
+                model.module.trust_optimizer_planes = True   # only the optimizer / load_state_dict touch the weights here
 
     # ---------------------------------------------------------------------------------------------- optimizer
     def _build_optimizer(self):
