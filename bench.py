@@ -136,7 +136,7 @@ def pixelnet_main(args):
            "attn_dropout_prob": 0.1, "hidden_act": "gelu", "layer_norm_eps": 1e-12, "initializer_range": 0.02,
            "MAX_ITEM_LIST_LENGTH": L, "seed": 2020, "encoder_name": args.encoder, "encoder_source": "transformers",
            "pretrain_path": None,
-           "fine_tune_arg": {"tune_scale": tune, "pre_trained": False, "activation": "relu", "dnn_layers": [],
+           "fine_tune_arg": {"tune_scale": tune, "pre_trained": False, "allow_random_backbone": True, "activation": "relu", "dnn_layers": [],
                              "method": "mean"}}
 
     class DL:
@@ -257,6 +257,10 @@ def main():
                     help="1-GPU validation knob: create a 1-rank RCCL group and run every gradient collective anyway")
     ap.add_argument("--graph-collectives", action="store_true",
                     help="capture the RCCL collectives inside the step hipGraph too (opt-in for world > 1)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="after the run, project the step of a W-rank data-parallel job on this ONE GPU: merge of W ranks' "
+                         "sparse-gradient blocks + the merged row update are measured on a run fed W batches per step, the "
+                         "collectives are modelled from bytes and a stated xGMI link rate (tools/world_projection.py)")
     ap.add_argument("--model", choices=("idnet", "pixelnet"), default="idnet",
                     help="idnet = the headline (BASELINE configs[1]); pixelnet = SASRec PixelNet + ViT end to end "
                          "(BASELINE configs[2]: train_batch_size 16, MAX_ITEM_LIST_LENGTH 10, 352 images per step)")
@@ -754,6 +758,13 @@ def main():
                                         "step; the lazy figure includes catch-up + apply on the aged, non-repeating stream"}
         del opt_d
 
+    if args.emulate_world > 1 and world == 1 and not custom:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import world_projection
+
+        del gstep
+        torch.cuda.empty_cache()
+        out["world_projection"] = world_projection.project(args.emulate_world, B=B, log=lambda *_: None)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(B)
     elif world == 1:

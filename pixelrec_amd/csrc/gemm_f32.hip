@@ -495,8 +495,14 @@ extern "C" int pxr_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float
     }
     return PXR_OK;
   }
-  const int skw = sk_force ? sk_workers(tiles, nk, g_batch, 1, sk_force)
-                           : ((tile_hint == 0 && split_hint == 0) ? sk_workers(t64, nk, g_batch, splits, 0) : 0);
+  int skw = sk_force ? sk_workers(tiles, nk, g_batch, 1, sk_force)
+                     : ((tile_hint == 0 && split_hint == 0) ? sk_workers(t64, nk, g_batch, splits, 0) : 0);
+  if (skw > 0 && !sk_force) {
+    // the heuristic's choice needs a scratch block for this stream: when the pool is exhausted (a long-lived process that
+    // keeps taking fresh streams) or cannot be created here (inside a capture), take the tile-per-workgroup kernel instead
+    SkScratch probe;
+    if (sk_scratch_for(st, &probe) != PXR_OK) skw = 0;
+  }
 #define PXR_GEMM_CASE(AK, BK_, E)                                                                            \
   rc = skw > 0 ? launch_gemm_sk<AK, BK_, E>(skw, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, st)        \
                : dispatch_tile<AK, BK_, E>(tile, A, lda, B, ldb, Cw, ldcw, M, N, K, bias, aux, ldaux, splits, ksplit_len, \

@@ -267,7 +267,9 @@ __global__ void __launch_bounds__(1024, (B3 ? 4 : 8)) score_thresh_kernel(ScoreT
   }
   __syncthreads();
   const int n_hist = *hcount;
-  const bool list_ok = n_hist <= ST4_HIST_CAP;             // (else: walk the global pairs per tile, as before)
+  // (else: walk the global pairs per tile, as before.  The packed pair keeps 20 bits for the item offset inside the split's
+  // range: a wider range -- few splits over a huge catalogue -- would run into the user field)
+  const bool list_ok = n_hist <= ST4_HIST_CAP && (r_hi - r_lo) <= (1ll << 20);
   for (int tn = tn0; tn < tn1; ++tn) {
     const int i0 = tn * ST_BM;
     if (tid < ST2_BITMAP_WORDS) bitmap[tid] = 0u;
@@ -335,7 +337,11 @@ __global__ void __launch_bounds__(256) topk_tau_kernel(const float* __restrict__
                                                        int* __restrict__ cnt) {
   const int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= B) return;
-  tau[u] = sample_val[(int64_t)u * K + (K - 1)];
+  // the sample pass and the main pass may compute a score with different kernels (f32-input MFMA vs the bf16x3 split): a
+  // score equal to the K-th best up to summation order must still pass `x >= tau`, so tau is lowered by 2^-18 |tau|
+  // (thousands of ulps: it only admits a few more candidates, the merge below decides)
+  const float t = sample_val[(int64_t)u * K + (K - 1)];
+  tau[u] = t - fabsf(t) * 3.814697265625e-06f;
   cnt[u] = 0;
 }
 
@@ -349,9 +355,9 @@ __global__ void __launch_bounds__(256) topk_cand_merge_kernel(const float* __res
   const int u = blockIdx.x * 4 + wave;
   if (u >= B) return;
   int n = cnt[u];
-  if (n > cap) {
+  if (n > cap || n < K) {    // dropped candidates, or fewer than K survivors (idx -1 in the output): both are errors the host raises
     if (status && lane == 0) atomicOr(status, PXR_STATUS_TOPK_OVERFLOW);
-    n = cap;
+    n = min(n, cap);
   }
   const float* pv = cand_val + (int64_t)u * cap;
   const int* pi = cand_idx + (int64_t)u * cap;

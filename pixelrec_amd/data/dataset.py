@@ -116,6 +116,23 @@ class SeqTrainBatcher:
         items = np.stack((pos, neg), axis=1)
         return items, tgt[:, 1:].astype(np.int64)
 
+    def estimate_exchange_rows(self, n_batches: int = 64, margin: float = 1.25) -> int:
+        """A row capacity for the data-parallel exchange of the sparse table gradient (`dp_exchange_rows: auto`): the
+        largest number of distinct item ids among the first `n_batches` batches of this rank's epoch-0 order (negatives
+        drawn like the host sampler does), times `margin`, rounded up to 256 and capped at the worst case B*(2L+1).  It is
+        a statistical bound -- a later batch that exceeds it sets the status word and the trainer raises at its next host
+        sync (pxr_merge_split_rows_f32) -- and it costs no training state: the batcher's random streams are functions of
+        (seed, epoch, rank) only."""
+        worst = self.batch_size * (2 * self.W - 1)
+        idx = self._indices()
+        rng = np.random.default_rng([self.neg_seed, 0, self.rank, 12345])
+        top = 0
+        for b in range(min(n_batches, len(self))):
+            rows = idx[b * self.batch_size:(b + 1) * self.batch_size]
+            items, _ = self.make_batch(rows, rng)
+            top = max(top, int(np.count_nonzero(np.unique(items))))
+        return int(min(worst, (int(top * margin) + 255) // 256 * 256))
+
     def __iter__(self):
         idx = self._indices()
         rng = np.random.default_rng([self.neg_seed, self.epoch, self.rank])

@@ -102,8 +102,8 @@ class _VisionTransformer(nn.Module):
         self.embeddings = _Embeddings(hidden, image_size, patch_size)
         self.pre_layrnorm = nn.LayerNorm(hidden, eps=eps)      # (sic) the HF attribute name
         self.encoder = _Encoder(n_layers, hidden, heads, inter, eps)
-        self.post_layernorm = nn.LayerNorm(hidden, eps=eps)    # kept for checkpoint keys; unused by 'mean'/'cls'
-                                                               # (the reference swaps it for Identity, load.py:112,116)
+        self.post_layernorm = nn.LayerNorm(hidden, eps=eps)    # load_model swaps it for Identity once the freeze indices
+                                                               # are assigned, as the reference does (load.py:112,116)
 
     def forward(self, pixel_values):
         x = self.pre_layrnorm(self.embeddings(pixel_values))
@@ -198,24 +198,30 @@ def _load_pretrained_backbone(model, name, config):
 
 
 def load_model(config):
-    """ViT branch of the reference's load_model (load.py:90-120).  With `pre_trained: True` the backbone weights must
-    come from local disk (`encoder_path` / the HF cache) or from `pretrain_path` (a Trainer checkpoint loaded by the
-    model afterwards); otherwise this raises instead of training on a frozen RANDOM backbone without saying so."""
+    """ViT branch of the reference's load_model (load.py:90-120).  The reference ALWAYS starts from the pre-trained
+    checkpoint (`CLIPVisionModel.from_pretrained` in both branches, load.py:94,101) and, with `pre_trained: False`,
+    re-initialises only the TRAINABLE tail (index >= tune_scale) with N(0, 0.02) (load.py:104-108) -- the frozen front keeps
+    the pre-trained weights either way.  Same here: the backbone weights must come from local disk (`encoder_path` / the HF
+    cache) or from `pretrain_path` (a Trainer checkpoint loaded by the model afterwards); otherwise this raises instead of
+    training on a frozen RANDOM backbone without saying so (`allow_random_backbone: True` opts out).  `post_layernorm` is
+    replaced by Identity AFTER the freeze indices are assigned (load.py:112,116): it counts for `tune_scale` but is not a
+    parameter of the model, its optimizer group or its checkpoints."""
     name, source = config["encoder_name"], config["encoder_source"]
     if source != "transformers" or name not in ENCODER_SHAPES:
         raise NotImplementedError(f"visual encoder {source}/{name} is outside this build's scope "
                                   f"(built: transformers/{sorted(ENCODER_SHAPES)})")
     ft = config["fine_tune_arg"] or {}
     tune_scale = ft.get("tune_scale", 0)
+    pre_trained = ft.get("pre_trained", True)
     model = CLIPVisionEncoder(*ENCODER_SHAPES[name])
-    if ft.get("pre_trained", True) and name != "clip-vit-tiny-test":
+    if name != "clip-vit-tiny-test":
         err = _load_pretrained_backbone(model, name, config)
         if err is not None and not config["pretrain_path"]:
             if not ft.get("allow_random_backbone", False):
                 raise RuntimeError(
-                    f"fine_tune_arg.pre_trained is set but no weights for 'openai/{name}' are available offline ({err}). "
-                    "Point `encoder_path` at a local copy of the HF checkpoint, give `pretrain_path`, or set "
-                    "fine_tune_arg.pre_trained: False (random init, as load.py:104-108) / allow_random_backbone: True.")
+                    f"no weights for 'openai/{name}' are available offline ({err}); the reference loads them in both "
+                    "fine_tune_arg.pre_trained branches (load.py:94,101).  Point `encoder_path` at a local copy of the HF "
+                    "checkpoint, give `pretrain_path`, or set fine_tune_arg.allow_random_backbone: True.")
             import logging
 
             logging.getLogger().warning("visual encoder %s: NO pre-trained weights loaded (%s); the first %d parameters "
@@ -223,10 +229,11 @@ def load_model(config):
     for index, (pname, param) in enumerate(model.named_parameters()):
         if index < tune_scale:
             param.requires_grad = False                                 # load.py:97-99
-        elif not ft.get("pre_trained", True):
+        elif not pre_trained:
             param.data.normal_(mean=0.0, std=0.02)                      # load.py:104-108
     method = ft.get("method", "mean")
     cls = {"mean": MeanItemEncoder, "cls": ClsItemEncoder}.get(method)
     if cls is None:
         raise NotImplementedError(f"fine_tune_arg.method={method!r} (built: mean, cls)")
+    model.vision_model.post_layernorm = nn.Identity()                   # load.py:112,116
     return cls(model, model.hidden, config["embedding_size"], ft.get("activation", "relu"), ft.get("dnn_layers"))

@@ -55,7 +55,9 @@ class NativeTower:
         n_layers = len(e.item_encoder.vision_model.encoder.layers)
         for i in range(n_layers):
             order += [f"{vm}encoder.layers.{i}.{s}" for s in _BLOCK_ORDER]
-        order += [vm + "post_layernorm.weight", vm + "post_layernorm.bias", "rec_fc.0.weight", "rec_fc.0.bias"]
+        # post_layernorm is Identity in a load_model() encoder (load.py:112,116); a bare CLIPVisionEncoder still carries it
+        order += [k for k in (vm + "post_layernorm.weight", vm + "post_layernorm.bias") if k in named]
+        order += ["rec_fc.0.weight", "rec_fc.0.bias"]
         assert set(order) == set(named), sorted(set(named) ^ set(order))
         return [(k, named[k]) for k in order]
 

@@ -253,7 +253,13 @@ class PxrAdamW:
         if self.has_table:
             sd.update(table_m=self._tm, table_v=self._tv)
         if layout == "torch":
-            return native_to_torch_state(sd, self.model)
+            out = native_to_torch_state(sd, self.model)
+            lead = getattr(self, "empty_leading_group", None)
+            if lead is not None:     # 4-key optim_args without trainable visual parameters: an empty modal group comes first
+                g0 = {"lr": lead["lr"], "betas": tuple(self.param_groups[0]["betas"]), "eps": self.param_groups[0]["eps"],
+                      "weight_decay": lead["weight_decay"], **_TORCH_GROUP_DEFAULTS, "params": []}
+                out["param_groups"] = [g0] + out["param_groups"]
+            return out
         if layout != "native":
             raise ValueError("layout must be 'native' or 'torch'")
         return sd

@@ -135,6 +135,9 @@ class Trainer:
             rec = PxrAdamW(m, lr=a["rec_lr"], weight_decay=a["rec_decay"])
             modal = [p for n, p in m.named_parameters() if "visual_encoder" in n and p.requires_grad]
             if not modal:
+                # the reference still builds TWO param groups here (an empty modal group + the rec group, trainer.py:93-96):
+                # keep that shape in torch-layout checkpoints so they load into its optimizer
+                rec.empty_leading_group = {"lr": a["modal_lr"], "weight_decay": a["modal_decay"]}
                 return rec
             # the visual-encoder group (trainer.py:86-89): the same fused AdamW kernel over the encoder's flat buffer
             from ..optim import VisualAdamW

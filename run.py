@@ -49,7 +49,29 @@ def build(local_rank, config_file=None, config_dict=None):
         net = ShardedSASRec(config, dataload).to(config["device"])
         return config, dataload, loaders, ShardedDataParallel(net)
     net = get_model(config["model"])(config, dataload).to(config["device"])
-    return config, dataload, loaders, DataParallel(net)
+    return config, dataload, loaders, DataParallel(net, exchange_rows=exchange_rows(config, loaders[0]))
+
+
+def exchange_rows(config, train_loader):
+    """`dp_exchange_rows` of the YAML: the row capacity of the data-parallel exchange of the sparse table gradient
+    (pixelrec_amd/parallel.GradSync).  Absent / 0: the worst case B*(2L+1) in ONE collective; an integer: that many rows per
+    rank (ids + count and rows travel in two collectives); "auto": a bound measured on this run's own batches
+    (SeqTrainBatcher.estimate_exchange_rows), the maximum over the ranks.  A batch that exceeds the capacity raises."""
+    xr = config["dp_exchange_rows"]
+    if not xr:
+        return None
+    if isinstance(xr, str):
+        if xr.lower() != "auto":
+            raise ValueError(f"dp_exchange_rows must be an integer or 'auto', got {xr!r}")
+        batcher = getattr(train_loader, "batcher", None)
+        if batcher is None or not hasattr(batcher, "estimate_exchange_rows"):
+            return None
+        xr = batcher.estimate_exchange_rows()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([xr], dtype=torch.int64, device=config["device"] if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            xr = int(t.item())
+    return int(xr)
 
 
 def _report(log, config, dataload, model):

@@ -128,6 +128,7 @@ def test_native_encoder_matches_torch_tower(method, tune):
     enc = enc.cuda()
     opt = VisualAdamW(enc, lr=1e-2, weight_decay=0.05, eps=1e-2)
     topt = torch.optim.AdamW([p for p in ref.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-2)
+    gmin = {}                                      # smallest |gradient| every element saw over the three steps
     for step in range(3):
         x = torch.randn(4, 3, 64, 64)
         w = torch.randn(4, 24) * 1e4
@@ -145,15 +146,23 @@ def test_native_encoder_matches_torch_tower(method, tune):
                 # (the key-projection bias has a mathematically ZERO gradient -- softmax is shift invariant -- so its
                 # entries are rounding noise of the whole backward pass: the floor is relative to the largest gradient)
                 assert err <= 3e-4 * max(q.grad.abs().max().item(), 1e-5 * gmax), (step, n, err)
+                gmin[n] = q.grad.abs() if n not in gmin else torch.minimum(gmin[n], q.grad.abs())
             else:
-                assert (not p.requires_grad) or "post_layernorm" in n
+                assert not p.requires_grad
         opt.step()
         topt.step()
     for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
-        # (AdamW divides by sqrt(v) + eps: elements whose gradient is of the order of eps turn an absolute gradient error
-        # into a parameter error of the same size; the patch-embedding weight has such elements -- 9e-5 on the f32-input
-        # MFMA, 1.4e-4 on the bf16x3 kernels, most other tensors 5e-6: tools/diag/vit_mode_diff.py)
-        assert (p.detach().cpu() - q).abs().max().item() < (3e-4 if "patch_embedding" in n else 1e-4), n
+        # AdamW moves an element by lr * m / (sqrt(v) + eps): where |g| is of the order of eps (1e-2 here) an absolute
+        # gradient error becomes a parameter error of the same size (lr / eps = 1) -- in torch as much as here, so such
+        # elements only get the loose bound (9e-5 on the f32-input MFMA, 1.4e-4 on the bf16x3 kernels for the patch
+        # embedding: tools/diag/vit_mode_diff.py).  Everywhere the gradient is solidly above eps the update is
+        # ~ lr * sign(g) and the match is tight: the 2e-5 bound holds there.
+        diff = (p.detach().cpu() - q).abs()
+        if n in gmin:
+            solid = gmin[n] > 0.1                  # 10 x eps
+            if solid.any():
+                assert diff[solid].max().item() < 2e-5, (n, diff[solid].max().item())
+        assert diff.max().item() < (3e-4 if "patch_embedding" in n else 1e-4), n
     with torch.no_grad():
         x = torch.randn(2, 3, 64, 64)
         tower = ref.item_encoder(x)[0]

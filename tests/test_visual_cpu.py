@@ -54,12 +54,48 @@ def test_pre_trained_without_local_weights_fails_loudly(tmp_path):
                "pretrain_path": None, "encoder_path": str(tmp_path / "no_such_checkpoint"),
                "fine_tune_arg": {"tune_scale": 165, "pre_trained": True, "activation": "relu", "dnn_layers": [],
                                  "method": "mean"}}
-        with pytest.raises(RuntimeError, match="pre_trained"):
+        with pytest.raises(RuntimeError, match="available offline"):
             visual.load_model(cfg)
-        cfg["fine_tune_arg"]["allow_random_backbone"] = True
+        # pre_trained: False loads the same checkpoint in the reference (load.py:101) -- it needs the weights just as much
+        cfg["fine_tune_arg"] = dict(cfg["fine_tune_arg"], pre_trained=False)
+        with pytest.raises(RuntimeError, match="available offline"):
+            visual.load_model(cfg)
+        cfg["fine_tune_arg"] = dict(cfg["fine_tune_arg"], pre_trained=True, allow_random_backbone=True)
         enc = visual.load_model(cfg)               # explicit opt-in: builds (with a logged warning)
         assert sum(not p.requires_grad for p in enc.item_encoder.parameters()) == 165
-        cfg["fine_tune_arg"] = dict(cfg["fine_tune_arg"], pre_trained=False, allow_random_backbone=False)
+        assert not any("post_layernorm" in n for n, _ in enc.named_parameters())       # Identity (load.py:112,116)
     finally:
         visual.CLIPVisionEncoder = saved
-    assert len(built) == 2
+    assert len(built) == 3
+
+
+def test_pre_trained_false_keeps_the_frozen_front_and_reinitialises_the_tail(tmp_path, monkeypatch):
+    """load.py:101-108: with `pre_trained: False` the reference STILL starts from the pre-trained checkpoint and re-draws only
+    the trainable tail (index >= tune_scale) from N(0, 0.02).  Round trip: a tiny HF `CLIPVisionModel` saved with
+    save_pretrained() is picked up through `encoder_path`."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+
+    from pixelrec_amd.model import visual
+
+    hidden, layers, heads, inter, image, patch = visual.ENCODER_SHAPES["clip-vit-tiny-test"]
+    torch.manual_seed(3)
+    hf = CLIPVisionModel(CLIPVisionConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                                          intermediate_size=inter, image_size=image, patch_size=patch))
+    hf.save_pretrained(tmp_path / "tiny_clip")
+    monkeypatch.setitem(visual.ENCODER_SHAPES, "clip-vit-tiny-disk", visual.ENCODER_SHAPES["clip-vit-tiny-test"])
+    ref = {("vision_model." + k if not k.startswith("vision_model.") else k): v for k, v in hf.state_dict().items()}
+    tune = 5 + 16 * 2                                # embeddings + pre-LN + blocks 0, 1 frozen; block 2 trains
+    for pre in (True, False):
+        cfg = {"encoder_name": "clip-vit-tiny-disk", "encoder_source": "transformers", "embedding_size": 24, "pretrain_path": None,
+               "encoder_path": str(tmp_path / "tiny_clip"),
+               "fine_tune_arg": {"tune_scale": tune, "pre_trained": pre, "activation": "relu", "dnn_layers": [], "method": "mean"}}
+        enc = visual.load_model(cfg)
+        named = list(enc.item_encoder.named_parameters())
+        assert len(named) == len(ref) - 2 and not any("post_layernorm" in n for n, _ in named)
+        for i, (n, p) in enumerate(named):
+            assert p.requires_grad == (i >= tune), n
+            same = torch.equal(p.detach(), ref[n])
+            if i < tune or pre:
+                assert same, (pre, n)                # the checkpoint's values: frozen front always, everything with pre_trained
+            else:
+                assert not same and abs(float(p.std()) - 0.02) < 0.01, (n, float(p.std()))   # re-drawn N(0, 0.02)

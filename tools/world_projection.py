@@ -1,0 +1,170 @@
+"""One-GPU projection of the W-rank data-parallel training step (VERDICT r2 "Next" #3a; reference collective: run.py:40).
+
+What a rank of a W-rank job does differently from the single-GPU step is (a) it receives W-1 sparse-gradient blocks
+(all-gather under the grouped weight-gradient GEMM) and the all-reduced flat gradient, (b) it merges W blocks and (c) its lazy
+AdamW row update covers the rows of ALL ranks' batches.  (b) and (c) are ordinary kernels and are MEASURED here, on the real
+state of a run whose every step consumes W distinct batches (so the per-row catch-up gaps are those of a W-rank job: ~W times
+shorter than on one GPU): rank 0's forward/backward is the real one, the other W-1 blocks come from a second model replica that
+never touches rank 0's optimizer state.  (a) is MODELLED: bytes / a stated per-link xGMI rate, overlapped as the product overlaps
+them (all-gather under the dW GEMM, all-reduce under merge + row update).
+
+usage (GPU box): python tools/world_projection.py [--world 8] [--steps 30] [--link-gbs 61]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+import torch
+
+import bench
+from pixelrec_amd import ops, synth
+from pixelrec_amd.model import SASRec
+from pixelrec_amd.optim import PxrAdamW
+
+
+def project(W=8, steps=30, age=60, link_gbs=61.0, latency_us=15.0, B=64, split=True, log=print, busbw_gbs=300.0):
+    dev = torch.device("cuda", 0)
+    NS = bench.NS
+    N, L, D = NS["n_items"], NS["L"], NS["D"]
+
+    class DL:
+        item_num = N
+
+    torch.manual_seed(2020)
+    with torch.device(dev):
+        m0 = SASRec(bench.model_config(0.1), DL())
+        m1 = SASRec(bench.model_config(0.1), DL())      # the "other ranks": produces blocks, has no optimizer
+    for m in (m0, m1):
+        m.train()
+        m.grad_scale = 1.0 / W
+        m.defer_weight_grad_join = True
+    opt = PxrAdamW(m0, lr=1e-4, weight_decay=0.1, table_update="lazy")
+    rng = np.random.default_rng(7)
+    zipf = synth.ZipfItems(N, seed=2020)
+    n_b = (age + steps + 4) * W
+    batches = [tuple(torch.from_numpy(a).to(dev) for a in synth.train_batch(N, B, L, rng, zipf)) for _ in range(n_b)]
+    one = torch.ones((), dtype=torch.float32, device=dev)
+    cap = B * (2 * L + 1)
+    Lb = ops._l.load()
+    block = int(Lb.pxr_packed_rows_bytes(cap, D))
+    head = int(Lb.pxr_packed_rows_offset(cap))
+    max_unique = max(int(np.count_nonzero(np.unique(b[0].cpu().numpy()))) for b in batches[:256])
+    cap_x = min(cap, (max_unique + 255) // 256 * 256)
+    packed_all = torch.empty(W * block, dtype=torch.uint8, device=dev)
+    heads_all = torch.empty(W * head, dtype=torch.uint8, device=dev)
+    rows_all = torch.empty(W * cap_x, D, dtype=torch.float32, device=dev)
+    merged_full = ops.SparseRows(W * cap, D, dev)
+    merged_split = ops.SparseRows(W * cap_x, D, dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    acc = {"fwd_bwd": 0.0, "merge_full": 0.0, "merge_split": 0.0, "opt_step_merged": 0.0, "unique_merged": 0.0,
+           "unique_own": 0.0}
+    cur = 0
+    for it in range(age + steps):
+        timed = it >= age
+        # the other ranks' blocks (untimed): W-1 forward/backward passes of the second replica on their own batches
+        for w in range(1, W):
+            m1(batches[cur + w]).backward(one)
+            sp = m1.sparse_table_grad
+            packed_all[w * block:(w + 1) * block].copy_(sp.packed)
+            heads_all[w * head:(w + 1) * head].copy_(sp.packed[:head])
+            rows_all[w * cap_x:(w + 1) * cap_x].copy_(sp.rows[:cap_x])
+        e0, e1, e2, e3, e4 = ev(), ev(), ev(), ev(), ev()
+        opt.zero_grad()
+        e0.record()
+        m0(batches[cur]).backward(one)                     # rank 0: catch-up of its rows, forward, backward, segsum, dW
+        e1.record()
+        sp = m0.sparse_table_grad
+        packed_all[:block].copy_(sp.packed)
+        heads_all[:head].copy_(sp.packed[:head])
+        rows_all[:cap_x].copy_(sp.rows[:cap_x])
+        e2.record()
+        ops.merge_split_rows(heads_all, rows_all, W, cap, cap_x, D, N, 1.0, out=merged_split)
+        e3.record()
+        mg = ops.merge_packed_rows(packed_all, W, cap, D, N, 1.0, out=merged_full)
+        e4.record()
+        m0.sparse_table_grad = merged_split if split else mg
+        e5, e6 = ev(), ev()
+        e5.record()
+        opt.step()                                         # merged row update (+ catch-up of other ranks' rows), flat update
+        e6.record()
+        m0.sparse_table_grad = sp
+        cur += W
+        if timed:
+            torch.cuda.synchronize()
+            acc["fwd_bwd"] += e0.elapsed_time(e1) * 1e3
+            acc["merge_split"] += e2.elapsed_time(e3) * 1e3
+            acc["merge_full"] += e3.elapsed_time(e4) * 1e3
+            acc["opt_step_merged"] += e5.elapsed_time(e6) * 1e3
+            acc["unique_merged"] += float((mg.idx[:int(mg.n)] > 0).sum())
+            acc["unique_own"] += float(int(sp.n))
+    for k in acc:
+        acc[k] /= steps
+    # the same run at W = 1 for reference (own rows only, single-GPU gaps are NOT reproduced here: see bench.py's line)
+    # ---- communication model -------------------------------------------------------------------------------------
+    link = link_gbs * 1e9          # bytes/s per link per direction actually achieved (MI355X xGMI: 7 links x ~153 GB/s
+    #                                bidirectional per GPU = ~76 GB/s per direction per peer; 0.8 of that by default)
+    full_bytes, split_bytes = block, head + cap_x * D * 4
+    t_ag_full = full_bytes / link * 1e6 + latency_us       # direct all-gather on a full mesh: every peer's block over its own link
+    t_ag_split = split_bytes / link * 1e6 + 2 * latency_us
+    flat_bytes = m0.flat_parameters()[0].numel() * 4
+    t_ar = 2.0 * (flat_bytes / W) / link * 1e6 + 2 * latency_us      # reduce-scatter + all-gather, W-1 chunks in parallel
+    # the dW GEMM that hides the all-gather: from one instrumented step
+    evs = []
+    ops.GEMM_TIMING = evs
+    m0(batches[0]).backward(one)
+    ops.GEMM_TIMING = None
+    torch.cuda.synchronize()
+    t_dw = sum(s.elapsed_time(e) * 1e3 for s, e, _, tag in evs if tag.startswith("grouped_dw"))
+    t_rows_flat = acc["opt_step_merged"]
+    res = {"world": W, "batch_per_gpu": B, "steps": steps, "measured_us": acc, "dw_gemm_us": t_dw,
+           "exchange": {"rows_capacity_full": cap, "rows_capacity_split": cap_x, "bytes_per_rank_full": full_bytes,
+                        "bytes_per_rank_split": split_bytes, "received_per_rank_full": (W - 1) * full_bytes,
+                        "received_per_rank_split": (W - 1) * split_bytes, "flat_bytes": flat_bytes},
+           "comm_model": {"link_gbs_per_direction": link_gbs, "latency_us": latency_us,
+                          "allgather_full_us": t_ag_full, "allgather_split_us": t_ag_split, "allreduce_flat_us": t_ar,
+                          "note": "full mesh: each peer's block arrives over its own xGMI link, so the all-gather time is one "
+                                  "block over one link; all-reduce = reduce-scatter + all-gather of 1/W chunks"}}
+    # second model of the same collectives: RCCL's measured-style bus bandwidth (all_gather / all_reduce busbw of rccl-tests on
+    # an 8-GPU xGMI node, ~300 GB/s at tens of MB): t = bytes_received / busbw (all-gather), 2 (W-1)/W bytes / busbw (all-reduce)
+    bus = busbw_gbs * 1e9
+    res["comm_model_busbw"] = {"busbw_gbs": busbw_gbs,
+                               "allgather_full_us": (W - 1) * full_bytes / bus * 1e6 + latency_us,
+                               "allgather_split_us": (W - 1) * split_bytes / bus * 1e6 + 2 * latency_us,
+                               "allreduce_flat_us": 2.0 * (W - 1) / W * flat_bytes / bus * 1e6 + latency_us}
+    for model, ag_f, ag_s, ar in (("links", t_ag_full, t_ag_split, t_ar),
+                                  ("busbw", res["comm_model_busbw"]["allgather_full_us"],
+                                   res["comm_model_busbw"]["allgather_split_us"], res["comm_model_busbw"]["allreduce_flat_us"])):
+        for name, t_ag, t_merge in (("full", ag_f, acc["merge_full"]), ("split", ag_s, acc["merge_split"])):
+            exposed_ag = max(0.0, t_ag - t_dw)             # the all-gather runs under the grouped dW GEMM
+            # the flat all-reduce starts when dW is done and runs under merge + row update (its wait sits in front of the flat
+            # update, ~0.85 of opt.step() in): only what exceeds them is exposed
+            exposed_ar = max(0.0, ar - t_merge - 0.85 * t_rows_flat)
+            step_us = acc["fwd_bwd"] + exposed_ag + t_merge + t_rows_flat + exposed_ar
+            res[f"projected_{name}_{model}"] = {"step_us": step_us, "exposed_allgather_us": exposed_ag,
+                                                "exposed_allreduce_us": exposed_ar, "sequences_per_s": W * B / step_us * 1e6}
+    res["note"] = ("fwd_bwd / merge / opt_step are eager-issue HIP-event times of THIS box (the single-GPU step of the same run "
+                   "issued the same way is fwd_bwd + opt.step() on own rows); divide projected sequences/s by the single-GPU "
+                   "eager figure of the same box for a scaling estimate")
+    log(json.dumps(res, indent=1))
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--age", type=int, default=60)
+    ap.add_argument("--link-gbs", type=float, default=61.0)
+    ap.add_argument("--busbw-gbs", type=float, default=300.0)
+    ap.add_argument("--full", action="store_true", help="apply the full (one-collective) merged list instead of the split one")
+    a = ap.parse_args()
+    t0 = time.time()
+    r = project(a.world, a.steps, a.age, a.link_gbs, split=not a.full, busbw_gbs=a.busbw_gbs)
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", f"world_projection_w{a.world}.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(r, open(out, "w"), indent=1)
+    print("elapsed", round(time.time() - t0, 1), "s")
