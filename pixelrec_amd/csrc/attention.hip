@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sB[ATT_MAXL * ATT_KLD];   // K chunk
   __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * 64];        // (dropped) probabilities
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;   // one XCD: consecutive sequences
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
 
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sP[ATT_MAXL * 64];   // dropped probabilities Pd
   __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * 64];   // dS / sqrt(d)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;   // one XCD: consecutive sequences
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
   const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];   // scores -> dropped probabilities
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;   // one XCD: consecutive sequences
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
 
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];   // dP, then dS / sqrt(d)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;   // one XCD: consecutive sequences
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
   const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_mfma1_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sV[ATT_MAXL * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;   // one XCD: consecutive sequences
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
   stage_tile_z<NT>(sQ, ATT_KLD, a.q + base, a.ld, L, d);
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sO[ATT_MAXL * ATT_KLD];   // dctx
   __shared__ __attribute__((aligned(16))) float sS[ATT_MAXL * ATT_SLD];   // dP -> Pd -> dS/sqrt(d)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;   // one XCD: consecutive sequences
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
   const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;
@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(ATTL_NT) attn_fwd_long_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sS[ATTL_MAXL * ATTL_SLD];   // scores -> dropped probabilities
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;   // one XCD: consecutive sequences
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
 
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(ATTL_NT) attn_bwd_long_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sS[ATTL_MAXL * ATTL_SLD];   // dPd -> Pd -> dS / sqrt(d)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;   // one XCD: consecutive sequences
   const int L = a.L, d = a.d;
   const int64_t base = (int64_t)b * L * a.ld + (int64_t)h * d;
   const int64_t cbase = (int64_t)b * L * a.ld_ctx + (int64_t)h * d;

@@ -349,14 +349,6 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmCfg<BM, BN, A_KC, B_K
   }
 }
 
-// XCD-aware bijective remap of a linear block id so that each of the 8 XCDs (block b runs on XCD b % 8)
-// works on one contiguous chunk of the tile sequence (cdna_hip_programming.md T1, bijective form).
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int xcd = bid & 7, q = nblk >> 3, rem = nblk & 7;
-  const int start = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-  return start + (bid >> 3);
-}
-
 // ---- epilogues (shared by gemm_f32.hip, gemm_b3.hip and score_topk.hip) ------------------------------------------
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD = 4, EPI_BIAS_GELU_GRAD = 5, EPI_MUL = 6,
        // the ViT blocks of the PixelNet image encoder (HF CLIPEncoderLayer; reference load.py:90-120):

@@ -165,8 +165,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
 }
 
 // x[rows, cols] (row stride ldx floats) -> planes (panel layout); a thread converts 8 consecutive values of a row
-__global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols8, P3Mat out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols8, P3Mat out,
+                                                           int xcd) {
+  // xcd: workgroups of one XCD (blockIdx % 8) take a CONTIGUOUS range of rows -- the range the same XCD's GEMM tiles read
+  const int64_t i = (int64_t)(xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x) * 256 + threadIdx.x;
   if (i >= rows * cols8) return;
   const int64_t row = i / cols8;
   const int c = (int)(i % cols8) * 8;
@@ -339,8 +341,9 @@ extern "C" int pxr_split_planes_f32(const float* x, int64_t rows, int64_t cols, 
   if (n == 0) return PXR_OK;
   PXR_REQUIRE((n + 255) / 256 < (1ll << 31), "pxr_split_planes_f32: too large");
   const P3Mat out{reinterpret_cast<__bf16*>(planes), plane_stride, panel_rows};
+  const int xcd = getenv("PXR_SPLIT_XCD") ? atoi(getenv("PXR_SPLIT_XCD")) : 1;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
-                     (int)(cols / 8), out);
+                     (int)(cols / 8), out, xcd);
   return pxr_check_launch("pxr_split_planes_f32");
 }
 
@@ -437,6 +440,10 @@ extern "C" int pxr_grouped_dw_planes_f32(int n, const void* const* dy, const int
   if (tile_hint == 0) tile_hint = t128 >= 192 ? 412812831 : 406406431;
   if (tile_hint == 812812830) return launch_dw_p3<P3Cfg<128, 128, 2, 4, 3>, false>(g, st);
   if (tile_hint == 412812831) return launch_dw_p3<P3Cfg<128, 128, 2, 2, 3>, true>(g, st);
+  if (tile_hint == 412812830) return launch_dw_p3<P3Cfg<128, 128, 2, 2, 3>, false>(g, st);
+  if (tile_hint == 412806440) return launch_dw_p3<P3Cfg<128, 64, 2, 2, 4>, false>(g, st);
+  if (tile_hint == 406406460) return launch_dw_p3<P3Cfg<64, 64, 2, 2, 6>, false>(g, st);
+  if (tile_hint == 406406430) return launch_dw_p3<P3Cfg<64, 64, 2, 2, 3>, false>(g, st);
   if (tile_hint == 406406431) return launch_dw_p3<P3Cfg<64, 64, 2, 2, 3>, true>(g, st);
   pxr_set_error("pxr_grouped_dw_planes_f32: tile %d is not instantiated", tile_hint);
   return PXR_ERR_BAD_ARG;

@@ -50,7 +50,7 @@ template <int VEC, bool GATHER, int RPW = 1>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
   if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  const int row0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * RPW;   // rows of one XCD are contiguous (pxr_common.h)
   if (row0 >= a.rows) return;
   const int D = a.D;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
     const int c = (k * 64 + lane) * 4;
     gam[k] = (c < D) ? *reinterpret_cast<const float4*>(a.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const int r0 = blockIdx.x * a.rows_per_block;
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);      // rows of one XCD are contiguous (pxr_common.h); partial index = blk
+  const int r0 = blk * a.rows_per_block;
   const int r1 = min(a.rows, r0 + a.rows_per_block);
   for (int row = r0 + wave; row < r1; row += 4) {
     float4 g4[VEC], xh[VEC];
@@ -271,8 +272,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
           g.x += og.x; g.y += og.y; g.z += og.z; g.w += og.w;
           b.x += ob.x; b.y += ob.y; b.z += ob.z; b.w += ob.w;
         }
-        *reinterpret_cast<float4*>(a.part + (int64_t)blockIdx.x * 2 * D + c) = g;
-        *reinterpret_cast<float4*>(a.part + (int64_t)blockIdx.x * 2 * D + D + c) = b;
+        *reinterpret_cast<float4*>(a.part + (int64_t)blk * 2 * D + c) = g;
+        *reinterpret_cast<float4*>(a.part + (int64_t)blk * 2 * D + D + c) = b;
       }
     }
   }

@@ -62,6 +62,22 @@ __device__ __forceinline__ void pxr_st_stream(float* p, const float4& v) {
   __builtin_nontemporal_store(t, reinterpret_cast<pxr_f32x4*>(p));
 }
 
+// ---------------------------------------------------------------- XCD placement
+namespace pxr {
+// XCD-aware bijective remap of a linear block id so that each of the 8 XCDs (block b runs on XCD b % 8)
+// works on one contiguous chunk of the tile sequence (cdna_hip_programming.md T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7, q = nblk >> 3, rem = nblk & 7;
+  const int start = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  return start + (bid >> 3);
+}
+}  // namespace pxr
+// Row-parallel producers (LayerNorm, attention, the plane split) use the SAME map as the GEMM tiles that read their output
+// next: with the M tile index slowest in the GEMM's tile order, XCD x multiplies the rows [x M/8, (x+1) M/8) -- when the
+// producer's workgroups on XCD x wrote exactly those rows, the operand is still in that XCD's L2 (measured on the
+// 3200 x 512 x 512 projection: 17.0 us behind an aligned producer, 20.1 us behind an interleaved one, 16.2 us L2-hot;
+// tools/xcd_align_probe.py).  Speed only: nothing depends on where a workgroup actually runs.
+
 // ---------------------------------------------------------------- wave / block reductions
 // Wave64 reductions on the VALU's DPP path instead of six ds_bpermute round trips through the LDS crossbar
 // (__shfl_xor): quad swaps, mirror within 8 / 16 lanes, then the gfx9 row broadcasts -- lane 63 ends up with the total

@@ -26,3 +26,40 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- GEMM modes -------------------------------------------------------------------------------------------------------
+# The product has three ways of running the same fp32 products: "planes" (default: bf16x3 on pre-split operands,
+# csrc/gemm_p3.cuh), "bf16x3" (the same split inside the GEMM main loop, csrc/gemm_b3.cuh; PXR_PLANES=0) and "f32" (the
+# f32-input MFMA kernels; PXR_GEMM_MODE=f32).  The model-level parity suites below run in ALL of them inside one
+# `pytest -m gpu`, so the driver's GPU run covers the fallbacks too (only the default mode was exercised).
+MODE_MODULES = {"test_gpu_sasrec": ("planes", "bf16x3", "f32"), "test_gpu_eval": ("planes", "bf16x3", "f32"),
+                "test_gpu_vit": ("planes", "f32"), "test_gpu_mosasrec": ("planes", "bf16x3", "f32"),
+                "test_gpu_fullsize": ("planes", "f32"), "test_gpu_lazy_adamw": ("planes", "bf16x3")}
+
+
+@pytest.fixture(autouse=True)
+def pxr_mode(request):
+    mode = getattr(request, "param", None)
+    if mode is None:
+        yield None
+        return
+    from pixelrec_amd import ops
+
+    prev_env = os.environ.get("PXR_PLANES")
+    prev = ops.set_gemm_mode("f32" if mode == "f32" else "bf16x3")
+    os.environ["PXR_PLANES"] = "1" if mode == "planes" else "0"
+    try:
+        yield mode
+    finally:
+        ops.set_gemm_mode(prev)
+        if prev_env is None:
+            os.environ.pop("PXR_PLANES", None)
+        else:
+            os.environ["PXR_PLANES"] = prev_env
+
+
+def pytest_generate_tests(metafunc):
+    modes = MODE_MODULES.get(metafunc.module.__name__.split(".")[-1])
+    if modes and metafunc.definition.get_closest_marker("gpu") is not None:
+        metafunc.parametrize("pxr_mode", modes, indirect=True)

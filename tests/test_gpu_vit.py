@@ -128,7 +128,7 @@ def test_native_encoder_matches_torch_tower(method, tune):
     enc = enc.cuda()
     opt = VisualAdamW(enc, lr=1e-2, weight_decay=0.05, eps=1e-2)
     topt = torch.optim.AdamW([p for p in ref.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-2)
-    gmin = {}                                      # smallest |gradient| every element saw over the three steps
+    gmin, gtop = {}, {}                            # smallest |gradient| every element saw over the three steps; largest per tensor
     for step in range(3):
         x = torch.randn(4, 3, 64, 64)
         w = torch.randn(4, 24) * 1e4
@@ -147,6 +147,7 @@ def test_native_encoder_matches_torch_tower(method, tune):
                 # entries are rounding noise of the whole backward pass: the floor is relative to the largest gradient)
                 assert err <= 3e-4 * max(q.grad.abs().max().item(), 1e-5 * gmax), (step, n, err)
                 gmin[n] = q.grad.abs() if n not in gmin else torch.minimum(gmin[n], q.grad.abs())
+                gtop[n] = max(gtop.get(n, 0.0), q.grad.abs().max().item())
             else:
                 assert not p.requires_grad
         opt.step()
@@ -156,10 +157,13 @@ def test_native_encoder_matches_torch_tower(method, tune):
         # gradient error becomes a parameter error of the same size (lr / eps = 1) -- in torch as much as here, so such
         # elements only get the loose bound (9e-5 on the f32-input MFMA, 1.4e-4 on the bf16x3 kernels for the patch
         # embedding: tools/diag/vit_mode_diff.py).  Everywhere the gradient is solidly above eps the update is
-        # ~ lr * sign(g) and the match is tight: the 2e-5 bound holds there.
+        # ~ lr * sign(g) and the match is tight: an absolute gradient error d (admitted above: 3e-4 of the tensor's largest
+        # gradient) moves the update by ~ lr * eps * d / g^2 per step, so the 2e-5 bound holds wherever
+        # g^2 > 3 steps * lr * eps * d / 2e-5.
         diff = (p.detach().cpu() - q).abs()
         if n in gmin:
-            solid = gmin[n] > 0.1                  # 10 x eps
+            d_adm = 3e-4 * gtop[n]
+            solid = gmin[n] > max(0.1, (3 * 1e-2 * 1e-2 * d_adm / 2e-5) ** 0.5)
             if solid.any():
                 assert diff[solid].max().item() < 2e-5, (n, diff[solid].max().item())
         assert diff.max().item() < (3e-4 if "patch_embedding" in n else 1e-4), n
