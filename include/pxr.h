@@ -315,6 +315,15 @@ int pxr_score_topk_f32(const float* users, int64_t ld_users, int B, const float*
                        const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx, float* topk_val,
                        void* ws, int64_t ws_bytes, void* stream);
 
+/* The same with both operands ALSO given as planes ("pre-split operands" above; both NULL: the plain function): on catalogues
+ * that take the two-pass threshold schedule the pass over every item tile runs on the planes as one LDS-DMA stream; the
+ * table's planes are made once per evaluation with pxr_split_planes_f32 (model/IDNet/sasrec.py:112,115-117). */
+int pxr_score_topk_planes_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
+                              const void* users_planes, int64_t users_plane_stride, int64_t users_panel_rows,
+                              const void* table_planes, int64_t table_plane_stride, int64_t table_panel_rows,
+                              const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx, float* topk_val,
+                              void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- optimizer ---------------------------------------------------------------------------------------------- */
 /* torch.optim.AdamW update (trainer.py:102,125), step is 1-based.  n must be a multiple of 4. */
 int pxr_adamw_flat_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,

@@ -94,35 +94,44 @@ __device__ __forceinline__ void p3_wait_tiles(int tiles) {
 }
 
 // One operand's DMA plan.  BX = tile extent along the operand's x (BM or BN), PPWX = pieces this wave issues per K tile,
-// KC = flavour.
+// KC = flavour.  A piece's source = lane * 16 (the only per-lane part: ONE VGPR) + a wave-uniform byte offset (plane,
+// 1 KiB run, tile origin: SGPRs, added to the K-tile offset in the instruction's scalar offset).
 template <int BX, int PPWX, bool KC>
 struct P3Operand {
   bufrsrc rs;
-  unsigned voff[PPWX];     // per-lane byte offset of each piece (loop-invariant)
-  unsigned dst[PPWX];      // LDS byte offset of each piece inside a stage (wave-uniform)
+  unsigned scal[PPWX];     // wave-uniform byte offset of each piece (loop-invariant)
+  unsigned dst0;           // LDS byte offset of this wave's first piece inside a stage (pieces are 1 KiB apart)
   unsigned soff, sstep;    // byte offset of the next K tile to issue / its step
   // m: the matrix; x0: tile origin along x; area: byte offset of this operand's planes inside a stage
   __device__ __forceinline__ void init(const P3Mat& m, int x0, int wave, int lane, unsigned area) {
     rs = make_rsrc(reinterpret_cast<const float*>(m.p), m.ps * 3 * 2);
+    // piece id q = wave * PPWX + j: plane-major, then 1 KiB run; its LDS offset inside the operand's area is q * 1024
+    dst0 = __builtin_amdgcn_readfirstlane(area + (unsigned)(wave * PPWX * 1024));
 #pragma unroll
     for (int j = 0; j < PPWX; ++j) {
-      const int q = wave * PPWX + j;                    // piece id: plane-major, then 1 KiB run
+      const int q = wave * PPWX + j;
       const int pl = q / (BX / 16), run = q % (BX / 16);
-      dst[j] = __builtin_amdgcn_readfirstlane(area + (unsigned)(pl * BX * 64 + run * 1024));
+      unsigned o;
       if constexpr (KC) {
         // runs are 16-row groups of the tile's rows inside panel kt
-        voff[j] = (unsigned)(pl * m.ps * 2) + (unsigned)((x0 + run * 16) * 64 + lane * 16);
+        o = (unsigned)(pl * m.ps * 2) + (unsigned)((x0 + run * 16) * 64);
       } else {
         // runs are (panel run / 2, 16-k-row half run % 2) of the 32 k-rows of tile kt
-        voff[j] = (unsigned)(pl * m.ps * 2) + (unsigned)((((int64_t)(x0 / 32 + run / 2) * m.pr + (run & 1) * 16) * 64) + lane * 16);
+        o = (unsigned)(pl * m.ps * 2) + (unsigned)(((int64_t)(x0 / 32 + run / 2) * m.pr + (run & 1) * 16) * 64);
       }
+      scal[j] = __builtin_amdgcn_readfirstlane(o);
     }
     soff = 0;
     sstep = KC ? (unsigned)(m.pr * 64) : 32u * 64u;
   }
   __device__ __forceinline__ void issue(unsigned stage_base) {
+    // lane * 16 is recomputed from the execution mask (two VALU ops) instead of being kept: in the 8-wave tiles every VGPR
+    // is an accumulator or a fragment, and a spilled offset would come back as a scratch LOAD inside the K loop -- a VMEM
+    // operation in front of which the compiler drains the whole DMA ring (vmcnt(0))
+    const unsigned lo = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) << 4;
 #pragma unroll
-    for (int j = 0; j < PPWX; ++j) p3_dma16(rs, voff[j], soff, __builtin_amdgcn_readfirstlane(stage_base + dst[j]));
+    for (int j = 0; j < PPWX; ++j)
+      p3_dma16(rs, lo, __builtin_amdgcn_readfirstlane(soff + scal[j]), __builtin_amdgcn_readfirstlane(stage_base + dst0 + j * 1024));
     soff += sstep;
   }
 };
@@ -302,6 +311,123 @@ __device__ __forceinline__ void gemm_p3_mainloop(typename Cfg::Acc& accs, const 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) accs.v[i][j][e] += (accm[i][j][e] + accl[i][j][e]);
+}
+
+// ---- the same product for a SEQUENCE of A tiles against one B tile as ONE DMA stream (full-catalogue scoring: item tiles
+// m_first, m_first + BM, ... x one block of users): the LDS ring never drains between tiles -- tile t+1's first K tiles are
+// in flight while `done(t, accs)` consumes tile t's accumulators.  `done` must not touch the staging LDS [0, LDS_BYTES)
+// and must not wait on vmcnt(0) more than it has to (that drains the ring); barriers inside it: p3_lds_barrier().  KC x KC.
+__device__ __forceinline__ void p3_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+template <class Cfg, class TileFn>
+__device__ __forceinline__ void gemm_p3_stream(const P3Mat& A, const P3Mat& B, int K, int m_first, int n0, int n_tiles, char* smem,
+                                               TileFn&& done) {
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, S = Cfg::STAGES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  const int nk = K / 32;
+  const int total = n_tiles * nk;
+  if (total <= 0) return;
+  typename Cfg::Acc accs;
+  f32x16 accm[TM][TN], accl[TM][TN];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accs.v[i][j][e] = 0.f; accm[i][j][e] = 0.f; accl[i][j][e] = 0.f; }
+  };
+  zero();
+  P3Operand<Cfg::BM, Cfg::A_PPW, true> opA;
+  P3Operand<Cfg::BN, Cfg::B_PPW, true> opB;
+  opA.init(A, m_first, wave, lane, 0u);
+  opB.init(B, n0, wave, lane, (unsigned)(3 * Cfg::A_PLANE));
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  const unsigned stepA = (unsigned)(A.pr * 64), stepB = (unsigned)(B.pr * 64);
+  unsigned i_stage = 0, i_kt = 0, i_tile_off = 0;           // next K tile to issue: stage, k index, byte offset of its item tile
+  auto issue = [&]() {
+    const unsigned sb = smem_base + i_stage * (unsigned)Cfg::STAGE;
+    opA.soff = i_kt * stepA + i_tile_off;
+    opB.soff = i_kt * stepB;
+    opA.issue(sb);
+    opB.issue(sb);
+    i_stage = (i_stage + 1 == (unsigned)S) ? 0u : i_stage + 1;
+    if (++i_kt == (unsigned)nk) { i_kt = 0; i_tile_off += (unsigned)(Cfg::BM * 64); }
+  };
+  // fragment addresses: FOUR per-lane byte offsets in all (A and B, k blocks 0 and 1: row * 64 + swizzled chunk); the stage
+  // is a scalar add per K tile, plane and 32-row block are immediate offsets of the ds_read (< 64 KiB)
+  static_assert(2 * Cfg::A_PLANE + (TM - 1) * 2048 < 65536 && 2 * Cfg::B_PLANE + (TN - 1) * 2048 < 65536, "ds_read immediate offsets");
+  int la[2], lb[2];
+  {
+    const int h = lane >> 5, r = lane & 31, swz = (r >> 2) & 3;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int co = (((kb << 1) + h) ^ swz) << 4;
+      la[kb] = (wm * Cfg::WM + r) * 64 + co;
+      lb[kb] = 3 * Cfg::A_PLANE + (wn * Cfg::WN + r) * 64 + co;
+    }
+  }
+  struct Frag {
+    p3_bf16x8 a[TM][3], b[TN][3];
+  };
+  auto read_frag = [&](Frag& f, int stage, int kb) {
+    const char* sa = smem + stage * Cfg::STAGE + la[kb];
+    const char* sb = smem + stage * Cfg::STAGE + lb[kb];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f.a[i][p] = *reinterpret_cast<const p3_bf16x8*>(sa + p * Cfg::A_PLANE + i * 2048);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f.b[j][p] = *reinterpret_cast<const p3_bf16x8*>(sb + p * Cfg::B_PLANE + j * 2048);
+    }
+  };
+  auto mfma = [&](const Frag& f) {
+#define PXR_P3_PROD(ACC, PA, PB)                                                                                \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA], f.b[j][PB], ACC[i][j], 0, 0, 0);
+    PXR_P3_PROD(accl, 2, 0)
+    PXR_P3_PROD(accm, 1, 0)
+    PXR_P3_PROD(accs.v, 0, 0)
+    PXR_P3_PROD(accl, 0, 2)
+    PXR_P3_PROD(accm, 0, 1)
+    PXR_P3_PROD(accl, 1, 1)
+#undef PXR_P3_PROD
+  };
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < total) issue();
+  Frag f0;
+  int st = 0, kt = 0, tile = 0;
+  for (int it = 0; it < total; ++it) {
+    p3_wait_tiles<Cfg::PPW>(min(total - 1 - it, S - 2));
+    __builtin_amdgcn_s_barrier();
+    if (it + S - 1 < total) issue();
+    // one fragment set at a time (the 8-wave tiles this loop serves hold 192 accumulator registers per lane; the second
+    // wave of the SIMD covers the LDS round trip between the two halves)
+    read_frag(f0, st, 0);
+    mfma(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(f0, st, 1);
+    mfma(f0);
+    st = (st + 1 == S) ? 0 : st + 1;
+    if (++kt == nk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) accs.v[i][j][e] += (accm[i][j][e] + accl[i][j][e]);
+      done(tile, accs);
+      zero();
+      kt = 0;
+      ++tile;
+    }
+  }
 }
 
 // ---- row epilogue: the accumulators go through LDS ([BM][BN + 4] fp32, the staging buffers are free) so that every thread

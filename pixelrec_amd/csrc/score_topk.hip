@@ -13,6 +13,7 @@
 // Ties: scores are continuous fp32 dot products, so ties only occur among -inf entries, which can reach the
 // list only when fewer than K unmasked items exist.
 #include "gemm_b3.cuh"
+#include "gemm_p3.cuh"
 
 #include <cstdlib>
 
@@ -443,6 +444,123 @@ static int pick_split(int B, int N) {
 
 }  // namespace pxr
 
+namespace pxr {
+// ---- the threshold pass on PRE-SPLIT operands (planes, gemm_p3.cuh): 256 items x 128 users per tile, 8 waves, and ONE
+// LDS-DMA stream over all item tiles of the workgroup (gemm_p3_stream): the ring does not drain between tiles, tile t's
+// comparison with tau runs while tile t+1's operands arrive.  Same candidates as score_thresh_kernel (the products are
+// those of GEMM mode bf16x3, bit for bit).
+constexpr int SP3_BM = 256, SP3_BN = 128;
+using Sp3Cfg = P3Cfg<SP3_BM, SP3_BN, 4, 2, 2>;
+constexpr int SP3_BITMAP_WORDS = SP3_BN * (SP3_BM / 32);
+constexpr int SP3_LDS = Sp3Cfg::LDS_BYTES + 4 * SP3_BITMAP_WORDS + 4 * ST4_HIST_CAP + 16;
+static_assert(SP3_LDS <= 160 * 1024, "LDS");
+
+__global__ void __launch_bounds__(Sp3Cfg::NT) score_thresh_p3_kernel(ScoreTopkArgs a, P3Mat table_p, P3Mat users_p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* bitmap = reinterpret_cast<unsigned*>(smem + Sp3Cfg::LDS_BYTES);
+  unsigned* hlist = bitmap + SP3_BITMAP_WORDS;             // (user_local << 20) | (item - first item of the range)
+  int* hcount = reinterpret_cast<int*>(hlist + ST4_HIST_CAP);
+  constexpr int NT = Sp3Cfg::NT;
+  const int tid = threadIdx.x;
+  const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
+  const int rb = t % a.row_blocks, sp = t / a.row_blocks;
+  const int u0 = rb * SP3_BN;
+  const int tiles = (a.N + SP3_BM - 1) / SP3_BM;
+  const int per = (tiles + a.n_split - 1) / a.n_split;
+  const int tn0 = sp * per, tn1 = min(tiles, tn0 + per);
+  if (tn0 >= tn1) return;
+  int hb = 0, he = 0;
+  if (a.hist_ptr) {
+    hb = a.hist_ptr[u0];
+    he = a.hist_ptr[min(a.B, u0 + SP3_BN)];
+  }
+  if (tid == 0) *hcount = 0;
+  __syncthreads();
+  const int64_t r_lo = (int64_t)tn0 * SP3_BM, r_hi = (int64_t)tn1 * SP3_BM;
+  for (int p = hb + tid; p < he; p += NT) {
+    const int64_t it = a.hist_items[p];
+    if (it >= r_lo && it < r_hi) {
+      int lo = u0, hi = min(a.B, u0 + SP3_BN) - 1;         // owner of pair p: hist_ptr[u] <= p < hist_ptr[u+1]
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.hist_ptr[mid] <= p) lo = mid; else hi = mid - 1;
+      }
+      const int pos = atomicAdd(hcount, 1);
+      if (pos < ST4_HIST_CAP) hlist[pos] = ((unsigned)(lo - u0) << 20) | (unsigned)(it - r_lo);
+    }
+  }
+  __syncthreads();
+  const int n_hist = *hcount;
+  const bool list_ok = n_hist <= ST4_HIST_CAP && (r_hi - r_lo) <= (1ll << 20);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Sp3Cfg::WGN, wn = wave % Sp3Cfg::WGN;
+  const int h = lane >> 5, r = lane & 31;
+  float thr[Sp3Cfg::TN];
+  bool uok[Sp3Cfg::TN];
+#pragma unroll
+  for (int j = 0; j < Sp3Cfg::TN; ++j) {
+    const int user = u0 + wn * Sp3Cfg::WN + j * 32 + r;
+    uok[j] = user < a.B;
+    thr[j] = uok[j] ? a.tau[user] : INFINITY;
+  }
+  gemm_p3_stream<Sp3Cfg>(table_p, users_p, a.D, tn0 * SP3_BM, u0, tn1 - tn0, smem, [&](int tile, const typename Sp3Cfg::Acc& accs) {
+    const int i0 = (tn0 + tile) * SP3_BM;
+    for (int w = tid; w < SP3_BITMAP_WORDS; w += NT) bitmap[w] = 0u;
+    p3_lds_barrier();
+    if (list_ok) {
+      const unsigned off0 = (unsigned)(i0 - (int)r_lo);
+      for (int q = tid; q < n_hist; q += NT) {
+        const unsigned e = hlist[q], off = e & 0xFFFFFu;
+        if (off >= off0 && off < off0 + SP3_BM) {
+          const int il = (int)(off - off0);
+          atomicOr(&bitmap[(e >> 20) * (SP3_BM / 32) + (il >> 5)], 1u << (il & 31));
+        }
+      }
+    } else {
+      for (int p = hb + tid; p < he; p += NT) {
+        const int64_t it = a.hist_items[p];
+        if (it >= i0 && it < i0 + SP3_BM) {
+          int lo = u0, hi = min(a.B, u0 + SP3_BN) - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.hist_ptr[mid] <= p) lo = mid; else hi = mid - 1;
+          }
+          const int il = (int)(it - i0);
+          atomicOr(&bitmap[(lo - u0) * (SP3_BM / 32) + (il >> 5)], 1u << (il & 31));
+        }
+      }
+    }
+    p3_lds_barrier();
+#pragma unroll
+    for (int j = 0; j < Sp3Cfg::TN; ++j) {
+      const int ul = wn * Sp3Cfg::WN + j * 32 + r;
+      const int user = u0 + ul;
+#pragma unroll
+      for (int i = 0; i < Sp3Cfg::TM; ++i) {
+        const unsigned bits = bitmap[ul * (SP3_BM / 32) + wm * (Sp3Cfg::WM / 32) + i];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int il = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int item = i0 + wm * Sp3Cfg::WM + i * 32 + il;
+          const float x = accs.v[i][j][e];
+          const bool cand = uok[j] && (x >= thr[j]) && item != 0 && item < a.N && !((bits >> il) & 1u);
+          if (__any(cand)) {
+            if (cand) {
+              const int pos = atomicAdd(&a.cand_cnt[user], 1);
+              if (pos < a.cand_cap) {
+                a.cand_val[(int64_t)user * a.cand_cap + pos] = x;
+                a.cand_idx[(int64_t)user * a.cand_cap + pos] = item;
+              }
+            }
+          }
+        }
+      }
+    }
+    p3_lds_barrier();                                      // the bitmap is re-zeroed at the top of the next tile
+  });
+}
+}  // namespace pxr
+
 using namespace pxr;
 
 // variant 4 (two passes around a threshold) pays off on big catalogues; small ones keep the register lists
@@ -469,7 +587,8 @@ extern "C" int64_t pxr_score_topk_ws_bytes(int B, int N, int K) {
   return (int64_t)B * cand * 8 + 256;
 }
 
-static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, float* topk_val, void* ws, hipStream_t st) {
+static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, float* topk_val, void* ws, hipStream_t st,
+                             const P3Mat* table_p = nullptr, const P3Mat* users_p = nullptr) {
   char* w = (char*)ws;
   const int64_t lb = lists_bytes(a.B, a.N, kt, 2) / 2;
   a.part_val = (float*)w;              a.part_idx = (int*)(w + lb);         w += 2 * lb;
@@ -497,7 +616,26 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
   // pass 2: every tile at full GEMM speed, survivors appended
   a.n_split = n_split_full;
   a.tile_stride = 1; a.tau = tau; a.cand_cnt = cnt; a.cand_val = cval; a.cand_idx = cidx; a.cand_cap = ST4_CAP;
-  if (pxr_get_gemm_mode() && a.D % 4 == 0)
+  if (table_p != nullptr) {
+    // planes: 256-item tiles, one workgroup per CU (156 KB of LDS), every CU the same number of tiles
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(score_thresh_p3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              SP3_LDS) != hipSuccess) {
+        (void)hipGetLastError();
+        pxr_set_error("pxr_score_topk_planes_f32: cannot reserve %d bytes of LDS", SP3_LDS);
+        return PXR_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    const int tiles256 = (a.N + SP3_BM - 1) / SP3_BM;
+    a.row_blocks = (a.B + SP3_BN - 1) / SP3_BN;
+    int ns = (256 + a.row_blocks - 1) / a.row_blocks;
+    if (ns > tiles256) ns = tiles256;
+    if (ns < 1) ns = 1;
+    a.n_split = ns;
+    hipLaunchKernelGGL(score_thresh_p3_kernel, dim3(a.row_blocks * a.n_split), dim3(Sp3Cfg::NT), SP3_LDS, st, a, *table_p, *users_p);
+  } else if (pxr_get_gemm_mode() && a.D % 4 == 0)
     hipLaunchKernelGGL(score_thresh_kernel<1>, grid, dim3(1024), 0, st, a);
   else
     hipLaunchKernelGGL(score_thresh_kernel<0>, grid, dim3(1024), 0, st, a);
@@ -509,12 +647,34 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
   return pxr_check_launch("pxr_score_topk_f32(candidate merge)");
 }
 
+extern "C" int pxr_score_topk_planes_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
+                                         const void* users_planes, int64_t users_plane_stride, int64_t users_panel_rows,
+                                         const void* table_planes, int64_t table_plane_stride, int64_t table_panel_rows,
+                                         const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx,
+                                         float* topk_val, void* ws, int64_t ws_bytes, void* stream);
+
 // Top-K item ids / scores per user of  users[B,D] x table[N,D]^T  with item 0 and each user's history masked.
 // hist_ptr int32 [B+1] / hist_items int64: CSR of the (history_u, history_i) pairs of seq_eval_collate (may be NULL).
 extern "C" int pxr_score_topk_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
                                   const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx,
                                   float* topk_val, void* ws, int64_t ws_bytes, void* stream) {
+  return pxr_score_topk_planes_f32(users, ld_users, B, table, N, D, nullptr, 0, 0, nullptr, 0, 0, hist_ptr, hist_items, K, topk_idx,
+                                   topk_val, ws, ws_bytes, stream);
+}
+// The same with the operands ALSO given as planes (include/pxr.h "pre-split operands"; both NULL: the plain function): on
+// catalogues that take the threshold schedule the main pass -- every item tile -- runs on the planes (gemm_p3_stream); the
+// sample pass keeps the fp32 operands.  The table's planes are made once per evaluation (pxr_split_planes_f32).
+extern "C" int pxr_score_topk_planes_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
+                                         const void* users_planes, int64_t users_plane_stride, int64_t users_panel_rows,
+                                         const void* table_planes, int64_t table_plane_stride, int64_t table_panel_rows,
+                                         const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx,
+                                         float* topk_val, void* ws, int64_t ws_bytes, void* stream) {
   PXR_REQUIRE(users && table && topk_idx && topk_val && ws, "pxr_score_topk_f32: null pointer");
+  PXR_REQUIRE((users_planes == nullptr) == (table_planes == nullptr), "pxr_score_topk_planes_f32: give both planes or neither");
+  PXR_REQUIRE(!users_planes || (D % 32 == 0 && p3_mat_ok(users_planes, users_plane_stride, users_panel_rows, B, D) &&
+                                p3_mat_ok(table_planes, table_plane_stride, table_panel_rows, N, D) &&
+                                table_plane_stride * 6 < 0x7FFFFFF0ll),
+              "pxr_score_topk_planes_f32: bad planes (D %% 32 == 0, three planes < 2 GiB)");
   PXR_REQUIRE(B > 0 && N > 0 && D > 0 && D % 4 == 0 && ld_users % 4 == 0, "pxr_score_topk_f32: bad shape");
   PXR_REQUIRE(!hist_ptr || hist_items, "pxr_score_topk_f32: hist_ptr without hist_items");
   const int kt = pick_kt(K);
@@ -527,7 +687,14 @@ extern "C" int pxr_score_topk_f32(const float* users, int64_t ld_users, int B, c
   a.n_split = pick_split(B, N);
   a.tile_stride = 1;
   if (pxr_score_topk_ws_bytes(B, N, K) > ws_bytes) { pxr_set_error("pxr_score_topk_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
-  if (use_thresh(N)) return score_topk_thresh(a, K, kt, topk_idx, topk_val, ws, (hipStream_t)stream);
+  if (use_thresh(N)) {
+    if (users_planes && pxr_get_gemm_mode()) {
+      const P3Mat tp{reinterpret_cast<__bf16*>(const_cast<void*>(table_planes)), table_plane_stride, table_panel_rows};
+      const P3Mat up{reinterpret_cast<__bf16*>(const_cast<void*>(users_planes)), users_plane_stride, users_panel_rows};
+      return score_topk_thresh(a, K, kt, topk_idx, topk_val, ws, (hipStream_t)stream, &tp, &up);
+    }
+    return score_topk_thresh(a, K, kt, topk_idx, topk_val, ws, (hipStream_t)stream);
+  }
   const int64_t cand = (int64_t)a.n_split * lists_per_split() * kt;
   if ((int64_t)B * cand * 8 + 256 > ws_bytes) { pxr_set_error("pxr_score_topk_f32: workspace too small"); return PXR_ERR_WORKSPACE; }
   a.part_val = (float*)ws;

@@ -924,10 +924,18 @@ def history_csr(history_u: torch.Tensor, history_i: torch.Tensor, B: int, device
     return ptr.to(device), history_i.to(device=device, dtype=torch.int64).contiguous()
 
 
+def score_planes_supported(table: torch.Tensor) -> bool:
+    """Whether the fused scoring can run its main pass on planes of this table (GEMM mode bf16x3, D % 32 == 0, three planes
+    below 2 GiB)."""
+    N, D = table.shape
+    return gemm_mode() == "bf16x3" and D % 32 == 0 and ((N + 31) // 32 * 32) * D * 6 < 0x7FFFFFF0
+
+
 def score_topk(users: torch.Tensor, ld_users: int, B: int, table: torch.Tensor, K: int, hist_ptr=None,
-               hist_items=None):
+               hist_items=None, table_planes: Planes | None = None):
     """Fused full-catalog scoring + masking + top-K (see pxr.h).  `users` may be a strided view (row stride
-    ld_users floats).  Returns (topk_idx int64 [B,K], topk_val fp32 [B,K])."""
+    ld_users floats).  Returns (topk_idx int64 [B,K], topk_val fp32 [B,K]).  table_planes: split_planes(table), made once
+    per evaluation -- the main pass over the catalogue then runs on pre-split operands (pxr_score_topk_planes_f32)."""
     Lb = _l.load()
     _req(users, torch.float32, "users", contiguous=False); _req(table, torch.float32, "table")
     N, D = table.shape
@@ -938,9 +946,13 @@ def score_topk(users: torch.Tensor, ld_users: int, B: int, table: torch.Tensor, 
     if ws_bytes < 0:
         raise _l.PxrError("score_topk: K must be in [1, 32]")
     ws = _ws.get(ws_bytes, table.device)
-    _l.check(Lb.pxr_score_topk_f32(_l.ptr(users), ld_users, B, _l.ptr(table), N, D, _l.ptr(hist_ptr),
-                                   _l.ptr(hist_items), K, _l.ptr(idx), _l.ptr(val), _l.ptr(ws), ws_bytes,
-                                   _l.stream_ptr()), "pxr_score_topk_f32")
+    up = None
+    if table_planes is not None:
+        u2 = torch.as_strided(users, (B, D), (ld_users, 1))
+        up = split_planes(u2)
+    _l.check(Lb.pxr_score_topk_planes_f32(_l.ptr(users), ld_users, B, _l.ptr(table), N, D, *_pl(up), *_pl(table_planes),
+                                          _l.ptr(hist_ptr), _l.ptr(hist_items), K, _l.ptr(idx), _l.ptr(val), _l.ptr(ws),
+                                          ws_bytes, _l.stream_ptr()), "pxr_score_topk_f32")
     return idx, val
 
 

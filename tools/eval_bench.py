@@ -28,8 +28,25 @@ def literal():
     return torch.topk(scores, 10, dim=-1)
 def fused():
     return ops.score_topk(users, D, B, table, 10, ptr, items)
+tp = ops.split_planes(table) if ops.score_planes_supported(table) else None
+def fused_planes():
+    return ops.score_topk(users, D, B, table, 10, ptr, items, table_planes=tp)
 v1, i1 = literal(); i2, v2 = fused()
 print("identical top-10:", torch.equal(i1, i2), "max |dval|", (v1 - v2).abs().max().item())
 tl, tf = timeit(literal), timeit(fused)
 fl = 2.0 * B * N * D
-print(f"literal (gemm + masks + torch.topk): {tl:.2f} ms   fused: {tf:.2f} ms   speed-up {tl/tf:.2f}x   fused effective {fl/tf/1e9:.1f} TFLOP/s ({fl/tf/1e9/157.3*100:.0f}% of fp32-MFMA peak)")
+b3 = ops.gemm_mode() == "bf16x3"
+pipe = (lambda t: 6 * fl / t / 1e9 / 2500.0) if b3 else (lambda t: fl / t / 1e9 / 157.3)
+print(f"literal (gemm + masks + torch.topk): {tl:.2f} ms   fused: {tf:.2f} ms   speed-up {tl/tf:.2f}x   fused effective {fl/tf/1e9:.1f} "
+      f"TFLOP/s algorithmic = {pipe(tf):.3f} of the {'bf16 MFMA pipe (6 products)' if b3 else 'f32-input MFMA peak'}")
+if tp is not None:
+    i3, v3 = fused_planes()
+    print("planes: identical top-10:", torch.equal(i1, i3), "identical to fused:", torch.equal(i2, i3) and torch.equal(v2, v3))
+    t_split = timeit(lambda: ops.split_planes(table, tp), iters=5)
+    tp3 = timeit(fused_planes)
+    print(f"fused on planes: {tp3:.2f} ms ({fl/tp3/1e9:.1f} TFLOP/s algorithmic = {pipe(tp3):.3f} of the bf16 pipe)   table split (once per "
+          f"evaluation): {t_split:.2f} ms")
+    import json
+    json.dump({"literal_ms": tl, "fused_ms": tf, "fused_planes_ms": tp3, "table_split_ms": t_split, "alg_tflops_fused_planes": fl / tp3 / 1e9,
+               "bf16_pipe_frac_fused_planes": pipe(tp3), "bf16_pipe_frac_fused": pipe(tf), "identical_top10": bool(torch.equal(i1, i3))},
+              open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "eval_bench.json"), "w"), indent=1)
