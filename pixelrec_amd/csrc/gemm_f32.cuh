@@ -357,7 +357,9 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_MUL_DGELU = 3, EPI_ADD
        EPI_BIAS_RELU = 9,         // C = relu(acc + bias)            (rec_fc of MeanItemEncoder, layers.py:121-128)
        // the other hidden_act choices of the reference's FeedForward (layers.py:642-649: relu / swish / tanh / sigmoid):
        EPI_BIAS_ACT_GRAD = 10,    // C = act(acc + bias), aux = act'(acc + bias); act = GemmBatch::act
-       EPI_LAST = 10 };
+       EPI_LAST = 10,
+       // planes GEMMs only (gemm_p3.hip): quick_gelu(acc + bias) without the derivative -- the frozen blocks of the image tower
+       EPI_BIAS_QGELU = 11 };
 enum { ACT_RELU = 3, ACT_SWISH = 4, ACT_TANH = 5, ACT_SIGMOID = 6 };
 
 // Batched launch: grid.z = batch index z; operand offsets (in floats) = (z / nb2) * x1 + (z % nb2) * x2 -- two levels, so
@@ -383,7 +385,8 @@ template <int EPI>
 struct EpiTraits {
   static constexpr bool READS_AUX = (EPI == EPI_MUL_DGELU || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_BIAS_ADD);
   static constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_GRAD || EPI == EPI_BIAS_ADD ||
-                                    EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ACT_GRAD);
+                                    EPI == EPI_BIAS_QGELU_GRAD || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ACT_GRAD ||
+                                    EPI == EPI_BIAS_QGELU);
 };
 // DIRECT: the epilogue reads `aux` from memory itself instead of from registers filled before the main loop (kernels
 // that have no registers to spare)

@@ -39,6 +39,9 @@ __device__ __forceinline__ float p3_epi_elem(float v, float bv, float av, float&
     v = v * sg;
   } else if constexpr (EPI == EPI_BIAS_RELU) {
     v = fmaxf(v + bv, 0.f);
+  } else if constexpr (EPI == EPI_BIAS_QGELU) {
+    v += bv;
+    v = v * sigmoid_1702(v);
   } else if constexpr (EPI == EPI_BIAS_ACT_GRAD) {
     v += bv;
     float dv;
@@ -314,7 +317,8 @@ static int epi_p3(int b_kc, int epilogue, P3Args& g, hipStream_t st) {
   if (b_kc) {
     switch (epilogue) {
       PXR_P3(true, EPI_NONE); PXR_P3(true, EPI_BIAS); PXR_P3(true, EPI_BIAS_GELU); PXR_P3(true, EPI_BIAS_GELU_GRAD);
-      PXR_P3(true, EPI_BIAS_ACT_GRAD);
+      PXR_P3(true, EPI_BIAS_ACT_GRAD); PXR_P3(true, EPI_BIAS_ADD); PXR_P3(true, EPI_BIAS_QGELU); PXR_P3(true, EPI_BIAS_QGELU_GRAD);
+      PXR_P3(true, EPI_BIAS_RELU);
     }
   } else {
     switch (epilogue) {

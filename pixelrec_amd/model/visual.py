@@ -151,6 +151,8 @@ class _ItemEncoderBase(nn.Module):
 
         self._native = NativeTower(self)
         self._anchor = None
+        # weights rewritten behind the tower's back (load_state_dict; the trainable blocks never use cached planes)
+        self.register_load_state_dict_post_hook(lambda mod, _keys: mod._native.drop_weight_planes())
         self.rec_fc = nn.Sequential(nn.Linear(input_dim, output_dim), act[act_name.lower() if isinstance(act_name, str) else act_name])
         nn.init.xavier_normal_(self.rec_fc[0].weight.data)
         nn.init.constant_(self.rec_fc[0].bias.data, 0)

@@ -22,6 +22,8 @@ overwrites, and `VisualAdamW` updates the trainable segments with the same fused
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import ops
@@ -44,6 +46,7 @@ class NativeTower:
         self.views = {}          # name (relative to enc) -> (offset, numel, shape)
         self.segments = []       # [(lo, hi)] flat ranges that receive gradients and optimizer updates
         self._scratch = {}
+        self._wplanes = {}       # block index -> weight planes of a forward-only block (planes mode)
 
     # ------------------------------------------------------------------------------------------ packing
     def _ordered(self):
@@ -86,6 +89,7 @@ class NativeTower:
                     segs.append((off, off + pad4(n)))
             off += pad4(n)
         self.flat, self.gflat, self.views, self.segments = flat, gflat, views, segs
+        self._wplanes = {}
 
     @staticmethod
     def _require_hip(dev):
@@ -138,7 +142,59 @@ class NativeTower:
                          (T * ld, d), (T * H, d))
         return ctx, (S if keep else None)
 
+    # ---- planes mode (csrc/gemm_p3.cuh): the blocks that only run FORWARD (the frozen front of the tower: 10 of 12 blocks at
+    # the shipped tune_scale, every block at inference) take their GEMM operands as pre-split bf16x3 planes -- LayerNorm and
+    # the fc1 epilogue write them, the frozen weights are split once.  Same products as GEMM mode bf16x3, bit for bit.
+    def _planes_on(self):
+        H, heads, d, T, _ = self._shape()
+        return (os.environ.get("PXR_PLANES", "1") != "0" and ops.gemm_mode() == "bf16x3" and H % 32 == 0
+                and self.view(f"item_encoder.vision_model.encoder.layers.0.mlp.fc1.weight").shape[0] % 32 == 0)
+
+    def _block_weight_planes(self, i):
+        """(qkv, out_proj, fc1, fc2) planes of block i: one split launch; kept for frozen blocks (ensure_packed /
+        load_state_dict drop the cache), redone at every forward for trainable ones."""
+        wp = self._wplanes.get(i)
+        if wp is None:
+            vm = "item_encoder.vision_model."
+            P = lambda s_, **kw: self.view(f"{vm}encoder.layers.{i}.{s_}", **kw)
+            wp = ops.split_planes_multi([P("self_attn.k_proj.weight", span=3), P("self_attn.out_proj.weight"),
+                                         P("mlp.fc1.weight"), P("mlp.fc2.weight")])
+            if i < self.first_trainable_block():
+                self._wplanes[i] = wp            # only FROZEN blocks are cached: a trainable block's weights move every step
+        return wp
+
+    def drop_weight_planes(self, trainable_only: bool = False):
+        """Forget cached weight planes: all of them (weights reloaded), or those of the blocks an optimizer step just rewrote
+        (they are only ever used by inference forwards between training steps)."""
+        if trainable_only:
+            first = self.first_trainable_block()
+            self._wplanes = {i: v for i, v in self._wplanes.items() if i < first}
+        else:
+            self._wplanes = {}
+
+    def _block_fwd_planes(self, i, x):
+        vm = "item_encoder.vision_model."
+        P = lambda s_, **kw: self.view(f"{vm}encoder.layers.{i}.{s_}", **kw)
+        H, heads, d, T, _ = self._shape()
+        n = x.shape[0]
+        Wqkv, Wo, W1, W2 = self._block_weight_planes(i)
+        _, _, _, h1p = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=False, planes=True)
+        qkv = torch.empty(n, T, 3 * H, dtype=torch.float32, device=x.device)
+        ops.gemm_planes(h1p, Wqkv, qkv.view(n * T, 3 * H), ops.EPI_BIAS, bias=P("self_attn.k_proj.bias", span=3))
+        ctx, _ = self._attn_fwd(qkv, n, T, heads, d, False)
+        ctxp = ops.split_planes(ctx.view(n * T, H))
+        x2 = torch.empty_like(x)
+        ops.gemm_planes(ctxp, Wo, x2.view(n * T, H), ops.EPI_BIAS_ADD, bias=P("self_attn.out_proj.bias"), aux=x.view(n * T, H))
+        _, _, _, h2p = ops.ln_residual_fwd(x2, None, P("layer_norm2.weight"), P("layer_norm2.bias"), 1e-5, save=False, planes=True)
+        fp = ops.Planes.alloc(n * T, W1.rows, x.device)
+        ops.gemm_planes(h2p, W1, None, ops.EPI_BIAS_QGELU, bias=P("mlp.fc1.bias"), Cp=fp)
+        x3 = torch.empty_like(x)
+        ops.gemm_planes(fp, W2, x3.view(n * T, H), ops.EPI_BIAS_ADD, bias=P("mlp.fc2.bias"), aux=x2.view(n * T, H))
+        return x3
+
     def _block_fwd(self, i, x, keep):
+        if not keep and self._planes_on():
+            return self._block_fwd_planes(i, x), None
         vm = "item_encoder.vision_model."
         P = lambda s, **kw: self.view(f"{vm}encoder.layers.{i}.{s}", **kw)
         H, heads, d, T, _ = self._shape()

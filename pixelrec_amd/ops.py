@@ -131,6 +131,7 @@ def embed_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------ GEMMs
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_ADD = 0, 1, 2, 3, 4
 EPI_BIAS_GELU_GRAD, EPI_MUL, EPI_BIAS_ADD, EPI_BIAS_QGELU_GRAD, EPI_BIAS_RELU, EPI_BIAS_ACT_GRAD = 5, 6, 7, 8, 9, 10
+EPI_BIAS_QGELU = 11         # planes GEMMs only: quick_gelu(x W^T + b), no derivative
 
 
 def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc, epilogue=EPI_NONE, bias=None,

@@ -361,6 +361,8 @@ class VisualAdamW:
                            self._v[lo - self._base:hi - self._base], g["lr"], b1, b2, g["eps"], g["weight_decay"],
                            self.step_count + 1)
         self.step_count += 1
+        if hasattr(t, "drop_weight_planes"):
+            t.drop_weight_planes(trainable_only=True)
 
     def _trainable(self):
         """[(name, parameter)] of the group in the reference's order: registration order, requires_grad only."""

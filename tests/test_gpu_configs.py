@@ -206,3 +206,78 @@ def test_emb4096_full_catalogue_lazy_equals_dense_and_reproducible():
     decay = (1.0 - 1e-3 * 0.1) ** 3
     r = t[untouched][:4096] / init["item_embedding.weight"][untouched][:4096]
     assert (r[torch.isfinite(r)] - decay).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ configs[2] at its real batch
+def test_pixelnet_step_at_the_shipped_batch_shape():
+    """BASELINE configs[2] at the batch the reference ships (overall/ViT.yaml + PixelNet/sasrec.yaml: train_batch_size 16,
+    MAX_ITEM_LIST_LENGTH 10, embedding 512, ViT-B/16 => 352 images of 224 x 224 per step).  The full-width oracle comparison
+    above uses a handful of images; at this size the HF oracle on the CPU would take minutes, so the step is held to
+    (a) the oracle on a SAMPLE of the images (tower + rec_fc + token mean, forward), (b) the oracle's sequence block + loss on
+    the product's own item vectors, (c) run-to-run bits, and (d) a sampled-gradient check: the directional derivative of the
+    loss along the gradient, by central differences of the product's own forward, matches |grad|^2 for the trainable encoder
+    tail and for rec_fc."""
+    from pixelrec_amd.model import MOSASRec
+    from pixelrec_amd.model.visual import ENCODER_SHAPES
+
+    name, tune, D, L, B = "clip-vit-base-patch16", 165, 512, 10, 16
+
+    class DL:
+        item_num = 40
+
+    torch.manual_seed(3)
+    hf = MO.hf_clip_vision(*ENCODER_SHAPES[name])
+    cfg = _pixel_config(name, tune, D, L)
+    cfg["n_heads"] = 4
+    m = MOSASRec(cfg, DL())
+    m.visual_encoder.item_encoder.load_state_dict(
+        {k: v for k, v in MO.hf_state_to_reference_names(hf).items() if "post_layernorm" not in k}, strict=True)
+    seq = {k: v for k, v in O.synth_params(40, D, L, 4, 2, seed=4).items() if k != "item_embedding.weight"}
+    m.load_state_dict(seq, strict=False)
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(0)
+    images = torch.randn(B, 2 * (L + 1), 3, 224, 224, generator=g).cuda()
+    mask = (torch.rand(B, L, generator=g) > 0.2).long().cuda()
+    mask[:, -1] = 1
+
+    def loss_of():
+        with torch.no_grad():
+            return float(m((images, mask)))
+
+    loss = m((images, mask))
+    loss.backward()
+    l0 = float(loss.detach())
+    assert np.isfinite(l0)
+    assert loss_of() == l0                                          # (c) deterministic
+    # (a) item vectors of 6 sampled images against HF + the MeanItemEncoder restatement
+    flat = images.flatten(0, 1)
+    pick = torch.tensor([0, 1, 57, 130, 200, 351])
+    rec_w, rec_b = m.visual_encoder.rec_fc[0].weight.detach().cpu(), m.visual_encoder.rec_fc[0].bias.detach().cpu()
+    with torch.no_grad():
+        ref_vec = MO.mean_item_encoder(hf, rec_w, rec_b, flat[pick.cuda()].cpu())
+        m.eval()
+        got_vec = m.compute_item(flat[pick.cuda()]).cpu()
+        all_vec = torch.cat([m.compute_item(flat[s:s + 88]) for s in range(0, flat.shape[0], 88)]).cpu()
+        m.train()
+    assert (got_vec - ref_vec).abs().max().item() < 2e-4 * max(1.0, ref_vec.abs().max().item())
+    assert (all_vec[pick] - ref_vec).abs().max().item() < 2e-4 * max(1.0, ref_vec.abs().max().item())
+    # (b) the oracle's sequence block + BPR loss on those item vectors == the product's loss
+    ocfg = {"n_layers": 2, "n_heads": 4, "layer_norm_eps": 1e-12}
+    ref_loss = MO.forward_loss({k: v for k, v in seq.items()}, all_vec.view(B, -1, 2, D), mask.cpu(), ocfg)
+    assert abs(l0 - float(ref_loss)) < 5e-5 * max(1.0, abs(float(ref_loss)))
+    # (d) sampled-gradient check along the gradient direction of two parameter groups
+    named = dict(m.named_parameters())
+    for key in ("visual_encoder.rec_fc.0.weight", "visual_encoder.item_encoder.vision_model.encoder.layers.11.mlp.fc2.weight"):
+        p = named[key]
+        gr = p.grad.detach().clone()
+        gn = float(gr.norm())
+        assert gn > 0
+        eps = 2e-2 / gn                                             # moves the loss by ~ +-2e-2
+        keep = p.data.clone()
+        p.data.add_(gr, alpha=eps)
+        lp = loss_of()
+        p.data.copy_(keep).sub_(gr, alpha=eps)
+        lm = loss_of()
+        p.data.copy_(keep)
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - gn * gn) <= 0.05 * gn * gn + 1e-6, (key, fd, gn * gn)
