@@ -226,6 +226,15 @@ int pxr_grouped_dw_planes_f32(int n, const void* const* dy, const int64_t* dy_pl
                               void* stream);
 
 /* ---- ViT image encoder, non-GEMM pieces (csrc/vit.hip) ------------------------------------------------------ */
+/* Fused self-attention of a tower block, forward (csrc/tower_attn.hip): per (image, head)
+ * ctx[b*T + t, 64 h ..] = softmax_t'(scale * q_t . k_t') v_t'; no mask, no dropout (HF CLIPAttention.forward as the item tower of
+ * REC/model/modules.py runs it).  q/k/v fp32, element (b, t, h, c) at p[(b*T + t)*ld + 64 h + c]; head size 64, T <= 288
+ * (pxr_tower_attn_supported).  Outputs: ctx fp32 [images*T, ld_ctx] and/or ctx as planes (at least one); lse (optional)
+ * [images*heads, T] = log sum_t' exp(scale * q.k).  The score matrix never exists in memory. */
+int pxr_tower_attn_supported(int T, int d);
+int pxr_tower_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads, int T, int d,
+                           float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t ctx_plane_stride,
+                           int64_t ctx_panel_rows, float* lse, void* stream);
 /* in place: S[row, :T] = softmax(scale * S[row, :T]), S[row, T:ld] = 0      (HF CLIPAttention, no mask / dropout) */
 int pxr_softmax_rows_f32(float* S, int64_t rows, int T, int ld, float scale, void* stream);
 /* in place on dP: dS = scale * P o (dP - rowsum(dP o P))                    (autograd of the above) */

@@ -1,0 +1,317 @@
+// tower_attn.hip -- fused self-attention of the visual item tower (CLIP ViT blocks: no mask, no dropout, head size 64),
+// forward.  Replaces, per block, the three launches S = Q K^T (batched GEMM) -> softmax rows -> O = P V (batched GEMM)
+// of model/vit_native.py::_attn_fwd, i.e. HF CLIPAttention.forward as the reference calls it through
+// REC/model/modules.py (item tower) -- and with them the [images x heads, T, T] score matrix in HBM (665 MB per ViT-B/16
+// block at 352 images: written once, read twice, rewritten once).
+//
+// One workgroup per (image, head); wave w owns the 32 queries 32 w .. 32 w + 31 (T = 197 -> 7 waves, T = 257 -> 9), keys
+// stream through LDS in chunks of 32 shared by all waves.  Both contractions run on v_mfma_f32_32x32x16_bf16 with the exact
+// bf16x3 split of their fp32 operands (hi | mid | lo, the 6 significant cross products, fp32 accumulation -- the same
+// arithmetic as the GEMMs of this library), TRANSPOSED so that the softmax never leaves the registers:
+//     S^T = K_chunk Q^T     C layout: lane = query, its 16 accumulator entries = 16 keys  -> the row max / row sum of a query
+//                           are reductions over a lane's own registers plus ONE exchange with lane ^ 32
+//     O^T += V_chunk^T P^T  P^T is needed as the B operand: lane = query, 8 keys per 16-key step -- exactly the entries the
+//                           lane already holds, up to a fixed permutation of the keys inside a 16-key step, which is applied
+//                           to V when it is staged (the contraction index order is free).  P never touches LDS or HBM.
+// Online softmax (running max m, running sum l per query, O^T rescaled by 2^(m_old - m_new) per chunk) in the log2 domain.
+// K and V are split into planes once per workgroup while they are staged (VALU on 2 x T x 64 values, against T^2 work);
+// Q fragments are split once per wave and stay in registers.  The context leaves as fp32 and/or as bf16x3 planes in the
+// panel layout the out-projection GEMM consumes (planes.cuh).
+#include <math.h>
+
+#include "planes.cuh"
+
+namespace pxr {
+
+typedef __bf16 ta_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ta_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ta_f32x4 __attribute__((ext_vector_type(4)));   // (HIP's float4 is a struct of unions: conditional loads of it end up in scratch)
+
+constexpr int TA_D = 64;        // head size
+constexpr int TA_KC = 32;       // keys per chunk
+constexpr int TA_KLD = 72;      // K chunk row stride (bf16): [key][dh], 144 B -> conflict-free 16-byte reads by lane = key
+constexpr int TA_VLD = 40;      // V^T chunk row stride (bf16): [dh][key slot], 80 B
+constexpr int TA_KPLANE = TA_KC * TA_KLD;        // elements per plane
+constexpr int TA_VPLANE = TA_D * TA_VLD;
+constexpr int TA_ITEMS = 256 + 128;              // staging work items per chunk: 256 for K (8 dh of a key), 128 for V (4 keys x 4 dh)
+
+struct TowerAttnArgs {
+  const float* q; const float* k; const float* v;   // element (image b, token t, head h, c) at p[(b*T + t)*ld + h*64 + c]
+  int64_t ld;
+  float* ctx; int64_t ld_ctx;                       // fp32 context [images*T, ld_ctx] (head h at column 64 h) or null
+  P3Mat op;                                         // context as planes of the [images*T, heads*64] matrix, or p == null
+  float* lse;                                       // [images*heads, T] natural-log sum of exp of the scaled scores, or null
+  int heads, T;
+  float scale_log2;                                 // head_size^-0.5 * log2(e)
+};
+
+struct TaStage {          // one thread's share of a K/V chunk in flight between global memory and LDS
+  ta_f32x4 r0, r1, r2, r3;
+};
+
+template <int NT>
+__device__ __forceinline__ void ta_load(TaStage (&st)[(TA_ITEMS + NT - 1) / NT], const TowerAttnArgs& a, int64_t base, int key0) {
+  constexpr int ITER = (TA_ITEMS + NT - 1) / NT;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int item = threadIdx.x + it * NT;
+    const ta_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (item < 256) {
+      const int key = key0 + (item >> 3), c = (item & 7) * 8;
+      const bool ok = key < a.T;
+      const float* src = a.k + base + (int64_t)key * a.ld + c;
+      st[it].r0 = ok ? *reinterpret_cast<const ta_f32x4*>(src) : z;
+      st[it].r1 = ok ? *reinterpret_cast<const ta_f32x4*>(src + 4) : z;
+      st[it].r2 = z; st[it].r3 = z;
+    } else {
+      const int j = (item - 256) & 127, kg = j >> 4, c = (j & 15) * 4;      // items >= TA_ITEMS load (and later drop) a duplicate
+      const int key = key0 + kg * 4;
+      const float* src = a.v + base + (int64_t)key * a.ld + c;
+      st[it].r0 = (key < a.T) ? *reinterpret_cast<const ta_f32x4*>(src) : z;
+      st[it].r1 = (key + 1 < a.T) ? *reinterpret_cast<const ta_f32x4*>(src + a.ld) : z;
+      st[it].r2 = (key + 2 < a.T) ? *reinterpret_cast<const ta_f32x4*>(src + 2 * a.ld) : z;
+      st[it].r3 = (key + 3 < a.T) ? *reinterpret_cast<const ta_f32x4*>(src + 3 * a.ld) : z;
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void ta_store(const TaStage (&st)[(TA_ITEMS + NT - 1) / NT], __bf16* sK, __bf16* sV) {
+  constexpr int ITER = (TA_ITEMS + NT - 1) / NT;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int item = threadIdx.x + it * NT;
+    if (item < 256) {
+      const int key = item >> 3, c = (item & 7) * 8;
+      const float v[8] = {st[it].r0.x, st[it].r0.y, st[it].r0.z, st[it].r0.w, st[it].r1.x, st[it].r1.y, st[it].r1.z, st[it].r1.w};
+      p3_u32x4 p[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned h, m, l;
+        p3_split2(v[2 * e], v[2 * e + 1], h, m, l);
+        p[0][e] = h; p[1][e] = m; p[2][e] = l;
+      }
+      __bf16* dst = sK + key * TA_KLD + c;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<p3_u32x4*>(dst + q * TA_KPLANE) = p[q];
+    } else if (item < TA_ITEMS) {
+      // keys 4 kg .. 4 kg + 3 of dh c .. c + 3, transposed: per dh one 8-byte run of 4 keys.  Key groups are stored in the
+      // order the P^T fragments hold them: inside a 16-key step  [0-3 | 8-11 | 4-7 | 12-15]  (slot group = kg with its two
+      // low bits swapped).
+      const int j = item - 256, kg = j >> 4, c = (j & 15) * 4;
+      const int sg = (kg & 4) | ((kg & 1) << 1) | ((kg >> 1) & 1);
+      __bf16* dst = sV + c * TA_VLD + sg * 4;
+      const TaStage& t = st[it];
+#define PXR_TA_VROW(i, f)                                                            \
+  {                                                                                  \
+    unsigned h0, m0, l0, h1, m1, l1;                                                 \
+    p3_split2(t.r0.f, t.r1.f, h0, m0, l0);                                           \
+    p3_split2(t.r2.f, t.r3.f, h1, m1, l1);                                           \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD) = p3_u32x2{h0, h1};             \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD + TA_VPLANE) = p3_u32x2{m0, m1}; \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD + 2 * TA_VPLANE) = p3_u32x2{l0, l1}; \
+  }
+      PXR_TA_VROW(0, x) PXR_TA_VROW(1, y) PXR_TA_VROW(2, z) PXR_TA_VROW(3, w)
+#undef PXR_TA_VROW
+    }
+  }
+}
+
+// acc += sum over the 6 significant products of (a0 + a1 + a2) (b0 + b1 + b2), smallest terms first
+__device__ __forceinline__ void ta_mma6(ta_f32x16& acc, const ta_bf16x8 (&a)[3], const ta_bf16x8 (&b)[3]) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void ta_split8(const float (&v)[8], ta_bf16x8 (&out)[3]) {
+  p3_u32x4 p[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned h, m, l;
+    p3_split2(v[2 * e], v[2 * e + 1], h, m, l);
+    p[0][e] = h; p[1][e] = m; p[2][e] = l;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) out[q] = __builtin_bit_cast(ta_bf16x8, p[q]);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) tower_attn_fwd_kernel(TowerAttnArgs a) {
+  constexpr int NT = NW * 64;
+  constexpr int ITER = (TA_ITEMS + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) __bf16 sK[2][3 * TA_KPLANE];
+  __shared__ __attribute__((aligned(16))) __bf16 sV[2][3 * TA_VPLANE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.heads, hd = bh - b * a.heads;
+  const int T = a.T;
+  const int64_t base = (int64_t)b * T * a.ld + (int64_t)hd * TA_D;
+  const int nchunk = (T + TA_KC - 1) / TA_KC;
+
+  TaStage st[ITER];
+  ta_load<NT>(st, a, base, 0);
+
+  // this wave's queries as B fragments of S^T = K Q^T: lane = query r, k slots = dh 16 ks + 8 hh .. + 7
+  const int q_row = wave * 32 + r;
+  ta_bf16x8 qf[4][3];
+  {
+    const bool ok = q_row < T;
+    const float* src = a.q + base + (int64_t)q_row * a.ld + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ta_f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+      if (ok) { x0 = *reinterpret_cast<const ta_f32x4*>(src + ks * 16); x1 = *reinterpret_cast<const ta_f32x4*>(src + ks * 16 + 4); }
+      const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      ta_split8(v, qf[ks]);
+    }
+  }
+  ta_store<NT>(st, sK[0], sV[0]);
+  __syncthreads();
+
+  ta_f32x16 accO[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accO[j][e] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;     // l_run: this lane's keys only (the two half-waves are added at the end)
+
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) ta_load<NT>(st, a, base, (c + 1) * TA_KC);
+    // ---- S^T chunk: rows = keys (A operand from LDS: lane = key r), columns = this wave's queries
+    ta_f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    const __bf16* kb = sK[buf] + r * TA_KLD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ta_bf16x8 kf[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) kf[q] = *reinterpret_cast<const ta_bf16x8*>(kb + q * TA_KPLANE + ks * 16);
+      ta_mma6(s, kf, qf[ks]);
+    }
+    // ---- online softmax of the lane's 16 keys: key(e) = 32 c + (e & 3) + 8 (e >> 2) + 4 hh
+    float mx = -INFINITY;
+    const bool tail = (c + 1) * TA_KC > T;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float x = s[e] * a.scale_log2;
+      if (tail && c * TA_KC + (e & 3) + 8 * (e >> 2) + 4 * hh >= T) x = -INFINITY;
+      s[e] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s[e] = __builtin_amdgcn_exp2f(s[e] - m_new);
+      psum += s[e];
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accO[j][e] *= alpha;
+    // ---- O^T += V^T P^T: entries 8 ks2 .. 8 ks2 + 7 are the lane's 8 key slots of 16-key step ks2
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const float pv[8] = {s[8 * ks2], s[8 * ks2 + 1], s[8 * ks2 + 2], s[8 * ks2 + 3],
+                           s[8 * ks2 + 4], s[8 * ks2 + 5], s[8 * ks2 + 6], s[8 * ks2 + 7]};
+      ta_bf16x8 pf[3];
+      ta_split8(pv, pf);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ta_bf16x8 vf[3];
+        const __bf16* vb = sV[buf] + (j * 32 + r) * TA_VLD + ks2 * 16 + hh * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) vf[q] = *reinterpret_cast<const ta_bf16x8*>(vb + q * TA_VPLANE);
+        ta_mma6(accO[j], vf, pf);
+      }
+    }
+    if (c + 1 < nchunk) ta_store<NT>(st, sK[buf ^ 1], sV[buf ^ 1]);
+    __syncthreads();
+  }
+
+  // ---- finish: O[q][dh] = O^T / l.  Entry e of block j is dh = 32 j + (e & 3) + 8 (e >> 2) + 4 hh: the two half-waves swap
+  // 4-value groups so that each lane owns 8 consecutive dh of two 8-groups (g = 2 t + hh), one 32-byte run / 16-byte plane chunk
+  const float l = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l;
+  const bool ok = q_row < T;
+  if (a.lse && ok && hh == 0) a.lse[(int64_t)bh * T + q_row] = (m_run + log2f(l)) * 0.6931471805599453f;
+  const int64_t orow = (int64_t)b * T + q_row;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float own[4], got[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float lo_g = accO[j][4 * (2 * t) + i] * inv, hi_g = accO[j][4 * (2 * t + 1) + i] * inv;
+        own[i] = hh ? hi_g : lo_g;
+        got[i] = __shfl_xor(hh ? lo_g : hi_g, 32);
+      }
+      float v8[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v8[i] = hh ? got[i] : own[i]; v8[4 + i] = hh ? own[i] : got[i]; }
+      const int col = hd * TA_D + j * 32 + 8 * (2 * t + hh);
+      if (ok) {
+        if (a.ctx) {
+          float* dst = a.ctx + orow * a.ld_ctx + col;
+          *reinterpret_cast<ta_f32x4*>(dst) = ta_f32x4{v8[0], v8[1], v8[2], v8[3]};
+          *reinterpret_cast<ta_f32x4*>(dst + 4) = ta_f32x4{v8[4], v8[5], v8[6], v8[7]};
+        }
+        if (a.op.p) p3_store8(a.op, orow, col, v8);
+      }
+    }
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+constexpr int TA_MAXW = 9;
+
+// 1 when pxr_tower_attn_fwd_f32 serves this shape
+extern "C" int pxr_tower_attn_supported(int T, int d) { return (d == TA_D && T >= 1 && T <= 32 * TA_MAXW) ? 1 : 0; }
+
+// ctx[b*T + t, 64 h .. 64 h + 63] = softmax_t'(scale * q_t . k_t') v_t'   per (image b, head h); no mask, no dropout.
+// q/k/v: fp32, element (b, t, h, c) at p[(b*T + t)*ld + 64 h + c] (the fused projection output is passed with three base
+// pointers).  Outputs: ctx fp32 and/or ctx planes (planes.cuh) -- at least one; lse optional ([images*heads, T]).
+extern "C" int pxr_tower_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads,
+                                      int T, int d, float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t c_ps,
+                                      int64_t c_pr, float* lse, void* stream) {
+  PXR_REQUIRE(q && k && v && images >= 0 && heads > 0, "pxr_tower_attn_fwd_f32: bad args");
+  PXR_REQUIRE(pxr_tower_attn_supported(T, d), "pxr_tower_attn_fwd_f32: head size %d / %d tokens not supported (64, <= %d)", d,
+              T, 32 * TA_MAXW);
+  PXR_REQUIRE(ctx || ctx_planes, "pxr_tower_attn_fwd_f32: no output");
+  PXR_REQUIRE(ld % 4 == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, "pxr_tower_attn_fwd_f32: q/k/v alignment");
+  PXR_REQUIRE(!ctx || (ld_ctx % 4 == 0 && ((uintptr_t)ctx & 15) == 0 && ld_ctx >= (int64_t)heads * d),
+              "pxr_tower_attn_fwd_f32: ctx layout");
+  PXR_REQUIRE(p3_mat_ok(ctx_planes, c_ps, c_pr, images * T, (int64_t)heads * d), "pxr_tower_attn_fwd_f32: ctx planes layout");
+  if (images == 0) return PXR_OK;
+  PXR_REQUIRE(images * heads < (1ll << 31), "pxr_tower_attn_fwd_f32: too many (image, head) pairs");
+  TowerAttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.ld = ld;
+  a.ctx = ctx; a.ld_ctx = ld_ctx;
+  a.op = P3Mat{(__bf16*)ctx_planes, c_ps, c_pr};
+  a.lse = lse;
+  a.heads = heads; a.T = T;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  const dim3 grid((unsigned)(images * heads));
+  hipStream_t s = (hipStream_t)stream;
+  switch ((T + 31) / 32) {
+#define PXR_TA_CASE(NW) case NW: hipLaunchKernelGGL(tower_attn_fwd_kernel<NW>, grid, dim3(NW * 64), 0, s, a); break;
+    PXR_TA_CASE(1) PXR_TA_CASE(2) PXR_TA_CASE(3) PXR_TA_CASE(4) PXR_TA_CASE(5) PXR_TA_CASE(6) PXR_TA_CASE(7) PXR_TA_CASE(8)
+    PXR_TA_CASE(9)
+#undef PXR_TA_CASE
+    default: PXR_REQUIRE(false, "pxr_tower_attn_fwd_f32: unreachable");
+  }
+  return pxr_check_launch("pxr_tower_attn_fwd_f32");
+}

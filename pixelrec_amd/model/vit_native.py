@@ -125,6 +125,8 @@ class NativeTower:
 
     def _attn_fwd(self, qkv, n, T, heads, d, keep):
         H, ld, Tp = heads * d, 3 * heads * d, (T + 3) & ~3
+        if not keep and ops.tower_attn_supported(T, d):
+            return ops.tower_attn_fwd(qkv.view(n * T, ld), n, T, heads, d, 2 * H, 0, H, d ** -0.5)[0], None
         key = ("S", n, T)
         S = None if keep else self._scratch.get(key)
         if S is None:
@@ -181,8 +183,11 @@ class NativeTower:
         _, _, _, h1p = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=False, planes=True)
         qkv = torch.empty(n, T, 3 * H, dtype=torch.float32, device=x.device)
         ops.gemm_planes(h1p, Wqkv, qkv.view(n * T, 3 * H), ops.EPI_BIAS, bias=P("self_attn.k_proj.bias", span=3))
-        ctx, _ = self._attn_fwd(qkv, n, T, heads, d, False)
-        ctxp = ops.split_planes(ctx.view(n * T, H))
+        if ops.tower_attn_supported(T, d):      # fused: no score matrix, the context leaves as planes
+            _, ctxp, _ = ops.tower_attn_fwd(qkv.view(n * T, 3 * H), n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=False, planes=True)
+        else:
+            ctx, _ = self._attn_fwd(qkv, n, T, heads, d, False)
+            ctxp = ops.split_planes(ctx.view(n * T, H))
         x2 = torch.empty_like(x)
         ops.gemm_planes(ctxp, Wo, x2.view(n * T, H), ops.EPI_BIAS_ADD, bias=P("self_attn.out_proj.bias"), aux=x.view(n * T, H))
         _, _, _, h2p = ops.ln_residual_fwd(x2, None, P("layer_norm2.weight"), P("layer_norm2.bias"), 1e-5, save=False, planes=True)

@@ -299,6 +299,29 @@ def gemm_batched(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, a_off, lda, 
                  "pxr_gemm_batched_f32")
 
 
+def tower_attn_supported(T: int, d: int) -> bool:
+    return os.environ.get("PXR_TOWER_ATTN", "1") != "0" and bool(_l.load().pxr_tower_attn_supported(int(T), int(d)))
+
+
+def tower_attn_fwd(qkv: torch.Tensor, n: int, T: int, heads: int, d: int, q_off: int, k_off: int, v_off: int, scale: float,
+                   ctx: bool = True, planes: bool = False, lse: bool = False):
+    """Fused attention of a tower block (pxr_tower_attn_fwd_f32) on the fused projection output qkv [n*T, ld]: q / k / v start at
+    columns q_off / k_off / v_off.  Returns (ctx fp32 [n, T, heads*d] | None, ctx Planes | None, lse [n*heads, T] | None)."""
+    _req(qkv, torch.float32, "qkv")
+    ld = qkv.shape[-1]
+    H = heads * d
+    out = torch.empty(n, T, H, dtype=torch.float32, device=qkv.device) if ctx else None
+    op = Planes.alloc(n * T, H, qkv.device) if planes else None
+    ls = torch.empty(n * heads, T, dtype=torch.float32, device=qkv.device) if lse else None
+    cp = _l.c_void_p
+    base = qkv.data_ptr()
+    with _gemm_timer(4.0 * T * T * d * n * heads, "tower_attn_fwd_kernel (fused QK^T / softmax / PV of a tower block)"):
+        _l.check(_l.load().pxr_tower_attn_fwd_f32(cp(base + 4 * q_off), cp(base + 4 * k_off), cp(base + 4 * v_off), ld, n, heads, T,
+                                                  d, float(scale), _l.ptr(out) if ctx else None, H, *_pl(op),
+                                                  _l.ptr(ls) if lse else None, _l.stream_ptr()), "pxr_tower_attn_fwd_f32")
+    return out, op, ls
+
+
 def softmax_rows(S: torch.Tensor, rows: int, T: int, ld: int, scale: float):
     _l.check(_l.load().pxr_softmax_rows_f32(_l.ptr(S), rows, T, ld, float(scale), _l.stream_ptr()), "pxr_softmax_rows_f32")
 
