@@ -362,6 +362,13 @@ int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t 
                        const void* cumlog, int64_t t_prev, int64_t t_apply, const int64_t* step_dev,
                        int64_t step_dev_bias, int64_t max_blocks, double beta1, double beta2, double eps,
                        void* stream);
+/* The catch-up part of pxr_adamw_rows_f32 on a RAW id list (the batch's item tensor as it is): ids[n_ids] may hold
+ * duplicates, 0 and out-of-range values (skipped).  The workgroup that raises last[row] to t_prev (atomicMax) replays the
+ * row, the ones of its duplicates find it current -- so the rows a forward pass reads can be brought up to date BEFORE the
+ * sort / unique of the batch's ids has run (it then runs beside the forward pass on a second stream). */
+int pxr_adamw_rows_ids_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D, const int64_t* ids,
+                           int64_t n_ids, const void* hyper, const void* cumlog, int64_t t_prev, const int64_t* step_dev,
+                           double beta1, double beta2, double eps, void* stream);
 /* pxr_adamw_flat_f32 with the step's scalars read from hyper[step] (or hyper[*step_dev + 1]). */
 int pxr_adamw_flat_tab_f32(float* p, const float* g, float* m, float* v, int64_t n, const void* hyper, int64_t step,
                            const int64_t* step_dev, double beta1, double beta2, double eps, void* stream);

@@ -15,6 +15,8 @@
 //     gradient this step).  HBM traffic per step = 6 x 4 B x N x D (read+write p, m, v) instead of the
 //     reference's 7 x 4 B plus the 2 x dense-gradient zero-fill/scatter; no 819 MB dense gradient exists.
 //     The kernel clears the slots it consumes, so the map is all -1 again afterwards.
+#include <string.h>
+
 #include "planes.cuh"
 
 #include <cstdlib>
@@ -161,6 +163,13 @@ struct RowsArgs {
   float one_m_b1, b2, one_m_b2, eps, b1;
   const int64_t* step_dev;   // optional: t_prev = *step_dev (completed steps), t_apply = t_prev+1 if t_apply != 0
   int t_prev_bias;           // added to *step_dev (1 = "through the step being applied right now": prefetched rows)
+  // claim mode (catch-up only, t_apply == 0): `rows` is a RAW id list of n_list entries -- duplicates, id 0 and out-of-range
+  // ids allowed -- e.g. the batch's item tensor as it is.  The group that raises last[row] (atomicMax) replays the row; the
+  // groups of its duplicates see it current and leave.  No sorted unique list is needed before the forward pass.
+  int claim; int64_t n_list; int64_t n_table;
+  // fast replay (default; PXR_LAZY_REPLAY=exact selects the bit-identical one): sqrt(v) and 1/denominator are carried from
+  // step to step (see adamw_rows_kernel) -- 8 VALU issue slots per element-step instead of 14
+  int fast; float sqrt_b2, log2_b2;
 };
 
 // One row is spread over LPR = ceil(D/EPL / 64) * 64 lanes (EPL = 2 or 4 elements per lane), so a row with a long gap is
@@ -187,8 +196,9 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
   const int rib = threadIdx.x / LPR;            // row of this block's group
   const int c = (threadIdx.x % LPR) * EPL;      // first column of this lane's elements
   const bool col_ok = c < a.D;
-  const int64_t n = a.rows ? (int64_t)(*a.n_rows) : a.n_fixed;
+  const int64_t n = a.rows ? (a.claim ? a.n_list : (int64_t)(*a.n_rows)) : a.n_fixed;
   const int64_t n_groups = (n + RPB - 1) / RPB;
+  __shared__ int s_claim[RPB];
   for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int64_t i = grp * RPB + rib;
     int64_t row = 0;
@@ -198,7 +208,14 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
       row = a.rows ? a.rows[i] : i;
       if (a.rows && row <= 0) work = false;   // id 0 = empty slot of a merged (non-compacted) row list
     }
-    if (work) {
+    if (a.claim) {
+      if (work && row >= a.n_table) work = false;
+      if ((threadIdx.x % LPR) == 0) s_claim[rib] = work ? atomicMax(a.last + row, a.t_prev) : a.t_prev;
+      __syncthreads();
+      k0 = s_claim[rib];
+      if (k0 >= a.t_prev) work = false;
+      __syncthreads();                        // s_claim is rewritten by the next group
+    } else if (work) {
       k0 = a.last[row];
       if (k0 >= a.t_prev && a.t_apply == 0) work = false;
     }
@@ -225,6 +242,52 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
 #pragma unroll
         for (int e = 0; e < EPL; ++e) adam_elem0(pe[e], me[e], ve[e], h);
       };
+      if (a.fast && s <= exact_end) {
+        // The zero-gradient recurrence without its two quarter-rate instructions per element-step: sqrt(v_t) =
+        // sqrt(v_0) sqrt(b2)^t is carried as a product, and 1/denom_t comes from 1/denom_{t-1} by Newton steps (the
+        // denominator moves by 0.05 % per step through sqrt(b2), plus what the settling bias correction adds: 1 % at optimizer
+        // step 64, 0.03 % at step 1000).  Differences to the dense sweep: < 1e-6 relative on update terms of at most a few lr
+        // each, i.e. ~1e-9 absolute on p over a 256-step gap (measured: tests/test_gpu_lazy_adamw.py, fast_replay tests);
+        // m exact to rounding, v = v_0 b2^gap in one rounding.
+        float se[EPL], re[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { se[e] = __builtin_amdgcn_sqrtf(ve[e]); re[e] = 0.f; }
+        const int s0 = s;
+        const int rcp_until = max(s0, 64);
+        // MODE 0: hardware reciprocal; 1: one Newton step; 2: two (optimizer steps < 1024, where the bias correction still
+        // moves the denominator by up to 1 % per step: one step would leave 6e-5 relative there, two leave it at rounding)
+        auto step_fast = [&](const float4 hs, const int mode) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            pe[e] = __fmul_rn(pe[e], hs.x);
+            me[e] = __fmul_rn(me[e], a.b1);
+            se[e] = __fmul_rn(se[e], a.sqrt_b2);
+            const float denom = fmaf(se[e], hs.z, h.eps);
+            if (mode == 0) {
+              re[e] = __builtin_amdgcn_rcpf(denom);
+            } else {
+              re[e] = __fmul_rn(re[e], fmaf(-denom, re[e], 2.0f));
+              if (mode == 2) re[e] = __fmul_rn(re[e], fmaf(-denom, re[e], 2.0f));
+            }
+            pe[e] = fmaf(-hs.y, __fmul_rn(me[e], re[e]), pe[e]);
+          }
+        };
+        for (; s <= exact_end && s <= rcp_until; ++s) step_fast(hyper[s], 0);
+        const int early_end = min(exact_end, 1023);
+        for (; s + 3 <= early_end; s += 4) {
+          const float4 h0 = hyper[s], h1 = hyper[s + 1], h2 = hyper[s + 2], h3 = hyper[s + 3];
+          step_fast(h0, 2); step_fast(h1, 2); step_fast(h2, 2); step_fast(h3, 2);
+        }
+        for (; s <= early_end; ++s) step_fast(hyper[s], 2);
+        for (; s + 3 <= exact_end; s += 4) {
+          const float4 h0 = hyper[s], h1 = hyper[s + 1], h2 = hyper[s + 2], h3 = hyper[s + 3];
+          step_fast(h0, 1); step_fast(h1, 1); step_fast(h2, 1); step_fast(h3, 1);
+        }
+        for (; s <= exact_end; ++s) step_fast(hyper[s], 1);
+        const float fv = __builtin_amdgcn_exp2f((float)(s - s0) * a.log2_b2);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ve[e] = __fmul_rn(ve[e], fv);
+      }
       // four steps per trip: their scalars are ONE scalar-cache line (64 B), waited for once
       for (; s + 3 <= exact_end; s += 4) {
         const float4 h0 = hyper[s], h1 = hyper[s + 1], h2 = hyper[s + 2], h3 = hyper[s + 3];
@@ -263,7 +326,7 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
       }
     }
     if constexpr (LPR > 64) __syncthreads();   // every wave of the row has read last[row]
-    if (work && (threadIdx.x % LPR) == 0) a.last[row] = a.t_apply ? a.t_apply : a.t_prev;
+    if (work && !a.claim && (threadIdx.x % LPR) == 0) a.last[row] = a.t_apply ? a.t_apply : a.t_prev;
   }
 }
 
@@ -271,9 +334,8 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
 // appends them.  step_dev != null: step = *step_dev + 1 (device counter => valid under hipGraph replay).
 // advance != 0 (needs step_dev): FIRST count the step that just finished (*step_dev += 1), then append the entry of the
 // next one -- the end-of-step form: one launch closes step t and prepares step t+1.
-__global__ void hyper_append_kernel(float4* hyper, double* cumlog, int64_t capacity, int64_t step,
-                                    int64_t* step_dev, double lr, double b1, double b2, double wd, int advance) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void hyper_append_body(float4* hyper, double* cumlog, int64_t capacity, int64_t step,
+                                                  int64_t* step_dev, double lr, double b1, double b2, double wd, int advance) {
   if (step_dev && advance) step_dev[0] += 1;
   if (step_dev) step = step_dev[0] + 1;
   if (step < 1 || step >= capacity) return;
@@ -283,6 +345,12 @@ __global__ void hyper_append_kernel(float4* hyper, double* cumlog, int64_t capac
   const double bc2 = 1.0 - pow(b2, (double)step);
   hyper[step] = make_float4(decay, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), 0.f);
   cumlog[step] = cumlog[step - 1] + log((double)decay);
+}
+
+__global__ void hyper_append_kernel(float4* hyper, double* cumlog, int64_t capacity, int64_t step,
+                                    int64_t* step_dev, double lr, double b1, double b2, double wd, int advance) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  hyper_append_body(hyper, cumlog, capacity, step, step_dev, lr, b1, b2, wd, advance);
 }
 
 // Weight matrices inside the flat buffer whose updated values are ALSO written as bf16x3 planes (the operand format of the
@@ -480,25 +548,17 @@ extern "C" int pxr_counter_add_i64(int64_t* counter, int64_t delta, void* stream
 // the call hipGraph-replayable.  step_dev_bias = 1 brings rows current through the step that is being applied right
 // now (its scalars are in the table): used for the rows of the NEXT batch, so that its forward finds them current.
 // max_blocks > 0 caps the grid (grid-stride loop inside): a thin launch for side-stream work.
-extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D,
-                                  const int64_t* rows, const int32_t* n_rows_dev, int64_t max_rows, const float* grows,
-                                  const void* hyper, const void* cumlog, int64_t t_prev, int64_t t_apply,
-                                  const int64_t* step_dev, int64_t step_dev_bias, int64_t max_blocks, double beta1,
-                                  double beta2, double eps, void* stream) {
-  PXR_REQUIRE(table && m && v && last && hyper && cumlog, "pxr_adamw_rows_f32: null pointer");
-  PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 4096, "pxr_adamw_rows_f32: bad shape (D <= 4096)");
-  PXR_REQUIRE(!rows || n_rows_dev, "pxr_adamw_rows_f32: row list needs its device count");
-  PXR_REQUIRE(t_prev >= 0 && (t_apply == 0 || t_apply == t_prev + 1), "pxr_adamw_rows_f32: t_apply must be t_prev+1 or 0");
-  RowsArgs a{};
-  a.p = table; a.m = m; a.v = v; a.last = last; a.rows = rows; a.n_rows = n_rows_dev; a.n_fixed = n_table;
-  a.grows = grows; a.hyper = (const float4*)hyper; a.cumlog = (const double*)cumlog;
-  a.t_prev = (int)t_prev; a.t_apply = (int)t_apply; a.D = D;
-  a.one_m_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_m_b2 = (float)(1.0 - beta2); a.eps = (float)eps;
-  a.b1 = (float)beta1;
-  a.step_dev = step_dev;
-  a.t_prev_bias = (int)step_dev_bias;
-  const int64_t work = rows ? max_rows : n_table;
+// PXR_LAZY_REPLAY=exact: replay missed steps with the dense sweep's own arithmetic (lazy == dense bit for bit for gaps <= 256)
+static bool lazy_replay_fast() {
+  const char* e = getenv("PXR_LAZY_REPLAY");
+  return !(e && strcmp(e, "exact") == 0);
+}
+static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blocks, int D, void* stream, const char* who) {
   if (work <= 0) return PXR_OK;
+  RowsArgs a = a_in;
+  a.fast = lazy_replay_fast() ? 1 : 0;
+  a.sqrt_b2 = sqrtf(a.b2);
+  a.log2_b2 = log2f(a.b2);
   hipStream_t st = (hipStream_t)stream;
   // 2 elements per lane up to D = 2048 (a 512-wide row = 4 waves), 4 beyond (block size caps at 1024 threads)
   const int epl = D <= 2048 ? 2 : 4;
@@ -523,5 +583,44 @@ extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* las
     if (tl <= 512) PXR_ROWS_CASE(512, 4); else PXR_ROWS_CASE(1024, 4);
   }
 #undef PXR_ROWS_CASE
-  return pxr_check_launch("pxr_adamw_rows_f32");
+  return pxr_check_launch(who);
+}
+extern "C" int pxr_adamw_rows_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D,
+                                  const int64_t* rows, const int32_t* n_rows_dev, int64_t max_rows, const float* grows,
+                                  const void* hyper, const void* cumlog, int64_t t_prev, int64_t t_apply,
+                                  const int64_t* step_dev, int64_t step_dev_bias, int64_t max_blocks, double beta1,
+                                  double beta2, double eps, void* stream) {
+  PXR_REQUIRE(table && m && v && last && hyper && cumlog, "pxr_adamw_rows_f32: null pointer");
+  PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 4096, "pxr_adamw_rows_f32: bad shape (D <= 4096)");
+  PXR_REQUIRE(!rows || n_rows_dev, "pxr_adamw_rows_f32: row list needs its device count");
+  PXR_REQUIRE(t_prev >= 0 && (t_apply == 0 || t_apply == t_prev + 1), "pxr_adamw_rows_f32: t_apply must be t_prev+1 or 0");
+  RowsArgs a{};
+  a.p = table; a.m = m; a.v = v; a.last = last; a.rows = rows; a.n_rows = n_rows_dev; a.n_fixed = n_table;
+  a.grows = grows; a.hyper = (const float4*)hyper; a.cumlog = (const double*)cumlog;
+  a.t_prev = (int)t_prev; a.t_apply = (int)t_apply; a.D = D;
+  a.one_m_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_m_b2 = (float)(1.0 - beta2); a.eps = (float)eps;
+  a.b1 = (float)beta1;
+  a.step_dev = step_dev;
+  a.t_prev_bias = (int)step_dev_bias;
+  return adamw_rows_launch(a, rows ? max_rows : n_table, max_blocks, D, stream, "pxr_adamw_rows_f32");
+}
+
+// Catch-up of the rows named by a RAW id list (claim mode, see RowsArgs): ids[n_ids] may hold duplicates, 0 and
+// out-of-range values (both skipped).  Same replay arithmetic as pxr_adamw_rows_f32 with t_apply = 0.
+extern "C" int pxr_adamw_rows_ids_f32(float* table, float* m, float* v, int32_t* last, int64_t n_table, int D,
+                                      const int64_t* ids, int64_t n_ids, const void* hyper, const void* cumlog,
+                                      int64_t t_prev, const int64_t* step_dev, double beta1, double beta2, double eps,
+                                      void* stream) {
+  PXR_REQUIRE(table && m && v && last && hyper && cumlog && ids, "pxr_adamw_rows_ids_f32: null pointer");
+  PXR_REQUIRE(n_table > 0 && D > 0 && D % 4 == 0 && D <= 4096, "pxr_adamw_rows_ids_f32: bad shape (D <= 4096)");
+  PXR_REQUIRE(t_prev >= 0 && n_ids >= 0, "pxr_adamw_rows_ids_f32: bad step / count");
+  RowsArgs a{};
+  a.p = table; a.m = m; a.v = v; a.last = last; a.rows = ids; a.n_rows = nullptr; a.n_fixed = n_table;
+  a.hyper = (const float4*)hyper; a.cumlog = (const double*)cumlog;
+  a.t_prev = (int)t_prev; a.t_apply = 0; a.D = D;
+  a.one_m_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_m_b2 = (float)(1.0 - beta2); a.eps = (float)eps;
+  a.b1 = (float)beta1;
+  a.step_dev = step_dev;
+  a.claim = 1; a.n_list = n_ids; a.n_table = n_table;
+  return adamw_rows_launch(a, n_ids, 0, D, stream, "pxr_adamw_rows_ids_f32");
 }

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
             y.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? y.w * inv_keep : 0.f;
           }
         }
-        *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
+        if (a.y) *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
         if (a.yp.p) p3_store4(a.yp, row, c, y);
       }
     }
@@ -389,7 +389,7 @@ extern "C" int pxr_ln_residual_fwd_planes_f32(const float* x, const float* res, 
                                               float eps, int rows, int D, float* y, float* xhat, float* rstd, float p_drop,
                                               uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* y_planes,
                                               int64_t y_plane_stride, int64_t y_panel_rows, void* stream) {
-  PXR_REQUIRE(x && gamma && beta && y, "pxr_ln_residual_fwd_f32: null pointer");
+  PXR_REQUIRE(x && gamma && beta && (y || y_planes), "pxr_ln_residual_fwd_f32: null pointer");   // y optional next to planes
   PXR_REQUIRE(p3_mat_ok(y_planes, y_plane_stride, y_panel_rows, rows, D), "pxr_ln_residual_fwd_planes_f32: bad planes");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && rows >= 0, "pxr_ln_residual_fwd_f32: bad shape");
   PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_ln_residual_fwd_f32: bad dropout p");

@@ -57,6 +57,8 @@ class SASRec(SeqRecCore):
         self._next_ws = None
         self._prefetched = None         # (SparseRows of the next batch) the optimizer advances through the current step
         self._prefetch_stream = None
+        self._sort_stream = None        # the batch's id sort runs beside the forward pass (lazy table optimizer)
+        self._sort_pending = False
 
     # state_dict key order of the reference: item_embedding first (sasrec.py:31-45); register order above differs only
     # in position, which load_state_dict does not care about.
@@ -142,9 +144,30 @@ class SASRec(SeqRecCore):
             need = ops.occ_ws_bytes(B, L)
             if self._occ_ws is None or self._occ_ws.numel() < need or self._occ_ws.device != items.device:
                 self._occ_ws = torch.empty(need, dtype=torch.uint8, device=items.device)
-            ops.sasrec_occ_sort(items, self.item_num, sp, self._occ_ws)
-            if self._table_hooks is not None:
-                self._table_hooks.catch_up_rows(sp.idx, sp.n, sp.cap)
+            hooks = self._table_hooks
+            if (hooks is not None and getattr(hooks, "table_update", None) == "lazy" and hasattr(hooks, "catch_up_ids")
+                    and os.environ.get("PXR_SORT_OVERLAP", "0") == "1"):
+                # OPT-IN schedule (PXR_SORT_OVERLAP=1).  The sorted unique list is first needed by the table-gradient segment
+                # sums in backward: only the catch-up stands between the batch and the forward pass, and it can take the raw
+                # id tensor (rows are claimed, duplicates drop out), so the sort / segment launches run beside it and the
+                # forward pass on a second stream; _after_input_grads joins it.  Measured on MI355X (profiles/r03, step
+                # timelines): the forward pass starts 16-20 us earlier, the cross-stream join in front of the segment sums
+                # costs ~11 us and the catch-up runs ~5 us longer beside the sort -- 0.965 ms/step either way.  Off by default.
+                main = torch.cuda.current_stream()
+                side = self._sort_stream
+                if side is None or side.device != main.device:
+                    side = self._sort_stream = torch.cuda.Stream(device=main.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.sasrec_occ_sort(items, self.item_num, sp, self._occ_ws)
+                self._sort_pending = True
+                if not hooks.catch_up_ids(items):
+                    self._join_sort()
+            else:
+                ops.sasrec_occ_sort(items, self.item_num, sp, self._occ_ws)
+            if hooks is not None:
+                if not self._sort_pending:
+                    hooks.catch_up_rows(sp.idx, sp.n, sp.cap)
                 nxt, self._next_items = self._next_items, None
                 if nxt is not None and getattr(self._table_hooks, "table_update", None) == "lazy":
                     self._start_prefetch(nxt.contiguous())
@@ -169,8 +192,15 @@ class SASRec(SeqRecCore):
         finally:
             self.training = was
 
+    def _join_sort(self):
+        """Order the current stream behind the id sort that runs beside the forward pass (no-op when there is none)."""
+        if self._sort_pending:
+            torch.cuda.current_stream().wait_stream(self._sort_stream)
+            self._sort_pending = False
+
     def _after_input_grads(self, dx0, coef, s):
         sp = self._local_sparse
+        self._join_sort()
         ops.sasrec_occ_segsum(self._occ_ws, dx0, s["out"], coef, self.item_num, sp, 1.0)
         self.sparse_table_grad = sp
         hook = getattr(self, "_sparse_ready_hook", None)

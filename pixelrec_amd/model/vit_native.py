@@ -174,32 +174,87 @@ class NativeTower:
         else:
             self._wplanes = {}
 
-    def _block_fwd_planes(self, i, x):
+    def _block_fwd_planes(self, i, x, keep=False):
+        """One block on the planes GEMMs.  keep=True (a trainable block of a training step) also returns what its backward
+        needs -- activations as planes where the weight-gradient / input-gradient GEMMs read them."""
         vm = "item_encoder.vision_model."
         P = lambda s_, **kw: self.view(f"{vm}encoder.layers.{i}.{s_}", **kw)
         H, heads, d, T, _ = self._shape()
         n = x.shape[0]
-        Wqkv, Wo, W1, W2 = self._block_weight_planes(i)
-        _, _, _, h1p = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=False, planes=True)
+        M = n * T
+        Wqkv, Wo, W1, W2 = W = self._block_weight_planes(i)
+        _, xh1, rs1, h1p = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=keep, planes=True, want_y=False)
         qkv = torch.empty(n, T, 3 * H, dtype=torch.float32, device=x.device)
-        ops.gemm_planes(h1p, Wqkv, qkv.view(n * T, 3 * H), ops.EPI_BIAS, bias=P("self_attn.k_proj.bias", span=3))
-        if ops.tower_attn_supported(T, d):      # fused: no score matrix, the context leaves as planes
-            _, ctxp, _ = ops.tower_attn_fwd(qkv.view(n * T, 3 * H), n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=False, planes=True)
+        ops.gemm_planes(h1p, Wqkv, qkv.view(M, 3 * H), ops.EPI_BIAS, bias=P("self_attn.k_proj.bias", span=3))
+        S = None
+        if not keep and ops.tower_attn_supported(T, d):      # fused: no score matrix, the context leaves as planes
+            _, ctxp, _ = ops.tower_attn_fwd(qkv.view(M, 3 * H), n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=False, planes=True)
         else:
-            ctx, _ = self._attn_fwd(qkv, n, T, heads, d, False)
-            ctxp = ops.split_planes(ctx.view(n * T, H))
+            ctx, S = self._attn_fwd(qkv, n, T, heads, d, keep)
+            ctxp = ops.split_planes(ctx.view(M, H))
         x2 = torch.empty_like(x)
-        ops.gemm_planes(ctxp, Wo, x2.view(n * T, H), ops.EPI_BIAS_ADD, bias=P("self_attn.out_proj.bias"), aux=x.view(n * T, H))
-        _, _, _, h2p = ops.ln_residual_fwd(x2, None, P("layer_norm2.weight"), P("layer_norm2.bias"), 1e-5, save=False, planes=True)
-        fp = ops.Planes.alloc(n * T, W1.rows, x.device)
-        ops.gemm_planes(h2p, W1, None, ops.EPI_BIAS_QGELU, bias=P("mlp.fc1.bias"), Cp=fp)
+        ops.gemm_planes(ctxp, Wo, x2.view(M, H), ops.EPI_BIAS_ADD, bias=P("self_attn.out_proj.bias"), aux=x.view(M, H))
+        _, xh2, rs2, h2p = ops.ln_residual_fwd(x2, None, P("layer_norm2.weight"), P("layer_norm2.bias"), 1e-5, save=keep, planes=True, want_y=False)
+        fp = ops.Planes.alloc(M, W1.rows, x.device)
+        gq = torch.empty(M, W1.rows, dtype=torch.float32, device=x.device) if keep else None
+        ops.gemm_planes(h2p, W1, None, ops.EPI_BIAS_QGELU_GRAD if keep else ops.EPI_BIAS_QGELU, bias=P("mlp.fc1.bias"), aux=gq, Cp=fp)
         x3 = torch.empty_like(x)
-        ops.gemm_planes(fp, W2, x3.view(n * T, H), ops.EPI_BIAS_ADD, bias=P("mlp.fc2.bias"), aux=x2.view(n * T, H))
-        return x3
+        ops.gemm_planes(fp, W2, x3.view(M, H), ops.EPI_BIAS_ADD, bias=P("mlp.fc2.bias"), aux=x2.view(M, H))
+        saved = dict(planes=True, W=W, xh1=xh1, rs1=rs1, h1p=h1p, qkv=qkv, P=S, ctxp=ctxp, xh2=xh2, rs2=rs2, h2p=h2p, gq=gq,
+                     fp=fp) if keep else None
+        return x3, saved
+
+    def _block_bwd_planes(self, i, dx3, s, defer):
+        """Backward of a block whose forward ran on planes: every GEMM operand is a plane set (the saved activations, the
+        gradients split once where they are produced in fp32), all four weight + bias gradients in one grouped launch."""
+        vm = "item_encoder.vision_model."
+        name = lambda t: f"{vm}encoder.layers.{i}.{t}"
+        P = lambda t, **kw: self.view(name(t), **kw)
+        G = lambda t, **kw: self.view(name(t), grad=True, **kw)
+        H, heads, d, T, _ = self._shape()
+        n = dx3.shape[0]
+        M = n * T
+        ld, Tp, bh = 3 * H, (T + 3) & ~3, n * heads
+        Wqkv, Wo, W1, W2 = s["W"]
+        lead = (n, T)
+        dx3p = ops.split_planes(dx3.view(M, H))
+        pend = [(dx3p, s["fp"], G("mlp.fc2.weight"), G("mlp.fc2.bias"))]
+        _, dup = ops.linear_bwd_input_planes(dx3p, W2, mul=s["gq"], want_fp32=False, want_planes=True)   # x quick_gelu'
+        pend.append((dup, s["h2p"], G("mlp.fc1.weight"), G("mlp.fc1.bias")))
+        dh2, _ = ops.linear_bwd_input_planes(dup, W1, lead_shape=lead)
+        dz2, _ = ops.ln_bwd(0, dh2, s["xh2"], s["rs2"], P("layer_norm2.weight"), G("layer_norm2.weight"),
+                            G("layer_norm2.bias"), defer=defer)
+        dx2 = ops.add(dx3, dz2)
+        dx2p = ops.split_planes(dx2.view(M, H))
+        pend.append((dx2p, s["ctxp"], G("self_attn.out_proj.weight"), G("self_attn.out_proj.bias")))
+        dctx, _ = ops.linear_bwd_input_planes(dx2p, Wo, lead_shape=lead)
+        dqkv = self._attn_bwd(s["qkv"], s["P"], dctx, n, T, heads, d)
+        dqkvp = ops.split_planes(dqkv.view(M, ld))
+        pend.append((dqkvp, s["h1p"], G("self_attn.k_proj.weight", span=3), G("self_attn.k_proj.bias", span=3)))
+        dh1, _ = ops.linear_bwd_input_planes(dqkvp, Wqkv, lead_shape=lead)
+        dz1, _ = ops.ln_bwd(0, dh1, s["xh1"], s["rs1"], P("layer_norm1.weight"), G("layer_norm1.weight"),
+                            G("layer_norm1.bias"), defer=defer)
+        dx = ops.add(dx2, dz1)
+        ops.grouped_dw_planes(pend)
+        return dx
+
+    def _attn_bwd(self, qkv, Pm, dctx, n, T, heads, d):
+        """d(q | k | v) of the materialized attention: four batched contractions + the row softmax backward."""
+        H = heads * d
+        ld, Tp, bh = 3 * H, (T + 3) & ~3, n * heads
+        dqkv = torch.empty_like(qkv)
+        dP = torch.empty_like(Pm)
+        sP, sQ, sC = (heads * T * Tp, T * Tp), (T * ld, d), (T * H, d)
+        ops.gemm_batched(False, False, T, d, T, Pm, 0, Tp, dctx, 0, H, dqkv, H, ld, bh, heads, sP, sC, sQ)    # dV = P^T dO
+        ops.gemm_batched(True, True, T, T, d, dctx, 0, H, qkv, H, ld, dP, 0, Tp, bh, heads, sC, sQ, sP)      # dP = dO V^T
+        ops.softmax_rows_bwd(Pm, dP, bh * T, T, Tp, d ** -0.5)                                            # dP := dS
+        ops.gemm_batched(True, False, T, d, T, dP, 0, Tp, qkv, 0, ld, dqkv, 2 * H, ld, bh, heads, sP, sQ, sQ)  # dQ = dS K
+        ops.gemm_batched(False, False, T, d, T, dP, 0, Tp, qkv, 2 * H, ld, dqkv, 0, ld, bh, heads, sP, sQ, sQ)  # dK = dS^T Q
+        return dqkv
 
     def _block_fwd(self, i, x, keep):
-        if not keep and self._planes_on():
-            return self._block_fwd_planes(i, x), None
+        if self._planes_on() and (not keep or os.environ.get("PXR_TOWER_TRAIN_PLANES", "1") != "0"):
+            return self._block_fwd_planes(i, x, keep)
         vm = "item_encoder.vision_model."
         P = lambda s, **kw: self.view(f"{vm}encoder.layers.{i}.{s}", **kw)
         H, heads, d, T, _ = self._shape()
@@ -253,6 +308,8 @@ class NativeTower:
 
     # ------------------------------------------------------------------------------------------ backward
     def _block_bwd(self, i, dx3, s, defer):
+        if s.get("planes"):
+            return self._block_bwd_planes(i, dx3, s, defer)
         vm = "item_encoder.vision_model."
         name = lambda t: f"{vm}encoder.layers.{i}.{t}"
         P = lambda t, **kw: self.view(name(t), **kw)
@@ -273,15 +330,7 @@ class NativeTower:
         # attention + residual:  x2 = x + ctx Wo^T + bo
         pend.append((dx2.view(M, H), s["ctx"].view(M, H), G("self_attn.out_proj.weight"), G("self_attn.out_proj.bias")))
         dctx = ops.linear_bwd_input(dx2, P("self_attn.out_proj.weight"))
-        qkv, Pm = s["qkv"], s["P"]
-        dqkv = torch.empty_like(qkv)
-        dP = torch.empty_like(Pm)
-        sP, sQ, sC = (heads * T * Tp, T * Tp), (T * ld, d), (T * H, d)
-        ops.gemm_batched(False, False, T, d, T, Pm, 0, Tp, dctx, 0, H, dqkv, H, ld, bh, heads, sP, sC, sQ)    # dV = P^T dO
-        ops.gemm_batched(True, True, T, T, d, dctx, 0, H, qkv, H, ld, dP, 0, Tp, bh, heads, sC, sQ, sP)      # dP = dO V^T
-        ops.softmax_rows_bwd(Pm, dP, bh * T, T, Tp, d ** -0.5)                                            # dP := dS
-        ops.gemm_batched(True, False, T, d, T, dP, 0, Tp, qkv, 0, ld, dqkv, 2 * H, ld, bh, heads, sP, sQ, sQ)  # dQ = dS K
-        ops.gemm_batched(False, False, T, d, T, dP, 0, Tp, qkv, 2 * H, ld, dqkv, 0, ld, bh, heads, sP, sQ, sQ)  # dK = dS^T Q
+        dqkv = self._attn_bwd(s["qkv"], s["P"], dctx, n, T, heads, d)
         pend.append((dqkv.view(M, ld), s["h1"].view(M, H), G("self_attn.k_proj.weight", span=3),
                      G("self_attn.k_proj.bias", span=3)))
         dh1 = ops.linear_bwd_input(dqkv, P("self_attn.k_proj.weight", span=3))

@@ -541,13 +541,16 @@ def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.
     return (y, xhat, rstd, yp) if planes else (y, xhat, rstd)
 
 
-def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None, planes: bool = False):
-    """y = LN(dropout(x) + res)  (layers.py:614-615, :670-671).  Returns (y, xhat, rstd) (+ y as Planes with planes=True)."""
+def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, save=True, step_dev=None, planes: bool = False,
+                    want_y: bool = True):
+    """y = LN(dropout(x) + res)  (layers.py:614-615, :670-671).  Returns (y, xhat, rstd) (+ y as Planes with planes=True;
+    want_y=False then skips the fp32 copy of y)."""
     Lb = _l.load()
     _req(x, torch.float32, "x")
     D = x.shape[-1]
     rows = x.numel() // D
-    y = torch.empty_like(x)
+    assert want_y or planes
+    y = torch.empty_like(x) if want_y else None
     xhat = torch.empty_like(x) if save else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
     yp = Planes.alloc(rows, D, x.device) if planes else None
@@ -1032,6 +1035,16 @@ def adamw_rows(table, m, v, last, hyper, cumlog, t_prev, t_apply, beta1, beta2, 
                                        t_apply, _l.ptr(step_dev), int(step_dev_bias), int(max_blocks), beta1, beta2, eps,
                                        _l.stream_ptr()),
                  "pxr_adamw_rows_f32")
+
+
+def adamw_rows_ids(table, m, v, last, hyper, cumlog, t_prev, beta1, beta2, eps, ids, step_dev=None):
+    """Catch-up of the rows named by a raw int64 id tensor (duplicates / 0 / out-of-range allowed): pxr_adamw_rows_ids_f32."""
+    _req(ids, torch.int64, "ids")
+    N, D = table.shape
+    with _gemm_timer(0.0, "adamw_rows_kernel (catch-up: batch rows, claimed from the raw id list)"):
+        _l.check(_l.load().pxr_adamw_rows_ids_f32(_l.ptr(table), _l.ptr(m), _l.ptr(v), _l.ptr(last), N, D, _l.ptr(ids),
+                                                  ids.numel(), _l.ptr(hyper), _l.ptr(cumlog), t_prev, _l.ptr(step_dev), beta1,
+                                                  beta2, eps, _l.stream_ptr()), "pxr_adamw_rows_ids_f32")
 
 
 def adamw_flat_tab(p, g, m, v, hyper, step, beta1, beta2, eps, step_dev=None, plane_segments=None):

@@ -179,6 +179,16 @@ class PxrAdamW:
                        self.step_count, 0, b1, b2, self.param_groups[0]["eps"], rows=idx, n_rows=n_dev, max_rows=cap,
                        step_dev=self._step_dev, max_blocks=max_blocks)
 
+    def catch_up_ids(self, ids):
+        """catch_up_rows on the batch's raw id tensor (duplicates and padding zeros allowed): needs no sorted unique list, so the
+        model can run the sort of the ids beside its forward pass.  False when there is nothing lazy to do."""
+        if self.table_update != "lazy" or self._last is None or not self.has_table:
+            return False
+        b1, b2 = self.param_groups[0]["betas"]
+        ops.adamw_rows_ids(self.model.item_embedding.weight.data, self._tm, self._tv, self._last, self._hyper, self._cumlog,
+                           self.step_count, b1, b2, self.param_groups[0]["eps"], ids, step_dev=self._step_dev)
+        return True
+
     def flush(self):
         """Bring EVERY row up to date (before evaluation, checkpointing, or reading the table as a whole)."""
         if self.table_update != "lazy" or not self._dirty or self._last is None:
@@ -238,7 +248,9 @@ class PxrAdamW:
                            plane_segments=segs)
         if segs:
             self.model.mark_weight_planes_fresh()
-        # close the step: count it on the device and prepare the next step's scalars -- one 1-thread launch
+        # close the step: count it on the device and prepare the next step's scalars -- one 1-thread launch.  (Folding it into
+        # the flat update as "the last workgroup to arrive closes the step" was measured: 4096 arrivals on one atomic cost
+        # +29 us on the launch to save this 5 us one, and a fenced variant for folded reductions 0.6 ms -- DESIGN.md dead ends.)
         ops.adamw_hyper_append(self._hyper, self._cumlog, self.step_count + 2, *cfg, step_dev=sd, advance=True)
         self.step_count += 1
 

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "fast_replay: lazy-AdamW test that runs in the default (fast) replay mode")
 
 
 def pytest_collection_modifyitems(config, items):

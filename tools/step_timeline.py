@@ -1,0 +1,20 @@
+"""Timeline of ONE training step out of a rocprofv3 kernel trace (start / end in us relative to the step's first kernel, queue id):
+shows what overlaps what.  usage: python tools/step_timeline.py <kernel_trace.csv> [out.txt]"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+ends = [i for i, r in enumerate(rows) if "adamw_flat_tab" in r["Kernel_Name"]]      # the step's last big launch
+if ends and ends[-1] + 1 < len(rows) and "hyper_append" in rows[ends[-1] + 1]["Kernel_Name"]:
+    ends = [i + 1 for i in ends]                                                    # ... followed by its closing launch
+if len(ends) < 3:
+    sys.exit("no complete step in the trace")
+lo, hi = ends[-3] + 1, ends[-2] + 1           # one whole step between two end-of-step launches
+t0 = int(rows[lo]["Start_Timestamp"])
+out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
+prev_end = t0
+for r in rows[lo:hi]:
+    s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
+    out.write("%8.1f %8.1f  dur %6.1f  q=%-3s %s\n" % (s, e, e - s, r.get("Queue_Id", "?"), r["Kernel_Name"][:90]))
+out.write("step span %.1f us, %d kernels\n" % ((int(rows[hi - 1]["End_Timestamp"]) - t0) / 1e3, hi - lo))
