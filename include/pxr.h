@@ -91,6 +91,15 @@ int pxr_merge_split_rows_f32(const void* heads_all, const float* rows_all, int W
 int pxr_sample_negatives_i64(const int64_t* pos, int B, int W, int64_t n_items, uint64_t seed, uint64_t batch_counter,
                              int64_t* items, int64_t* masked_index, void* stream);
 
+/* Row-sharded table, hit-row exchange as an all-to-all (model/sharded.py): split a rank's ascending unique id list (count on
+ * the device) by owner (id % W) into W request lists of pp_cap slots -- req[W, pp_cap] ascending, pad_id beyond the count;
+ * pos[W, pp_cap] = the id's index in the unique list (-1 for padding); counts[W].  An owner with more than pp_cap hits sets
+ * status bit 16 (PXR_STATUS_SHARD_OVERFLOW) and loses its surplus.  pxr_scatter_rows_f32: dst[row_offset + pos[i], :] =
+ * src[i, :] for pos[i] >= 0 (the rows that came back, put at their place in the compact block). */
+int pxr_shard_bucket_ids_i64(const int64_t* ids, const int32_t* n_dev, int W, int64_t n_table, int64_t pp_cap, int64_t pad_id,
+                             int64_t* req, int32_t* pos, int32_t* counts, void* stream);
+int pxr_scatter_rows_f32(const float* src, const int32_t* pos, int64_t n_src, int D, float* dst, int64_t dst_rows,
+                         int row_offset, void* stream);
 /* Row-sharded table (north_star "embedding table optionally row-sharded", BASELINE configs[3]): owner of id =
  * id % W, its row in the owner's shard = id / W + 1 (local row 0 = all-zero dummy).  local_rows[i] = that row if this
  * rank owns ids[i] (0 < id < n_table), else 0.  pxr_ids_to_compact: out[i] = 1 + position of ids[i] in the ascending

@@ -962,7 +962,73 @@ __global__ void __launch_bounds__(256) ids_to_compact_kernel(const int64_t* __re
   }
   out[i] = (id > 0 && lo < *n_uniq && uniq[lo] == id) ? lo + 1 : 0;
 }
+// The hit-row exchange of the row-sharded table as an ALL-TO-ALL (sharded.py): rank q asks owner o only for the rows o owns.
+// shard_bucket_kernel splits q's ascending unique id list by owner into W request lists of pp_cap slots (ascending, PAD
+// beyond the count) and remembers where each requested id sits in the unique list (pos), so that the rows coming back can be
+// put straight at their place in the compact block.  One workgroup; wave w serves owners w, w + 16, ...: a ballot
+// compaction over the list keeps each bucket in list order (deterministic, no atomics).  An owner with more than pp_cap
+// hits sets PXR_STATUS_SHARD_OVERFLOW (its surplus is dropped -- the host raises at the next status check).
+__global__ void __launch_bounds__(1024) shard_bucket_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ n_dev,
+                                                            int W, int64_t n_table, int pp_cap, int64_t pad,
+                                                            int64_t* __restrict__ req, int32_t* __restrict__ pos,
+                                                            int32_t* __restrict__ counts, int* status) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = *n_dev;
+  for (int o = wave; o < W; o += 16) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const int64_t id = i < n ? ids[i] : -1;
+      const bool mine = id > 0 && id < n_table && (int)(id % W) == o;
+      const unsigned long long m = __ballot(mine);
+      if (mine) {
+        const int j = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (j < pp_cap) { req[(int64_t)o * pp_cap + j] = id; pos[(int64_t)o * pp_cap + j] = i; }
+      }
+      cnt += __popcll(m);
+    }
+    for (int j = min(cnt, pp_cap) + lane; j < pp_cap; j += 64) { req[(int64_t)o * pp_cap + j] = pad; pos[(int64_t)o * pp_cap + j] = -1; }
+    if (lane == 0) {
+      counts[o] = cnt;
+      if (cnt > pp_cap && status) atomicOr(status, PXR_STATUS_SHARD_OVERFLOW);
+    }
+  }
+}
+// dst[row_offset + pos[i], :] = src[i, :] for pos[i] >= 0: one wave per source row
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ pos,
+                                                           int64_t n_src, int D, float* __restrict__ dst, int64_t dst_rows,
+                                                           int row_offset) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_src) return;
+  const int64_t r = pos[i];
+  if (r < 0 || r + row_offset >= dst_rows) return;
+  const float4* s4 = reinterpret_cast<const float4*>(src + i * D);
+  float4* d4 = reinterpret_cast<float4*>(dst + (r + row_offset) * D);
+  for (int c = lane; c < D / 4; c += 64) d4[c] = s4[c];
+}
 }  // namespace pxr
+
+extern "C" int pxr_shard_bucket_ids_i64(const int64_t* ids, const int32_t* n_dev, int W, int64_t n_table, int64_t pp_cap,
+                                        int64_t pad_id, int64_t* req, int32_t* pos, int32_t* counts, void* stream) {
+  PXR_REQUIRE(ids && n_dev && req && pos && counts, "pxr_shard_bucket_ids_i64: null pointer");
+  PXR_REQUIRE(W >= 1 && W <= 1024 && n_table > 0 && pp_cap > 0 && pp_cap < (1ll << 30) && pad_id >= n_table,
+              "pxr_shard_bucket_ids_i64: bad args");
+  hipLaunchKernelGGL(pxr::shard_bucket_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, n_dev, W, n_table, (int)pp_cap,
+                     pad_id, req, pos, counts, pxr_status_word());
+  return pxr_check_launch("pxr_shard_bucket_ids_i64");
+}
+
+extern "C" int pxr_scatter_rows_f32(const float* src, const int32_t* pos, int64_t n_src, int D, float* dst, int64_t dst_rows,
+                                    int row_offset, void* stream) {
+  PXR_REQUIRE(n_src >= 0 && D > 0 && D % 4 == 0 && dst_rows >= 0 && row_offset >= 0, "pxr_scatter_rows_f32: bad shape");
+  if (n_src == 0) return PXR_OK;
+  PXR_REQUIRE(src && pos && dst, "pxr_scatter_rows_f32: null pointer");
+  PXR_REQUIRE((n_src + 3) / 4 < (1ll << 31), "pxr_scatter_rows_f32: too many rows");
+  hipLaunchKernelGGL(pxr::scatter_rows_kernel, dim3((unsigned)((n_src + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, pos,
+                     n_src, D, dst, dst_rows, row_offset);
+  return pxr_check_launch("pxr_scatter_rows_f32");
+}
 
 extern "C" int pxr_shard_local_rows_i64(const int64_t* ids, int64_t n, int W, int rank, int64_t n_table,
                                         int64_t* local_rows, void* stream) {

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "pxr_embed_grad_rows_f32": (_I, [_P, _I64, _P, _I, _I64, _F, _P, _P, _P, _P, _I64, _P]),
     "pxr_sample_negatives_i64": (_I, [_P, _I, _I, _I64, _U64, _U64, _P, _P, _P]),
     "pxr_shard_local_rows_i64": (_I, [_P, _I64, _I, _I, _I64, _P, _P]),
+    "pxr_shard_bucket_ids_i64": (_I, [_P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "pxr_scatter_rows_f32": (_I, [_P, _P, _I64, _I, _P, _I64, _I, _P]),
     "pxr_ids_to_compact_i64": (_I, [_P, _I64, _P, _P, _P, _P]),
     "pxr_shard_first_rows_i64": (_I, [_P, _I, _I64, _I, _I64, _P, _P]),
     "pxr_merge_rows_ws_bytes": (_I64, [_I, _I64]),

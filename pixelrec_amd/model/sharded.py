@@ -9,11 +9,17 @@ an all-zero dummy ("index 0 = not mine / contributes zeros").  AdamW moments and
 rows only (PxrAdamW sizes itself from `item_embedding.weight`).  Per training step and rank:
 
   1. occurrence sort of the batch -> this rank's ascending unique ids U_r (padded to a fixed capacity);
-  2. all-gather of the W id lists; every rank brings the requested rows IT owns up to date (lazy AdamW catch-up) and
-     gathers them into a [W, cap, D] block that is zero wherever it is not the owner;
-  3. reduce-scatter(SUM) of those blocks: rank q receives the rows of U_q -- exactly one non-zero contribution per
-     slot, so the sum is exact;  the forward / backward kernels then run on that [cap + 1, D] block with the batch
-     re-indexed onto it (`pxr_ids_to_compact_i64`): same kernels, same arithmetic as the replicated model;
+  2. the hit rows are fetched from their owners by an ALL-TO-ALL pair (`row_exchange = "alltoall"`, default): U_r is split
+     by owner into W request lists of `pair_cap` slots (`pxr_shard_bucket_ids_i64`), all-to-all of the requests, every rank
+     brings the requested rows it owns up to date (lazy AdamW catch-up) and gathers them, all-to-all of the rows back,
+     `pxr_scatter_rows_f32` puts them at their place in the compact block.  Per rank and step ~ |U_r| rows cross the fabric
+     (pair_cap = |U_r| / W x slack per pair), against W x cap rows for
+  3. the older `row_exchange = "reduce_scatter"`: all-gather of the W full id lists, every rank serves a [W, cap, D] block that
+     is zero wherever it is not the owner, reduce-scatter(SUM) -- exactly one non-zero contribution per slot, so the sum is
+     exact.  Kept as the fallback without a capacity bound (a batch whose hits pile up on one owner beyond pair_cap sets a
+     status bit that raises at the next check; nothing is dropped silently).
+     Either way the forward / backward kernels then run on the [cap + 1, D] block with the batch re-indexed onto it
+     (`pxr_ids_to_compact_i64`): same kernels, same arithmetic as the replicated model;
   4. the sparse gradient (global ids, rows) is exchanged and merged exactly as in the replicated mode
      (pixelrec_amd.parallel.GradSync); each rank then keeps only the rows it owns (`pxr_shard_local_rows_i64`) and its
      AdamW touches its shard only.
@@ -39,6 +45,11 @@ class ShardedSASRec(SASRec):
         self._full_cache = None
         self._group = None
         self._force_collectives = False     # tests: run the collectives even in a world of one (1-rank RCCL group)
+        cfg = lambda key, default: config[key] if (key in config and config[key] is not None) else default
+        self.row_exchange = str(cfg("shard_row_exchange", "alltoall"))       # YAML keys of this build (no reference analogue)
+        self.pair_slack = float(cfg("shard_pair_slack", 1.5))
+        if self.row_exchange not in ("alltoall", "reduce_scatter"):
+            raise ValueError(f"shard_row_exchange must be 'alltoall' or 'reduce_scatter', got {self.row_exchange!r}")
 
     # ------------------------------------------------------------------------------------------ (re)sharding
     def shard(self, rank: int | None = None, world: int | None = None, group=None):
@@ -128,11 +139,61 @@ class ShardedSASRec(SASRec):
         if self._occ_ws is None or self._occ_ws.numel() < need or self._occ_ws.device != items.device:
             self._occ_ws = torch.empty(need, dtype=torch.uint8, device=items.device)
         ops.sasrec_occ_sort(items, self.item_num, sp, self._occ_ws)                       # 1. U_r
-        ar = torch.arange(cap, device=items.device, dtype=torch.int32)
+        if self.row_exchange == "alltoall":
+            block = self._fetch_rows_alltoall(sp, cap, D)
+        else:
+            block = self._fetch_rows_reduce_scatter(sp, cap, D)
+        items_c = ops.ids_to_compact(items, sp.idx, sp.n)
+        self._block = block
+        return self._forward_core(block, items_c, masked_index, True)
+
+    def pair_cap(self, cap: int) -> int:
+        """Slots of one (requester, owner) pair: the expected cap / W hits of a pair x pair_slack + 64, never more than cap."""
+        W = self._shard_world
+        if W == 1:
+            return cap
+        return min(cap, (int(cap / W * self.pair_slack) + 64 + 63) // 64 * 64)
+
+    def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
+        """send[o] goes to rank o; returns recv with recv[q] = what rank q sent here.  send: [W, ...] contiguous."""
+        W, rank = self._shard_world, self._shard_rank
+        if not (W > 1 or self._force_collectives):
+            return send
+        if dist.get_backend(self._group) == "nccl":
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self._group)
+            return recv
+        parts = [torch.empty_like(send) for _ in range(W)]      # gloo (tests): all-gather everything, keep what is addressed here
+        dist.all_gather(parts, send, group=self._group)
+        return torch.stack([p[rank] for p in parts])
+
+    def _fetch_rows_alltoall(self, sp, cap, D):
+        """Step 2 of the module docstring: [cap + 1, D] block with row 1 + j = the table row of U_r[j]."""
+        W, rank, dev = self._shard_world, self._shard_rank, sp.idx.device
+        pp = self.pair_cap(cap)
+        req, pos, _ = ops.shard_bucket_ids(sp.idx, sp.n, W, self.item_num, pp, PAD_ID)
+        got = self._all_to_all(req)                                                       # [W, pp]: what each rank wants from me
+        flat = got.view(-1)
+        loc = ops.shard_local_rows(flat, W, rank, self.item_num)
+        if self._table_hooks is not None:                                                 # owned rows up to date
+            # an id requested by several ranks must be replayed by ONE wave: work list = first request only
+            first = ops.shard_first_rows(flat, W, rank, self.item_num) if W > 1 else loc
+            n_all = torch.full((1,), W * pp, dtype=torch.int32, device=dev)
+            self._table_hooks.catch_up_rows(first, n_all, W * pp)
+        serve = ops.embed_gather(self.item_embedding.weight.data, loc).view(W, pp, D)     # zero rows where padded
+        recv = self._all_to_all(serve)                                                    # [W, pp, D]: my rows, by owner
+        block = torch.zeros(cap + 1, D, dtype=torch.float32, device=dev)
+        ops.scatter_rows(recv.view(W * pp, D), pos.view(-1), block, row_offset=1)
+        return block
+
+    def _fetch_rows_reduce_scatter(self, sp, cap, D):
+        """Step 3 of the module docstring (no capacity bound; W x the traffic)."""
+        W, rank, dev = self._shard_world, self._shard_rank, sp.idx.device
+        ar = torch.arange(cap, device=dev, dtype=torch.int32)
         ids_mine = torch.where(ar < sp.n, sp.idx, PAD_ID)
         comm = W > 1 or self._force_collectives
         if comm:                                                                          # 2. who needs what
-            ids_all = torch.empty(W * cap, dtype=torch.int64, device=items.device)
+            ids_all = torch.empty(W * cap, dtype=torch.int64, device=dev)
             if dist.get_backend(self._group) == "nccl":
                 dist.all_gather_into_tensor(ids_all, ids_mine, group=self._group)
             else:   # gloo (tests)
@@ -143,23 +204,21 @@ class ShardedSASRec(SASRec):
         if self._table_hooks is not None:                                                 #    owned rows up to date
             # an id requested by several ranks must be replayed by ONE wave: work list = first request only
             first = ops.shard_first_rows(ids_all, W, rank, self.item_num) if W > 1 else loc
-            n_all = torch.full((1,), W * cap, dtype=torch.int32, device=items.device)
+            n_all = torch.full((1,), W * cap, dtype=torch.int32, device=dev)
             self._table_hooks.catch_up_rows(first, n_all, W * cap)
         serve = ops.embed_gather(self.item_embedding.weight.data, loc)                    #    zeros where not the owner
         if comm:                                                                          # 3. rows of U_r arrive
             if dist.get_backend(self._group) == "nccl":
-                mine = torch.empty(cap, D, dtype=torch.float32, device=items.device)
+                mine = torch.empty(cap, D, dtype=torch.float32, device=dev)
                 dist.reduce_scatter_tensor(mine, serve, op=dist.ReduceOp.SUM, group=self._group)
             else:   # gloo (tests): no reduce-scatter -> all-reduce and keep this rank's slice
                 dist.all_reduce(serve, op=dist.ReduceOp.SUM, group=self._group)
                 mine = serve.view(W, cap, D)[rank]
         else:
             mine = serve
-        block = torch.zeros(cap + 1, D, dtype=torch.float32, device=items.device)
+        block = torch.zeros(cap + 1, D, dtype=torch.float32, device=dev)
         block[1:] = mine
-        items_c = ops.ids_to_compact(items, sp.idx, sp.n)
-        self._block = block
-        return self._forward_core(block, items_c, masked_index, True)
+        return block
 
     def _backward_train(self, grad_out):
         if not self._sharded:

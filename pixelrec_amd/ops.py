@@ -107,6 +107,9 @@ def raise_on_bad_indices(device=None):
     if v & 4:
         raise RuntimeError("fused scoring + top-k: the per-user candidate buffer of the threshold pass overflowed "
                            "(results may miss items); set PXR_TOPK_VARIANT=2")
+    if v & 16:
+        raise RuntimeError("row-sharded table: one rank owned more of a batch's hit rows than the per-pair request capacity "
+                           "(ShardedSASRec.pair_slack); rows were dropped -- raise the slack or use row_exchange='reduce_scatter'")
     if v & 2:
         raise RuntimeError("data-parallel row exchange: a rank's batch touched more unique table rows than the configured "
                            "exchange capacity (GradSync(exchange_rows=...)); gradient rows were dropped -- raise the bound")
@@ -857,6 +860,29 @@ def shard_local_rows(ids: torch.Tensor, world: int, rank: int, n_table: int) -> 
     _l.check(Lb.pxr_shard_local_rows_i64(_l.ptr(ids), ids.numel(), world, rank, n_table, _l.ptr(out), _l.stream_ptr()),
              "pxr_shard_local_rows_i64")
     return out
+
+
+def shard_bucket_ids(ids: torch.Tensor, n_dev: torch.Tensor, world: int, n_table: int, pp_cap: int, pad_id: int):
+    """Ascending unique ids (count on the device) -> per-owner request lists: (req int64 [world, pp_cap], pos int32
+    [world, pp_cap], counts int32 [world]) -- pxr_shard_bucket_ids_i64."""
+    _req(ids, torch.int64, "ids"); _req(n_dev, torch.int32, "n_dev")
+    device_status(ids.device)
+    req = torch.empty(world, pp_cap, dtype=torch.int64, device=ids.device)
+    pos = torch.empty(world, pp_cap, dtype=torch.int32, device=ids.device)
+    counts = torch.empty(world, dtype=torch.int32, device=ids.device)
+    _l.check(_l.load().pxr_shard_bucket_ids_i64(_l.ptr(ids), _l.ptr(n_dev), world, n_table, pp_cap, pad_id, _l.ptr(req),
+                                                _l.ptr(pos), _l.ptr(counts), _l.stream_ptr()), "pxr_shard_bucket_ids_i64")
+    return req, pos, counts
+
+
+def scatter_rows(src: torch.Tensor, pos: torch.Tensor, dst: torch.Tensor, row_offset: int = 0):
+    """dst[row_offset + pos[i], :] = src[i, :] where pos[i] >= 0 (pxr_scatter_rows_f32)."""
+    _req(src, torch.float32, "src"); _req(pos, torch.int32, "pos"); _req(dst, torch.float32, "dst")
+    D = src.shape[-1]
+    assert dst.shape[-1] == D and pos.numel() == src.numel() // D
+    _l.check(_l.load().pxr_scatter_rows_f32(_l.ptr(src), _l.ptr(pos), pos.numel(), D, _l.ptr(dst), dst.numel() // D, row_offset,
+                                            _l.stream_ptr()), "pxr_scatter_rows_f32")
+    return dst
 
 
 def shard_first_rows(ids_all: torch.Tensor, world: int, rank: int, n_table: int) -> torch.Tensor:

@@ -133,3 +133,52 @@ def install(monkeypatch):
     monkeypatch.setenv("PXR_PLANES", "0")
     monkeypatch.setenv("PXR_TOWER_ATTN", "0")
     monkeypatch.setattr(vit_native.NativeTower, "_require_hip", staticmethod(lambda dev: None))
+
+
+# ---- row-sharded table helpers (csrc/embed_grad.hip: shard_* / scatter_rows kernels), restated in torch for the CPU test of
+# the exchange choreography (tests/test_sharded_exchange_gloo.py).  Same contracts as the pixelrec_amd.ops wrappers.
+def shard_bucket_ids(ids, n_dev, world, n_table, pp_cap, pad_id):
+    n = int(n_dev[0])
+    req = torch.full((world, pp_cap), pad_id, dtype=torch.int64)
+    pos = torch.full((world, pp_cap), -1, dtype=torch.int32)
+    counts = torch.zeros(world, dtype=torch.int32)
+    for i in range(n):
+        v = int(ids[i])
+        if 0 < v < n_table:
+            o = v % world
+            j = int(counts[o])
+            if j < pp_cap:
+                req[o, j] = v
+                pos[o, j] = i
+            counts[o] += 1
+    return req, pos, counts
+
+
+def shard_local_rows(ids, world, rank, n_table):
+    ok = (ids > 0) & (ids < n_table) & (ids % world == rank)
+    return torch.where(ok, ids // world + 1, torch.zeros_like(ids))
+
+
+def shard_first_rows(ids_all, world, rank, n_table):
+    cap = ids_all.numel() // world
+    out = shard_local_rows(ids_all, world, rank, n_table).clone()
+    seen = set()
+    for q in range(world):
+        for j in range(cap):
+            t = q * cap + j
+            if int(out[t]):
+                v = int(ids_all[t])
+                if v in seen:
+                    out[t] = 0
+                seen.add(v)
+    return out
+
+
+def embed_gather(table, idx):
+    return table[idx]
+
+
+def scatter_rows(src, pos, dst, row_offset=0):
+    keep = pos >= 0
+    dst[pos[keep].long() + row_offset] = src[keep]
+    return dst

@@ -58,8 +58,9 @@ def _train(dp, model, batches, lr=1e-3, table_update="lazy"):
     return losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
 
+@pytest.mark.parametrize("exchange", ["alltoall", "reduce_scatter"])
 @pytest.mark.parametrize("table_update", ["lazy", "dense"])
-def test_single_rank_sharded_equals_plain(table_update):
+def test_single_rank_sharded_equals_plain(table_update, exchange):
     from pixelrec_amd.model import SASRec, ShardedDataParallel, ShardedSASRec
     from pixelrec_amd.parallel import DataParallel
 
@@ -69,7 +70,8 @@ def test_single_rank_sharded_equals_plain(table_update):
     plain = SASRec(CFG, DL()).cuda().train()
     l0, sd0 = _train(DataParallel(plain), plain, batches, table_update=table_update)
     torch.manual_seed(4)
-    sh = ShardedSASRec(CFG, DL()).cuda().train()
+    sh = ShardedSASRec({**CFG, "shard_row_exchange": exchange}, DL()).cuda().train()
+    assert sh.row_exchange == exchange
     dp = ShardedDataParallel(sh)
     assert sh.item_embedding.weight.shape == (N + 1, D)            # world of one: every row + the dummy row 0
     l1, sd1 = _train(dp, sh, batches, table_update=table_update)
@@ -142,8 +144,9 @@ def _worker(rank, port, mode, results, shape=SMALL):
             losses.append(one(dp2, m2, opt2, batches[-1]))
             results[(mode, rank)] = (losses, {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
             return
-        if mode == "sharded":
-            m = ShardedSASRec(CFG, DL()).cuda().train()
+        if mode in ("sharded", "sharded_rs"):
+            # "sharded": hit rows by the all-to-all pair (default); "sharded_rs": by all-gather + reduce-scatter
+            m = ShardedSASRec({**CFG, "shard_row_exchange": "reduce_scatter" if mode == "sharded_rs" else "alltoall"}, DL()).cuda().train()
             dp = ShardedDataParallel(m)
             assert m.item_embedding.weight.shape == ((N - rank + 1) // 2 + 1, D)
         else:
@@ -155,10 +158,14 @@ def _worker(rank, port, mode, results, shape=SMALL):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape,modes", [(SMALL, ("replicated", "sharded", "sharded_resume")),
+@pytest.mark.parametrize("shape,modes", [(SMALL, ("replicated", "sharded", "sharded_rs", "sharded_resume")),
                                          (WIDE, ("replicated", "sharded"))], ids=["emb64", "emb4096"])
-def test_two_rank_sharded_equals_replicated(shape, modes):
+def test_two_rank_sharded_equals_replicated(shape, modes, monkeypatch):
     """emb4096 = BASELINE configs[3]: D = 4096 WITH table_sharding: row, two ranks, == the replicated run bit for bit."""
+    # exact replay: the checkpoint in the middle of "sharded_resume" flushes every row, i.e. splits replays that the
+    # uninterrupted runs do in one go -- bit-identical only with the dense sweep's own arithmetic (the default fast replay
+    # differs by ~1e-9 there; tests/test_gpu_lazy_adamw.py)
+    monkeypatch.setenv("PXR_LAZY_REPLAY", "exact")
     _use(shape)
     out = {}
     with mp.Manager() as mgr:
@@ -172,6 +179,11 @@ def test_two_rank_sharded_equals_replicated(shape, modes):
         assert l_rep == l_sh
         for k in sd_rep:
             assert _same(sd_rep[k], sd_sh[k]), (rank, k)
+        if "sharded_rs" in modes:                                       # the older exchange: same bits
+            l_rs, sd_rs = out[("sharded_rs", rank)]
+            assert l_rs == l_rep
+            for k in sd_rep:
+                assert _same(sd_rep[k], sd_rs[k]), (rank, k, "reduce_scatter")
         if "sharded_resume" not in modes:
             continue
         l_res, sd_res = out[("sharded_resume", rank)]                  # checkpoint round trip in the middle: same bits
@@ -180,3 +192,33 @@ def test_two_rank_sharded_equals_replicated(shape, modes):
             assert torch.equal(sd_rep[k], sd_res[k]), (rank, k)
     for k in out[("sharded", 0)][1]:                               # and both ranks agree on the gathered state
         assert _same(out[("sharded", 0)][1][k], out[("sharded", 1)][1][k]), k
+
+
+def test_bucket_and_scatter_kernels_against_their_restatement():
+    """pxr_shard_bucket_ids_i64 / pxr_scatter_rows_f32 == tests/emu_ops.py (the torch restatement the CPU gloo test runs on),
+    including an owner that overflows its pair capacity (status bit 16 -> RuntimeError at the next check)."""
+    from pixelrec_amd import ops
+    from pixelrec_amd.parallel import PAD_ID
+    from tests import emu_ops
+
+    n_table, W = 5000, 5
+    g = torch.Generator().manual_seed(3)
+    ids = torch.unique(torch.randint(1, n_table, (700,), generator=g))
+    n = ids.numel()
+    idx = torch.full((1024,), 777, dtype=torch.int64)
+    idx[:n] = ids
+    nd = torch.tensor([n], dtype=torch.int32)
+    for pp in (256, 100):                                   # 100 < n / W ~ 130: every owner overflows
+        req, pos, cnt = ops.shard_bucket_ids(idx.cuda(), nd.cuda(), W, n_table, pp, PAD_ID)
+        r0, p0, c0 = emu_ops.shard_bucket_ids(idx, nd, W, n_table, pp, PAD_ID)
+        assert torch.equal(req.cpu(), r0) and torch.equal(pos.cpu(), p0) and torch.equal(cnt.cpu(), c0)
+        if pp == 256:
+            ops.raise_on_bad_indices()
+        else:
+            with pytest.raises(RuntimeError, match="row-sharded"):
+                ops.raise_on_bad_indices()
+    src = torch.randn(W * 256, 64, generator=g)
+    dst = torch.zeros(1025, 64)
+    want = emu_ops.scatter_rows(src, p0_full := emu_ops.shard_bucket_ids(idx, nd, W, n_table, 256, PAD_ID)[1].view(-1), dst.clone(), 1)
+    got = ops.scatter_rows(src.cuda(), p0_full.cuda(), dst.cuda(), 1)
+    assert torch.equal(got.cpu(), want)

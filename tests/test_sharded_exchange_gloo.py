@@ -1,0 +1,81 @@
+"""Row-sharded table, hit-row exchange (pixelrec_amd/model/sharded.py): the collective choreography of BOTH exchanges on two
+CPU ranks over gloo, with the HIP helper kernels replaced by their torch restatements (tests/emu_ops.py).  What is checked is
+the plumbing a GPU-less box can check: request lists by owner, the all-to-all pair, the ownership arithmetic, the scatter
+back into the compact block -- the block every rank ends up with must be full_table[U_r] exactly, for both exchanges.  The
+kernels themselves and the end-to-end bit-equality with the replicated model are GPU tests (tests/test_gpu_sharded.py)."""
+import os
+import socket
+import types
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+N, D, CAP = 501, 8, 96
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, port, world, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pixelrec_amd import ops
+        from pixelrec_amd.model.sharded import ShardedSASRec
+        from tests import emu_ops
+
+        for name in ("shard_bucket_ids", "shard_local_rows", "shard_first_rows", "embed_gather", "scatter_rows"):
+            setattr(ops, name, getattr(emu_ops, name))
+        g = torch.Generator().manual_seed(7)
+        full = torch.randn(N, D, generator=g)
+        full[0] = 0
+        m = ShardedSASRec.__new__(ShardedSASRec)          # only the exchange methods are exercised: no parameters needed
+        m._shard_rank, m._shard_world, m._sharded, m._group, m._force_collectives = rank, world, True, None, False
+        m.item_num, m._table_hooks, m.pair_slack = N, None, 1.5
+        local = ShardedSASRec.scatter_rows(m, full)
+        m.item_embedding = types.SimpleNamespace(weight=types.SimpleNamespace(data=local))
+        out = {}
+        for trial, n_ids in enumerate((60, 1, 0, CAP)):
+            gi = torch.Generator().manual_seed(100 * trial + rank)
+            ids = torch.unique(torch.randint(1, N, (n_ids,), generator=gi)) if n_ids else torch.zeros(0, dtype=torch.int64)
+            n = ids.numel()
+            idx = torch.full((CAP,), 12345678, dtype=torch.int64)      # stale tail beyond the count, as the sort leaves it
+            idx[:n] = ids
+            sp = types.SimpleNamespace(idx=idx, n=torch.tensor([n], dtype=torch.int32))
+            a = m._fetch_rows_alltoall(sp, CAP, D)
+            b = m._fetch_rows_reduce_scatter(sp, CAP, D)
+            want = torch.zeros(CAP + 1, D)
+            want[1:1 + n] = full[ids]
+            out[trial] = (bool(torch.equal(a, want)), bool(torch.equal(b, want)), m.pair_cap(CAP))
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_both_hit_row_exchanges_deliver_the_requested_rows_on_two_ranks():
+    world = 2
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_worker, args=(_free_port(), world, results), nprocs=world, join=True)
+        res = dict(results)
+    assert set(res) == {0, 1}
+    for rank, out in res.items():
+        for trial, (ok_a2a, ok_rs, pp) in out.items():
+            assert ok_a2a, (rank, trial, "all-to-all")
+            assert ok_rs, (rank, trial, "reduce-scatter")
+            assert pp == CAP                                  # tiny capacities never cut the pair lists below the worst case
+
+
+def test_pair_capacity_shrinks_with_the_world():
+    from pixelrec_amd.model.sharded import ShardedSASRec
+    m = ShardedSASRec.__new__(ShardedSASRec)
+    m.pair_slack = 1.5
+    cap = 64 * (2 * 50 + 1)
+    for W, want in ((1, cap), (2, 4928), (8, 1280)):
+        m._shard_world = W
+        assert m.pair_cap(cap) == want
+    # 8 ranks: 8 x 1280 = 10 240 request slots and rows per rank against 8 x 6 464 = 51 712 for the reduce-scatter exchange
