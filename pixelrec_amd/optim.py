@@ -36,9 +36,19 @@ def reference_rec_parameter_names(model):
     SASRec   (sasrec.py:31-45):   item_embedding, position_embedding, trm_encoder layers, LayerNorm;
     MOSASRec (mosasrec.py:30-47): [visual_encoder first], position_embedding, LayerNorm, trm_encoder layers."""
     layers = [n for i in range(model.n_layers) for n in _layer_names(i)]
-    if hasattr(model, "item_embedding"):
+    if has_item_table(model):
         return ["item_embedding.weight", "position_embedding.weight"] + layers + ["LayerNorm.weight", "LayerNorm.bias"]
+    if hasattr(model, "encoder_parameter_names"):
+        # FSASRec (fsasrec.py:34-49): the item encoder's parameters, position_embedding, trm_encoder layers, LayerNorm
+        return (list(model.encoder_parameter_names()) + ["position_embedding.weight"] + layers
+                + ["LayerNorm.weight", "LayerNorm.bias"])
     return ["position_embedding.weight", "LayerNorm.weight", "LayerNorm.bias"] + layers
+
+
+def has_item_table(model) -> bool:
+    """True for the ID model: `item_embedding` is the nn.Embedding that is updated sparsely / lazily and exchanged as rows.
+    (FSASRec also has an `item_embedding`, but it is an encoder module whose parameters live in the flat buffer.)"""
+    return isinstance(getattr(model, "item_embedding", None), torch.nn.Embedding)
 
 
 def is_torch_adamw_state(sd) -> bool:
@@ -62,7 +72,7 @@ def native_to_torch_state(sd, model, first_index=0):
             if name == "item_embedding.weight":
                 m, v = sd["table_m"], sd["table_v"]
             else:
-                off, n, shape = model._views[_short_name(name)]
+                off, n, shape = model._views[_short_name(name, model)]
                 m, v = sd["m"][off:off + n].view(shape), sd["v"][off:off + n].view(shape)
             state[first_index + j] = {"step": torch.tensor(float(step)), "exp_avg": m.detach().clone(),
                                       "exp_avg_sq": v.detach().clone()}
@@ -90,7 +100,7 @@ def torch_to_native_state(sd, model, group_index=-1):
         if name == "item_embedding.weight":
             out["table_m"], out["table_v"] = st["exp_avg"], st["exp_avg_sq"]
             continue
-        off, n, shape = model._views[_short_name(name)]
+        off, n, shape = model._views[_short_name(name, model)]
         if tuple(st["exp_avg"].shape) != tuple(shape):
             raise ValueError(f"optimizer state of {name}: shape {tuple(st['exp_avg'].shape)} != {tuple(shape)}")
         m[off:off + n].copy_(st["exp_avg"].reshape(-1))
@@ -99,14 +109,17 @@ def torch_to_native_state(sd, model, group_index=-1):
         raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state this optimizer can resume")
     out["step"] = steps.pop() if steps else 0
     out["m"], out["v"] = m, v
-    if hasattr(model, "item_embedding") and "table_m" not in out:
+    if has_item_table(model) and "table_m" not in out:
         t = model.item_embedding.weight
         out["table_m"], out["table_v"] = torch.zeros_like(t), torch.zeros_like(t)
     return out
 
 
-def _short_name(name):
+def _short_name(name, model=None):
     """reference parameter name -> key of SeqRecCore._views (the flat-buffer layout)."""
+    extra = model.encoder_parameter_names() if (model is not None and hasattr(model, "encoder_parameter_names")) else {}
+    if name in extra:
+        return extra[name]
     if name == "position_embedding.weight":
         return "pos"
     if name.startswith("LayerNorm."):
@@ -136,7 +149,7 @@ class PxrAdamW:
         self._dirty = False          # lazy mode: some rows lag behind step_count (set by step, cleared by flush)
         self._seeded_cfg = None      # hyper-parameters the table entry of step_count+1 was written with (None: not yet)
         self.param_groups = [{"lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}]
-        self.has_table = hasattr(model, "item_embedding")
+        self.has_table = has_item_table(model)
         if table_update == "lazy" and self.has_table:
             model.register_table_hooks(self)
 
@@ -312,7 +325,7 @@ def clip_grad_norm_(model, max_norm, norm_type=2.0, **_ignored):
         model.wait_flat_grads()
     _, gflat = model.flat_parameters()
     sq = gflat.pow(2).sum()
-    sp = getattr(model, "sparse_table_grad", None) if hasattr(model, "item_embedding") else None
+    sp = getattr(model, "sparse_table_grad", None) if has_item_table(model) else None
     live = None
     if sp is not None:
         ar = torch.arange(sp.rows.shape[0], device=sp.rows.device, dtype=torch.int32)

@@ -19,6 +19,8 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from .optim import has_item_table
+
 
 def world_info():
     if dist.is_available() and dist.is_initialized():
@@ -165,7 +167,7 @@ class GradSync:
             return
         flat, _ = self.model.flat_parameters()
         dist.broadcast(flat, src=src, group=self.group)
-        if hasattr(self.model, "item_embedding"):
+        if has_item_table(self.model):
             dist.broadcast(self.model.item_embedding.weight.data, src=src, group=self.group)
         for p in self._extra_params():
             dist.broadcast(p.data, src=src, group=self.group)
@@ -200,7 +202,7 @@ class GradSync:
             for p in self._extra_params():      # (an encoder that has not run yet has no packed gradients)
                 if p.grad is not None:
                     waits.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        if hasattr(self.model, "item_embedding"):
+        if has_item_table(self.model):
             if self._pending is None:
                 self.start_sparse_exchange()
             pending, self._pending = self._pending, None

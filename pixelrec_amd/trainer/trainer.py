@@ -370,7 +370,9 @@ class Trainer:
         """Fused path: encoder -> pxr_score_topk_f32 (scores never reach HBM)."""
         user, history_index, positive_u, positive_i = batched_data
         m = self.model.module
-        out, last = (m.encode_last(user.to(self.device), self.item_feature) if self.use_modality
+        from ..optim import has_item_table
+        # models whose item vectors come from an encoder (MOSASRec, FSASRec) read the sequence's rows from item_feature
+        out, last = (m.encode_last(user.to(self.device), self.item_feature) if (self.use_modality or not has_item_table(m))
                      else m.encode_last(user.to(self.device)))
         B, L, D = out.shape
         ptr = items = None
