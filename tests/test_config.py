@@ -29,9 +29,18 @@ def test_reference_parameter_order_maps_onto_the_flat_layout():
     from oracle import sasrec_oracle as O
     from pixelrec_amd.optim import _short_name, reference_rec_parameter_names
 
+    import torch
+
     class IdModel:
         n_layers = 2
-        item_embedding = object()
+        item_embedding = torch.nn.Embedding(3, 4)         # the ID model's table (optim.has_item_table)
+
+    class FeatModel:                                      # FSASRec: `item_embedding` is an encoder module
+        n_layers = 2
+        item_embedding = torch.nn.Sequential()
+
+        def encoder_parameter_names(self):
+            return {"item_embedding.rec_fc.0.weight": "enc.0.w", "item_embedding.rec_fc.0.bias": "enc.0.b"}
 
     class PixelModel:
         n_layers = 2
@@ -40,6 +49,10 @@ def test_reference_parameter_order_maps_onto_the_flat_layout():
     assert names == list(O.synth_params(20, 8, 4, 2, 2, seed=0).keys())      # the oracle mirrors the reference module tree
     pix = reference_rec_parameter_names(PixelModel())
     assert pix[:3] == ["position_embedding.weight", "LayerNorm.weight", "LayerNorm.bias"] and len(pix) == len(names) - 1
+    feat = reference_rec_parameter_names(FeatModel())     # fsasrec.py:34-49: encoder, position table, layers, LayerNorm
+    assert feat[:3] == ["item_embedding.rec_fc.0.weight", "item_embedding.rec_fc.0.bias", "position_embedding.weight"]
+    assert feat[-2:] == ["LayerNorm.weight", "LayerNorm.bias"] and len(feat) == len(names) + 1
+    assert [_short_name(n, FeatModel()) for n in feat[:3]] == ["enc.0.w", "enc.0.b", "pos"]
     short = [_short_name(n) for n in names[1:]]
     assert short[0] == "pos" and short[-2:] == ["ln0.w", "ln0.b"]
     assert short[1:5] == ["0.q.w", "0.q.b", "0.k.w", "0.k.b"] and "1.f2.b" in short and "1.ln2.w" in short
