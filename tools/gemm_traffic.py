@@ -9,7 +9,8 @@ def main():
     d = json.load(open(src))
     n, b, per = 0, 0.0, {}
     for k, v in d.items():
-        if ("gemm_kernel" in k or "gemm_sk_kernel" in k or "grouped_dw" in k or "gemm_b3_kernel" in k) and "hbm_bytes_per_launch" in v:
+        if ("gemm_kernel" in k or "gemm_sk_kernel" in k or "grouped_dw" in k or "gemm_b3_kernel" in k
+                or "gemm_p3_kernel" in k) and "hbm_bytes_per_launch" in v:
             n += v["launches"]
             b += v["launches"] * v["hbm_bytes_per_launch"]
             per[k] = {"launches": v["launches"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
