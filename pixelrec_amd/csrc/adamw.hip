@@ -170,6 +170,7 @@ struct RowsArgs {
   // fast replay (default; PXR_LAZY_REPLAY=exact selects the bit-identical one): sqrt(v) and 1/denominator are carried from
   // step to step (see adamw_rows_kernel) -- 8 VALU issue slots per element-step instead of 14
   int fast; float sqrt_b2, log2_b2;
+  int window;                // replayed steps per row before the closed form takes over (PXR_LAZY_EXACT; PXR_LAZY_WINDOW: a measuring knob)
 };
 
 // One row is spread over LPR = ceil(D/EPL / 64) * 64 lanes (EPL = 2 or 4 elements per lane), so a row with a long gap is
@@ -208,6 +209,15 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
       row = a.rows ? a.rows[i] : i;
       if (a.rows && row <= 0) work = false;   // id 0 = empty slot of a merged (non-compacted) row list
     }
+    // p / m / v are requested together with last[row] (both need only the row id): one memory round trip less on the
+    // dependent chain  row id -> last -> values  that every group walks before it can compute (rows that turn out to be
+    // current -- few -- have read 6 KB for nothing)
+    const bool in_table = work && (!a.claim || row < a.n_table);
+    const int64_t o = row * a.D + c;
+    V p4 = {}, m4 = {}, v4 = {};
+    if (in_table && col_ok) {
+      p4 = *reinterpret_cast<const V*>(a.p + o); m4 = *reinterpret_cast<const V*>(a.m + o); v4 = *reinterpret_cast<const V*>(a.v + o);
+    }
     if (a.claim) {
       if (work && row >= a.n_table) work = false;
       if ((threadIdx.x % LPR) == 0) s_claim[rib] = work ? atomicMax(a.last + row, a.t_prev) : a.t_prev;
@@ -226,17 +236,14 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
       float pe[EPL], me[EPL], ve[EPL];
 #pragma unroll
       for (int e = 0; e < EPL; ++e) pe[e] = me[e] = ve[e] = 0.f;
-      const int64_t o = row * a.D + c;
       if (col_ok) {
-        const V p4 = *reinterpret_cast<const V*>(a.p + o), m4 = *reinterpret_cast<const V*>(a.m + o),
-                v4 = *reinterpret_cast<const V*>(a.v + o);
         pe[0] = p4.x; pe[1] = p4.y; me[0] = m4.x; me[1] = m4.y; ve[0] = v4.x; ve[1] = v4.y;
         if constexpr (EPL == 4) { pe[2] = p4.z; pe[3] = p4.w; me[2] = m4.z; me[3] = m4.w; ve[2] = v4.z; ve[3] = v4.w; }
       }
       AdamHyper h;
       h.one_m_b1 = a.one_m_b1; h.b2 = a.b2; h.one_m_b2 = a.one_m_b2; h.eps = a.eps;
       int s = k0 + 1;
-      const int exact_end = min(a.t_prev, k0 + PXR_LAZY_EXACT);
+      const int exact_end = min(a.t_prev, k0 + a.window);
       auto replay = [&](const float4 hs) {
         h.decay = hs.x; h.step_size = hs.y; h.inv_sqrt_bc2 = hs.z;
 #pragma unroll
@@ -249,27 +256,38 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
         // step 64, 0.03 % at step 1000).  Differences to the dense sweep: < 1e-6 relative on update terms of at most a few lr
         // each, i.e. ~1e-9 absolute on p over a 256-step gap (measured: tests/test_gpu_lazy_adamw.py, fast_replay tests);
         // m exact to rounding, v = v_0 b2^gap in one rounding.
-        float se[EPL], re[EPL];
+        // Two elements per instruction: the recurrence is written on float2 values so that it compiles to the packed fp32
+        // instructions of the CDNA VALU (v_pk_mul_f32 / v_pk_fma_f32) -- this loop is VALU-issue bound (4464 rows x 80
+        // replayed steps x 512 elements per training step), so that halves its time.
+        constexpr int NP = EPL / 2;
+        p3_f32x2 pv[NP], mv[NP], sv[NP], rv[NP];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) { se[e] = __builtin_amdgcn_sqrtf(ve[e]); re[e] = 0.f; }
+        for (int q = 0; q < NP; ++q) {
+          pv[q] = p3_f32x2{pe[2 * q], pe[2 * q + 1]};
+          mv[q] = p3_f32x2{me[2 * q], me[2 * q + 1]};
+          sv[q] = p3_f32x2{__builtin_amdgcn_sqrtf(ve[2 * q]), __builtin_amdgcn_sqrtf(ve[2 * q + 1])};
+          rv[q] = p3_f32x2{0.f, 0.f};
+        }
         const int s0 = s;
         const int rcp_until = max(s0, 64);
+        const p3_f32x2 b1v = {a.b1, a.b1}, sbv = {a.sqrt_b2, a.sqrt_b2}, epsv = {h.eps, h.eps}, two = {2.0f, 2.0f};
         // MODE 0: hardware reciprocal; 1: one Newton step; 2: two (optimizer steps < 1024, where the bias correction still
         // moves the denominator by up to 1 % per step: one step would leave 6e-5 relative there, two leave it at rounding)
         auto step_fast = [&](const float4 hs, const int mode) {
+          const p3_f32x2 dec = {hs.x, hs.x}, nss = {-hs.y, -hs.y}, isb = {hs.z, hs.z};
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            pe[e] = __fmul_rn(pe[e], hs.x);
-            me[e] = __fmul_rn(me[e], a.b1);
-            se[e] = __fmul_rn(se[e], a.sqrt_b2);
-            const float denom = fmaf(se[e], hs.z, h.eps);
+          for (int q = 0; q < NP; ++q) {
+            pv[q] = pv[q] * dec;
+            mv[q] = mv[q] * b1v;
+            sv[q] = sv[q] * sbv;
+            const p3_f32x2 denom = __builtin_elementwise_fma(sv[q], isb, epsv);
             if (mode == 0) {
-              re[e] = __builtin_amdgcn_rcpf(denom);
+              rv[q] = p3_f32x2{__builtin_amdgcn_rcpf(denom[0]), __builtin_amdgcn_rcpf(denom[1])};
             } else {
-              re[e] = __fmul_rn(re[e], fmaf(-denom, re[e], 2.0f));
-              if (mode == 2) re[e] = __fmul_rn(re[e], fmaf(-denom, re[e], 2.0f));
+              rv[q] = rv[q] * __builtin_elementwise_fma(-denom, rv[q], two);
+              if (mode == 2) rv[q] = rv[q] * __builtin_elementwise_fma(-denom, rv[q], two);
             }
-            pe[e] = fmaf(-hs.y, __fmul_rn(me[e], re[e]), pe[e]);
+            pv[q] = __builtin_elementwise_fma(nss, mv[q] * rv[q], pv[q]);
           }
         };
         for (; s <= exact_end && s <= rcp_until; ++s) step_fast(hyper[s], 0);
@@ -285,6 +303,11 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
         }
         for (; s <= exact_end; ++s) step_fast(hyper[s], 1);
         const float fv = __builtin_amdgcn_exp2f((float)(s - s0) * a.log2_b2);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          pe[2 * q] = pv[q][0]; pe[2 * q + 1] = pv[q][1];
+          me[2 * q] = mv[q][0]; me[2 * q + 1] = mv[q][1];
+        }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) ve[e] = __fmul_rn(ve[e], fv);
       }
@@ -559,9 +582,13 @@ static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blo
   a.fast = lazy_replay_fast() ? 1 : 0;
   a.sqrt_b2 = sqrtf(a.b2);
   a.log2_b2 = log2f(a.b2);
+  const char* w = getenv("PXR_LAZY_WINDOW");
+  a.window = w ? atoi(w) : PXR_LAZY_EXACT;
+  if (a.window < 0 || a.window > PXR_LAZY_EXACT) a.window = PXR_LAZY_EXACT;
   hipStream_t st = (hipStream_t)stream;
   // 2 elements per lane up to D = 2048 (a 512-wide row = 4 waves), 4 beyond (block size caps at 1024 threads)
-  const int epl = D <= 2048 ? 2 : 4;
+  int epl = D <= 2048 ? 2 : 4;
+  if (const char* e = getenv("PXR_ROWS_EPL")) { if (atoi(e) == 4 && D % 4 == 0) epl = 4; }    // measuring knob
   const int lpr = ((D / epl + 63) / 64) * 64;          // lanes per row
   const int tl = lpr <= 64 ? 64 : (lpr <= 128 ? 128 : (lpr <= 256 ? 256 : (lpr <= 512 ? 512 : 1024)));
   const int rpb = tl >= 256 ? 1 : 256 / tl;          // == the kernel's RPB
@@ -580,7 +607,13 @@ static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blo
       default: PXR_ROWS_CASE(1024, 2); break;
     }
   } else {
-    if (tl <= 512) PXR_ROWS_CASE(512, 4); else PXR_ROWS_CASE(1024, 4);
+    switch (tl) {
+      case 64: PXR_ROWS_CASE(64, 4); break;
+      case 128: PXR_ROWS_CASE(128, 4); break;
+      case 256: PXR_ROWS_CASE(256, 4); break;
+      case 512: PXR_ROWS_CASE(512, 4); break;
+      default: PXR_ROWS_CASE(1024, 4); break;
+    }
   }
 #undef PXR_ROWS_CASE
   return pxr_check_launch(who);

@@ -76,13 +76,25 @@ struct P3Args {
   float* aux;
   int64_t ldaux;
   int tiles_m, tiles_n, n_fastest, act, dbg;
+  int group_m;             // > 1: tiles are walked in groups of group_m row tiles x all column tiles (see gemm_p3_kernel)
 };
 
 template <class Cfg, bool B_KC, int EPI, bool EARLY>
 __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-  const int tm = g.n_fastest ? t / g.tiles_n : t % g.tiles_m, tn = g.n_fastest ? t % g.tiles_n : t / g.tiles_m;
+  int tm = g.n_fastest ? t / g.tiles_n : t % g.tiles_m, tn = g.n_fastest ? t % g.tiles_n : t / g.tiles_m;
+  if (g.group_m > 1) {
+    // L2 blocking for tall GEMMs (ViT tower: M = 69 344 tokens): with the row tile slowest, the ~32 workgroups an XCD runs at
+    // a time are one row tile x 24+ column tiles, so the whole B operand streams through that XCD's 4 MB L2 once per ROW TILE
+    // (measured: 3.2x the algorithmic bytes over the fabric).  Walking group_m row tiles per column tile makes the concurrent
+    // set group_m x (32 / group_m) tiles: B streams once per group_m row tiles.
+    const int per_group = g.group_m * g.tiles_n;
+    const int grp = t / per_group, r = t - grp * per_group;
+    const int gsize = min(g.group_m, g.tiles_m - grp * g.group_m);
+    tm = grp * g.group_m + r % gsize;
+    tn = r / gsize;
+  }
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
   // 16-byte accesses when every row of C / aux starts 16-byte aligned and the chunk is whole; scalar otherwise (ragged N)
   const bool vec_ok = (g.N % 8 == 0) && (g.ldc % 4 == 0) && (g.ldaux % 4 == 0);
@@ -295,6 +307,8 @@ static int launch_p3(P3Args& g, hipStream_t st) {
   g.tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
   static const int xcd_env = getenv("PXR_GEMM_XCD") ? atoi(getenv("PXR_GEMM_XCD")) : -1;
   g.n_fastest = xcd_env >= 0 ? xcd_env : (g.M > g.N ? 1 : 0);
+  static const int group_env = getenv("PXR_P3_GROUP_M") ? atoi(getenv("PXR_P3_GROUP_M")) : 0;
+  g.group_m = (g.n_fastest && group_env > 1 && g.tiles_m >= 8 * group_env && g.tiles_n >= 4) ? group_env : 1;
   g.dbg = getenv("PXR_P3_DBG") ? atoi(getenv("PXR_P3_DBG")) : 0;   // timing experiments only (gemm_p3.cuh)
   auto kern = gemm_p3_kernel<Cfg, B_KC, EPI, EARLY>;
   static bool attr_set = false;     // > 64 KB of dynamic LDS needs the opt-in once per kernel
