@@ -36,6 +36,17 @@ MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_
 B3_PRODUCTS = 6.0           # bf16 products issued per fp32 multiply in GEMM mode bf16x3 (gemm_b3.cuh)
 
 
+def _pixelnet_traffic(encoder, B):
+    """HBM/fabric bytes per GEMM-family launch of the shipped PixelNet shape (PMC passes of tools/r03_final.sh), else None."""
+    f = os.path.join(ROOT, "profiles", "r03", "pixelnet", "pixelnet_gemm_traffic_summary.json")
+    if encoder != "clip-vit-base-patch16" or B != 16 or not os.path.exists(f):
+        return None
+    try:
+        return json.load(open(f)).get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def mfma_roof(alg_flops, seconds, b3):
     """`achieved`/`peak`/`frac` of an MFMA-bound kernel against the pipe it RUNS on ("if a bf16-split scheme is
     used quote that peak instead").  bf16x3: achieved = the 6 bf16 products per algorithmic fp32 multiply actually executed,
@@ -208,10 +219,12 @@ def pixelnet_main(args):
                         "kernel": "gemm_b3_kernel / gemm_kernel + grouped dW (bf16x3: v_mfma_f32_32x32x16_bf16 on the exact 3 x bf16 "
                                   "split; f32: v_mfma_f32_32x32x2_f32 -- see gemm_mode): ViT blocks, batched "
                                                    "attention contractions, rec_fc, sequence block",
-                        **mfma_roof(g_fl, g_s, ops.gemm_mode() == "bf16x3"), "traffic": None,
+                        **mfma_roof(g_fl, g_s, ops.gemm_mode() == "bf16x3"), "traffic": _pixelnet_traffic(args.encoder, B),
                         "gemm_time_per_step_ms": g_s / max(n_inst, 1) * 1e3, "algorithmic_gflop_per_step": g_fl / max(n_inst, 1) / 1e9,
                         "launches_per_step": len(gem) / max(n_inst, 1),
-                        "note": "HIP events around every GEMM launch of extra eager steps (sum of durations; one stream)"},
+                        "note": "HIP events around every GEMM launch of extra eager steps (sum of durations; one stream); `traffic` = "
+                                "fabric bytes per GEMM-family launch from the separate rocprofv3 --pmc passes of this command "
+                                "(profiles/r03/pixelnet/pixelnet_gemm_traffic_summary.json; null for other shapes)"},
            "cpu_baseline": None}
     import ctypes
     ctypes.CDLL(None).fflush(None)
@@ -562,7 +575,7 @@ def main():
 
     per_kernel = per_tag(gemm_events, 1e12, "tflops")
     traffic = None
-    tr_file = os.path.join(ROOT, "profiles", "r02", "pmc", "gemm_traffic_summary.json")
+    tr_file = os.path.join(ROOT, "profiles", "r03", "pmc", "gemm_traffic_summary.json")
     if os.path.exists(tr_file) and not custom and B == 64:
         try:
             traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
@@ -588,7 +601,7 @@ def main():
                     "of durations in the default one-stream schedule), x 6 in bf16x3 mode = the bf16 products executed; peak = the "
                     "dense peak of the pipe the kernels run on (bf16 MFMA 2.5 PFLOP/s in bf16x3 mode, f32-input MFMA 157.3 "
                     "TFLOP/s in f32 mode); `algorithmic_tflops` is the fp32-equivalent rate; `traffic` = HBM bytes per "
-                    "launch from the separate rocprofv3 --pmc pass of this command (profiles/r02/pmc)"}
+                    "launch from the separate rocprofv3 --pmc pass of this command (profiles/r03/pmc)"}
     hbm_kernels = per_tag(other_events, 1e9, "gbs")
 
     out = {
