@@ -244,6 +244,13 @@ int pxr_tower_attn_supported(int T, int d);
 int pxr_tower_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads, int T, int d,
                            float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t ctx_plane_stride,
                            int64_t ctx_panel_rows, float* lse, void* stream);
+/* Backward of pxr_tower_attn_fwd_f32 (the trainable blocks of the tower): dq | dk | dv from dctx, recomputing the
+ * probabilities from the forward's lse -- no [images*heads, T, T] matrix is saved or written.  ctx = the forward's fp32
+ * output (for delta = rowsum(dctx o ctx)); delta_ws = [images*heads, T] floats of scratch; dq / dk / dv are addressed like
+ * q / k / v with row stride ld_d (three column ranges of one [images*T, 3*heads*64] matrix in the tower).  Two launches. */
+int pxr_tower_attn_bwd_f32(const float* q, const float* k, const float* v, int64_t ld, const float* dctx, const float* ctx,
+                           int64_t ld_c, const float* lse, int64_t images, int heads, int T, int d, float scale, float* dq,
+                           float* dk, float* dv, int64_t ld_d, float* delta_ws, void* stream);
 /* in place: S[row, :T] = softmax(scale * S[row, :T]), S[row, T:ld] = 0      (HF CLIPAttention, no mask / dropout) */
 int pxr_softmax_rows_f32(float* S, int64_t rows, int T, int ld, float scale, void* stream);
 /* in place on dP: dS = scale * P o (dP - rowsum(dP o P))                    (autograd of the above) */

@@ -272,6 +272,332 @@ __global__ void __launch_bounds__(NW * 64) tower_attn_fwd_kernel(TowerAttnArgs a
     }
 }
 
+// =====================================================================================================================
+// Backward (the trainable blocks of the tower): dQ, dK, dV from dO, recomputing P from the saved log-sum-exp -- the
+// [images x heads, T, T] probability matrix is neither saved by the forward nor written by the backward.
+//   delta_q = sum_c dO[q,c] O[q,c]          (= sum_k P[q,k] dP[q,k]: the softmax Jacobian's row term)
+//   P = exp(scale S - lse),  dP = dO V^T,  dS = P o (dP - delta) * scale,   dQ = dS K,  dK = dS^T Q,  dV = P^T dO
+// Two launches, both with the forward's structure (one workgroup per (image, head), a wave owns a block of 32 rows, the other
+// side streams through LDS in chunks of 32 rows, every contraction on the bf16x3 MFMA path, C-layout accumulators re-used
+// as B operands so that P / dS never leave the registers):
+//   tower_attn_bwd_dq_kernel   wave = 32 QUERIES (as in the forward: S^T, dP^T with lane = query), keys stream;
+//                              dQ^T += K^T dS^T.  Also writes delta.
+//   tower_attn_bwd_dkv_kernel  wave = 32 KEYS (S, dP with lane = key), queries stream with their lse / delta;
+//                              dV^T += dO^T P,  dK^T += Q^T dS.
+// Cost: 72 + 96 MFMA groups per (32 x 32) block pair against 48 in the forward.
+struct TowerBwdArgs {
+  const float* q; const float* k; const float* v; int64_t ld;      // as in the forward
+  const float* dctx; const float* ctx; int64_t ld_c;                // dO and O: [images*T, ld_c], head h at column 64 h
+  const float* lse;                                                 // [images*heads, T] from the forward
+  float* delta;                                                     // [images*heads, T] workspace: written by dq, read by dkv
+  float* dq; float* dk; float* dv; int64_t ld_d;                    // outputs, element (b, t, h, c) at p[(b*T + t)*ld_d + 64 h + c]
+  int heads, T;
+  float scale, scale_log2;
+};
+
+struct TaBlk { ta_f32x4 r0, r1, r2, r3; };     // rows 4 kg .. 4 kg + 3, columns c .. c + 3 of a 32 x 64 chunk
+
+__device__ __forceinline__ void ta_blk_load(TaBlk& t, const float* src, int64_t ld, int row0, int T, int j) {
+  const int kg = j >> 4, c = (j & 15) * 4, row = row0 + 4 * kg;
+  const float* p = src + (int64_t)row * ld + c;
+  const ta_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  t.r0 = (row < T) ? *reinterpret_cast<const ta_f32x4*>(p) : z;
+  t.r1 = (row + 1 < T) ? *reinterpret_cast<const ta_f32x4*>(p + ld) : z;
+  t.r2 = (row + 2 < T) ? *reinterpret_cast<const ta_f32x4*>(p + 2 * ld) : z;
+  t.r3 = (row + 3 < T) ? *reinterpret_cast<const ta_f32x4*>(p + 3 * ld) : z;
+}
+// kc: [row][dh] planes (A operand, k = dh);  tr: [dh][row slot] planes (A operand, k = rows in fragment order); either may be null
+__device__ __forceinline__ void ta_blk_store(const TaBlk& t, int j, __bf16* kc, __bf16* tr) {
+  const int kg = j >> 4, c = (j & 15) * 4;
+  if (kc) {
+    __bf16* dst = kc + (4 * kg) * TA_KLD + c;
+#define PXR_TA_KROW(i, R)                                                                    \
+  {                                                                                          \
+    unsigned h0, m0, l0, h1, m1, l1;                                                         \
+    p3_split2(t.R.x, t.R.y, h0, m0, l0);                                                     \
+    p3_split2(t.R.z, t.R.w, h1, m1, l1);                                                     \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_KLD) = p3_u32x2{h0, h1};                     \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_KLD + TA_KPLANE) = p3_u32x2{m0, m1};         \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_KLD + 2 * TA_KPLANE) = p3_u32x2{l0, l1};     \
+  }
+    PXR_TA_KROW(0, r0) PXR_TA_KROW(1, r1) PXR_TA_KROW(2, r2) PXR_TA_KROW(3, r3)
+#undef PXR_TA_KROW
+  }
+  if (tr) {
+    const int sg = (kg & 4) | ((kg & 1) << 1) | ((kg >> 1) & 1);
+    __bf16* dst = tr + c * TA_VLD + sg * 4;
+#define PXR_TA_TROW(i, f)                                                                    \
+  {                                                                                          \
+    unsigned h0, m0, l0, h1, m1, l1;                                                         \
+    p3_split2(t.r0.f, t.r1.f, h0, m0, l0);                                                   \
+    p3_split2(t.r2.f, t.r3.f, h1, m1, l1);                                                   \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD) = p3_u32x2{h0, h1};                     \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD + TA_VPLANE) = p3_u32x2{m0, m1};         \
+    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD + 2 * TA_VPLANE) = p3_u32x2{l0, l1};     \
+  }
+    PXR_TA_TROW(0, x) PXR_TA_TROW(1, y) PXR_TA_TROW(2, z) PXR_TA_TROW(3, w)
+#undef PXR_TA_TROW
+  }
+}
+
+// B fragments of a wave's own 32 rows (lane = row r, k slots = dh 16 ks + 8 hh ..): rows >= T are zero
+__device__ __forceinline__ void ta_row_frags(ta_bf16x8 (&f)[4][3], const float* src, bool ok, int hh) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    ta_f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+    if (ok) { x0 = *reinterpret_cast<const ta_f32x4*>(src + ks * 16 + hh * 8); x1 = *reinterpret_cast<const ta_f32x4*>(src + ks * 16 + hh * 8 + 4); }
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    ta_split8(v, f[ks]);
+  }
+}
+
+// acc (two 32 x 32 blocks of a TRANSPOSED result: lane = output row, entries = 64 columns) -> dst[row][0 .. 63] fp32
+__device__ __forceinline__ void ta_store_rows(const ta_f32x16 (&acc)[2], float* dst, bool ok, int hh) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float own[4], got[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float lo_g = acc[j][4 * (2 * t) + i], hi_g = acc[j][4 * (2 * t + 1) + i];
+        own[i] = hh ? hi_g : lo_g;
+        got[i] = __shfl_xor(hh ? lo_g : hi_g, 32);
+      }
+      if (ok) {
+        float* d = dst + j * 32 + 8 * (2 * t + hh);
+        *reinterpret_cast<ta_f32x4*>(d) = hh ? ta_f32x4{got[0], got[1], got[2], got[3]} : ta_f32x4{own[0], own[1], own[2], own[3]};
+        *reinterpret_cast<ta_f32x4*>(d + 4) = hh ? ta_f32x4{own[0], own[1], own[2], own[3]} : ta_f32x4{got[0], got[1], got[2], got[3]};
+      }
+    }
+}
+
+constexpr int TB_ITEMS = 256;                                             // two matrices x 128 blocks of 4 x 4 per chunk
+constexpr int TB_DQ_BUF = 2 * 3 * TA_KPLANE + 3 * TA_VPLANE;              // K kc | V kc | K tr        (bf16 elements)
+constexpr int TB_DKV_BUF = 2 * 3 * TA_KPLANE + 2 * 3 * TA_VPLANE + 128;   // Q kc | dO kc | Q tr | dO tr | lse2[32] delta[32] (as 128 bf16 slots)
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) tower_attn_bwd_dq_kernel(TowerBwdArgs a) {
+  constexpr int NT = NW * 64;
+  constexpr int ITER = (TB_ITEMS + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) char ta_smem[];
+  __bf16* sm = reinterpret_cast<__bf16*>(ta_smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.heads, hd = bh - b * a.heads;
+  const int T = a.T;
+  const int64_t base = (int64_t)b * T * a.ld + (int64_t)hd * TA_D;
+  const int64_t cbase = (int64_t)b * T * a.ld_c + (int64_t)hd * TA_D;
+  const int nchunk = (T + TA_KC - 1) / TA_KC;
+  auto kkc = [&](int buf) { return sm + buf * TB_DQ_BUF; };
+  auto vkc = [&](int buf) { return sm + buf * TB_DQ_BUF + 3 * TA_KPLANE; };
+  auto ktr = [&](int buf) { return sm + buf * TB_DQ_BUF + 6 * TA_KPLANE; };
+  TaBlk st[ITER];
+  auto load = [&](int key0) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int item = threadIdx.x + it * NT;
+      if (item < 128) ta_blk_load(st[it], a.k + base, a.ld, key0, T, item);
+      else if (item < TB_ITEMS) ta_blk_load(st[it], a.v + base, a.ld, key0, T, item - 128);
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int item = threadIdx.x + it * NT;
+      if (item < 128) ta_blk_store(st[it], item, kkc(buf), ktr(buf));
+      else if (item < TB_ITEMS) ta_blk_store(st[it], item - 128, vkc(buf), nullptr);
+    }
+  };
+  load(0);
+
+  const int q_row = wave * 32 + r;
+  const bool ok = q_row < T;
+  ta_bf16x8 qf[4][3], dof[4][3];
+  ta_row_frags(qf, a.q + base + (int64_t)q_row * a.ld, ok, hh);
+  ta_row_frags(dof, a.dctx + cbase + (int64_t)q_row * a.ld_c, ok, hh);
+  float dsum = 0.f;
+  if (ok) {
+    const float* po = a.ctx + cbase + (int64_t)q_row * a.ld_c + hh * 8;
+    const float* pd = a.dctx + cbase + (int64_t)q_row * a.ld_c + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const ta_f32x4 o0 = *reinterpret_cast<const ta_f32x4*>(po + ks * 16), o1 = *reinterpret_cast<const ta_f32x4*>(po + ks * 16 + 4);
+      const ta_f32x4 d0 = *reinterpret_cast<const ta_f32x4*>(pd + ks * 16), d1 = *reinterpret_cast<const ta_f32x4*>(pd + ks * 16 + 4);
+      dsum += (o0.x * d0.x + o0.y * d0.y) + (o0.z * d0.z + o0.w * d0.w) + (o1.x * d1.x + o1.y * d1.y) + (o1.z * d1.z + o1.w * d1.w);
+    }
+  }
+  const float delta = dsum + __shfl_xor(dsum, 32);
+  const float lse2 = ok ? a.lse[(int64_t)bh * T + q_row] * 1.4426950408889634f : 0.f;
+  if (ok && hh == 0) a.delta[(int64_t)bh * T + q_row] = delta;
+  store(0);
+  __syncthreads();
+
+  ta_f32x16 accQ[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accQ[j][e] = 0.f;
+
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) load((c + 1) * TA_KC);
+    ta_f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+    const __bf16* kb = kkc(buf) + r * TA_KLD + hh * 8;
+    const __bf16* vb = vkc(buf) + r * TA_KLD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ta_bf16x8 f[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const ta_bf16x8*>(kb + q * TA_KPLANE + ks * 16);
+      ta_mma6(s, f, qf[ks]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const ta_bf16x8*>(vb + q * TA_KPLANE + ks * 16);
+      ta_mma6(dp, f, dof[ks]);
+    }
+    // dS^T of the lane's query against its 16 keys: key(e) = 32 c + (e & 3) + 8 (e >> 2) + 4 hh
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const bool real = c * TA_KC + (e & 3) + 8 * (e >> 2) + 4 * hh < T;
+      const float p = real ? __builtin_amdgcn_exp2f(fmaf(s[e], a.scale_log2, -lse2)) : 0.f;
+      s[e] = p * (dp[e] - delta) * a.scale;
+    }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const float dv8[8] = {s[8 * ks2], s[8 * ks2 + 1], s[8 * ks2 + 2], s[8 * ks2 + 3],
+                            s[8 * ks2 + 4], s[8 * ks2 + 5], s[8 * ks2 + 6], s[8 * ks2 + 7]};
+      ta_bf16x8 dsf[3];
+      ta_split8(dv8, dsf);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ta_bf16x8 f[3];
+        const __bf16* tb = ktr(buf) + (j * 32 + r) * TA_VLD + ks2 * 16 + hh * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const ta_bf16x8*>(tb + q * TA_VPLANE);
+        ta_mma6(accQ[j], f, dsf);
+      }
+    }
+    if (c + 1 < nchunk) store(buf ^ 1);
+    __syncthreads();
+  }
+  ta_store_rows(accQ, a.dq + ((int64_t)b * T + q_row) * a.ld_d + (int64_t)hd * TA_D, ok, hh);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) tower_attn_bwd_dkv_kernel(TowerBwdArgs a) {
+  constexpr int NT = NW * 64;
+  constexpr int ITER = (TB_ITEMS + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) char ta_smem[];
+  __bf16* sm = reinterpret_cast<__bf16*>(ta_smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / a.heads, hd = bh - b * a.heads;
+  const int T = a.T;
+  const int64_t base = (int64_t)b * T * a.ld + (int64_t)hd * TA_D;
+  const int64_t cbase = (int64_t)b * T * a.ld_c + (int64_t)hd * TA_D;
+  const int nchunk = (T + TA_KC - 1) / TA_KC;
+  auto qkc = [&](int buf) { return sm + buf * TB_DKV_BUF; };
+  auto dkc = [&](int buf) { return sm + buf * TB_DKV_BUF + 3 * TA_KPLANE; };
+  auto qtr = [&](int buf) { return sm + buf * TB_DKV_BUF + 6 * TA_KPLANE; };
+  auto dtr = [&](int buf) { return sm + buf * TB_DKV_BUF + 6 * TA_KPLANE + 3 * TA_VPLANE; };
+  auto stat = [&](int buf) { return reinterpret_cast<float*>(sm + buf * TB_DKV_BUF + 6 * TA_KPLANE + 6 * TA_VPLANE); };   // lse2[32] | delta[32]
+  TaBlk st[ITER];
+  float st_stat = 0.f;
+  auto load = [&](int q0) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int item = threadIdx.x + it * NT;
+      if (item < 128) ta_blk_load(st[it], a.q + base, a.ld, q0, T, item);
+      else if (item < TB_ITEMS) ta_blk_load(st[it], a.dctx + cbase, a.ld_c, q0, T, item - 128);
+    }
+    if (threadIdx.x < 64) {      // lane < 32: lse (as log2, +inf for rows beyond T => P = 0); lanes 32..63: delta
+      const int q = q0 + (threadIdx.x & 31);
+      st_stat = (threadIdx.x < 32) ? (q < T ? a.lse[(int64_t)bh * T + q] * 1.4426950408889634f : INFINITY)
+                                   : (q < T ? a.delta[(int64_t)bh * T + q] : 0.f);
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int item = threadIdx.x + it * NT;
+      if (item < 128) ta_blk_store(st[it], item, qkc(buf), qtr(buf));
+      else if (item < TB_ITEMS) ta_blk_store(st[it], item - 128, dkc(buf), dtr(buf));
+    }
+    if (threadIdx.x < 64) stat(buf)[threadIdx.x] = st_stat;
+  };
+  load(0);
+
+  const int k_row = wave * 32 + r;
+  const bool ok = k_row < T;
+  ta_bf16x8 kf[4][3], vf[4][3];
+  ta_row_frags(kf, a.k + base + (int64_t)k_row * a.ld, ok, hh);
+  ta_row_frags(vf, a.v + base + (int64_t)k_row * a.ld, ok, hh);
+  store(0);
+  __syncthreads();
+
+  ta_f32x16 accK[2], accV[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accK[j][e] = 0.f; accV[j][e] = 0.f; }
+
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) load((c + 1) * TA_KC);
+    // S and dP of the lane's key against the chunk's 32 queries: query(e) = (e & 3) + 8 (e >> 2) + 4 hh
+    ta_f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+    const __bf16* qb = qkc(buf) + r * TA_KLD + hh * 8;
+    const __bf16* db = dkc(buf) + r * TA_KLD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ta_bf16x8 f[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const ta_bf16x8*>(qb + q * TA_KPLANE + ks * 16);
+      ta_mma6(s, f, kf[ks]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const ta_bf16x8*>(db + q * TA_KPLANE + ks * 16);
+      ta_mma6(dp, f, vf[ks]);
+    }
+    const float* stq = stat(buf);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[e], a.scale_log2, -stq[q])) : 0.f;
+      s[e] = p;
+      dp[e] = p * (dp[e] - stq[32 + q]) * a.scale;
+    }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const float p8[8] = {s[8 * ks2], s[8 * ks2 + 1], s[8 * ks2 + 2], s[8 * ks2 + 3], s[8 * ks2 + 4], s[8 * ks2 + 5], s[8 * ks2 + 6], s[8 * ks2 + 7]};
+      const float d8[8] = {dp[8 * ks2], dp[8 * ks2 + 1], dp[8 * ks2 + 2], dp[8 * ks2 + 3], dp[8 * ks2 + 4], dp[8 * ks2 + 5], dp[8 * ks2 + 6], dp[8 * ks2 + 7]};
+      ta_bf16x8 pf[3], dsf[3];
+      ta_split8(p8, pf);
+      ta_split8(d8, dsf);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ta_bf16x8 f[3];
+        const __bf16* tb = dtr(buf) + (j * 32 + r) * TA_VLD + ks2 * 16 + hh * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const ta_bf16x8*>(tb + q * TA_VPLANE);
+        ta_mma6(accV[j], f, pf);                                        // dV^T += dO^T P
+        const __bf16* tq = qtr(buf) + (j * 32 + r) * TA_VLD + ks2 * 16 + hh * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const ta_bf16x8*>(tq + q * TA_VPLANE);
+        ta_mma6(accK[j], f, dsf);                                       // dK^T += Q^T dS
+      }
+    }
+    if (c + 1 < nchunk) store(buf ^ 1);
+    __syncthreads();
+  }
+  const int64_t orow = ((int64_t)b * T + k_row) * a.ld_d + (int64_t)hd * TA_D;
+  ta_store_rows(accK, a.dk + orow, ok, hh);
+  ta_store_rows(accV, a.dv + orow, ok, hh);
+}
+
 }  // namespace pxr
 
 using namespace pxr;
@@ -314,4 +640,51 @@ extern "C" int pxr_tower_attn_fwd_f32(const float* q, const float* k, const floa
     default: PXR_REQUIRE(false, "pxr_tower_attn_fwd_f32: unreachable");
   }
   return pxr_check_launch("pxr_tower_attn_fwd_f32");
+}
+
+// d(q | k | v) of pxr_tower_attn_fwd_f32 from dctx, the forward's ctx and lse (both fp32).  delta_ws: [images*heads, T] floats
+// of scratch.  dq / dk / dv use the q / k / v addressing with row stride ld_d (they may be three column ranges of one matrix).
+extern "C" int pxr_tower_attn_bwd_f32(const float* q, const float* k, const float* v, int64_t ld, const float* dctx,
+                                      const float* ctx, int64_t ld_c, const float* lse, int64_t images, int heads, int T, int d,
+                                      float scale, float* dq, float* dk, float* dv, int64_t ld_d, float* delta_ws, void* stream) {
+  PXR_REQUIRE(q && k && v && dctx && ctx && lse && dq && dk && dv && delta_ws && images >= 0 && heads > 0,
+              "pxr_tower_attn_bwd_f32: bad args");
+  PXR_REQUIRE(pxr_tower_attn_supported(T, d), "pxr_tower_attn_bwd_f32: head size %d / %d tokens not supported (64, <= %d)", d,
+              T, 32 * TA_MAXW);
+  PXR_REQUIRE(ld % 4 == 0 && ld_c % 4 == 0 && ld_d % 4 == 0, "pxr_tower_attn_bwd_f32: row strides must be multiples of 4");
+  PXR_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dctx | (uintptr_t)ctx | (uintptr_t)dq | (uintptr_t)dk |
+                (uintptr_t)dv) & 15) == 0, "pxr_tower_attn_bwd_f32: 16-byte alignment");
+  if (images == 0) return PXR_OK;
+  PXR_REQUIRE(images * heads < (1ll << 31), "pxr_tower_attn_bwd_f32: too many (image, head) pairs");
+  TowerBwdArgs a;
+  a.q = q; a.k = k; a.v = v; a.ld = ld; a.dctx = dctx; a.ctx = ctx; a.ld_c = ld_c; a.lse = lse; a.delta = delta_ws;
+  a.dq = dq; a.dk = dk; a.dv = dv; a.ld_d = ld_d; a.heads = heads; a.T = T;
+  a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+  const dim3 grid((unsigned)(images * heads));
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int lds_dq = 2 * TB_DQ_BUF * 2, lds_dkv = 2 * TB_DKV_BUF * 2;      // two buffers of bf16
+  switch ((T + 31) / 32) {
+#define PXR_TB_CASE(NW)                                                                                                     \
+  case NW: {                                                                                                                \
+    static bool attr = false;                                                                                               \
+    if (!attr) {                                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(tower_attn_bwd_dq_kernel<NW>),                                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq) != hipSuccess ||                          \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(tower_attn_bwd_dkv_kernel<NW>),                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv) != hipSuccess) {                         \
+        (void)hipGetLastError();                                                                                            \
+        pxr_set_error("pxr_tower_attn_bwd_f32: cannot reserve %d bytes of LDS", lds_dkv);                                   \
+        return PXR_ERR_LAUNCH;                                                                                              \
+      }                                                                                                                     \
+      attr = true;                                                                                                          \
+    }                                                                                                                       \
+    hipLaunchKernelGGL(tower_attn_bwd_dq_kernel<NW>, grid, dim3(NW * 64), lds_dq, s, a);                                    \
+    hipLaunchKernelGGL(tower_attn_bwd_dkv_kernel<NW>, grid, dim3(NW * 64), lds_dkv, s, a);                                  \
+  } break;
+    PXR_TB_CASE(1) PXR_TB_CASE(2) PXR_TB_CASE(3) PXR_TB_CASE(4) PXR_TB_CASE(5) PXR_TB_CASE(6) PXR_TB_CASE(7) PXR_TB_CASE(8)
+    PXR_TB_CASE(9)
+#undef PXR_TB_CASE
+    default: PXR_REQUIRE(false, "pxr_tower_attn_bwd_f32: unreachable");
+  }
+  return pxr_check_launch("pxr_tower_attn_bwd_f32");
 }

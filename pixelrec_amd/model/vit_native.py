@@ -186,9 +186,13 @@ class NativeTower:
         _, xh1, rs1, h1p = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=keep, planes=True, want_y=False)
         qkv = torch.empty(n, T, 3 * H, dtype=torch.float32, device=x.device)
         ops.gemm_planes(h1p, Wqkv, qkv.view(M, 3 * H), ops.EPI_BIAS, bias=P("self_attn.k_proj.bias", span=3))
-        S = None
-        if not keep and ops.tower_attn_supported(T, d):      # fused: no score matrix, the context leaves as planes
-            _, ctxp, _ = ops.tower_attn_fwd(qkv.view(M, 3 * H), n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=False, planes=True)
+        S = ctx = lse = None
+        fused_bwd = keep and ops.tower_attn_supported(T, d) and os.environ.get("PXR_TOWER_ATTN_BWD", "1") != "0"
+        if (not keep or fused_bwd) and ops.tower_attn_supported(T, d):
+            # fused: no score matrix, the context leaves as planes; a trainable block also keeps the fp32 context and the
+            # log-sum-exp its fused backward recomputes the probabilities from
+            ctx, ctxp, lse = ops.tower_attn_fwd(qkv.view(M, 3 * H), n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=fused_bwd,
+                                                planes=True, lse=fused_bwd)
         else:
             ctx, S = self._attn_fwd(qkv, n, T, heads, d, keep)
             ctxp = ops.split_planes(ctx.view(M, H))
@@ -200,8 +204,8 @@ class NativeTower:
         ops.gemm_planes(h2p, W1, None, ops.EPI_BIAS_QGELU_GRAD if keep else ops.EPI_BIAS_QGELU, bias=P("mlp.fc1.bias"), aux=gq, Cp=fp)
         x3 = torch.empty_like(x)
         ops.gemm_planes(fp, W2, x3.view(M, H), ops.EPI_BIAS_ADD, bias=P("mlp.fc2.bias"), aux=x2.view(M, H))
-        saved = dict(planes=True, W=W, xh1=xh1, rs1=rs1, h1p=h1p, qkv=qkv, P=S, ctxp=ctxp, xh2=xh2, rs2=rs2, h2p=h2p, gq=gq,
-                     fp=fp) if keep else None
+        saved = dict(planes=True, W=W, xh1=xh1, rs1=rs1, h1p=h1p, qkv=qkv, P=S, ctx=ctx, lse=lse, ctxp=ctxp, xh2=xh2, rs2=rs2,
+                     h2p=h2p, gq=gq, fp=fp) if keep else None
         return x3, saved
 
     def _block_bwd_planes(self, i, dx3, s, defer):
@@ -228,7 +232,11 @@ class NativeTower:
         dx2p = ops.split_planes(dx2.view(M, H))
         pend.append((dx2p, s["ctxp"], G("self_attn.out_proj.weight"), G("self_attn.out_proj.bias")))
         dctx, _ = ops.linear_bwd_input_planes(dx2p, Wo, lead_shape=lead)
-        dqkv = self._attn_bwd(s["qkv"], s["P"], dctx, n, T, heads, d)
+        if s["P"] is None:          # the forward ran the fused attention: so does the backward
+            dqkv = ops.tower_attn_bwd(s["qkv"].view(M, ld), dctx.view(M, H), s["ctx"].view(M, H), s["lse"], n, T, heads, d,
+                                      2 * H, 0, H, d ** -0.5).view(n, T, ld)
+        else:
+            dqkv = self._attn_bwd(s["qkv"], s["P"], dctx, n, T, heads, d)
         dqkvp = ops.split_planes(dqkv.view(M, ld))
         pend.append((dqkvp, s["h1p"], G("self_attn.k_proj.weight", span=3), G("self_attn.k_proj.bias", span=3)))
         dh1, _ = ops.linear_bwd_input_planes(dqkvp, Wqkv, lead_shape=lead)

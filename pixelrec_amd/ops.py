@@ -325,6 +325,24 @@ def tower_attn_fwd(qkv: torch.Tensor, n: int, T: int, heads: int, d: int, q_off:
     return out, op, ls
 
 
+def tower_attn_bwd(qkv: torch.Tensor, dctx: torch.Tensor, ctx: torch.Tensor, lse: torch.Tensor, n: int, T: int, heads: int, d: int,
+                   q_off: int, k_off: int, v_off: int, scale: float) -> torch.Tensor:
+    """Backward of tower_attn_fwd (pxr_tower_attn_bwd_f32): -> dqkv with the layout of qkv (every column of the q / k / v
+    ranges is written).  ctx / lse: the forward's fp32 context and log-sum-exp."""
+    _req(qkv, torch.float32, "qkv"); _req(dctx, torch.float32, "dctx"); _req(ctx, torch.float32, "ctx"); _req(lse, torch.float32, "lse")
+    ld, H = qkv.shape[-1], heads * d
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(n * heads * T, dtype=torch.float32, device=qkv.device)
+    cp = _l.c_void_p
+    b, g = qkv.data_ptr(), dqkv.data_ptr()
+    with _gemm_timer(10.0 * T * T * d * n * heads, "tower_attn_bwd_{dq,dkv}_kernel (fused attention backward of a tower block)"):
+        _l.check(_l.load().pxr_tower_attn_bwd_f32(cp(b + 4 * q_off), cp(b + 4 * k_off), cp(b + 4 * v_off), ld, _l.ptr(dctx),
+                                                  _l.ptr(ctx), H, _l.ptr(lse), n, heads, T, d, float(scale), cp(g + 4 * q_off),
+                                                  cp(g + 4 * k_off), cp(g + 4 * v_off), ld, _l.ptr(ws), _l.stream_ptr()),
+                 "pxr_tower_attn_bwd_f32")
+    return dqkv
+
+
 def softmax_rows(S: torch.Tensor, rows: int, T: int, ld: int, scale: float):
     _l.check(_l.load().pxr_softmax_rows_f32(_l.ptr(S), rows, T, ld, float(scale), _l.stream_ptr()), "pxr_softmax_rows_f32")
 

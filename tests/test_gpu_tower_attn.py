@@ -44,3 +44,37 @@ def test_tower_attn_rejects_unsupported_shapes():
     qkv = torch.zeros(2 * 10, 3 * 32, device="cuda")
     with pytest.raises(RuntimeError):
         ops.tower_attn_fwd(qkv, 2, 10, 1, 32, 64, 0, 32, 1.0)
+
+
+@pytest.mark.parametrize("T", [1, 5, 33, 64, 197, 257])
+@pytest.mark.parametrize("spread", [1.0, 4.0])
+def test_tower_attn_bwd_matches_fp64_autograd(T, spread):
+    """pxr_tower_attn_bwd_f32 (probabilities recomputed from the forward's log-sum-exp, nothing T x T in memory) against
+    torch autograd of the fp64 restatement; yardstick = what fp32 autograd achieves on the same inputs."""
+    from pixelrec_amd import ops
+    n, heads, d = 2, 3, 64
+    H = heads * d
+    g = torch.Generator().manual_seed(500 + T)
+    qkv = torch.randn(n * T, 3 * H, generator=g) * spread
+    dctx = torch.randn(n, T, H, generator=g)
+
+    def grads(dtype):
+        x = qkv.to(dtype).requires_grad_(True)
+        ctx, _ = _ref(x, n, T, heads, d, dtype)
+        (ctx * dctx.to(dtype)).sum().backward()
+        return x.grad
+
+    ref, ref32 = grads(torch.float64), grads(torch.float32)
+    q = qkv.cuda()
+    ctx, _, lse = ops.tower_attn_fwd(q, n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=True, planes=False, lse=True)
+    got = ops.tower_attn_bwd(q, dctx.cuda().view(n * T, H), ctx.view(n * T, H), lse, n, T, heads, d, 2 * H, 0, H, d ** -0.5)
+    assert got.shape == qkv.shape and bool(torch.isfinite(got).all())
+    scale = float(ref.abs().max())
+    err32 = float((ref32.double() - ref).abs().max())
+    err = float((got.cpu().double() - ref).abs().max())
+    assert err < max(3e-6 * scale, 3.0 * err32), (err, err32, scale)
+    for name, lo in (("k", 0), ("v", H), ("q", 2 * H)):           # every one of the three ranges carries signal
+        if T > 1 or name == "v":                                  # (one token: the softmax is constant, dq = dk = 0 exactly)
+            assert float(ref[:, lo:lo + H].abs().max()) > 0 and float(got[:, lo:lo + H].abs().max()) > 0, name
+        else:
+            assert float(got[:, lo:lo + H].abs().max()) == 0.0, name
