@@ -77,4 +77,4 @@ def test_tower_attn_bwd_matches_fp64_autograd(T, spread):
         if T > 1 or name == "v":                                  # (one token: the softmax is constant, dq = dk = 0 exactly)
             assert float(ref[:, lo:lo + H].abs().max()) > 0 and float(got[:, lo:lo + H].abs().max()) > 0, name
         else:
-            assert float(got[:, lo:lo + H].abs().max()) == 0.0, name
+            assert float(got[:, lo:lo + H].abs().max()) < 1e-5 * scale, name      # rounding of 1 - exp(s - lse) and dP - delta
