@@ -311,6 +311,16 @@ int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* q, const fl
                      const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d,
                      float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* stream);
 
+/* ---- GRU4Rec (code/REC/model/IDNet/gru4rec.py; torch.nn.GRU, bias=False): the gate arithmetic of one time step --------- */
+/* r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r gh_n), h = (1 - z) n + z h_prev; gi, gh [B, 3H] in
+ * torch's r | z | n order, h_prev [B, H] or NULL (zeros), save (optional) [B, 4H] = r | z | n | gh_n.  The matrix products
+ * around it are pxr_linear_* / pxr_gemm_f32 calls. */
+int pxr_gru_gates_fwd_f32(const float* gi, const float* gh, const float* h_prev, float* h_out, float* save, int64_t B, int H,
+                          void* stream);
+/* dh = everything that reaches h_t  ->  dgi, dgh [B, 3H] and the direct part dh * z of d h_{t-1} (autograd of the above) */
+int pxr_gru_gates_bwd_f32(const float* dh, const float* save, const float* h_prev, float* dgi, float* dgh, float* dh_prev,
+                          int64_t B, int H, void* stream);
+
 /* ---- training head ------------------------------------------------------------------------------------------ */
 /* loss = mean_b(-sum_t log(sigmoid(pos-neg)+1e-8) * mask)            sasrec.py:88-92; loss stays on the device */
 int pxr_bpr_loss_fwd_f32(const float* out, const float* table, int64_t n_table, const int64_t* items,

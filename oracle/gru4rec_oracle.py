@@ -1,0 +1,49 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's GRU4Rec (code/REC/model/IDNet/gru4rec.py:50-87), the GRU
+written out step by step (torch.nn.GRU's documented equations with bias=False: r | z | n gate order).  Imported by tests/
+only.  Pinned against the reference itself: tests/golden/gru4rec_tiny.npz is written by oracle/make_golden_gru4rec.py from
+`REC.model.IDNet.gru4rec.GRU4Rec` run unmodified; tests/test_gru4rec_golden.py checks this file against it.
+"""
+import torch
+
+
+def gru_stack(params, x, n_layers):
+    """x [B, L, E] -> h of the top layer [B, L, H]  (gru4rec.py:60 / :77, h_0 = 0)."""
+    B, L, _ = x.shape
+    for k in range(n_layers):
+        w_ih, w_hh = params[f"gru_layers.weight_ih_l{k}"], params[f"gru_layers.weight_hh_l{k}"]
+        H = w_hh.shape[1]
+        h = x.new_zeros(B, H)
+        outs = []
+        for t in range(L):
+            gi, gh = x[:, t] @ w_ih.t(), h @ w_hh.t()
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            h = (1 - z) * n + z * h
+            outs.append(h)
+        x = torch.stack(outs, dim=1)
+    return x
+
+
+def encode(params, seq_ids, n_layers):
+    """item ids [B, L] -> dense(GRU(E[ids])) [B, L, E]  (dropout inactive: the shipped dropout_prob is 0)."""
+    out = gru_stack(params, params["item_embedding.weight"][seq_ids], n_layers)
+    return out @ params["dense.weight"].t() + params["dense.bias"]
+
+
+def forward_loss(params, items, masked_index, n_layers):
+    """gru4rec.py:50-68."""
+    pos_ids, neg_ids = items[:, 0], items[:, 1]
+    out = encode(params, pos_ids[:, :-1], n_layers)
+    E = params["item_embedding.weight"]
+    pos = (out * E[pos_ids[:, 1:]]).sum(-1)
+    neg = (out * E[neg_ids[:, 1:]]).sum(-1)
+    loss = -(torch.log((pos - neg).sigmoid() + 1e-8) * masked_index).sum(-1)
+    return loss.mean(-1)
+
+
+@torch.no_grad()
+def predict(params, item_seq, item_feature, n_layers):
+    """gru4rec.py:71-82."""
+    out = encode({**params, "item_embedding.weight": item_feature}, item_seq, n_layers)
+    return out[:, -1] @ item_feature.t()

@@ -1,0 +1,164 @@
+"""GRU4Rec (IDNet) -- drop-in for `REC.model.IDNet.gru4rec.GRU4Rec` (code/REC/model/IDNet/gru4rec.py:10-87): item-ID
+embeddings -> dropout -> `nn.GRU(bias=False, batch_first=True)` -> `dense` -> the same BPR-style loss against one sampled
+negative per position as SASRec.  A sibling backbone sharing SASRec's step shape: everything around the
+recurrent block is SASRec's machinery, inherited unchanged --
+
+  * the item table: occurrence sort of the batch's ids, lazy AdamW catch-up of exactly those rows before they are read,
+    sparse (id, row) table gradient from the segmented row sums, `state_dict` hooks (`model/sasrec.py`);
+  * the BPR head (`pxr_bpr_loss_{fwd,bwd}_f32`: target rows read straight from the table), `predict` / `encode_last` /
+    `compute_item_all`, the fused scoring + top-k evaluation;
+  * the flat parameter / gradient buffers, `PxrAdamW`, `GraphedTrainStep`, `DataParallel` (`model/seqcore.py`).
+
+What is new is the recurrent block.  Per layer: ONE GEMM for x_t W_ih^T of all time steps, then per step a GEMM
+h_{t-1} W_hh^T ([B, H] x [H, 3H]) + the gate kernel (`csrc/gru.hip`); the backward walks the steps in reverse (gate backward
++ one GEMM d gh_t W_hh with the direct d h_{t-1} path as its additive epilogue operand) and forms every weight gradient of the
+step in one grouped launch at the end (d W_hh = sum_t d gh_t^T h_{t-1} is a single [3H, B L] x [B L, H] product).  The
+recurrence itself is 2 L small launches per layer and direction -- correct and deterministic, not tuned: the headline path
+of this build is SASRec.
+
+Contract kept: `input_type`; `__init__(config, dataload)` with the reference's keys (`embedding_size`, `hidden_size` as a
+multiplier, `num_layers`, `dropout_prob`); `forward((items [B, 2, L+1], masked_index [B, L])) -> loss`; `predict`;
+`compute_item_all`; `state_dict` keys `item_embedding.weight`, `gru_layers.weight_{ih,hh}_l{k}`, `dense.{weight,bias}`.
+Limit: `dropout_prob` must be 0 for training (the shipped IDNet/gru4rec.yaml value); a positive value raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.enum_type import InputType
+from .sasrec import SASRec
+from .seqcore import PxrError, SeqRecCore
+
+
+class GRU4Rec(SASRec):
+    input_type = InputType.SEQ
+
+    def __init__(self, config, dataload):
+        SeqRecCore.__init__(self)
+        self.embedding_size = config["embedding_size"]
+        self.gru_hidden = config["hidden_size"] * config["embedding_size"]      # gru4rec.py:17: a multiplier
+        self.num_layers = config["num_layers"]
+        self.dropout_prob = float(config["dropout_prob"] or 0.0)
+        self.item_num = dataload.item_num
+        self.max_seq_length = config["MAX_ITEM_LIST_LENGTH"]
+        self.hidden_size = self.embedding_size                                   # width of the table rows / of `out` (SASRec's name)
+        self.inner_size = self.gru_hidden
+        self.n_layers = self.num_layers
+        if self.embedding_size % 4 or self.gru_hidden % 4:
+            raise ValueError("embedding_size and hidden_size * embedding_size must be multiples of 4 (16-byte vector accesses)")
+        self.item_embedding = nn.Embedding(self.item_num, self.embedding_size, padding_idx=0)
+        self.emb_dropout = nn.Dropout(self.dropout_prob)
+        self.gru_layers = nn.GRU(input_size=self.embedding_size, hidden_size=self.gru_hidden, num_layers=self.num_layers,
+                                 bias=False, batch_first=True)                   # parameter container: never called
+        self.dense = nn.Linear(self.gru_hidden, self.embedding_size)
+        self.apply(self._init_weights)
+        self._init_runtime_state(config)
+        self._init_table_state()
+
+    def _init_weights(self, module):
+        """gru4rec.py:43-48: xavier-normal table, xavier-uniform for LAYER 0's GRU matrices only (deeper layers and `dense`
+        keep torch's defaults)."""
+        if isinstance(module, nn.Embedding):
+            nn.init.xavier_normal_(module.weight)
+        elif isinstance(module, nn.GRU):
+            nn.init.xavier_uniform_(module.weight_hh_l0)
+            nn.init.xavier_uniform_(module.weight_ih_l0)
+
+    # ------------------------------------------------------------------------------------------ flat packing
+    def _flat_specs(self):
+        specs = []
+        for k in range(self.num_layers):
+            specs += [(f"gru.{k}.ih", getattr(self.gru_layers, f"weight_ih_l{k}")),
+                      (f"gru.{k}.hh", getattr(self.gru_layers, f"weight_hh_l{k}"))]
+        return specs + [("dense.w", self.dense.weight), ("dense.b", self.dense.bias)]
+
+    def _first_flat_parameter(self):
+        return self.gru_layers.weight_ih_l0
+
+    def rec_parameter_names(self):
+        """{reference parameter name: flat-buffer key} in the order the reference registers them (gru4rec.py:26-36): what
+        torch.optim.AdamW numbers its state in (optim.reference_rec_parameter_names)."""
+        out = {"item_embedding.weight": None}
+        for k in range(self.num_layers):
+            out[f"gru_layers.weight_ih_l{k}"] = f"gru.{k}.ih"
+            out[f"gru_layers.weight_hh_l{k}"] = f"gru.{k}.hh"
+        out["dense.weight"], out["dense.bias"] = "dense.w", "dense.b"
+        return out
+
+    def _planes_on(self) -> bool:          # the recurrent block runs on the fp32-operand GEMM entry points
+        return False
+
+    def weight_plane_segments(self):
+        return None
+
+    def refresh_weight_planes(self):
+        return None
+
+    # ------------------------------------------------------------------------------------------ recurrent block
+    def _encode(self, table, idx, idx_bstride, B, keymask, km_bstride, train: bool):
+        """row ids into `table` -> dense(GRU(rows)) [B, L, E] (gru4rec.py:50-62 / :72-79).  idx: [B, idx_bstride] ids whose
+        first L columns are the input sequence.  Internally time-major so that every step reads contiguous [B, .] slabs."""
+        L, E, Hh = self.max_seq_length, self.embedding_size, self.gru_hidden
+        if train and self.dropout_prob > 0:
+            raise NotImplementedError("GRU4Rec: emb_dropout with dropout_prob > 0 is not built (IDNet/gru4rec.yaml ships 0)")
+        ids_tm = idx.reshape(B, idx_bstride)[:, :L].t().contiguous()                     # [L, B]
+        x = ops.embed_gather(table, ids_tm)                                              # [L, B, E]
+        dev = x.device
+        layers = []
+        for k in range(self.num_layers):
+            Wih, Whh = self._p(f"gru.{k}.ih"), self._p(f"gru.{k}.hh")
+            gi = ops.linear_fwd(x, Wih, None)                                            # [L, B, 3H]: all steps at once
+            h = torch.empty(L, B, Hh, dtype=torch.float32, device=dev)
+            save = torch.empty(L, B, 4 * Hh, dtype=torch.float32, device=dev) if train else None
+            gh0 = torch.zeros(B, 3 * Hh, dtype=torch.float32, device=dev)                # h_{-1} = 0  =>  gh_0 = 0
+            for t in range(L):
+                gh = gh0 if t == 0 else ops.linear_fwd(h[t - 1], Whh, None)              # [B, 3H]
+                ops.gru_gates_fwd(gi[t], gh, h[t - 1] if t else None, h[t], save[t] if train else None)
+            if train:
+                layers.append(dict(x=x, h=h, save=save))
+            x = h
+        out_tm = ops.linear_fwd(x, self._p("dense.w"), self._p("dense.b"))               # [L, B, E]
+        out = out_tm.transpose(0, 1).contiguous()                                        # [B, L, E]: what the BPR head reads
+        return out, (dict(layers=layers, ids_tm=ids_tm) if train else None)
+
+    def _backward_core(self, grad_out, table):
+        """Backward of SeqRecCore._forward_core for the recurrent block: fills the flat gradient buffer, hands the gradient
+        w.r.t. the gathered input rows to the table machinery (`_after_input_grads`)."""
+        s = self._saved
+        if s is None:
+            raise PxrError("backward() without a training-mode forward()")
+        B, L, E, Hh = s["B"], self.max_seq_length, self.embedding_size, self.gru_hidden
+        g = lambda name: self._p(name, grad=True)
+        gsd = grad_out.reshape(1).to(torch.float32).contiguous()
+        dout, coef = ops.bpr_loss_bwd(s["pos"], s["neg"], table, s["items"], s["mask"], E, self.grad_scale, gsd)
+        dout_tm = dout.transpose(0, 1).contiguous()                                      # [L, B, E]
+        top = s["layers"][-1]
+        pend = [(dout_tm.view(L * B, E), top["h"].view(L * B, Hh), g("dense.w"), g("dense.b"))]
+        dh_out = ops.linear_bwd_input(dout_tm, self._p("dense.w"))                       # [L, B, H]: d loss / d h_t (output path)
+        dev = dout.device
+        for k in reversed(range(self.num_layers)):
+            a = s["layers"][k]
+            Wih, Whh = self._p(f"gru.{k}.ih"), self._p(f"gru.{k}.hh")
+            h, save = a["h"], a["save"]
+            dgi = torch.empty(L, B, 3 * Hh, dtype=torch.float32, device=dev)
+            dgh = torch.empty(L, B, 3 * Hh, dtype=torch.float32, device=dev)
+            direct = torch.empty(B, Hh, dtype=torch.float32, device=dev)
+            carry = None                                                                 # d loss / d h_t through step t + 1
+            for t in reversed(range(L)):
+                dh_t = dh_out[t] if carry is None else ops.add(dh_out[t], carry)
+                ops.gru_gates_bwd(dh_t, save[t], h[t - 1] if t else None, dgi[t], dgh[t], direct)
+                if t:
+                    carry = ops.linear_bwd_input(dgh[t], Whh, add=direct)                # d h_{t-1} = dh z + d gh_t W_hh
+            hprev = torch.cat((torch.zeros(1, B, Hh, dtype=torch.float32, device=dev), h[:-1]), dim=0)
+            pend.append((dgi.view(L * B, 3 * Hh), a["x"].view(L * B, -1), g(f"gru.{k}.ih"), None))
+            pend.append((dgh.view(L * B, 3 * Hh), hprev.view(L * B, Hh), g(f"gru.{k}.hh"), None))
+            dh_out = ops.linear_bwd_input(dgi, Wih)                                      # [L, B, in]: the layer below / the rows
+        dx0 = dh_out.transpose(0, 1).contiguous()                                        # [B, L, E]
+        self._after_input_grads(dx0, coef, s)
+        ops.grouped_linear_bwd_weight(pend)        # every weight (and the dense bias) gradient of the step: one launch
+        self._saved = None
+        ops.counter_add(self._drop_dev, 1)
+        self._step_counter += 1
+        return dx0, coef, s

@@ -46,6 +46,10 @@ class SASRec(SeqRecCore):
         self._build_core(config)
         self.item_embedding = nn.Embedding(self.item_num, self.hidden_size, padding_idx=0)
         self.apply(self._init_weights)   # incl. table row 0 (sasrec.py:49,56)
+        self._init_table_state()
+
+    def _init_table_state(self):
+        """Bookkeeping of the sparsely updated item table (shared with the sibling ID backbones)."""
         self.sparse_table_grad = None   # the table gradient the optimizer will apply (local, or merged across ranks)
         self._local_sparse = None       # reusable output buffer of this rank's backward
         self._table_hooks = None        # the lazy optimizer (catch_up_rows / flush) when one is attached

@@ -87,7 +87,11 @@ class SeqRecCore(BaseModel):
                                                      self.layer_norm_eps)
         self.LayerNorm = nn.LayerNorm(self.hidden_size, eps=self.layer_norm_eps)
         self.dropout = nn.Dropout(self.hidden_dropout_prob)
+        self._init_runtime_state(config)
 
+    def _init_runtime_state(self, config):
+        """Everything a model on the flat-buffer / hand-written-backward machinery carries besides its architecture (also used
+        by the sibling backbones that bring their own layers: gru4rec.py)."""
         self._flat = None            # packed non-table parameters
         self._gflat = None           # packed gradients (same layout)
         self._views = {}
@@ -153,9 +157,13 @@ class SeqRecCore(BaseModel):
                       (f"{i}.ln2.w", f.LayerNorm.weight), (f"{i}.ln2.b", f.LayerNorm.bias)]
         return specs
 
+    def _first_flat_parameter(self):
+        """The parameter at offset 0 of the flat buffer (its address tells whether the buffer is still the packed one)."""
+        return self.position_embedding.weight
+
     def _ensure_packed(self):
         """(Re)build the flat parameter / gradient buffers when the parameters moved (e.g. after .to(device))."""
-        w0 = self.position_embedding.weight
+        w0 = self._first_flat_parameter()
         if self._flat is not None and self._flat.device == w0.device and w0.data_ptr() == self._flat.data_ptr():
             return
         dev = w0.device

@@ -343,6 +343,20 @@ def tower_attn_bwd(qkv: torch.Tensor, dctx: torch.Tensor, ctx: torch.Tensor, lse
     return dqkv
 
 
+def gru_gates_fwd(gi, gh, h_prev, h_out, save=None):
+    """One GRU step's gates (pxr_gru_gates_fwd_f32): gi, gh [B, 3H]; h_prev [B, H] | None; writes h_out [B, H] (and save [B, 4H])."""
+    B, H = h_out.shape
+    _l.check(_l.load().pxr_gru_gates_fwd_f32(_l.ptr(gi), _l.ptr(gh), _l.ptr(h_prev), _l.ptr(h_out), _l.ptr(save), B, H,
+                                             _l.stream_ptr()), "pxr_gru_gates_fwd_f32")
+
+
+def gru_gates_bwd(dh, save, h_prev, dgi, dgh, dh_prev):
+    """Backward of gru_gates_fwd (pxr_gru_gates_bwd_f32): dh [B, H] -> dgi, dgh [B, 3H], dh_prev [B, H] = dh * z."""
+    B, H = dh.shape
+    _l.check(_l.load().pxr_gru_gates_bwd_f32(_l.ptr(dh), _l.ptr(save), _l.ptr(h_prev), _l.ptr(dgi), _l.ptr(dgh), _l.ptr(dh_prev),
+                                             B, H, _l.stream_ptr()), "pxr_gru_gates_bwd_f32")
+
+
 def softmax_rows(S: torch.Tensor, rows: int, T: int, ld: int, scale: float):
     _l.check(_l.load().pxr_softmax_rows_f32(_l.ptr(S), rows, T, ld, float(scale), _l.stream_ptr()), "pxr_softmax_rows_f32")
 

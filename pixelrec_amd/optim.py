@@ -35,6 +35,8 @@ def reference_rec_parameter_names(model):
     from .parameters() -- the order torch.optim.AdamW.state_dict() numbers its per-parameter state in:
     SASRec   (sasrec.py:31-45):   item_embedding, position_embedding, trm_encoder layers, LayerNorm;
     MOSASRec (mosasrec.py:30-47): [visual_encoder first], position_embedding, LayerNorm, trm_encoder layers."""
+    if hasattr(model, "rec_parameter_names"):          # a backbone that is not the Transformer block (GRU4Rec)
+        return list(model.rec_parameter_names())
     layers = [n for i in range(model.n_layers) for n in _layer_names(i)]
     if has_item_table(model):
         return ["item_embedding.weight", "position_embedding.weight"] + layers + ["LayerNorm.weight", "LayerNorm.bias"]
@@ -120,6 +122,8 @@ def _short_name(name, model=None):
     extra = model.encoder_parameter_names() if (model is not None and hasattr(model, "encoder_parameter_names")) else {}
     if name in extra:
         return extra[name]
+    if model is not None and hasattr(model, "rec_parameter_names"):
+        return model.rec_parameter_names()[name]
     if name == "position_embedding.weight":
         return "pos"
     if name.startswith("LayerNorm."):
