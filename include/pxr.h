@@ -321,6 +321,12 @@ int pxr_gru_gates_fwd_f32(const float* gi, const float* gh, const float* h_prev,
 int pxr_gru_gates_bwd_f32(const float* dh, const float* save, const float* h_prev, float* dgi, float* dgh, float* dh_prev,
                           int64_t B, int H, void* stream);
 
+/* ---- NextItNet (code/REC/model/IDNet/nextitnet.py:160-194): the causal dilated convolution as a GEMM ------------------ */
+/* xcol[b L + t, c k + j] = x[b, t - (k-1-j) dilation, c] (0 left of the sequence): conv = xcol . W.view(C_out, C_in k)^T + bias
+ * with the reference's Conv2d weight [C_out, C_in, 1, k] used in place.  col2im is its transpose (the input gradient). */
+int pxr_causal_im2col_f32(const float* x, float* xcol, int64_t B, int L, int C, int k, int dilation, void* stream);
+int pxr_causal_col2im_f32(const float* dxcol, float* dx, int64_t B, int L, int C, int k, int dilation, void* stream);
+
 /* ---- training head ------------------------------------------------------------------------------------------ */
 /* loss = mean_b(-sum_t log(sigmoid(pos-neg)+1e-8) * mask)            sasrec.py:88-92; loss stays on the device */
 int pxr_bpr_loss_fwd_f32(const float* out, const float* table, int64_t n_table, const int64_t* items,

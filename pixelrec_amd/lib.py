@@ -90,6 +90,8 @@ _SIGNATURES = {
     "pxr_tower_attn_supported": (_I, [_I, _I]),
     "pxr_tower_attn_fwd_f32": (_I, [_P, _P, _P, _I64, _I64, _I, _I, _I, _F, _P, _I64, _P, _I64, _I64, _P, _P]),
     "pxr_tower_attn_bwd_f32": (_I, [_P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I, _I, _I, _F, _P, _P, _P, _I64, _P, _P]),
+    "pxr_causal_im2col_f32": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
+    "pxr_causal_col2im_f32": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
     "pxr_gru_gates_fwd_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P]),
     "pxr_gru_gates_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _P]),
     "pxr_softmax_rows_f32": (_I, [_P, _I64, _I, _I, _F, _P]),

@@ -1,0 +1,194 @@
+"""NextItNet (IDNet) -- drop-in for `REC.model.IDNet.nextitnet.NextItNet` (code/REC/model/IDNet/nextitnet.py:13-113 with the
+residual block (b) of :160-194): item-ID embeddings -> a stack of residual blocks, each two CAUSAL DILATED 1-D convolutions
+(kernel k, dilations d and 2 d; zero padding on the left only) followed by LayerNorm(eps 1e-8) + ReLU, plus the block
+input -> optional `final_layer` -> the same BPR-style loss against one sampled negative per position as SASRec.  No padding
+mask anywhere, as in the reference.
+
+A sibling backbone sharing SASRec's step shape.  Like `gru4rec.py`, everything around the block is this
+build's SASRec machinery, inherited: the sparsely updated item table (id sort, lazy AdamW catch-up, sparse row gradient), the
+BPR head, `predict` / fused top-k evaluation, the flat parameter buffer, `PxrAdamW`, `GraphedTrainStep`, `DataParallel`.
+
+The convolution is a GEMM on an im2col matrix whose column order (c k + j) is the memory order of the reference's
+`nn.Conv2d` weight `[C_out, C_in, 1, k]`, so the parameter is used IN PLACE (`csrc/conv1d.hip`: `pxr_causal_im2col_f32` and
+its transpose `pxr_causal_col2im_f32` for the input gradient); bias in the GEMM epilogue; LayerNorm forward / backward are the
+library's kernels; all weight and bias gradients of the step come from one grouped launch.
+
+Contract kept: `input_type`; `__init__(config, dataload)` with the reference's keys (`embedding_size`, `block_num`,
+`dilations`, `kernel_size`, `final_layer`, `reg_weight`); `forward`, `predict`, `compute_item_all`, `reg_loss_rb`; `state_dict`
+keys `item_embedding.weight`, `residual_blocks.{i}.{conv1,ln1,conv2,ln2}.{weight,bias}`, `final_layer.{weight,bias}`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.enum_type import InputType
+from .sasrec import SASRec
+from .seqcore import PxrError, SeqRecCore
+
+
+class ResidualBlock_b(nn.Module):
+    """Parameter container with the reference's names and shapes (nextitnet.py:160-172); never called."""
+
+    def __init__(self, in_channel, out_channel, kernel_size=3, dilation=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channel, out_channel, kernel_size=(1, kernel_size), padding=0, dilation=dilation)
+        self.ln1 = nn.LayerNorm(out_channel, eps=1e-8)
+        self.conv2 = nn.Conv2d(out_channel, out_channel, kernel_size=(1, kernel_size), padding=0, dilation=dilation * 2)
+        self.ln2 = nn.LayerNorm(out_channel, eps=1e-8)
+        self.dilation = dilation
+        self.kernel_size = kernel_size
+
+
+class NextItNet(SASRec):
+    input_type = InputType.SEQ
+    LN_EPS = 1e-8
+
+    def __init__(self, config, dataload):
+        SeqRecCore.__init__(self)
+        self.embedding_size = config["embedding_size"]
+        self.residual_channels = config["embedding_size"]
+        self.block_num = config["block_num"]
+        self.dilations = list(config["dilations"]) * self.block_num            # nextitnet.py:22: [1, 4, 1, 4, ...]
+        self.kernel_size = config["kernel_size"]
+        self.reg_weight = config["reg_weight"] or 0.0
+        self.item_num = dataload.item_num
+        self.max_seq_length = config["MAX_ITEM_LIST_LENGTH"]
+        self.hidden_size = self.embedding_size
+        self.inner_size = self.embedding_size
+        self.n_layers = len(self.dilations)
+        if self.embedding_size % 4:
+            raise ValueError("embedding_size must be a multiple of 4 (16-byte vector accesses)")
+        self.item_embedding = nn.Embedding(self.item_num, self.embedding_size, padding_idx=0)
+        self.residual_blocks = nn.Sequential(*[ResidualBlock_b(self.residual_channels, self.residual_channels,
+                                                               kernel_size=self.kernel_size, dilation=d) for d in self.dilations])
+        self.final_layer = nn.Linear(self.residual_channels, self.embedding_size) if config["final_layer"] else nn.Identity()
+        self.apply(self._init_weights)
+        self._init_runtime_state(config)
+        self._init_table_state()
+
+    def _init_weights(self, module):
+        """nextitnet.py:49-56: U(-1/sqrt(N), 1/sqrt(N)) table, xavier-normal Linear with bias 0.1; Conv2d / LayerNorm keep
+        torch's defaults."""
+        if isinstance(module, nn.Embedding):
+            stdv = np.sqrt(1.0 / self.item_num)
+            nn.init.uniform_(module.weight.data, -stdv, stdv)
+        elif isinstance(module, nn.Linear):
+            nn.init.xavier_normal_(module.weight.data)
+            if module.bias is not None:
+                nn.init.constant_(module.bias.data, 0.1)
+
+    def reg_loss_rb(self):
+        """nextitnet.py:80-89 (defined by the reference, not part of its forward)."""
+        loss_rb = 0
+        if self.reg_weight > 0.0:
+            for name, parm in self.residual_blocks.named_parameters():
+                if name.endswith("weight"):
+                    loss_rb = loss_rb + torch.norm(parm, 2)
+        return self.reg_weight * loss_rb
+
+    # ------------------------------------------------------------------------------------------ flat packing
+    _BLOCK_PARTS = (("conv1", "c1"), ("ln1", "l1"), ("conv2", "c2"), ("ln2", "l2"))
+
+    def _flat_specs(self):
+        specs = []
+        for i, blk in enumerate(self.residual_blocks):
+            for mod, short in self._BLOCK_PARTS:
+                m = getattr(blk, mod)
+                specs += [(f"rb.{i}.{short}.w", m.weight), (f"rb.{i}.{short}.b", m.bias)]
+        if isinstance(self.final_layer, nn.Linear):
+            specs += [("final.w", self.final_layer.weight), ("final.b", self.final_layer.bias)]
+        return specs
+
+    def _first_flat_parameter(self):
+        return self.residual_blocks[0].conv1.weight
+
+    def rec_parameter_names(self):
+        """{reference parameter name: flat-buffer key} in the reference's registration order (nextitnet.py:29-43)."""
+        out = {"item_embedding.weight": None}
+        for i in range(len(self.dilations)):
+            for mod, short in self._BLOCK_PARTS:
+                out[f"residual_blocks.{i}.{mod}.weight"] = f"rb.{i}.{short}.w"
+                out[f"residual_blocks.{i}.{mod}.bias"] = f"rb.{i}.{short}.b"
+        if isinstance(self.final_layer, nn.Linear):
+            out["final_layer.weight"], out["final_layer.bias"] = "final.w", "final.b"
+        return out
+
+    def _planes_on(self) -> bool:
+        return False
+
+    def weight_plane_segments(self):
+        return None
+
+    def refresh_weight_planes(self):
+        return None
+
+    # ------------------------------------------------------------------------------------------ residual blocks
+    def _conv_ln_relu(self, x, i, which, dilation, train):
+        """relu(LN(conv(x))) for conv `which` (1 | 2) of block i; returns (out, what the backward needs | None)."""
+        C, k = self.residual_channels, self.kernel_size
+        xc = ops.causal_im2col(x, k, dilation)                                           # [B, L, C k]
+        W = self._p(f"rb.{i}.c{which}.w").view(C, C * k)                                 # the Conv2d weight, in place
+        a = ops.linear_fwd(xc, W, self._p(f"rb.{i}.c{which}.b"))
+        y, xhat, rstd = ops.ln_residual_fwd(a, None, self._p(f"rb.{i}.l{which}.w"), self._p(f"rb.{i}.l{which}.b"), self.LN_EPS,
+                                            save=train)
+        r = torch.relu(y)
+        return r, (dict(xc=xc, xhat=xhat, rstd=rstd, r=r) if train else None)
+
+    def _encode(self, table, idx, idx_bstride, B, keymask, km_bstride, train: bool):
+        """row ids into `table` -> final_layer(residual_blocks(rows)) [B, L, E] (nextitnet.py:58-70 / :95-101)."""
+        L = self.max_seq_length
+        ids = idx.reshape(B, idx_bstride)[:, :L].contiguous()
+        x = ops.embed_gather(table, ids)                                                 # [B, L, C]
+        blocks = []
+        for i, d in enumerate(self.dilations):
+            r1, s1 = self._conv_ln_relu(x, i, 1, d, train)
+            r2, s2 = self._conv_ln_relu(r1, i, 2, 2 * d, train)
+            x = ops.add(r2, x)                                                           # nextitnet.py:181
+            blocks.append((s1, s2))
+        if isinstance(self.final_layer, nn.Linear):
+            out = ops.linear_fwd(x, self._p("final.w"), self._p("final.b"))
+        else:
+            out = x
+        return out, (dict(blocks=blocks, x_last=x) if train else None)
+
+    def _conv_ln_relu_bwd(self, g, s, i, which, dilation, pend, defer):
+        """d loss / d(relu(LN(conv(x)))) -> d loss / d x; queues the conv's weight / bias gradient, the LayerNorm's go to `defer`."""
+        C, k = self.residual_channels, self.kernel_size
+        B, L = g.shape[0], g.shape[1]
+        dy = (g * (s["r"] > 0)).contiguous()
+        gp = lambda name: self._p(name, grad=True)
+        da, _ = ops.ln_bwd(0, dy, s["xhat"], s["rstd"], self._p(f"rb.{i}.l{which}.w"), gp(f"rb.{i}.l{which}.w"),
+                           gp(f"rb.{i}.l{which}.b"), defer=defer)
+        pend.append((da.view(B * L, C), s["xc"].view(B * L, C * k), gp(f"rb.{i}.c{which}.w").view(C, C * k), gp(f"rb.{i}.c{which}.b")))
+        dxc = ops.linear_bwd_input(da, self._p(f"rb.{i}.c{which}.w").view(C, C * k))    # [B, L, C k]
+        return ops.causal_col2im(dxc, k, dilation)
+
+    def _backward_core(self, grad_out, table):
+        s = self._saved
+        if s is None:
+            raise PxrError("backward() without a training-mode forward()")
+        B, L, E = s["B"], self.max_seq_length, self.embedding_size
+        gsd = grad_out.reshape(1).to(torch.float32).contiguous()
+        d, coef = ops.bpr_loss_bwd(s["pos"], s["neg"], table, s["items"], s["mask"], E, self.grad_scale, gsd)
+        pend = []
+        defer = ops.DeferredReductions()
+        if isinstance(self.final_layer, nn.Linear):
+            pend.append((d.view(B * L, E), s["x_last"].view(B * L, -1), self._p("final.w", grad=True), self._p("final.b", grad=True)))
+            d = ops.linear_bwd_input(d, self._p("final.w"))
+        for i in reversed(range(len(self.dilations))):
+            s1, s2 = s["blocks"][i]
+            dil = self.dilations[i]
+            dr1 = self._conv_ln_relu_bwd(d, s2, i, 2, 2 * dil, pend, defer)
+            dx = self._conv_ln_relu_bwd(dr1, s1, i, 1, dil, pend, defer)
+            d = ops.add(dx, d)                                                           # the residual path
+        dx0 = d.contiguous()
+        self._after_input_grads(dx0, coef, s)
+        ops.grouped_linear_bwd_weight(pend)        # every conv / final-layer weight and bias gradient of the step: one launch
+        defer.flush()
+        self._saved = None
+        ops.counter_add(self._drop_dev, 1)
+        self._step_counter += 1
+        return dx0, coef, s

@@ -343,6 +343,25 @@ def tower_attn_bwd(qkv: torch.Tensor, dctx: torch.Tensor, ctx: torch.Tensor, lse
     return dqkv
 
 
+def causal_im2col(x: torch.Tensor, k: int, dilation: int) -> torch.Tensor:
+    """x [B, L, C] -> xcol [B, L, C*k] with xcol[b, t, c*k + j] = x[b, t - (k-1-j)*dilation, c] (pxr_causal_im2col_f32)."""
+    _req(x, torch.float32, "x")
+    B, L, C = x.shape
+    out = torch.empty(B, L, C * k, dtype=torch.float32, device=x.device)
+    _l.check(_l.load().pxr_causal_im2col_f32(_l.ptr(x), _l.ptr(out), B, L, C, k, dilation, _l.stream_ptr()), "pxr_causal_im2col_f32")
+    return out
+
+
+def causal_col2im(dxcol: torch.Tensor, k: int, dilation: int) -> torch.Tensor:
+    """The transpose of causal_im2col: dxcol [B, L, C*k] -> dx [B, L, C] (pxr_causal_col2im_f32)."""
+    _req(dxcol, torch.float32, "dxcol")
+    B, L, Ck = dxcol.shape
+    out = torch.empty(B, L, Ck // k, dtype=torch.float32, device=dxcol.device)
+    _l.check(_l.load().pxr_causal_col2im_f32(_l.ptr(dxcol), _l.ptr(out), B, L, Ck // k, k, dilation, _l.stream_ptr()),
+             "pxr_causal_col2im_f32")
+    return out
+
+
 def gru_gates_fwd(gi, gh, h_prev, h_out, save=None):
     """One GRU step's gates (pxr_gru_gates_fwd_f32): gi, gh [B, 3H]; h_prev [B, H] | None; writes h_out [B, H] (and save [B, 4H])."""
     B, H = h_out.shape
