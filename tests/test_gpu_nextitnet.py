@@ -107,7 +107,8 @@ def test_nextitnet_training_steps_follow_torch_adamw_on_the_oracle():
     sd = m.state_dict()
     for k, v in ref.items():
         diff = (sd[k].cpu().double() - v.detach()).abs()
-        # Single-step gradients agree with the oracle to ~1e-7 at this shape (tools/diag/nextitnet_grad_check.py) and one
+        # Single-step gradients agree with the oracle to ~1e-7 at this shape (checked below in
+        # test_nextitnet_single_step_gradients_at_the_shipped_dilations) and one
         # PxrAdamW step from equal state and gradients equals torch.optim.AdamW (tests/test_gpu_sasrec.py).  Over several steps
         # Adam normalises every element's step to ~lr whatever the gradient's size: where a gradient is at rounding level (conv
         # taps that mostly see the zero padding left of a 10-step sequence) its SIGN is noise on either side, those weights part
@@ -153,3 +154,38 @@ def test_trainer_runs_nextitnet_end_to_end(tmp_path):
     topt = torch.optim.AdamW(tparams, lr=1.0, weight_decay=0.5)
     topt.load_state_dict(ck["optimizer"])
     assert topt.state[tparams[1]]["exp_avg"].shape == tparams[1].shape == (32, 32, 1, 3)
+
+
+def test_nextitnet_single_step_gradients_at_the_shipped_dilations():
+    """One step at emb 64, dilations 2 x [1, 4] (second convolutions at 2 and 8, L = 10: taps that only ever see the left
+    padding), every non-table gradient against the fp64 oracle: the measured error is ~1e-7."""
+    from oracle import nextitnet_oracle as NO
+    from pixelrec_amd.model import NextItNet
+
+    n, e, l, b = 500, 64, 10, 8
+    dil = [1, 4]
+
+    class DL:
+        item_num = n
+
+    torch.manual_seed(3)
+    m = NextItNet(_config(False, e=e, blocks=2, dil=dil, l=l), DL())
+    ref = {k: v.detach().clone().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    m = m.cuda().train()
+    rng = np.random.default_rng(6)
+    items = torch.from_numpy(rng.integers(1, n, size=(b, 2, l + 1)).astype(np.int64))
+    mask = torch.ones(b, l, dtype=torch.int64)
+    loss = m((items.cuda(), mask.cuda()))
+    loss.backward()
+    rl = NO.forward_loss(ref, items, mask, dil * 2)
+    rl.backward()
+    assert abs(float(loss.detach()) - float(rl.detach())) < 2e-6 * abs(float(rl.detach()))
+    for name, p in m.named_parameters():
+        if name == "item_embedding.weight":
+            continue
+        want = ref[name].grad
+        err = (p.grad.cpu().double() - want).abs().max().item()
+        assert err < 2e-6 * max(1.0, want.abs().max().item()), (name, err)
+    dead = ref["residual_blocks.1.conv2.weight"].grad[:, :, 0, 0]            # dilation 8, tap 0 reaches back 16 > L positions
+    assert float(dead.abs().max()) == 0.0
+    assert float(m.residual_blocks[1].conv2.weight.grad[:, :, 0, 0].abs().max()) == 0.0
