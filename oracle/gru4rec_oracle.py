@@ -47,3 +47,12 @@ def predict(params, item_seq, item_feature, n_layers):
     """gru4rec.py:71-82."""
     out = encode({**params, "item_embedding.weight": item_feature}, item_seq, n_layers)
     return out[:, -1] @ item_feature.t()
+
+
+def forward_loss_rows(params, item_emb, masked_index, n_layers):
+    """PixelNet's MOGRU4Rec.forward after the image encoder (code/REC/model/PixelNet/mogru4rec.py:45-63): item_emb
+    [B, L+1, 2, D] with pos | neg interleaved -- the same composition as MOSASRec (oracle/mosasrec_oracle.py)."""
+    pos, neg = item_emb[:, :, 0], item_emb[:, :, 1]
+    out = gru_stack(params, pos[:, :-1], n_layers) @ params["dense.weight"].t() + params["dense.bias"]
+    ps, ns = (out * pos[:, 1:]).sum(-1), (out * neg[:, 1:]).sum(-1)
+    return (-(torch.log((ps - ns).sigmoid() + 1e-8) * masked_index).sum(-1)).mean(-1)

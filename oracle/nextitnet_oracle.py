@@ -29,7 +29,10 @@ def layer_norm(x, w, b, eps=1e-8):
 
 
 def encode(params, seq_ids, dilations):
-    x = params["item_embedding.weight"][seq_ids]
+    return encode_rows(params, params["item_embedding.weight"][seq_ids], dilations)
+
+
+def encode_rows(params, x, dilations):
     for i, d in enumerate(dilations):
         p = lambda n: params[f"residual_blocks.{i}.{n}"]
         o = torch.relu(layer_norm(causal_conv(x, p("conv1.weight"), p("conv1.bias"), d), p("ln1.weight"), p("ln1.bias")))
@@ -56,3 +59,12 @@ def predict(params, item_seq, item_feature, dilations):
     """nextitnet.py:92-106 (the sequence is embedded with the model's own table)."""
     out = encode(params, item_seq, dilations)
     return out[:, -1] @ item_feature.t()
+
+
+def forward_loss_rows(params, item_emb, masked_index, dilations):
+    """PixelNet's MONextItNet.forward after the image encoder (code/REC/model/PixelNet/monextitnet.py:55-73): item_emb
+    [B, L+1, 2, D] with pos | neg interleaved."""
+    pos, neg = item_emb[:, :, 0], item_emb[:, :, 1]
+    out = encode_rows(params, pos[:, :-1], dilations)
+    ps, ns = (out * pos[:, 1:]).sum(-1), (out * neg[:, 1:]).sum(-1)
+    return (-(torch.log((ps - ns).sigmoid() + 1e-8) * masked_index).sum(-1)).mean(-1)

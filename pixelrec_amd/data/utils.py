@@ -16,7 +16,8 @@ from ..parallel import world_info
 from .dataload import Data
 from .dataset import SeqEvalBatcher, SeqEvalDataset, SeqTrainBatcher, seq_eval_collate
 
-SUPPORTED = {"SASRec": "SEQ", "MOSASRec": "SEQ", "FSASRec": "SEQ", "GRU4Rec": "SEQ", "NextItNet": "SEQ"}      # REC/data/utils.py:24-31
+SUPPORTED = {"SASRec": "SEQ", "MOSASRec": "SEQ", "FSASRec": "SEQ", "GRU4Rec": "SEQ", "NextItNet": "SEQ",
+             "MOGRU4Rec": "SEQ", "MONextItNet": "SEQ"}      # REC/data/utils.py:24-31
 
 
 def load_data(config):

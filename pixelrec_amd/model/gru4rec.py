@@ -32,39 +32,26 @@ from .sasrec import SASRec
 from .seqcore import PxrError, SeqRecCore
 
 
-class GRU4Rec(SASRec):
-    input_type = InputType.SEQ
+class GRUBlock:
+    """The recurrent block as a mixin: parameters (`gru_layers`, `dense`), flat packing, forward and hand-written backward.
+    Used by GRU4Rec (rows from the item table) and by PixelNet's MOGRU4Rec (rows from the image encoder, mogru4rec.py)."""
 
-    def __init__(self, config, dataload):
-        SeqRecCore.__init__(self)
+    def _build_gru(self, config, dataload):
         self.embedding_size = config["embedding_size"]
         self.gru_hidden = config["hidden_size"] * config["embedding_size"]      # gru4rec.py:17: a multiplier
         self.num_layers = config["num_layers"]
         self.dropout_prob = float(config["dropout_prob"] or 0.0)
         self.item_num = dataload.item_num
         self.max_seq_length = config["MAX_ITEM_LIST_LENGTH"]
-        self.hidden_size = self.embedding_size                                   # width of the table rows / of `out` (SASRec's name)
+        self.hidden_size = self.embedding_size                                   # width of the rows / of `out` (SASRec's name)
         self.inner_size = self.gru_hidden
         self.n_layers = self.num_layers
         if self.embedding_size % 4 or self.gru_hidden % 4:
             raise ValueError("embedding_size and hidden_size * embedding_size must be multiples of 4 (16-byte vector accesses)")
-        self.item_embedding = nn.Embedding(self.item_num, self.embedding_size, padding_idx=0)
         self.emb_dropout = nn.Dropout(self.dropout_prob)
         self.gru_layers = nn.GRU(input_size=self.embedding_size, hidden_size=self.gru_hidden, num_layers=self.num_layers,
                                  bias=False, batch_first=True)                   # parameter container: never called
         self.dense = nn.Linear(self.gru_hidden, self.embedding_size)
-        self.apply(self._init_weights)
-        self._init_runtime_state(config)
-        self._init_table_state()
-
-    def _init_weights(self, module):
-        """gru4rec.py:43-48: xavier-normal table, xavier-uniform for LAYER 0's GRU matrices only (deeper layers and `dense`
-        keep torch's defaults)."""
-        if isinstance(module, nn.Embedding):
-            nn.init.xavier_normal_(module.weight)
-        elif isinstance(module, nn.GRU):
-            nn.init.xavier_uniform_(module.weight_hh_l0)
-            nn.init.xavier_uniform_(module.weight_ih_l0)
 
     # ------------------------------------------------------------------------------------------ flat packing
     def _flat_specs(self):
@@ -80,7 +67,7 @@ class GRU4Rec(SASRec):
     def rec_parameter_names(self):
         """{reference parameter name: flat-buffer key} in the order the reference registers them (gru4rec.py:26-36): what
         torch.optim.AdamW numbers its state in (optim.reference_rec_parameter_names)."""
-        out = {"item_embedding.weight": None}
+        out = {"item_embedding.weight": None} if isinstance(getattr(self, "item_embedding", None), nn.Embedding) else {}
         for k in range(self.num_layers):
             out[f"gru_layers.weight_ih_l{k}"] = f"gru.{k}.ih"
             out[f"gru_layers.weight_hh_l{k}"] = f"gru.{k}.hh"
@@ -162,3 +149,24 @@ class GRU4Rec(SASRec):
         ops.counter_add(self._drop_dev, 1)
         self._step_counter += 1
         return dx0, coef, s
+
+
+class GRU4Rec(GRUBlock, SASRec):
+    input_type = InputType.SEQ
+
+    def __init__(self, config, dataload):
+        SeqRecCore.__init__(self)
+        self.item_embedding = nn.Embedding(dataload.item_num, config["embedding_size"], padding_idx=0)   # gru4rec.py:25
+        self._build_gru(config, dataload)
+        self.apply(self._init_weights)
+        self._init_runtime_state(config)
+        self._init_table_state()
+
+    def _init_weights(self, module):
+        """gru4rec.py:43-48: xavier-normal table, xavier-uniform for LAYER 0's GRU matrices only (deeper layers and `dense`
+        keep torch's defaults)."""
+        if isinstance(module, nn.Embedding):
+            nn.init.xavier_normal_(module.weight)
+        elif isinstance(module, nn.GRU):
+            nn.init.xavier_uniform_(module.weight_hh_l0)
+            nn.init.xavier_uniform_(module.weight_ih_l0)

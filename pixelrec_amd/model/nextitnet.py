@@ -42,18 +42,18 @@ class ResidualBlock_b(nn.Module):
         self.kernel_size = kernel_size
 
 
-class NextItNet(SASRec):
-    input_type = InputType.SEQ
+class NextItBlock:
+    """The stack of residual blocks (b) as a mixin: parameters, flat packing, forward and hand-written backward.  Used by
+    NextItNet (rows from the item table) and by PixelNet's MONextItNet (rows from the image encoder, monextitnet.py)."""
     LN_EPS = 1e-8
 
-    def __init__(self, config, dataload):
-        SeqRecCore.__init__(self)
+    def _build_blocks(self, config, dataload):
         self.embedding_size = config["embedding_size"]
         self.residual_channels = config["embedding_size"]
         self.block_num = config["block_num"]
         self.dilations = list(config["dilations"]) * self.block_num            # nextitnet.py:22: [1, 4, 1, 4, ...]
         self.kernel_size = config["kernel_size"]
-        self.reg_weight = config["reg_weight"] or 0.0
+        self.reg_weight = getattr(self, "reg_weight", 0.0)
         self.item_num = dataload.item_num
         self.max_seq_length = config["MAX_ITEM_LIST_LENGTH"]
         self.hidden_size = self.embedding_size
@@ -61,13 +61,9 @@ class NextItNet(SASRec):
         self.n_layers = len(self.dilations)
         if self.embedding_size % 4:
             raise ValueError("embedding_size must be a multiple of 4 (16-byte vector accesses)")
-        self.item_embedding = nn.Embedding(self.item_num, self.embedding_size, padding_idx=0)
         self.residual_blocks = nn.Sequential(*[ResidualBlock_b(self.residual_channels, self.residual_channels,
                                                                kernel_size=self.kernel_size, dilation=d) for d in self.dilations])
         self.final_layer = nn.Linear(self.residual_channels, self.embedding_size) if config["final_layer"] else nn.Identity()
-        self.apply(self._init_weights)
-        self._init_runtime_state(config)
-        self._init_table_state()
 
     def _init_weights(self, module):
         """nextitnet.py:49-56: U(-1/sqrt(N), 1/sqrt(N)) table, xavier-normal Linear with bias 0.1; Conv2d / LayerNorm keep
@@ -107,7 +103,7 @@ class NextItNet(SASRec):
 
     def rec_parameter_names(self):
         """{reference parameter name: flat-buffer key} in the reference's registration order (nextitnet.py:29-43)."""
-        out = {"item_embedding.weight": None}
+        out = {"item_embedding.weight": None} if isinstance(getattr(self, "item_embedding", None), nn.Embedding) else {}
         for i in range(len(self.dilations)):
             for mod, short in self._BLOCK_PARTS:
                 out[f"residual_blocks.{i}.{mod}.weight"] = f"rb.{i}.{short}.w"
@@ -192,3 +188,16 @@ class NextItNet(SASRec):
         ops.counter_add(self._drop_dev, 1)
         self._step_counter += 1
         return dx0, coef, s
+
+
+class NextItNet(NextItBlock, SASRec):
+    input_type = InputType.SEQ
+
+    def __init__(self, config, dataload):
+        SeqRecCore.__init__(self)
+        self.reg_weight = config["reg_weight"] or 0.0
+        self.item_embedding = nn.Embedding(dataload.item_num, config["embedding_size"], padding_idx=0)   # nextitnet.py:29
+        self._build_blocks(config, dataload)
+        self.apply(self._init_weights)
+        self._init_runtime_state(config)
+        self._init_table_state()
