@@ -93,3 +93,44 @@ def test_mo_sibling_loss_and_gradients_match_the_composed_oracle(name):
         else:
             want = NO.encode_rows({k: v.detach() for k, v in sp.items()}, ref_feat[seq], [1, 2, 1, 2])[:, -1] @ ref_feat.t()
         assert (scores.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("name,model_yaml", [
+    ("MOGRU4Rec", "model: MOGRU4Rec\nnum_layers: 1\nembedding_size: 32\nhidden_size: 1\ndropout_prob: 0\ninitializer_range: 0.02\n"),
+    ("MONextItNet", "model: MONextItNet\nembedding_size: 32\nkernel_size: 3\nblock_num: 2\ndilations: [1,4]\nfinal_layer: False\n"),
+])
+def test_mo_sibling_trainer_end_to_end(tmp_path, name, model_yaml):
+    """PixelNet/{gru4rec,nextitnet}.yaml-shaped runs through the main.py surface: data -> model -> Trainer.fit / evaluate with
+    the HBM-resident image store, two optimizer groups, full-sort evaluation over encoder-produced item features."""
+    from pixelrec_amd.config import Config
+    from pixelrec_amd.data import bulid_dataloader, load_data
+    from pixelrec_amd.optim import OptimizerGroup
+    from pixelrec_amd.parallel import DataParallel
+    from pixelrec_amd.trainer import Trainer
+    from pixelrec_amd.utils import get_model
+    from tests.golden_util import GOLDEN_DIR
+
+    my, ov = tmp_path / "m.yaml", tmp_path / "o.yaml"
+    my.write_text(model_yaml)
+    ov.write_text(f"seed: 2020\nstate: INFO\nuse_modality: True\nreproducibility: True\ncheckpoint_dir: '{tmp_path}/saved'\n"
+                  f"log_path: '{tmp_path}/log'\nshow_progress: False\nMAX_ITEM_LIST_LENGTH: 6\ndata_path: {GOLDEN_DIR}/\n"
+                  "dataset: TinyInter\nimage_path: 'synthetic:64'\nencoder_name: 'clip-vit-tiny-test'\n"
+                  "encoder_source: 'transformers'\nepochs: 3\ntrain_batch_size: 8\n"
+                  "fine_tune_arg: {tune_scale: 37, pre_trained: True, activation: 'relu', dnn_layers: [], method: 'mean'}\n"
+                  "optim_args: {modal_lr: 0.001, rec_lr: 0.001, modal_decay: 0, rec_decay: 0.1}\n"
+                  "eval_batch_size: 16\ntopk: [5,10]\nmetrics: ['Recall', 'NDCG']\nvalid_metric: NDCG@10\n"
+                  "metric_decimal_place: 7\neval_step: 1\nstopping_step: 30\n")
+    config = Config([str(my), str(ov)])
+    config["device"] = torch.device("cuda", 0)
+    dataload = load_data(config)
+    train, valid, test = bulid_dataloader(config, dataload)
+    model = get_model(config["model"])(config, dataload).to(config["device"])
+    assert type(model).__name__ == name
+    trainer = Trainer(config, DataParallel(model))
+    assert isinstance(trainer.optimizer, OptimizerGroup)
+    trainer.fit(train, valid, saved=True)
+    losses = [trainer.train_loss_dict[e] for e in sorted(trainer.train_loss_dict)]
+    assert len(losses) == 3 and losses[-1] < losses[0]
+    out = trainer.evaluate(test, load_best_model=True)
+    assert set(out) == {"recall@5", "recall@10", "ndcg@5", "ndcg@10"}
+    assert trainer.item_feature.shape == (dataload.item_num, 32)
