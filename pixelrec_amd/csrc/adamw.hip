@@ -583,8 +583,11 @@ static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blo
   a.fast = lazy_replay_fast() ? 1 : 0;
   a.sqrt_b2 = sqrtf(a.b2);
   a.log2_b2 = log2f(a.b2);
+  // Replayed steps per row before the closed form takes over.  Exact mode: 256 (the bit-identity window of the tests).  Fast
+  // mode: 128 -- the Adam terms dropped beyond it sum to < 31.6 lr rho^128 / (1 - rho) = 4.7e-4 lr (rho = b1 / sqrt(b2) = 0.90045;
+  // 4.7e-8 at lr 1e-4, against the 1e-5 parity budget), and the rows at the cap are the ones that set the kernel's duration.
   const char* w = getenv("PXR_LAZY_WINDOW");
-  a.window = w ? atoi(w) : PXR_LAZY_EXACT;
+  a.window = w ? atoi(w) : (a.fast ? PXR_LAZY_EXACT / 2 : PXR_LAZY_EXACT);
   if (a.window < 0 || a.window > PXR_LAZY_EXACT) a.window = PXR_LAZY_EXACT;
   hipStream_t st = (hipStream_t)stream;
   // 2 elements per lane up to D = 2048 (a 512-wide row = 4 waves), 4 beyond (block size caps at 1024 threads)
