@@ -64,7 +64,7 @@ __device__ __forceinline__ void ta_load(TaStage (&st)[(TA_ITEMS + NT - 1) / NT],
       st[it].r1 = ok ? *reinterpret_cast<const ta_f32x4*>(src + 4) : z;
       st[it].r2 = z; st[it].r3 = z;
     } else {
-      const int j = (item - 256) & 127, kg = j >> 4, c = (j & 15) * 4;      // items >= TA_ITEMS load (and later drop) a duplicate
+      const int j = (item - 256) & 127, kg = j & 7, c = (j >> 3) * 4;       // items >= TA_ITEMS load (and later drop) a duplicate
       const int key = key0 + kg * 4;
       const float* src = a.v + base + (int64_t)key * a.ld + c;
       st[it].r0 = (key < a.T) ? *reinterpret_cast<const ta_f32x4*>(src) : z;
@@ -98,7 +98,8 @@ __device__ __forceinline__ void ta_store(const TaStage (&st)[(TA_ITEMS + NT - 1)
       // keys 4 kg .. 4 kg + 3 of dh c .. c + 3, transposed: per dh one 8-byte run of 4 keys.  Key groups are stored in the
       // order the P^T fragments hold them: inside a 16-key step  [0-3 | 8-11 | 4-7 | 12-15]  (slot group = kg with its two
       // low bits swapped).
-      const int j = item - 256, kg = j >> 4, c = (j & 15) * 4;
+      // (consecutive lanes = consecutive key groups: their 8-byte transposed writes land 2-4 words apart instead of 16 banks apart)
+      const int j = item - 256, kg = j & 7, c = (j >> 3) * 4;
       const int sg = (kg & 4) | ((kg & 1) << 1) | ((kg >> 1) & 1);
       __bf16* dst = sV + c * TA_VLD + sg * 4;
       const TaStage& t = st[it];
@@ -298,7 +299,7 @@ struct TowerBwdArgs {
 struct TaBlk { ta_f32x4 r0, r1, r2, r3; };     // rows 4 kg .. 4 kg + 3, columns c .. c + 3 of a 32 x 64 chunk
 
 __device__ __forceinline__ void ta_blk_load(TaBlk& t, const float* src, int64_t ld, int row0, int T, int j) {
-  const int kg = j >> 4, c = (j & 15) * 4, row = row0 + 4 * kg;
+  const int kg = j & 7, c = (j >> 3) * 4, row = row0 + 4 * kg;
   const float* p = src + (int64_t)row * ld + c;
   const ta_f32x4 z = {0.f, 0.f, 0.f, 0.f};
   t.r0 = (row < T) ? *reinterpret_cast<const ta_f32x4*>(p) : z;
@@ -308,7 +309,7 @@ __device__ __forceinline__ void ta_blk_load(TaBlk& t, const float* src, int64_t 
 }
 // kc: [row][dh] planes (A operand, k = dh);  tr: [dh][row slot] planes (A operand, k = rows in fragment order); either may be null
 __device__ __forceinline__ void ta_blk_store(const TaBlk& t, int j, __bf16* kc, __bf16* tr) {
-  const int kg = j >> 4, c = (j & 15) * 4;
+  const int kg = j & 7, c = (j >> 3) * 4;       // lanes of a wave: 8 row groups x 8 column quads (transposed writes conflict-free)
   if (kc) {
     __bf16* dst = kc + (4 * kg) * TA_KLD + c;
 #define PXR_TA_KROW(i, R)                                                                    \
