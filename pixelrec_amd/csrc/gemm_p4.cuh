@@ -1,0 +1,329 @@
+// gemm_p4.cuh -- the planes GEMM main loop for BIG tiles (ViT tower, full-catalogue scoring, wide weight gradients):
+// eight waves in two groups that run half a k block apart ("ping-pong"), a ring of 16-wide k blocks in LDS.
+//
+// Why a second main loop.  gemm_p3.cuh's 256x128 tile keeps all eight waves in lockstep: per 32-wide K tile every wave
+// waits at the barrier, issues its 9 LDS-DMA pieces, reads 24 fragments and only then multiplies -- the two waves of a SIMD
+// do their memory work at the SAME time and then contend for the SAME matrix pipe (MI355X_MICROARCH.md "Two waves per SIMD").
+// Measured (profiles/r03): the pipe is busy 57 % of the cycles the clock actually delivers.  Here the waves 0-3 (group 0) and
+// 4-7 (group 1; wave w and w + 4 share a SIMD) alternate roles every barrier: while one group issues its 24 MFMAs of a
+// 16-wide k block (C segment), the other one reads its 12 fragments of the next k block and issues its share of the DMA
+// (L segment).  Same arithmetic, same order of products and of k as gemm_p3.cuh with NACC = 3: bit-identical results.
+//
+// LDS ring.  A slot holds ONE 16-wide k block of the tile: for each operand, plane and 32-row block one 1 KiB piece that IS
+// the MFMA fragment image -- lane l = (h = l >> 5, r = l & 31) finds its 8 k values (k = 8 h .. 8 h + 7 of the block, row r) at
+// byte 16 l: a fragment read is one ds_read_b128 at lane * 16 + an immediate, conflict-free by construction.  The panel layout in
+// memory (planes.cuh) is unchanged: an LDS-DMA lane may fetch its 16 bytes from anywhere, only the LDS side is linear, so lane l
+// of a KC piece reads chunk (2 kb + h) ^ ((r >> 2) & 3) of row r's 64-byte segment.  (The two half pieces of a K tile are
+// issued one L segment apart: the second one hits the lines the first one pulled into L1 / L2.)  XC operands (k along the
+// panel rows: dX, dW) keep gemm_p3's image -- a 1 KiB run of 16 k rows x 32 x, read with ds_read_b64_tr_b16 -- which is
+// already one k block per piece.
+//
+// Synchronisation (slot-time t = the interval between workgroup barriers t and t + 1; group 1 passes one extra barrier
+// first, so it runs one slot-time behind):   group 0:  L_j at t = 2 j, C_j at 2 j + 1;   group 1:  L_j at 2 j + 1, C_j at 2 j + 2.
+//   * RAW.  A wave ends L_j with s_waitcnt vmcnt(its pieces of k blocks > j + 1 may fly): its pieces of k block j + 1 have
+//     landed; the barrier that opens slot-time 2 j + 2 has been passed by every wave after that wait, and k block j + 1 is
+//     first read at 2 j + 2 (cdna_hip_programming.md "read a staged buffer one phase AFTER the wait that retires it").
+//   * WAR.  k block j + NS - 1 is issued in L_j into the ring slot of k block j - 1, whose last reader is group 1's L_{j-1}
+//     at slot-time 2 j - 1; every L segment ends with lgkmcnt(0) before its barrier, and the issue happens at t >= 2 j.
+//   * Prefetch distance: a piece is needed 2 (NS - 1) - 1 slot-times (~ 4 000 cycles at NS = 4) after it is issued.
+#pragma once
+#include "gemm_p3.cuh"
+
+namespace pxr {
+
+template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int NACC_>
+struct P4Cfg {
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_, NACC = NACC_;
+  static constexpr int G = WGM * WGN, NT = 64 * G, BK = 16;
+  static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+  static constexpr int A_FR = BM / 32, B_FR = BN / 32;                      // 32-row fragment blocks per operand
+  static constexpr int A_PIECES = 3 * A_FR, B_PIECES = 3 * B_FR;            // 1 KiB pieces per k block
+  static constexpr int SLOT = (A_PIECES + B_PIECES) * 1024;
+  static constexpr int LDS_BYTES = NS * SLOT;
+  static constexpr int EPI_LD = BN + 4;
+  static constexpr bool PINGPONG = true;
+  static_assert(G == 8, "two groups of four waves");
+  static_assert(A_FR % 2 == 0 && B_FR % 2 == 0, "each group issues half of an operand's pieces");
+  static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile = 32x32 blocks");
+  static_assert(NS >= 3 && NS <= 8, "ring slots");
+  static_assert(NACC == 1 || NACC == 2 || NACC == 3, "accumulator sets");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static constexpr bool EPI_FITS = BM * EPI_LD * 4 <= LDS_BYTES;     // p3_row_epilogue stages the fp32 tile in the ring's LDS
+  struct Acc {
+    f32x16 v[TM][TN];
+  };
+};
+
+// wait until at most `batches` of this wave's DMA batches (n pieces each) are still in flight
+__device__ __forceinline__ void p4_wait_batches(int batches, int n) {
+  const int c = batches * n;
+  // wave-uniform: a scalar compare chain; counts a wave cannot have fall through to the next larger wait (harmless: waits longer)
+  if (c >= 18) p3_wait_vm<18>();
+  else if (c >= 15) p3_wait_vm<15>();
+  else if (c >= 12) p3_wait_vm<12>();
+  else if (c >= 10) p3_wait_vm<10>();
+  else if (c >= 9) p3_wait_vm<9>();
+  else if (c >= 8) p3_wait_vm<8>();
+  else if (c >= 6) p3_wait_vm<6>();
+  else if (c >= 5) p3_wait_vm<5>();
+  else if (c >= 4) p3_wait_vm<4>();
+  else if (c >= 3) p3_wait_vm<3>();
+  else if (c >= 2) p3_wait_vm<2>();
+  else if (c >= 1) p3_wait_vm<1>();
+  else p3_wait_vm<0>();
+}
+
+// One operand's share of a wave's DMA batch.  FR = 32-row blocks of the tile along the operand's x, KC = flavour.
+template <int FR, bool KC>
+struct P4Operand {
+  static constexpr int PG = 3 * FR / 2;          // pieces per wave group and k block
+  static constexpr int MAXP = (PG + 3) / 4;      // ... per wave (waves with wi + 4 t >= PG skip piece t)
+  bufrsrc rs;
+  unsigned scal[MAXP];     // loop-invariant byte offset of each piece (plane, block, tile origin)
+  unsigned dst[MAXP];      // byte offset of each piece inside a ring slot
+  int n;                   // pieces this wave issues per k block
+  unsigned kstep;          // KC: bytes per 32-wide K tile (= 2 k blocks);  XC: 1024 per k block
+  // m: the matrix; x0: tile origin along x; piece0: index of this operand's first piece inside a slot
+  __device__ __forceinline__ void init(const P3Mat& m, int x0, int grp, int wi, int piece0) {
+    rs = make_rsrc(reinterpret_cast<const float*>(m.p), m.ps * 3 * 2);
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) {
+      const int q = min(PG * grp + wi + 4 * t, 3 * FR - 1);
+      const int pl = q / FR, blk = q % FR;
+      unsigned o;
+      if constexpr (KC) o = (unsigned)(pl * m.ps * 2) + (unsigned)((x0 + blk * 32) * 64);
+      else o = (unsigned)(pl * m.ps * 2) + (unsigned)(((int64_t)(x0 / 32 + blk) * m.pr) * 64);
+      scal[t] = __builtin_amdgcn_readfirstlane(o);
+      dst[t] = __builtin_amdgcn_readfirstlane((unsigned)((piece0 + q) * 1024));
+    }
+    n = __builtin_amdgcn_readfirstlane(min(MAXP, (PG - wi + 3) / 4));
+    kstep = KC ? (unsigned)(m.pr * 64) : 1024u;
+  }
+  // k block j into the ring slot at LDS byte address slot_base
+  __device__ __forceinline__ void issue(int j, unsigned slot_base) {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned voff, koff;
+    if constexpr (KC) {
+      const unsigned r = lane & 31u, h = lane >> 5;
+      voff = (r << 6) + ((((unsigned)(j & 1) << 1 | h) ^ ((r >> 2) & 3u)) << 4);
+      koff = (unsigned)(j >> 1) * kstep;
+    } else {
+      voff = lane << 4;
+      koff = (unsigned)j * 1024u;
+    }
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t)
+      if (t < n) p3_dma16(rs, voff, __builtin_amdgcn_readfirstlane(koff + scal[t]), __builtin_amdgcn_readfirstlane(slot_base + dst[t]));
+  }
+};
+
+// per-lane byte offsets of the fragment reads inside a piece
+template <bool KC>
+struct P4FragOff {
+  int off[2];
+  __device__ __forceinline__ void init(int lane) {
+    if constexpr (KC) {
+      off[0] = lane * 16;
+      off[1] = 0;
+    } else {
+      // P3Frag<false> for a piece that holds the 16 k rows of ONE k block of a panel run: 16-lane group g = x block (g & 1) of 16
+      // columns, k half h = g >> 1; lane li of the group addresses k row 8 h + (li >> 2) (+ 4 for the second read)
+      const int h = lane >> 5, li = lane & 15, x16 = (lane >> 4) & 1;
+      const int chunk = 2 * x16 + ((li & 3) >> 1), inner = (li & 1) * 8;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = 8 * h + 4 * t + (li >> 2);
+        off[t] = row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4) + inner;
+      }
+    }
+  }
+  __device__ __forceinline__ p3_bf16x8 read(const char* piece) const {
+    if constexpr (KC) {
+      return *reinterpret_cast<const p3_bf16x8*>(piece + off[0]);
+    } else {
+      typedef __attribute__((address_space(3))) p3_bf16x4 lds_v4;
+      const p3_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(piece + off[0]));
+      const p3_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(piece + off[1]));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
+};
+
+// the running state of one tile product; split into begin / k loop / end so that a persistent caller can keep the ring full
+// across output tiles (p4_stream below)
+template <class Cfg, bool A_KC, bool B_KC, bool ONES = false>
+struct P4Loop {
+  static constexpr int TM = Cfg::TM, TN = Cfg::TN, NS = Cfg::NS, PF = Cfg::NS - 1, NACC = Cfg::NACC;
+  static constexpr int NB_HI = P4Operand<Cfg::A_FR, A_KC>::MAXP + P4Operand<Cfg::B_FR, B_KC>::MAXP;   // most pieces a wave issues per k block
+  struct Frag {
+    p3_bf16x8 a[TM][3], b[TN][3];
+  };
+  P4Operand<Cfg::A_FR, A_KC> opA;
+  P4Operand<Cfg::B_FR, B_KC> opB;
+  P4FragOff<A_KC> foA;
+  P4FragOff<B_KC> foB;
+  char* smem;
+  unsigned smem_base;
+  int grp, wm, wn, nb;          // nb = pieces per batch of this wave
+
+  __device__ __forceinline__ void init(const P3Mat& A, const P3Mat& B, int m0, int n0, char* smem_) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    grp = wave >> 2;
+    wm = wave / Cfg::WGN;
+    wn = wave % Cfg::WGN;
+    smem = smem_;
+    smem_base = (unsigned)(size_t)smem_;
+    opA.init(A, m0, grp, wave & 3, 0);
+    opB.init(B, n0, grp, wave & 3, Cfg::A_PIECES);
+    nb = opA.n + opB.n;
+    foA.init(lane);
+    foB.init(lane);
+  }
+  __device__ __forceinline__ void issue(int j, int slot) {
+    const unsigned sb = smem_base + (unsigned)slot * (unsigned)Cfg::SLOT;
+    opA.issue(j, sb);
+    opB.issue(j, sb);
+  }
+  __device__ __forceinline__ void read_frag(Frag& f, int slot) const {
+    const char* s = smem + slot * Cfg::SLOT;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f.a[i][p] = foA.read(s + (p * Cfg::A_FR + wm * TM + i) * 1024);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f.b[j][p] = foB.read(s + (Cfg::A_PIECES + p * Cfg::B_FR + wn * TN + j) * 1024);
+    }
+  }
+};
+
+// six products per (block, 16-wide k block); consecutive MFMAs never share an accumulator.  NACC = 3: gemm_p3's three sets
+// (hi*hi | the 2^-8 terms | the 2^-16 terms) -- bit-identical to it; 2: hi*hi | everything else; 1: one set, small terms first.
+template <class Cfg, class Frag>
+__device__ __forceinline__ void p4_mfma(const Frag& f, f32x16 (&accs)[Cfg::TM][Cfg::TN], f32x16 (&accm)[Cfg::NACC >= 2 ? Cfg::TM : 1][Cfg::TN],
+                                        f32x16 (&accl)[Cfg::NACC >= 3 ? Cfg::TM : 1][Cfg::TN]) {
+  constexpr int TM = Cfg::TM, TN = Cfg::TN;
+#define PXR_P4_PROD(ACC, PA, PB)                                                                                \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA], f.b[j][PB], ACC[i][j], 0, 0, 0);
+  if constexpr (Cfg::NACC == 3) {
+    PXR_P4_PROD(accl, 2, 0)        // lo  * hi
+    PXR_P4_PROD(accm, 1, 0)        // mid * hi
+    PXR_P4_PROD(accs, 0, 0)        // hi  * hi
+    PXR_P4_PROD(accl, 0, 2)        // hi  * lo
+    PXR_P4_PROD(accm, 0, 1)        // hi  * mid
+    PXR_P4_PROD(accl, 1, 1)        // mid * mid
+  } else if constexpr (Cfg::NACC == 2) {
+    PXR_P4_PROD(accm, 2, 0)
+    PXR_P4_PROD(accs, 0, 0)
+    PXR_P4_PROD(accm, 0, 2)
+    PXR_P4_PROD(accm, 1, 1)
+    PXR_P4_PROD(accm, 1, 0)
+    PXR_P4_PROD(accm, 0, 1)
+  } else {
+    PXR_P4_PROD(accs, 2, 0)
+    PXR_P4_PROD(accs, 0, 2)
+    PXR_P4_PROD(accs, 1, 1)
+    PXR_P4_PROD(accs, 1, 0)
+    PXR_P4_PROD(accs, 0, 1)
+    PXR_P4_PROD(accs, 0, 0)
+  }
+#undef PXR_P4_PROD
+}
+
+// acc tile (m0, n0) = A_op x B_op over k in [0, K) (K % 32 == 0), operands as planes.
+// ONES (dW only): additionally accumulate in `ones_acc[i]` the products of the A fragments with an all-ones B fragment.
+// dbg (timing experiments only, results are wrong): 1 = no group stagger, 2 = no DMA, 4 = no MFMAs, 8 = no s_setprio,
+// 16 = no fragment reads
+template <class Cfg, bool A_KC, bool B_KC, bool ONES = false>
+__device__ __forceinline__ void gemm_p4_mainloop(typename Cfg::Acc& acc_out, const P3Mat& A, const P3Mat& B, int K, int m0, int n0,
+                                                 char* smem, f32x16* ones_acc = nullptr, int dbg = 0) {
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, NS = Cfg::NS, PF = NS - 1, NACC = Cfg::NACC;
+  using Loop = P4Loop<Cfg, A_KC, B_KC, ONES>;
+  f32x16 accm[NACC >= 2 ? TM : 1][TN], accl[NACC >= 3 ? TM : 1][TN];
+  auto& accs = acc_out.v;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        accs[i][j][e] = 0.f;
+        if constexpr (NACC >= 2) accm[i][j][e] = 0.f;
+        if constexpr (NACC >= 3) accl[i][j][e] = 0.f;
+      }
+  if constexpr (ONES) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ones_acc[i][e] = 0.f;
+  }
+  const int nkb = K / 16;
+  if (nkb <= 0) return;
+  Loop L;
+  L.init(A, B, m0, n0, smem);
+  p3_bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  // ---- prologue: k blocks 0 .. PF-1 in flight, k block 0 landed ----------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (s < nkb && !(dbg & 2)) L.issue(s, s);
+  p4_wait_batches(min(PF - 1, nkb - 1), L.nb);
+  __builtin_amdgcn_s_barrier();
+  if (L.grp == 1 && !(dbg & 1)) __builtin_amdgcn_s_barrier();          // group 1 runs one slot-time behind
+  typename Loop::Frag f;
+  int slot = 0, islot = PF % NS;
+  for (int j = 0; j < nkb; ++j) {
+    // ---- L segment ----------------------------------------------------------------------------------------------------------
+    if (!(dbg & 16)) L.read_frag(f, slot);
+    // ... and wait until this wave's pieces of k block j + 1 have landed: the batches of k blocks j + 2 .. may stay in flight
+    if (j + PF < nkb) {
+      if (!(dbg & 2)) L.issue(j + PF, islot);
+      islot = (islot + 1 == NS) ? 0 : islot + 1;
+      constexpr int NB_HI = Loop::NB_HI;
+      if (L.nb == NB_HI) p3_wait_vm<(PF - 1) * NB_HI>();
+      else if (L.nb == NB_HI - 1) p3_wait_vm<(PF - 1) * (NB_HI - 1)>();
+      else p4_wait_batches(PF - 1, L.nb);
+    } else {
+      p4_wait_batches(max(nkb - 2 - j, 0), L.nb);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C segment ----------------------------------------------------------------------------------------------------------
+    if (!(dbg & 4)) {
+      if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
+      p4_mfma<Cfg>(f, accs, accm, accl);
+      if constexpr (ONES) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) ones_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][p], ones, ones_acc[i], 0, 0, 0);
+      }
+      if (!(dbg & 8)) __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+  }
+  if (L.grp == 0 && !(dbg & 1)) __builtin_amdgcn_s_barrier();
+  __syncthreads();   // the staging LDS is reused by the epilogues
+  if constexpr (NACC >= 2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if constexpr (NACC == 3) accs[i][j][e] += (accm[i][j][e] + accl[i][j][e]);
+          else accs[i][j][e] += accm[i][j][e];
+        }
+  }
+}
+
+}  // namespace pxr

@@ -1,0 +1,242 @@
+// p4_lab.hip -- standalone A/B harness for the big-tile planes GEMM main loops (gemm_p3.cuh lockstep vs gemm_p4.cuh ping-pong).
+// Not part of the product: builds to an executable (tools/lab/build.sh), runs a matrix of (variant, shape, dbg) on one GPU and
+// prints TF/s (six bf16 products per fp32 multiply counted) + the difference from the gemm_p3 result on the same operands.
+//   usage: p4_lab [iters]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../pixelrec_amd/csrc/gemm_p4.cuh"
+
+void pxr_set_error(const char*, ...) {}
+int32_t* pxr_status_word(void) { return nullptr; }
+
+using namespace pxr;
+
+#define CK(x)                                                                         \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(1);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+__global__ void fill_normal(float* x, int64_t n, uint32_t seed, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t a = pxr_hash32(seed, 1, (uint64_t)i), b = pxr_hash32(seed, 2, (uint64_t)i);
+  const float u1 = ((a >> 8) + 1) * (1.0f / 16777217.0f), u2 = (b >> 8) * (1.0f / 16777216.0f);
+  x[i] = scale * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+}
+__global__ void split_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols8, P3Mat out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols8) return;
+  const int64_t row = i / cols8;
+  const int c = (int)(i % cols8) * 8;
+  const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
+  const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  p3_store8(out, row, c, v);
+}
+// X[R][C] -> X^T planes (rows = C, cols = R): the x-contiguous storage of an operand
+__global__ void split_t_kernel(const float* __restrict__ x, int64_t R, int64_t C, P3Mat out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over C x (R / 8)
+  const int64_t r8 = R / 8;
+  if (i >= C * r8) return;
+  const int64_t c = i / r8;
+  const int r0 = (int)(i % r8) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = x[(int64_t)(r0 + e) * C + c];
+  p3_store8(out, c, r0, v);
+}
+__global__ void diff_kernel(const float* a, const float* b, int64_t n, float* out /* [0] max |a-b|, [1] max |a| */) {
+  float d = 0.f, m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    d = fmaxf(d, fabsf(a[i] - b[i]));
+    m = fmaxf(m, fabsf(a[i]));
+  }
+  d = wave_max(d); m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(reinterpret_cast<int*>(out), __float_as_int(d));
+    atomicMax(reinterpret_cast<int*>(out) + 1, __float_as_int(m));
+  }
+}
+
+struct LabArgs {
+  P3Mat A, B;
+  float* C;
+  int M, N, K, tiles_m, tiles_n, dbg;
+  unsigned long long* clk;     // [0] shader cycles, [1] 100 MHz ticks spent by workgroup 0 (effective clock under this kernel's load)
+};
+
+template <class Cfg, bool A_KC, bool B_KC>
+__device__ __forceinline__ void lab_mainloop(typename Cfg::Acc& accs, const LabArgs& g, int m0, int n0, char* smem) {
+  if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, A_KC, B_KC>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
+  else gemm_p3_mainloop<Cfg, A_KC, B_KC, false>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
+}
+
+template <class Cfg, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(Cfg::NT) lab_kernel(const LabArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const bool n_fastest = g.M > g.N;
+  const int tm = n_fastest ? t / g.tiles_n : t % g.tiles_m, tn = n_fastest ? t % g.tiles_n : t / g.tiles_m;
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+  typename Cfg::Acc accs;
+  lab_mainloop<Cfg, A_KC, B_KC>(accs, g, m0, n0, smem);
+  if constexpr (Cfg::BM * Cfg::EPI_LD * 4 <= Cfg::LDS_BYTES) {
+    p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, [&](int, int row, int col, int nv, float (&v)[8]) {
+      float* cp = g.C + (int64_t)row * g.N + col;
+      if (nv == 8) {
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        for (int e = 0; e < nv; ++e) cp[e] = v[e];
+      }
+    });
+  } else {
+    // direct stores from the accumulators (lab only: 128-byte row segments per half wave)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN, h = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int col = n0 + wn * Cfg::WN + j * 32 + r;
+          if (row < g.M && col < g.N) g.C[(int64_t)row * g.N + col] = accs.v[i][j][e];
+        }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && g.clk) {
+    g.clk[0] = __builtin_readcyclecounter() - c0;
+    g.clk[1] = wall_clock64() - r0;
+  }
+}
+
+struct Planes {
+  __bf16* p = nullptr;
+  P3Mat m{};
+};
+static Planes make_planes(const float* x, int64_t R, int64_t C, bool transposed) {
+  // planes of X (rows R, cols C) or of X^T
+  const int64_t rows = transposed ? C : R, cols = transposed ? R : C;
+  const int64_t pr = (rows + 31) / 32 * 32, ps = pr * cols;
+  Planes P;
+  CK(hipMalloc(&P.p, (size_t)ps * 3 * 2 + 4096));
+  CK(hipMemset(P.p, 0, (size_t)ps * 3 * 2 + 4096));
+  P.m = P3Mat{P.p, ps, pr};
+  if (!transposed) {
+    const int64_t n = R * (C / 8);
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, x, C, R, (int)(C / 8), P.m);
+  } else {
+    const int64_t n = C * (R / 8);
+    hipLaunchKernelGGL(split_t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, x, R, C, P.m);
+  }
+  CK(hipDeviceSynchronize());
+  return P;
+}
+
+template <class Cfg, bool A_KC, bool B_KC>
+static float run(const char* name, LabArgs g, int iters, const float* ref, float* diffbuf, bool quiet = false) {
+  g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+  g.tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
+  auto kern = lab_kernel<Cfg, A_KC, B_KC>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+  const dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), blk(Cfg::NT);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, grid, blk, Cfg::LDS_BYTES, 0, g);
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, blk, Cfg::LDS_BYTES, 0, g);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / iters;
+  const double tf6 = 12.0 * g.M * g.N * (double)g.K / us / 1e6;
+  unsigned long long hc[2] = {0, 1};
+  if (g.clk) CK(hipMemcpy(hc, g.clk, 16, hipMemcpyDeviceToHost));
+  const double ghz = (double)hc[0] / ((double)hc[1] / 100e6) / 1e9;
+  float hd[2] = {0.f, 0.f};
+  if (ref && g.dbg == 0) {
+    CK(hipMemset(diffbuf, 0, 8));
+    hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, 0, (const float*)g.C, ref, (int64_t)g.M * g.N, diffbuf);
+    CK(hipMemcpy(hd, diffbuf, 8, hipMemcpyDeviceToHost));
+  }
+  if (!quiet)
+    printf("  %-34s dbg=%-2d %9.1f us  %7.1f TF(6p)  frac %.3f  clk %.2f GHz  maxdiff %.3g (max|c| %.3g)\n", name, g.dbg, us, tf6,
+           tf6 / 2500.0, ghz, hd[0], hd[1]);
+  fflush(stdout);
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return (float)us;
+}
+
+#ifndef LAB_VARIANTS
+#define LAB_VARIANTS 1
+#endif
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 10;
+  const char* only = argc > 2 ? argv[2] : "";
+  struct Shape { const char* name; int M, N, K; };
+  const Shape shapes[] = {
+      {"scoring  items x users", 400128, 1024, 512},
+      {"vit fc1", 69344, 3072, 768},
+      {"vit fc2", 69344, 768, 3072},
+      {"vit qkv", 69344, 2304, 768},
+  };
+  float* diffbuf;
+  CK(hipMalloc(&diffbuf, 8));
+  unsigned long long* clk;
+  CK(hipMalloc(&clk, 16));
+  for (const Shape& s : shapes) {
+    if (only[0] && !strstr(s.name, only)) continue;
+    printf("== %s  M=%d N=%d K=%d\n", s.name, s.M, s.N, s.K);
+    float *A, *B, *C, *Cref;
+    CK(hipMalloc(&A, (size_t)s.M * s.K * 4));
+    CK(hipMalloc(&B, (size_t)s.N * s.K * 4));
+    CK(hipMalloc(&C, (size_t)s.M * s.N * 4));
+    CK(hipMalloc(&Cref, (size_t)s.M * s.N * 4));
+    hipLaunchKernelGGL(fill_normal, dim3((unsigned)(((int64_t)s.M * s.K + 255) / 256)), dim3(256), 0, 0, A, (int64_t)s.M * s.K, 11u, 1.0f);
+    hipLaunchKernelGGL(fill_normal, dim3((unsigned)(((int64_t)s.N * s.K + 255) / 256)), dim3(256), 0, 0, B, (int64_t)s.N * s.K, 12u, 0.05f);
+    CK(hipDeviceSynchronize());
+    Planes Ap = make_planes(A, s.M, s.K, false), Bp = make_planes(B, s.N, s.K, false);
+    Planes Bt = make_planes(B, s.N, s.K, true);      // B^T: [K][N] storage -> the XC flavour of the same product
+    LabArgs g{};
+    g.A = Ap.m; g.B = Bp.m; g.M = s.M; g.N = s.N; g.K = s.K; g.dbg = 0; g.clk = clk;
+    // reference: the lockstep 256x128 tile of gemm_p3.cuh
+    g.C = Cref;
+    run<P3Cfg<256, 128, 4, 2, 2>, true, true>("p3 256x128 s2 (baseline)", g, iters, nullptr, diffbuf);
+    g.C = C;
+    for (int dbg : {0, 8, 1, 2, 4, 16, 6}) {
+      g.dbg = dbg;
+      run<P4Cfg<256, 128, 4, 2, 4, 3>, true, true>("p4 256x128 ns4 acc3", g, iters, Cref, diffbuf);
+    }
+    g.dbg = 0;
+    run<P4Cfg<256, 128, 4, 2, 4, 2>, true, true>("p4 256x128 ns4 acc2", g, iters, Cref, diffbuf);
+    run<P4Cfg<256, 128, 4, 2, 4, 1>, true, true>("p4 256x128 ns4 acc1", g, iters, Cref, diffbuf);
+    run<P4Cfg<256, 128, 4, 2, 3, 3>, true, true>("p4 256x128 ns3 acc3", g, iters, Cref, diffbuf);
+    run<P4Cfg<256, 128, 2, 4, 4, 3>, true, true>("p4 256x128 ns4 acc3 wg2x4", g, iters, Cref, diffbuf);
+    // the dX flavour: B as [K][N] planes
+    g.B = Bt.m;
+    run<P3Cfg<256, 128, 4, 2, 2>, true, false>("p3 256x128 s2  B=XC", g, iters, Cref, diffbuf);
+    run<P4Cfg<256, 128, 4, 2, 4, 3>, true, false>("p4 256x128 ns4 acc3  B=XC", g, iters, Cref, diffbuf);
+    // zero-filled operands: the same instruction stream at the clock the power budget allows without data toggling
+    CK(hipMemset(Ap.p, 0, (size_t)Ap.m.ps * 6)); CK(hipMemset(Bp.p, 0, (size_t)Bp.m.ps * 6));
+    g.B = Bp.m;
+    run<P3Cfg<256, 128, 4, 2, 2>, true, true>("p3 256x128 s2  ZERO operands", g, iters, nullptr, diffbuf);
+    run<P4Cfg<256, 128, 4, 2, 4, 3>, true, true>("p4 256x128 ns4 acc3  ZERO operands", g, iters, nullptr, diffbuf);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(Cref));
+    CK(hipFree(Ap.p)); CK(hipFree(Bp.p)); CK(hipFree(Bt.p));
+  }
+  return 0;
+}
