@@ -5,7 +5,7 @@
 // Reference call sites replaced: the nn.Linear forwards of the sequence block (layers.py:586-588,613,666,669), their
 // autograd input / weight gradients, the full-catalogue scoring product (sasrec.py:112) -- the same products pxr_gemm_f32
 // computes, from operands that were split once by their producer instead of once per reading tile.
-#include "gemm_p3.cuh"
+#include "gemm_p4.cuh"
 
 #include <cstdlib>
 
@@ -99,11 +99,14 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
   // 16-byte accesses when every row of C / aux starts 16-byte aligned and the chunk is whole; scalar otherwise (ragged N)
   const bool vec_ok = (g.N % 8 == 0) && (g.ldc % 4 == 0) && (g.ldaux % 4 == 0);
   using Map = P3ChunkMap<Cfg>;
-  constexpr bool PRE_AUX = EpiTraits<EPI>::READS_AUX && Map::CPT <= 4;
+  // operands the epilogue reads are fetched before the main loop where the thread's chunks are few (the lockstep tiles); the
+  // ping-pong tiles (8 chunks per thread and pass, every register an accumulator) read them in the epilogue
+  constexpr bool PRE = !Cfg::PINGPONG;
+  constexpr bool PRE_AUX = PRE && EpiTraits<EPI>::READS_AUX && Map::CPT <= 4;
   float bpre[8], apre[PRE_AUX ? Map::CPT : 1][8];
   const int pc = n0 + Map::col8();
-  const bool pre_ok = vec_ok && pc + 8 <= g.N;
-  if constexpr (EpiTraits<EPI>::HAS_BIAS) {
+  const bool pre_ok = PRE && vec_ok && pc + 8 <= g.N;
+  if constexpr (EpiTraits<EPI>::HAS_BIAS && PRE) {
     if (pre_ok) {
       const float4 b0 = *reinterpret_cast<const float4*>(g.bias + pc), b1 = *reinterpret_cast<const float4*>(g.bias + pc + 4);
       bpre[0] = b0.x; bpre[1] = b0.y; bpre[2] = b0.z; bpre[3] = b0.w; bpre[4] = b1.x; bpre[5] = b1.y; bpre[6] = b1.z; bpre[7] = b1.w;
@@ -122,14 +125,20 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
     }
   }
   typename Cfg::Acc accs;
-  gemm_p3_mainloop<Cfg, true, B_KC, EARLY>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
-  p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, [&](int it, int row, int col, int nv, float (&v)[8]) {
+  if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, true, B_KC>(accs, g.A, g.B, g.K, m0, n0, smem);
+  else gemm_p3_mainloop<Cfg, true, B_KC, EARLY>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
+  auto chunk = [&](int it, int row, int col, int nv, float (&v)[8]) {
     float bv[8], av[8], ao[8];
     const bool vec = vec_ok && nv == 8;
     if constexpr (EpiTraits<EPI>::HAS_BIAS) {
       if (vec) {
+        if constexpr (PRE) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = bpre[e];
+          for (int e = 0; e < 8; ++e) bv[e] = bpre[e];
+        } else {
+          const float4 b0 = *reinterpret_cast<const float4*>(g.bias + col), b1 = *reinterpret_cast<const float4*>(g.bias + col + 4);
+          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = e < nv ? g.bias[col + e] : 0.f;
@@ -176,7 +185,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
       }
     }
     if (g.Cp.p != nullptr) p3_store8(g.Cp, row, col, v);      // (output planes: N % 32 == 0, chunks are whole)
-  });
+  };
+  if constexpr (Cfg::PINGPONG) p4_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, [&](int row, int col, int nv, float (&v)[8]) { chunk(0, row, col, nv, v); });
+  else p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, chunk);
 }
 
 // x[rows, cols] (row stride ldx floats) -> planes (panel layout); a thread converts 8 consecutive values of a row
@@ -415,7 +426,17 @@ extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A,
     const int64_t t256 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
     static const int env_small = getenv("PXR_P3_TILE_SMALL") ? atoi(getenv("PXR_P3_TILE_SMALL")) : 406406430;   // A/B knobs
     static const int env_wide = getenv("PXR_P3_TILE_WIDE") ? atoi(getenv("PXR_P3_TILE_WIDE")) : 412806420;
-    tile_hint = t256 >= 512 ? 825612820 : (N >= 1024 ? env_wide : env_small);
+    // big problems: the ping-pong tiles (gemm_p4.cuh).  256x256 with ONE accumulator set (fp32-sequential-grade rounding, see
+    // DESIGN.md) when it does not cost more rounds of 256 workgroups than 256x128 (bit-identical to the lockstep tiles) would
+    static const int env_p4 = getenv("PXR_P4") ? atoi(getenv("PXR_P4")) : 1;              // 0: the round-3 lockstep 256x128 tile
+    static const int env_acc1 = getenv("PXR_P4_ACC1") ? atoi(getenv("PXR_P4_ACC1")) : 1;  // 0: never the one-set 256x256 tile
+    if (t256 >= 512 && env_p4) {
+      const int64_t t256sq = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+      const int64_t r_sq = 2 * ((t256sq + 255) / 256), r_128 = (t256 + 255) / 256;
+      tile_hint = (env_acc1 && N >= 256 && r_sq <= r_128) ? 425625631 : 425612833;
+    } else {
+      tile_hint = t256 >= 512 ? 825612820 : (N >= 1024 ? env_wide : env_small);
+    }
   }
 #define PXR_P3_TILE(CODE, EARLY, ...) \
   if (tile_hint == CODE) return epi_p3<P3Cfg<__VA_ARGS__>, EARLY>(b_kc, epilogue, g, st)
@@ -428,6 +449,10 @@ extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A,
   PXR_P3_TILE(812812830, false, 128, 128, 2, 4, 3);
   PXR_P3_TILE(825612820, false, 256, 128, 4, 2, 2);
 #undef PXR_P3_TILE
+  // ping-pong tiles: 4 | BM | BN | ring slots | accumulator sets
+  if (tile_hint == 425612833) return epi_p3<P4Cfg<256, 128, 4, 2, 3, 3>, false>(b_kc, epilogue, g, st);
+  if (tile_hint == 425612832) return epi_p3<P4Cfg<256, 128, 4, 2, 3, 2>, false>(b_kc, epilogue, g, st);
+  if (tile_hint == 425625631) return epi_p3<P4Cfg<256, 256, 4, 2, 3, 1>, false>(b_kc, epilogue, g, st);
   pxr_set_error("pxr_gemm_planes_f32: tile %d is not instantiated", tile_hint);
   return PXR_ERR_BAD_ARG;
 }

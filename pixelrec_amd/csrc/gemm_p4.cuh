@@ -31,16 +31,20 @@
 
 namespace pxr {
 
-template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int NACC_>
+// DMA_: where a wave issues its pieces of k block j + NS - 1:  0 = in L_j after the fragment reads;  1 = the A pieces in L_j, the B
+// pieces between the MFMAs of C_j;  2 = all of them between the MFMAs of C_j (one piece per product group);  3 = in L_j BEFORE the reads
+template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int NACC_, int DMA_ = 0>
 struct P4Cfg {
-  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_, NACC = NACC_;
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_, NACC = NACC_, DMA = DMA_;
   static constexpr int G = WGM * WGN, NT = 64 * G, BK = 16;
   static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
   static constexpr int A_FR = BM / 32, B_FR = BN / 32;                      // 32-row fragment blocks per operand
   static constexpr int A_PIECES = 3 * A_FR, B_PIECES = 3 * B_FR;            // 1 KiB pieces per k block
   static constexpr int SLOT = (A_PIECES + B_PIECES) * 1024;
-  static constexpr int LDS_BYTES = NS * SLOT;
-  static constexpr int EPI_LD = BN + 4;
+  static constexpr int RING_BYTES = NS * SLOT;
+  // the epilogue stages the fp32 tile in LDS in passes of EPI_COLS columns ([BM][EPI_COLS + 4] floats, p4_row_epilogue)
+  static constexpr int EPI_COLS = BN > 128 ? 128 : BN, EPI_LD = EPI_COLS + 4, EPI_BYTES = BM * EPI_LD * 4;
+  static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
   static constexpr bool PINGPONG = true;
   static_assert(G == 8, "two groups of four waves");
   static_assert(A_FR % 2 == 0 && B_FR % 2 == 0, "each group issues half of an operand's pieces");
@@ -48,22 +52,21 @@ struct P4Cfg {
   static_assert(NS >= 3 && NS <= 8, "ring slots");
   static_assert(NACC == 1 || NACC == 2 || NACC == 3, "accumulator sets");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-  static constexpr bool EPI_FITS = BM * EPI_LD * 4 <= LDS_BYTES;     // p3_row_epilogue stages the fp32 tile in the ring's LDS
+  static_assert(BN % EPI_COLS == 0 && (64 * G) % (EPI_COLS / 8) == 0 && BM % (64 * G / (EPI_COLS / 8)) == 0, "epilogue chunk map");
   struct Acc {
     f32x16 v[TM][TN];
   };
 };
 
-// wait until at most `batches` of this wave's DMA batches (n pieces each) are still in flight
-__device__ __forceinline__ void p4_wait_batches(int batches, int n) {
-  const int c = batches * n;
-  // wave-uniform: a scalar compare chain; counts a wave cannot have fall through to the next larger wait (harmless: waits longer)
+// wait until at most c of this wave's LDS-DMA pieces are still in flight (c wave-uniform: a scalar compare chain)
+__device__ __forceinline__ void p4_wait_pieces(int c) {
   if (c >= 18) p3_wait_vm<18>();
   else if (c >= 15) p3_wait_vm<15>();
   else if (c >= 12) p3_wait_vm<12>();
   else if (c >= 10) p3_wait_vm<10>();
   else if (c >= 9) p3_wait_vm<9>();
   else if (c >= 8) p3_wait_vm<8>();
+  else if (c >= 7) p3_wait_vm<7>();
   else if (c >= 6) p3_wait_vm<6>();
   else if (c >= 5) p3_wait_vm<5>();
   else if (c >= 4) p3_wait_vm<4>();
@@ -99,18 +102,26 @@ struct P4Operand {
     n = __builtin_amdgcn_readfirstlane(min(MAXP, (PG - wi + 3) / 4));
     kstep = KC ? (unsigned)(m.pr * 64) : 1024u;
   }
-  // k block j into the ring slot at LDS byte address slot_base
-  __device__ __forceinline__ void issue(int j, unsigned slot_base) {
+  // per-lane source offset of a piece of k block j (recomputed from the execution mask instead of being kept: with three
+  // accumulator sets every VGPR is taken, and a spilled offset would come back as a scratch LOAD inside the K loop -- a VMEM
+  // operation in front of which the compiler drains the whole DMA ring), and the wave-uniform offset of the k block
+  __device__ __forceinline__ unsigned lane_off(int j) const {
     const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    unsigned voff, koff;
     if constexpr (KC) {
       const unsigned r = lane & 31u, h = lane >> 5;
-      voff = (r << 6) + ((((unsigned)(j & 1) << 1 | h) ^ ((r >> 2) & 3u)) << 4);
-      koff = (unsigned)(j >> 1) * kstep;
+      return (r << 6) + (((((unsigned)(j & 1) << 1) | h) ^ ((r >> 2) & 3u)) << 4);
     } else {
-      voff = lane << 4;
-      koff = (unsigned)j * 1024u;
+      return lane << 4;
     }
+  }
+  __device__ __forceinline__ unsigned k_off(int j) const { return KC ? (unsigned)(j >> 1) * kstep : (unsigned)j * 1024u; }
+  // piece t of k block j into the ring slot at LDS byte address slot_base
+  __device__ __forceinline__ void issue_one(int t, int j, unsigned slot_base) const {
+    if (t < n) p3_dma16(rs, lane_off(j), __builtin_amdgcn_readfirstlane(k_off(j) + scal[t]), __builtin_amdgcn_readfirstlane(slot_base + dst[t]));
+  }
+  // all of this wave's pieces of k block j
+  __device__ __forceinline__ void issue(int j, unsigned slot_base) const {
+    const unsigned voff = lane_off(j), koff = k_off(j);
 #pragma unroll
     for (int t = 0; t < MAXP; ++t)
       if (t < n) p3_dma16(rs, voff, __builtin_amdgcn_readfirstlane(koff + scal[t]), __builtin_amdgcn_readfirstlane(slot_base + dst[t]));
@@ -149,12 +160,16 @@ struct P4FragOff {
   }
 };
 
-// the running state of one tile product; split into begin / k loop / end so that a persistent caller can keep the ring full
-// across output tiles (p4_stream below)
-template <class Cfg, bool A_KC, bool B_KC, bool ONES = false>
+// the per-wave state of a tile product: DMA plans of both operands, fragment addresses, the wave's place in the tile
+template <class Cfg, bool A_KC, bool B_KC>
 struct P4Loop {
-  static constexpr int TM = Cfg::TM, TN = Cfg::TN, NS = Cfg::NS, PF = Cfg::NS - 1, NACC = Cfg::NACC;
-  static constexpr int NB_HI = P4Operand<Cfg::A_FR, A_KC>::MAXP + P4Operand<Cfg::B_FR, B_KC>::MAXP;   // most pieces a wave issues per k block
+  static constexpr int TM = Cfg::TM, TN = Cfg::TN, NS = Cfg::NS, PF = Cfg::NS - 1;
+  static constexpr int MAXA = P4Operand<Cfg::A_FR, A_KC>::MAXP, MAXB = P4Operand<Cfg::B_FR, B_KC>::MAXP;
+  // pieces of earlier-needed k blocks that may still be in flight when a wave certifies k block j + 1 at the end of L_j
+  // (gemm_p4.cuh header, "RAW"): whole batches of the k blocks j + 2 .. issued so far, per operand
+  static constexpr int KEEP_A = (Cfg::DMA == 2) ? PF - 2 : PF - 1;
+  static constexpr int KEEP_B = (Cfg::DMA == 1 || Cfg::DMA == 2) ? PF - 2 : PF - 1;
+  static_assert(KEEP_A >= 0 && KEEP_B >= 0, "pieces issued in the C segments need one more ring slot");
   struct Frag {
     p3_bf16x8 a[TM][3], b[TN][3];
   };
@@ -164,7 +179,7 @@ struct P4Loop {
   P4FragOff<B_KC> foB;
   char* smem;
   unsigned smem_base;
-  int grp, wm, wn, nb;          // nb = pieces per batch of this wave
+  int grp, wm, wn, keep;        // keep = KEEP_A * (A pieces per batch) + KEEP_B * (B pieces per batch) of this wave
 
   __device__ __forceinline__ void init(const P3Mat& A, const P3Mat& B, int m0, int n0, char* smem_) {
     const int tid = threadIdx.x;
@@ -177,14 +192,28 @@ struct P4Loop {
     smem_base = (unsigned)(size_t)smem_;
     opA.init(A, m0, grp, wave & 3, 0);
     opB.init(B, n0, grp, wave & 3, Cfg::A_PIECES);
-    nb = opA.n + opB.n;
+    keep = KEEP_A * opA.n + KEEP_B * opB.n;
     foA.init(lane);
     foB.init(lane);
   }
-  __device__ __forceinline__ void issue(int j, int slot) {
-    const unsigned sb = smem_base + (unsigned)slot * (unsigned)Cfg::SLOT;
-    opA.issue(j, sb);
-    opB.issue(j, sb);
+  __device__ __forceinline__ unsigned slot_addr(int slot) const { return smem_base + (unsigned)slot * (unsigned)Cfg::SLOT; }
+  __device__ __forceinline__ void issue(int j, int slot) const {
+    opA.issue(j, slot_addr(slot));
+    opB.issue(j, slot_addr(slot));
+  }
+  __device__ __forceinline__ void issue_a(int j, int slot) const { opA.issue(j, slot_addr(slot)); }
+  // piece number u of the wave's batch (the A pieces first)
+  __device__ __forceinline__ void issue_nth(int u, int j, int slot) const {
+    if (u < MAXA) opA.issue_one(u, j, slot_addr(slot));
+    else if (u < MAXA + MAXB) opB.issue_one(u - MAXA, j, slot_addr(slot));
+  }
+  // steady state: everything but `keep` pieces has landed
+  __device__ __forceinline__ void wait_steady() const {
+    constexpr int C_HI = KEEP_A * MAXA + KEEP_B * MAXB, C_LO = C_HI - KEEP_B, C_LO2 = C_HI - KEEP_A;
+    if (keep == C_HI) p3_wait_vm<C_HI>();
+    else if (keep == C_LO) p3_wait_vm<C_LO>();
+    else if (keep == C_LO2) p3_wait_vm<C_LO2>();
+    else p4_wait_pieces(keep);
   }
   __device__ __forceinline__ void read_frag(Frag& f, int slot) const {
     const char* s = smem + slot * Cfg::SLOT;
@@ -200,47 +229,56 @@ struct P4Loop {
 
 // six products per (block, 16-wide k block); consecutive MFMAs never share an accumulator.  NACC = 3: gemm_p3's three sets
 // (hi*hi | the 2^-8 terms | the 2^-16 terms) -- bit-identical to it; 2: hi*hi | everything else; 1: one set, small terms first.
-template <class Cfg, class Frag>
+// `between(g)` runs after product group g = 0 .. 4, pinned there (DMA pieces issued among the MFMAs).
+struct P4NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <class Cfg, bool HOOK, class Frag, class Hook>
 __device__ __forceinline__ void p4_mfma(const Frag& f, f32x16 (&accs)[Cfg::TM][Cfg::TN], f32x16 (&accm)[Cfg::NACC >= 2 ? Cfg::TM : 1][Cfg::TN],
-                                        f32x16 (&accl)[Cfg::NACC >= 3 ? Cfg::TM : 1][Cfg::TN]) {
+                                        f32x16 (&accl)[Cfg::NACC >= 3 ? Cfg::TM : 1][Cfg::TN], Hook&& between) {
   constexpr int TM = Cfg::TM, TN = Cfg::TN;
-#define PXR_P4_PROD(ACC, PA, PB)                                                                                \
+#define PXR_P4_PROD(G, ACC, PA, PB)                                                                             \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
-      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA], f.b[j][PB], ACC[i][j], 0, 0, 0);
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA], f.b[j][PB], ACC[i][j], 0, 0, 0);           \
+  if constexpr (HOOK && G < 5) {                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    between(G);                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+  }
   if constexpr (Cfg::NACC == 3) {
-    PXR_P4_PROD(accl, 2, 0)        // lo  * hi
-    PXR_P4_PROD(accm, 1, 0)        // mid * hi
-    PXR_P4_PROD(accs, 0, 0)        // hi  * hi
-    PXR_P4_PROD(accl, 0, 2)        // hi  * lo
-    PXR_P4_PROD(accm, 0, 1)        // hi  * mid
-    PXR_P4_PROD(accl, 1, 1)        // mid * mid
+    PXR_P4_PROD(0, accl, 2, 0)        // lo  * hi
+    PXR_P4_PROD(1, accm, 1, 0)        // mid * hi
+    PXR_P4_PROD(2, accs, 0, 0)        // hi  * hi
+    PXR_P4_PROD(3, accl, 0, 2)        // hi  * lo
+    PXR_P4_PROD(4, accm, 0, 1)        // hi  * mid
+    PXR_P4_PROD(5, accl, 1, 1)        // mid * mid
   } else if constexpr (Cfg::NACC == 2) {
-    PXR_P4_PROD(accm, 2, 0)
-    PXR_P4_PROD(accs, 0, 0)
-    PXR_P4_PROD(accm, 0, 2)
-    PXR_P4_PROD(accm, 1, 1)
-    PXR_P4_PROD(accm, 1, 0)
-    PXR_P4_PROD(accm, 0, 1)
+    PXR_P4_PROD(0, accm, 2, 0)
+    PXR_P4_PROD(1, accs, 0, 0)
+    PXR_P4_PROD(2, accm, 0, 2)
+    PXR_P4_PROD(3, accm, 1, 1)
+    PXR_P4_PROD(4, accm, 1, 0)
+    PXR_P4_PROD(5, accm, 0, 1)
   } else {
-    PXR_P4_PROD(accs, 2, 0)
-    PXR_P4_PROD(accs, 0, 2)
-    PXR_P4_PROD(accs, 1, 1)
-    PXR_P4_PROD(accs, 1, 0)
-    PXR_P4_PROD(accs, 0, 1)
-    PXR_P4_PROD(accs, 0, 0)
+    PXR_P4_PROD(0, accs, 2, 0)
+    PXR_P4_PROD(1, accs, 0, 2)
+    PXR_P4_PROD(2, accs, 1, 1)
+    PXR_P4_PROD(3, accs, 1, 0)
+    PXR_P4_PROD(4, accs, 0, 1)
+    PXR_P4_PROD(5, accs, 0, 0)
   }
 #undef PXR_P4_PROD
 }
 
 // acc tile (m0, n0) = A_op x B_op over k in [0, K) (K % 32 == 0), operands as planes.
 // ONES (dW only): additionally accumulate in `ones_acc[i]` the products of the A fragments with an all-ones B fragment.
-// dbg (timing experiments only, results are wrong): 1 = no group stagger, 2 = no DMA, 4 = no MFMAs, 8 = no s_setprio,
+// dbg (compile-time; timing experiments only, results are wrong): 1 = no group stagger, 2 = no DMA, 4 = no MFMAs, 8 = no s_setprio,
 // 16 = no fragment reads
-template <class Cfg, bool A_KC, bool B_KC, bool ONES = false>
+template <class Cfg, bool A_KC, bool B_KC, bool ONES = false, int dbg = 0>
 __device__ __forceinline__ void gemm_p4_mainloop(typename Cfg::Acc& acc_out, const P3Mat& A, const P3Mat& B, int K, int m0, int n0,
-                                                 char* smem, f32x16* ones_acc = nullptr, int dbg = 0) {
+                                                 char* smem, f32x16* ones_acc = nullptr) {
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NS = Cfg::NS, PF = NS - 1, NACC = Cfg::NACC;
-  using Loop = P4Loop<Cfg, A_KC, B_KC, ONES>;
+  using Loop = P4Loop<Cfg, A_KC, B_KC>;
   f32x16 accm[NACC >= 2 ? TM : 1][TN], accl[NACC >= 3 ? TM : 1][TN];
   auto& accs = acc_out.v;
 #pragma unroll
@@ -271,25 +309,27 @@ __device__ __forceinline__ void gemm_p4_mainloop(typename Cfg::Acc& acc_out, con
 #pragma unroll
   for (int s = 0; s < PF; ++s)
     if (s < nkb && !(dbg & 2)) L.issue(s, s);
-  p4_wait_batches(min(PF - 1, nkb - 1), L.nb);
+  p4_wait_pieces(min(PF - 1, nkb - 1) * (L.opA.n + L.opB.n));
   __builtin_amdgcn_s_barrier();
   if (L.grp == 1 && !(dbg & 1)) __builtin_amdgcn_s_barrier();          // group 1 runs one slot-time behind
   typename Loop::Frag f;
   int slot = 0, islot = PF % NS;
   for (int j = 0; j < nkb; ++j) {
+    const bool more = (j + PF < nkb) && !(dbg & 2);                      // k block j + PF is issued during this iteration
     // ---- L segment ----------------------------------------------------------------------------------------------------------
-    if (!(dbg & 16)) L.read_frag(f, slot);
-    // ... and wait until this wave's pieces of k block j + 1 have landed: the batches of k blocks j + 2 .. may stay in flight
-    if (j + PF < nkb) {
-      if (!(dbg & 2)) L.issue(j + PF, islot);
-      islot = (islot + 1 == NS) ? 0 : islot + 1;
-      constexpr int NB_HI = Loop::NB_HI;
-      if (L.nb == NB_HI) p3_wait_vm<(PF - 1) * NB_HI>();
-      else if (L.nb == NB_HI - 1) p3_wait_vm<(PF - 1) * (NB_HI - 1)>();
-      else p4_wait_batches(PF - 1, L.nb);
-    } else {
-      p4_wait_batches(max(nkb - 2 - j, 0), L.nb);
+    if constexpr (Cfg::DMA == 3) {
+      if (more) L.issue(j + PF, islot);
     }
+    if (!(dbg & 16)) L.read_frag(f, slot);
+    if constexpr (Cfg::DMA == 0) {
+      if (more) L.issue(j + PF, islot);
+    } else if constexpr (Cfg::DMA == 1) {
+      if (more) L.issue_a(j + PF, islot);
+    }
+    // this wave's pieces of k block j + 1 have landed (the tail simply waits for everything: nothing newer is in flight that a
+    // later k block could not wait for as well)
+    if (j + PF < nkb) L.wait_steady();
+    else p3_wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -297,7 +337,17 @@ __device__ __forceinline__ void gemm_p4_mainloop(typename Cfg::Acc& acc_out, con
     // ---- C segment ----------------------------------------------------------------------------------------------------------
     if (!(dbg & 4)) {
       if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
-      p4_mfma<Cfg>(f, accs, accm, accl);
+      if constexpr (Cfg::DMA == 1) {
+        p4_mfma<Cfg, true>(f, accs, accm, accl, [&](int g) {
+          if (more && g < Loop::MAXB) L.issue_nth(Loop::MAXA + g, j + PF, islot);
+        });
+      } else if constexpr (Cfg::DMA == 2) {
+        p4_mfma<Cfg, true>(f, accs, accm, accl, [&](int g) {
+          if (more) L.issue_nth(g, j + PF, islot);
+        });
+      } else {
+        p4_mfma<Cfg, false>(f, accs, accm, accl, P4NoHook());
+      }
       if constexpr (ONES) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -310,6 +360,7 @@ __device__ __forceinline__ void gemm_p4_mainloop(typename Cfg::Acc& acc_out, con
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     slot = (slot + 1 == NS) ? 0 : slot + 1;
+    if (j + PF < nkb) islot = (islot + 1 == NS) ? 0 : islot + 1;
   }
   if (L.grp == 0 && !(dbg & 1)) __builtin_amdgcn_s_barrier();
   __syncthreads();   // the staging LDS is reused by the epilogues
@@ -323,6 +374,45 @@ __device__ __forceinline__ void gemm_p4_mainloop(typename Cfg::Acc& acc_out, con
           if constexpr (NACC == 3) accs[i][j][e] += (accm[i][j][e] + accl[i][j][e]);
           else accs[i][j][e] += accm[i][j][e];
         }
+  }
+}
+
+// ---- row epilogue (p3_row_epilogue for tiles whose fp32 image exceeds the LDS: EPI_COLS columns per pass): every thread owns 8
+// CONSECUTIVE columns of a row.  `fn(row, col, nv, v)` is called once per (row, 8-column chunk) that starts inside the matrix. ----
+template <class Cfg, class Fn>
+__device__ __forceinline__ void p4_row_epilogue(const typename Cfg::Acc& accs, char* smem, int M, int N, int m0, int n0, Fn&& fn) {
+  float* t = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN, h = lane >> 5, r = lane & 31;
+  constexpr int EC = Cfg::EPI_COLS, NP = Cfg::BN / EC, CPR = EC / 8, RPI = Cfg::NT / CPR, CPT = Cfg::BM / RPI;
+  const int c8 = (threadIdx.x % CPR) * 8;
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    if (pass) __syncthreads();                         // everybody has read the previous pass
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col0 = wn * Cfg::WN + j * 32 - pass * EC;
+      if (col0 >= 0 && col0 < EC) {                    // wave-uniform
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            t[row * Cfg::EPI_LD + col0 + r] = accs.v[i][j][e];
+          }
+      }
+    }
+    __syncthreads();
+    const int col = n0 + pass * EC + c8;
+#pragma unroll
+    for (int it = 0; it < CPT; ++it) {
+      const int row = it * RPI + threadIdx.x / CPR;
+      if (m0 + row >= M || col >= N) continue;
+      const float4 a = *reinterpret_cast<const float4*>(t + row * Cfg::EPI_LD + c8);
+      const float4 b = *reinterpret_cast<const float4*>(t + row * Cfg::EPI_LD + c8 + 4);
+      float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      fn(m0 + row, col, min(8, N - col), v);
+    }
   }
 }
 

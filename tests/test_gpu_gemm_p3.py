@@ -7,7 +7,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TILES = [0, 406406430, 406406431, 412806420, 406412820, 812812830, 825612820]
+TILES = [0, 406406430, 406406431, 412806420, 406412820, 812812830, 825612820, 425612833, 425612832, 425625631]
+# the ping-pong tiles of gemm_p4.cuh: ...833 keeps gemm_p3's three accumulator sets (bit-identical), ...832 folds the small terms into
+# one set and ...631 (256x256) runs ONE accumulator set: same products, different rounding points -- held to the fp64 bound only
+NOT_BIT_IDENTICAL = {425612832, 425625631}
 
 
 def _tol(ref, K):
@@ -31,7 +34,10 @@ def test_forward_matches_fp64_and_the_in_loop_split(tile, M, N, K):
     if N % 4 == 0:
         y0 = torch.empty(M, N, device="cuda")
         ops.gemm(True, True, M, N, K, xs, K, Ws, K, y0, N, ops.EPI_BIAS, bias=bs, use_ws=False, tile_hint=9064)
-        assert torch.equal(y, y0)                  # the planes ARE the terms gemm_b3 computes on the fly: same bits
+        if tile in NOT_BIT_IDENTICAL:
+            assert (y - y0).abs().max().item() <= 0.05 * _tol(ref, K)
+        else:
+            assert torch.equal(y, y0)              # the planes ARE the terms gemm_b3 computes on the fly: same bits
     if N % 32 == 0:
         yp = ops.Planes.alloc(M, N, "cuda")
         ops.gemm_planes(xp, Wp, None, ops.EPI_BIAS, bias=bs, tile_hint=tile, Cp=yp)      # planes only, no fp32 store
@@ -55,7 +61,10 @@ def test_input_gradient_flavour(tile, M, N, K):
         assert (dx.double().cpu() - ref).abs().max().item() <= _tol(ref, K) * (4 if epi == ops.EPI_MUL else 1)
         dx0 = torch.empty(M, N, device="cuda")
         ops.gemm(True, False, M, N, K, dy, K, W, N, dx0, N, epi, aux=aux, ldaux=N, use_ws=False, tile_hint=9064)
-        assert torch.equal(dx, dx0)
+        if tile in NOT_BIT_IDENTICAL:
+            assert (dx - dx0).abs().max().item() <= 0.05 * _tol(ref, K) * (4 if epi == ops.EPI_MUL else 1)
+        else:
+            assert torch.equal(dx, dx0)
 
 
 @pytest.mark.parametrize("tile", [0, 412812831, 812812830, 406406431])

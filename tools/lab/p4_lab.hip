@@ -67,6 +67,14 @@ __global__ void diff_kernel(const float* a, const float* b, int64_t n, float* ou
   }
 }
 
+__global__ void mismatch_kernel(const float* a, const float* b, int64_t n, unsigned long long* out /* [0] count, [1] first index */) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (a[i] != b[i]) {
+      atomicAdd(out, 1ull);
+      atomicMin(out + 1, (unsigned long long)i);
+    }
+}
+
 struct LabArgs {
   P3Mat A, B;
   float* C;
@@ -74,13 +82,13 @@ struct LabArgs {
   unsigned long long* clk;     // [0] shader cycles, [1] 100 MHz ticks spent by workgroup 0 (effective clock under this kernel's load)
 };
 
-template <class Cfg, bool A_KC, bool B_KC>
+template <class Cfg, bool A_KC, bool B_KC, int DBG>
 __device__ __forceinline__ void lab_mainloop(typename Cfg::Acc& accs, const LabArgs& g, int m0, int n0, char* smem) {
-  if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, A_KC, B_KC>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
-  else gemm_p3_mainloop<Cfg, A_KC, B_KC, false>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
+  if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, A_KC, B_KC, false, (DBG & 31)>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr);
+  else gemm_p3_mainloop<Cfg, A_KC, B_KC, false>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, DBG & 31);
 }
 
-template <class Cfg, bool A_KC, bool B_KC>
+template <class Cfg, bool A_KC, bool B_KC, int DBG>
 __global__ void __launch_bounds__(Cfg::NT) lab_kernel(const LabArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
@@ -89,9 +97,11 @@ __global__ void __launch_bounds__(Cfg::NT) lab_kernel(const LabArgs g) {
   const int tm = n_fastest ? t / g.tiles_n : t % g.tiles_m, tn = n_fastest ? t % g.tiles_n : t / g.tiles_m;
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
   typename Cfg::Acc accs;
-  lab_mainloop<Cfg, A_KC, B_KC>(accs, g, m0, n0, smem);
+  lab_mainloop<Cfg, A_KC, B_KC, DBG>(accs, g, m0, n0, smem);
+  constexpr bool nostore = (DBG & 32) != 0;
   if constexpr (Cfg::BM * Cfg::EPI_LD * 4 <= Cfg::LDS_BYTES) {
     p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, [&](int, int row, int col, int nv, float (&v)[8]) {
+      if (nostore && v[0] != 1.2345e38f) return;
       float* cp = g.C + (int64_t)row * g.N + col;
       if (nv == 8) {
         *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -101,18 +111,26 @@ __global__ void __launch_bounds__(Cfg::NT) lab_kernel(const LabArgs g) {
       }
     });
   } else {
-    // direct stores from the accumulators (lab only: 128-byte row segments per half wave)
+    // direct stores from the accumulators through a buffer descriptor (rows beyond M are dropped by the bounds check; N % BN == 0)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN, h = lane >> 5, r = lane & 31;
+    const bufrsrc rc = make_rsrc(g.C, (int64_t)g.M * g.N * 4);
+    const unsigned voff = (unsigned)(((int64_t)(m0 + wm * Cfg::WM + 4 * h) * g.N + n0 + wn * Cfg::WN + r) * 4);
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int col = n0 + wn * Cfg::WN + j * 32 + r;
-          if (row < g.M && col < g.N) g.C[(int64_t)row * g.N + col] = accs.v[i][j][e];
+          if (nostore && accs.v[i][j][e] != 1.2345e38f) continue;
+          if constexpr ((DBG & 64) != 0) {
+            const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, col = n0 + wn * Cfg::WN + j * 32 + r;
+            if (row < g.M && col < g.N) g.C[(int64_t)row * g.N + col] = accs.v[i][j][e];
+            continue;
+          }
+          const unsigned so = (unsigned)((i * 32 + (e & 3) + 8 * (e >> 2)) * g.N + j * 32) * 4u;
+          const float val = accs.v[i][j][e];      // (bit_cast of a vector ELEMENT lvalue reads element 0: clang quirk)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rc, voff, so, 0);
         }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && g.clk) {
@@ -144,11 +162,12 @@ static Planes make_planes(const float* x, int64_t R, int64_t C, bool transposed)
   return P;
 }
 
-template <class Cfg, bool A_KC, bool B_KC>
+template <class Cfg, bool A_KC, bool B_KC, int DBG = 0>
 static float run(const char* name, LabArgs g, int iters, const float* ref, float* diffbuf, bool quiet = false) {
   g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
   g.tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
-  auto kern = lab_kernel<Cfg, A_KC, B_KC>;
+  g.dbg = DBG;
+  auto kern = lab_kernel<Cfg, A_KC, B_KC, DBG>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
   const dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), blk(Cfg::NT);
   for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, grid, blk, Cfg::LDS_BYTES, 0, g);
@@ -167,10 +186,23 @@ static float run(const char* name, LabArgs g, int iters, const float* ref, float
   if (g.clk) CK(hipMemcpy(hc, g.clk, 16, hipMemcpyDeviceToHost));
   const double ghz = (double)hc[0] / ((double)hc[1] / 100e6) / 1e9;
   float hd[2] = {0.f, 0.f};
-  if (ref && g.dbg == 0) {
+  if (ref && (g.dbg & 63) == 0) {
     CK(hipMemset(diffbuf, 0, 8));
     hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, 0, (const float*)g.C, ref, (int64_t)g.M * g.N, diffbuf);
     CK(hipMemcpy(hd, diffbuf, 8, hipMemcpyDeviceToHost));
+  }
+  if (hd[0] != 0.f) {
+    unsigned long long* mm;
+    CK(hipMalloc(&mm, 16));
+    unsigned long long init[2] = {0ull, ~0ull}, res[2];
+    CK(hipMemcpy(mm, init, 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(mismatch_kernel, dim3(1024), dim3(256), 0, 0, (const float*)g.C, ref, (int64_t)g.M * g.N, mm);
+    CK(hipMemcpy(res, mm, 16, hipMemcpyDeviceToHost));
+    float va = 0, vb = 0;
+    CK(hipMemcpy(&va, g.C + res[1], 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&vb, ref + res[1], 4, hipMemcpyDeviceToHost));
+    printf("    MISMATCH: %llu of %lld elements; first at row %llu col %llu: got %g want %g\n", res[0], (long long)g.M * g.N, res[1] / g.N,
+           res[1] % g.N, va, vb);
+    CK(hipFree(mm));
   }
   if (!quiet)
     printf("  %-34s dbg=%-2d %9.1f us  %7.1f TF(6p)  frac %.3f  clk %.2f GHz  maxdiff %.3g (max|c| %.3g)\n", name, g.dbg, us, tf6,
@@ -217,24 +249,18 @@ int main(int argc, char** argv) {
     g.C = Cref;
     run<P3Cfg<256, 128, 4, 2, 2>, true, true>("p3 256x128 s2 (baseline)", g, iters, nullptr, diffbuf);
     g.C = C;
-    for (int dbg : {0, 8, 1, 2, 4, 16, 6}) {
-      g.dbg = dbg;
-      run<P4Cfg<256, 128, 4, 2, 4, 3>, true, true>("p4 256x128 ns4 acc3", g, iters, Cref, diffbuf);
-    }
-    g.dbg = 0;
-    run<P4Cfg<256, 128, 4, 2, 4, 2>, true, true>("p4 256x128 ns4 acc2", g, iters, Cref, diffbuf);
-    run<P4Cfg<256, 128, 4, 2, 4, 1>, true, true>("p4 256x128 ns4 acc1", g, iters, Cref, diffbuf);
-    run<P4Cfg<256, 128, 4, 2, 3, 3>, true, true>("p4 256x128 ns3 acc3", g, iters, Cref, diffbuf);
-    run<P4Cfg<256, 128, 2, 4, 4, 3>, true, true>("p4 256x128 ns4 acc3 wg2x4", g, iters, Cref, diffbuf);
-    // the dX flavour: B as [K][N] planes
-    g.B = Bt.m;
-    run<P3Cfg<256, 128, 4, 2, 2>, true, false>("p3 256x128 s2  B=XC", g, iters, Cref, diffbuf);
-    run<P4Cfg<256, 128, 4, 2, 4, 3>, true, false>("p4 256x128 ns4 acc3  B=XC", g, iters, Cref, diffbuf);
+    const bool n256 = s.N % 256 == 0;
+#define RUN(NAME, DBG, ...) run<__VA_ARGS__, true, true, DBG>(NAME, g, iters, Cref, diffbuf)
+    RUN("p4 256x128 ns3 acc3 dma0", 0, P4Cfg<256, 128, 4, 2, 3, 3, 0>);
+    RUN("p4 256x128 ns3 acc3 dma0 plainstore", 64, P4Cfg<256, 128, 4, 2, 3, 3, 0>);
+    RUN("p4 256x128 ns4 acc3 dma0", 0, P4Cfg<256, 128, 4, 2, 4, 3, 0>);
+    RUN("p3 128x128 s3 4 waves (2 WG/CU)", 0, P3Cfg<128, 128, 2, 2, 3>);
     // zero-filled operands: the same instruction stream at the clock the power budget allows without data toggling
     CK(hipMemset(Ap.p, 0, (size_t)Ap.m.ps * 6)); CK(hipMemset(Bp.p, 0, (size_t)Bp.m.ps * 6));
     g.B = Bp.m;
     run<P3Cfg<256, 128, 4, 2, 2>, true, true>("p3 256x128 s2  ZERO operands", g, iters, nullptr, diffbuf);
-    run<P4Cfg<256, 128, 4, 2, 4, 3>, true, true>("p4 256x128 ns4 acc3  ZERO operands", g, iters, nullptr, diffbuf);
+    run<P4Cfg<256, 128, 4, 2, 3, 3, 0>, true, true>("p4 256x128 ns3 acc3  ZERO operands", g, iters, nullptr, diffbuf);
+
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(Cref));
     CK(hipFree(Ap.p)); CK(hipFree(Bp.p)); CK(hipFree(Bt.p));
   }
