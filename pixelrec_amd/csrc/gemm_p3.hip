@@ -79,6 +79,13 @@ struct P3Args {
   int group_m;             // > 1: tiles are walked in groups of group_m row tiles x all column tiles (see gemm_p3_kernel)
 };
 
+template <class Cfg, bool PP>
+struct P4Map {
+  static constexpr int CPT = 1;
+};
+template <class Cfg>
+struct P4Map<Cfg, true> : P4ChunkMap<Cfg> {};
+
 template <class Cfg, bool B_KC, int EPI, bool EARLY>
 __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,8 +109,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
   // operands the epilogue reads are fetched before the main loop where the thread's chunks are few (the lockstep tiles); the
   // ping-pong tiles (8 chunks per thread and pass, every register an accumulator) read them in the epilogue
   constexpr bool PRE = !Cfg::PINGPONG;
-  constexpr bool PRE_AUX = PRE && EpiTraits<EPI>::READS_AUX && Map::CPT <= 4;
-  float bpre[8], apre[PRE_AUX ? Map::CPT : 1][8];
+  constexpr bool PP = Cfg::PINGPONG;
+  constexpr bool PRE_AUX = EpiTraits<EPI>::READS_AUX && (PP || Map::CPT <= 4);
+  constexpr int APRE = !PRE_AUX ? 1 : (PP ? (int)P4Map<Cfg, PP>::CPT : (int)Map::CPT);
+  float bpre[8], apre[APRE][8];
   const int pc = n0 + Map::col8();
   const bool pre_ok = PRE && vec_ok && pc + 8 <= g.N;
   if constexpr (EpiTraits<EPI>::HAS_BIAS && PRE) {
@@ -112,7 +121,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
       bpre[0] = b0.x; bpre[1] = b0.y; bpre[2] = b0.z; bpre[3] = b0.w; bpre[4] = b1.x; bpre[5] = b1.y; bpre[6] = b1.z; bpre[7] = b1.w;
     }
   }
-  if constexpr (PRE_AUX) {
+  if constexpr (PRE_AUX && PRE) {
 #pragma unroll
     for (int it = 0; it < Map::CPT; ++it) {
       const int row = m0 + Map::row(it);
@@ -132,13 +141,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
     const bool vec = vec_ok && nv == 8;
     if constexpr (EpiTraits<EPI>::HAS_BIAS) {
       if (vec) {
-        if constexpr (PRE) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bv[e] = bpre[e];
-        } else {
-          const float4 b0 = *reinterpret_cast<const float4*>(g.bias + col), b1 = *reinterpret_cast<const float4*>(g.bias + col + 4);
-          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-        }
+        for (int e = 0; e < 8; ++e) bv[e] = bpre[e];
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = e < nv ? g.bias[col + e] : 0.f;
@@ -186,8 +190,27 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
     }
     if (g.Cp.p != nullptr) p3_store8(g.Cp, row, col, v);      // (output planes: N % 32 == 0, chunks are whole)
   };
-  if constexpr (Cfg::PINGPONG) p4_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, [&](int row, int col, int nv, float (&v)[8]) { chunk(0, row, col, nv, v); });
-  else p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, chunk);
+  if constexpr (PP) {
+    p4_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0,
+                         [&](int it, int row, int col, int nv) {
+                           if (!(vec_ok && nv == 8)) return;
+                           if constexpr (EpiTraits<EPI>::HAS_BIAS) {
+                             if (it == 0) {          // the thread's column chunk is the same for all its rows of a pass
+                               const float4 b0 = *reinterpret_cast<const float4*>(g.bias + col), b1 = *reinterpret_cast<const float4*>(g.bias + col + 4);
+                               bpre[0] = b0.x; bpre[1] = b0.y; bpre[2] = b0.z; bpre[3] = b0.w; bpre[4] = b1.x; bpre[5] = b1.y; bpre[6] = b1.z; bpre[7] = b1.w;
+                             }
+                           }
+                           if constexpr (PRE_AUX) {
+                             const float* ap = g.aux + (int64_t)row * g.ldaux + col;
+                             const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+                             apre[it][0] = a0.x; apre[it][1] = a0.y; apre[it][2] = a0.z; apre[it][3] = a0.w;
+                             apre[it][4] = a1.x; apre[it][5] = a1.y; apre[it][6] = a1.z; apre[it][7] = a1.w;
+                           }
+                         },
+                         chunk);
+  } else {
+    p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, chunk);
+  }
 }
 
 // x[rows, cols] (row stride ldx floats) -> planes (panel layout); a thread converts 8 consecutive values of a row

@@ -119,6 +119,13 @@ struct P4Operand {
   __device__ __forceinline__ void issue_one(int t, int j, unsigned slot_base) const {
     if (t < n) p3_dma16(rs, lane_off(j), __builtin_amdgcn_readfirstlane(k_off(j) + scal[t]), __builtin_amdgcn_readfirstlane(slot_base + dst[t]));
   }
+  // all of this wave's pieces of k block j, `extra` bytes further into the operand (a later tile of a stream)
+  __device__ __forceinline__ void issue_at(int j, unsigned slot_base, unsigned extra) const {
+    const unsigned voff = lane_off(j), koff = k_off(j) + extra;
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t)
+      if (t < n) p3_dma16(rs, voff, __builtin_amdgcn_readfirstlane(koff + scal[t]), __builtin_amdgcn_readfirstlane(slot_base + dst[t]));
+  }
   // all of this wave's pieces of k block j
   __device__ __forceinline__ void issue(int j, unsigned slot_base) const {
     const unsigned voff = lane_off(j), koff = k_off(j);
@@ -377,17 +384,137 @@ __device__ __forceinline__ void gemm_p4_mainloop(typename Cfg::Acc& acc_out, con
   }
 }
 
+// ---- the same product for a SEQUENCE of A tiles against one B tile as ONE k-block stream (full-catalogue scoring: item tiles
+// m_first, m_first + BM, ... x one block of users; KC x KC): the ring never drains between tiles.  After the last k block of tile t
+// every wave calls `done(t, accs)` on ITS accumulators (all sets folded) at the head of its next L segment -- while the other wave
+// group multiplies -- and clears them.  `done` must not touch the LDS ring and must not contain workgroup barriers (the two groups
+// reach it one slot-time apart); global atomics / stores are fine.
+template <class Cfg, class TileFn>
+__device__ __forceinline__ void gemm_p4_stream(const P3Mat& A, const P3Mat& B, int K, int m_first, int n0, int n_tiles, char* smem,
+                                               TileFn&& done) {
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, NS = Cfg::NS, PF = NS - 1, NACC = Cfg::NACC;
+  static_assert(Cfg::DMA == 0, "the stream issues its pieces in the L segments");
+  using Loop = P4Loop<Cfg, true, true>;
+  const int nkb = K / 16;
+  const int total = n_tiles * nkb;
+  if (total <= 0) return;
+  typename Cfg::Acc acc;
+  auto& accs = acc.v;
+  f32x16 accm[NACC >= 2 ? TM : 1][TN], accl[NACC >= 3 ? TM : 1][TN];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          accs[i][j][e] = 0.f;
+          if constexpr (NACC >= 2) accm[i][j][e] = 0.f;
+          if constexpr (NACC >= 3) accl[i][j][e] = 0.f;
+        }
+  };
+  zero();
+  Loop L;
+  L.init(A, B, m_first, n0, smem);
+  // the issue cursor: k block i_j of item tile i_tile; the A pieces of a later tile start i_tile * BM rows further down the panels
+  int i_j = 0;
+  unsigned i_tile_off = 0;
+  auto issue_next = [&](int slot) {
+    const unsigned sb = L.slot_addr(slot);
+    L.opA.issue_at(i_j, sb, i_tile_off);
+    L.opB.issue(i_j, sb);
+    if (++i_j == nkb) { i_j = 0; i_tile_off += (unsigned)(Cfg::BM * 64); }
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (s < total) issue_next(s);
+  p4_wait_pieces(min(PF - 1, total - 1) * (L.opA.n + L.opB.n));
+  __builtin_amdgcn_s_barrier();
+  if (L.grp == 1) __builtin_amdgcn_s_barrier();                         // group 1 runs one slot-time behind
+  typename Loop::Frag f;
+  int slot = 0, islot = PF % NS, j = 0, tile = 0;
+  bool pending = false;                                                  // tile `tile - 1` is complete in the accumulators
+  for (int it = 0; it < total; ++it) {
+    if (pending) {
+      if constexpr (NACC >= 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              if constexpr (NACC == 3) accs[i][jj][e] += (accm[i][jj][e] + accl[i][jj][e]);
+              else accs[i][jj][e] += accm[i][jj][e];
+            }
+      }
+      done(tile - 1, acc);
+      zero();
+      pending = false;
+    }
+    // ---- L segment
+    L.read_frag(f, slot);
+    const bool more = it + PF < total;
+    if (more) {
+      issue_next(islot);
+      L.wait_steady();
+    } else {
+      p3_wait_vm<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C segment
+    __builtin_amdgcn_s_setprio(1);
+    p4_mfma<Cfg, false>(f, accs, accm, accl, P4NoHook());
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+    if (more) islot = (islot + 1 == NS) ? 0 : islot + 1;
+    if (++j == nkb) { j = 0; ++tile; pending = true; }
+  }
+  if (L.grp == 0) __builtin_amdgcn_s_barrier();
+  if constexpr (NACC >= 2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if constexpr (NACC == 3) accs[i][jj][e] += (accm[i][jj][e] + accl[i][jj][e]);
+          else accs[i][jj][e] += accm[i][jj][e];
+        }
+  }
+  done(tile - 1, acc);
+}
+
 // ---- row epilogue (p3_row_epilogue for tiles whose fp32 image exceeds the LDS: EPI_COLS columns per pass): every thread owns 8
-// CONSECUTIVE columns of a row.  `fn(row, col, nv, v)` is called once per (row, 8-column chunk) that starts inside the matrix. ----
-template <class Cfg, class Fn>
-__device__ __forceinline__ void p4_row_epilogue(const typename Cfg::Acc& accs, char* smem, int M, int N, int m0, int n0, Fn&& fn) {
+// CONSECUTIVE columns of a row.  Per pass: `pre(it, row, col, nv)` for each of the thread's chunks FIRST (the loads of what the
+// epilogue reads -- bias, residual, saved derivative -- go out before the accumulators are staged, so their latency hides behind the
+// LDS round trip instead of serialising with the stores chunk by chunk; the accumulator sets folded after the K loop left the
+// registers for it), then `fn(it, row, col, nv, v)` once per chunk.  Chunks outside the matrix are skipped in both. --------------
+template <class Cfg>
+struct P4ChunkMap {
+  static constexpr int EC = Cfg::EPI_COLS, NP = Cfg::BN / EC, CPR = EC / 8, RPI = Cfg::NT / CPR, CPT = Cfg::BM / RPI;
+};
+template <class Cfg, class Pre, class Fn>
+__device__ __forceinline__ void p4_row_epilogue(const typename Cfg::Acc& accs, char* smem, int M, int N, int m0, int n0, Pre&& pre, Fn&& fn) {
   float* t = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN, h = lane >> 5, r = lane & 31;
-  constexpr int EC = Cfg::EPI_COLS, NP = Cfg::BN / EC, CPR = EC / 8, RPI = Cfg::NT / CPR, CPT = Cfg::BM / RPI;
+  using Map = P4ChunkMap<Cfg>;
+  constexpr int EC = Map::EC, NP = Map::NP, CPR = Map::CPR, RPI = Map::RPI, CPT = Map::CPT;
   const int c8 = (threadIdx.x % CPR) * 8;
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
+    const int col = n0 + pass * EC + c8;
+#pragma unroll
+    for (int it = 0; it < CPT; ++it) {
+      const int row = it * RPI + threadIdx.x / CPR;
+      if (m0 + row < M && col < N) pre(it, m0 + row, col, min(8, N - col));
+    }
     if (pass) __syncthreads();                         // everybody has read the previous pass
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
@@ -403,7 +530,6 @@ __device__ __forceinline__ void p4_row_epilogue(const typename Cfg::Acc& accs, c
       }
     }
     __syncthreads();
-    const int col = n0 + pass * EC + c8;
 #pragma unroll
     for (int it = 0; it < CPT; ++it) {
       const int row = it * RPI + threadIdx.x / CPR;
@@ -411,7 +537,7 @@ __device__ __forceinline__ void p4_row_epilogue(const typename Cfg::Acc& accs, c
       const float4 a = *reinterpret_cast<const float4*>(t + row * Cfg::EPI_LD + c8);
       const float4 b = *reinterpret_cast<const float4*>(t + row * Cfg::EPI_LD + c8 + 4);
       float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      fn(m0 + row, col, min(8, N - col), v);
+      fn(it, m0 + row, col, min(8, N - col), v);
     }
   }
 }

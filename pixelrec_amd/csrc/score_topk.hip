@@ -13,7 +13,7 @@
 // Ties: scores are continuous fp32 dot products, so ties only occur among -inf entries, which can reach the
 // list only when fewer than K unmasked items exist.
 #include "gemm_b3.cuh"
-#include "gemm_p3.cuh"
+#include "gemm_p4.cuh"
 
 #include <cstdlib>
 
@@ -348,10 +348,13 @@ __global__ void __launch_bounds__(256) topk_tau_kernel(const float* __restrict__
 
 // one wave per user: the K best of its cnt[u] appended candidates, descending by value, ties by ascending item id
 // (independent of the append order).  A count above the capacity sets the status word: candidates were dropped.
-__global__ void __launch_bounds__(256) topk_cand_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+// hist_ptr / hist_items (may be null): candidates whose item is in the user's history list are dropped here (value -inf) when
+// the pass that appended them did not mask the history itself (score_thresh_p4_kernel).
+__global__ void __launch_bounds__(256) topk_cand_merge_kernel(float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                               const int* __restrict__ cnt, int cap, int B, int K,
                                                               int64_t* __restrict__ out_idx, float* __restrict__ out_val,
-                                                              int32_t* status) {
+                                                              int32_t* status, const int* __restrict__ hist_ptr,
+                                                              const int64_t* __restrict__ hist_items) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int u = blockIdx.x * 4 + wave;
   if (u >= B) return;
@@ -360,8 +363,19 @@ __global__ void __launch_bounds__(256) topk_cand_merge_kernel(const float* __res
     if (status && lane == 0) atomicOr(status, PXR_STATUS_TOPK_OVERFLOW);
     n = min(n, cap);
   }
-  const float* pv = cand_val + (int64_t)u * cap;
+  float* pv = cand_val + (int64_t)u * cap;
   const int* pi = cand_idx + (int64_t)u * cap;
+  if (hist_ptr != nullptr) {
+    const int hb = hist_ptr[u], he = hist_ptr[u + 1];
+    if (he > hb) {
+      for (int c = lane; c < n; c += 64) {
+        const int64_t id = pi[c];
+        bool seen = false;
+        for (int p = hb; p < he; ++p) seen |= (hist_items[p] == id);
+        if (seen) pv[c] = -INFINITY;        // (this lane re-reads pv[c] below: same thread, program order)
+      }
+    }
+  }
   float last_v = INFINITY;
   int last_id = -1;
   for (int k = 0; k < K; ++k) {
@@ -559,6 +573,59 @@ __global__ void __launch_bounds__(Sp3Cfg::NT) score_thresh_p3_kernel(ScoreTopkAr
     p3_lds_barrier();                                      // the bitmap is re-zeroed at the top of the next tile
   });
 }
+
+// ---- the same pass on the ping-pong main loop (gemm_p4.cuh; round 4): one k-block stream over all item tiles of the workgroup,
+// the comparison with tau runs wave by wave at the head of the next tile's first L segment -- no workgroup barrier, no LDS: the
+// (user, item) pairs of the users' HISTORY are no longer masked here (the bitmap needed two barriers per tile) but in the
+// candidate merge (topk_cand_merge_kernel drops candidates found in the user's history list): at most `history length` extra
+// candidates per user.  Products, k order and accumulator sets are gemm_p3's: the same candidate VALUES as before, bit for bit.
+using Sp4Cfg = P4Cfg<SP3_BM, SP3_BN, 4, 2, 3, 3>;
+__global__ void __launch_bounds__(Sp4Cfg::NT) score_thresh_p4_kernel(ScoreTopkArgs a, P3Mat table_p, P3Mat users_p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
+  const int rb = t % a.row_blocks, sp = t / a.row_blocks;
+  const int u0 = rb * SP3_BN;
+  const int tiles = (a.N + SP3_BM - 1) / SP3_BM;
+  const int per = (tiles + a.n_split - 1) / a.n_split;
+  const int tn0 = sp * per, tn1 = min(tiles, tn0 + per);
+  if (tn0 >= tn1) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / Sp4Cfg::WGN, wn = wave % Sp4Cfg::WGN;
+  gemm_p4_stream<Sp4Cfg>(table_p, users_p, a.D, tn0 * SP3_BM, u0, tn1 - tn0, smem, [&](int tile, const typename Sp4Cfg::Acc& accs) {
+    // every per-lane value of the comparison is derived HERE from an opaque lane id: anything hoisted out of the k-block stream
+    // would have to live beside 192 accumulator + 48 fragment registers and comes back as scratch traffic inside the K loop
+    // (a VMEM wait in front of the DMA ring).  tau is re-read per tile (L2-resident, once per 32 k blocks).
+    unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane));
+    const int h = (int)(lane >> 5), r = (int)(lane & 31u);
+    const int i0 = (tn0 + tile) * SP3_BM + wm * Sp4Cfg::WM + 4 * h;
+#pragma unroll
+    for (int j = 0; j < Sp4Cfg::TN; ++j) {
+      const int user = u0 + wn * Sp4Cfg::WN + j * 32 + r;
+      const float thr_j = user < a.B ? a.tau[user] : INFINITY;          // users past B never pass
+#pragma unroll
+      for (int i = 0; i < Sp4Cfg::TM; ++i) {
+        // most 32x32 blocks hold no candidate at all: one wave-wide test per block, the per-element work only behind it
+        float mx = accs.v[i][j][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, accs.v[i][j][e]);
+        if (!__any(mx >= thr_j)) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int item = i0 + i * 32 + (e & 3) + 8 * (e >> 2);
+          const float x = accs.v[i][j][e];
+          if (x >= thr_j && item != 0 && item < a.N) {
+            const int pos = atomicAdd(&a.cand_cnt[user], 1);
+            if (pos < a.cand_cap) {
+              a.cand_val[(int64_t)user * a.cand_cap + pos] = x;
+              a.cand_idx[(int64_t)user * a.cand_cap + pos] = item;
+            }
+          }
+        }
+      }
+    }
+  });
+}
 }  // namespace pxr
 
 using namespace pxr;
@@ -616,17 +683,23 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
   // pass 2: every tile at full GEMM speed, survivors appended
   a.n_split = n_split_full;
   a.tile_stride = 1; a.tau = tau; a.cand_cnt = cnt; a.cand_val = cval; a.cand_idx = cidx; a.cand_cap = ST4_CAP;
+  bool hist_in_merge = false;
   if (table_p != nullptr) {
-    // planes: 256-item tiles, one workgroup per CU (156 KB of LDS), every CU the same number of tiles
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(score_thresh_p3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              SP3_LDS) != hipSuccess) {
+    // planes: 256-item tiles, one workgroup per CU, every CU the same number of tiles.  Default: round 3's lockstep stream with
+    // the history bitmap; PXR_SCORE_P4=1 (read per call: a measuring / test knob): the ping-pong stream (score_thresh_p4_kernel),
+    // measured equal on the 1024 x 400 001 x 512 evaluation (2.146 vs 2.137 ms: 32 k blocks per tile are too few to amortise
+    // the per-tile comparison, and the history scan moves into the merge: + 50 us)
+    const int env_p4 = getenv("PXR_SCORE_P4") ? atoi(getenv("PXR_SCORE_P4")) : 0;
+    const void* kern = env_p4 ? reinterpret_cast<const void*>(score_thresh_p4_kernel) : reinterpret_cast<const void*>(score_thresh_p3_kernel);
+    const int lds = env_p4 ? Sp4Cfg::LDS_BYTES : SP3_LDS;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[env_p4 ? 1 : 0]) {
+      if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
         (void)hipGetLastError();
-        pxr_set_error("pxr_score_topk_planes_f32: cannot reserve %d bytes of LDS", SP3_LDS);
+        pxr_set_error("pxr_score_topk_planes_f32: cannot reserve %d bytes of LDS", lds);
         return PXR_ERR_LAUNCH;
       }
-      attr_set = true;
+      attr_set[env_p4 ? 1 : 0] = true;
     }
     const int tiles256 = (a.N + SP3_BM - 1) / SP3_BM;
     a.row_blocks = (a.B + SP3_BN - 1) / SP3_BN;
@@ -634,7 +707,12 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
     if (ns > tiles256) ns = tiles256;
     if (ns < 1) ns = 1;
     a.n_split = ns;
-    hipLaunchKernelGGL(score_thresh_p3_kernel, dim3(a.row_blocks * a.n_split), dim3(Sp3Cfg::NT), SP3_LDS, st, a, *table_p, *users_p);
+    if (env_p4) {
+      hist_in_merge = a.hist_ptr != nullptr;
+      hipLaunchKernelGGL(score_thresh_p4_kernel, dim3(a.row_blocks * a.n_split), dim3(Sp4Cfg::NT), lds, st, a, *table_p, *users_p);
+    } else {
+      hipLaunchKernelGGL(score_thresh_p3_kernel, dim3(a.row_blocks * a.n_split), dim3(Sp3Cfg::NT), lds, st, a, *table_p, *users_p);
+    }
   } else if (pxr_get_gemm_mode() && a.D % 4 == 0)
     hipLaunchKernelGGL(score_thresh_kernel<1>, grid, dim3(1024), 0, st, a);
   else
@@ -642,8 +720,9 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
   int rc = pxr_check_launch("pxr_score_topk_f32(threshold pass)");
   if (rc) return rc;
   // pass 3: K best candidates per user
-  hipLaunchKernelGGL(topk_cand_merge_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, (const float*)cval, (const int*)cidx,
-                     (const int*)cnt, ST4_CAP, a.B, K, topk_idx, topk_val, pxr_status_word());
+  hipLaunchKernelGGL(topk_cand_merge_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, cval, (const int*)cidx,
+                     (const int*)cnt, ST4_CAP, a.B, K, topk_idx, topk_val, pxr_status_word(),
+                     hist_in_merge ? a.hist_ptr : (const int*)nullptr, hist_in_merge ? a.hist_items : (const int64_t*)nullptr);
   return pxr_check_launch("pxr_score_topk_f32(candidate merge)");
 }
 

@@ -9,6 +9,8 @@
   configs[3]      : emb 4096 on the full 408 001-item catalogue: lazy == dense table AdamW and run-to-run bits (the
                     row-sharded emb-4096 case lives in tests/test_gpu_sharded.py).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -56,6 +58,17 @@ def test_fused_topk_full_eval_shape():
     # the k-th value really is the k-th largest of the row: nothing outside the list beats it
     kth = rv[:, -1:]
     assert int((scores > kth).sum(dim=1).max()) <= K - 1
+    # the evaluation's default: the main pass on a pre-split table (planes), lockstep stream and ping-pong stream (the latter
+    # masks the history in the candidate merge): same products, same order -> the same ids and the same bits
+    assert ops.score_planes_supported(table)
+    tp = ops.split_planes(table)
+    for p4 in ("0", "1"):
+        os.environ["PXR_SCORE_P4"] = p4
+        try:
+            idx_p, val_p = ops.score_topk(users, D, B, table, K, ptr, items, table_planes=tp)
+        finally:
+            os.environ.pop("PXR_SCORE_P4", None)
+        assert torch.equal(idx_p, idx) and torch.equal(val_p, val), f"planes top-k (PXR_SCORE_P4={p4}) differs"
 
 
 # ------------------------------------------------------------------------------------------------ configs[2] / [4]

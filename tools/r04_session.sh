@@ -55,3 +55,10 @@ if has b2048; then
   rm -f "$P/b2048_kernel_trace.csv"; find "$P" -name "*.db" -delete
   head -40 "$P/b2048_kernel_stats.csv" | cut -c1-200
 fi
+cd "$REPO"
+if has evaltest; then
+  ( time timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_eval.py tests/test_gpu_misc.py -m gpu -q -x 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -15 ) > "$OUT/pytest_eval.log" 2>&1
+  tail -n 8 "$OUT/pytest_eval.log"
+  timeout 300 python tools/eval_bench.py > "$OUT/eval_bench.log" 2>&1; grep -v amdgpu.ids "$OUT/eval_bench.log" | tail
+  PXR_SCORE_P4=0 timeout 300 python tools/eval_bench.py > "$OUT/eval_bench_p4off.log" 2>&1; grep -v amdgpu.ids "$OUT/eval_bench_p4off.log" | tail
+fi
