@@ -273,6 +273,12 @@ int pxr_attn_rows_bwd_f32(const float* P, float* dPD, int B, int H, int L, int l
                           uint32_t stream_id, const int64_t* step_dev, int d, void* stream);
 /* out = a + b (n floats, n % 4 == 0): the two branches of a residual-stream gradient */
 int pxr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* y = dropout(x): y[i] = x[i] / (1 - p) where the library's counter hash of (seed + *step_dev, stream_id, i) keeps element i, else
+ * 0 (n floats, n % 4 == 0, 16-byte aligned; step_dev may be NULL).  Applied to the upstream gradient it is its own backward: the
+ * mask is regenerated, not stored.  Replaces nn.Dropout on the gathered item embeddings of GRU4Rec
+ * (REC/model/IDNet/gru4rec.py:26,59); masks restated for the oracle in oracle/dropout_rng.py. */
+int pxr_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                    void* stream);
 
 /* y = x W^T + b (act=1: erf-GELU, pre-activation saved; act=2: erf-GELU, gelu'(pre-activation) saved)
  *                                                          layers.py:586-588,613,666-667,669; sasrec.py:112 */

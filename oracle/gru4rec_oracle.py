@@ -25,16 +25,20 @@ def gru_stack(params, x, n_layers):
     return x
 
 
-def encode(params, seq_ids, n_layers):
-    """item ids [B, L] -> dense(GRU(E[ids])) [B, L, E]  (dropout inactive: the shipped dropout_prob is 0)."""
-    out = gru_stack(params, params["item_embedding.weight"][seq_ids], n_layers)
+def encode(params, seq_ids, n_layers, emb_keep=None, p_drop=0.0):
+    """item ids [B, L] -> dense(GRU(emb_dropout(E[ids]))) [B, L, E]  (gru4rec.py:58-62).  emb_keep: boolean keep mask [B, L, E] of
+    the embedding dropout (None = inactive: evaluation, or the shipped dropout_prob 0); kept values are scaled by 1 / (1 - p)."""
+    x = params["item_embedding.weight"][seq_ids]
+    if emb_keep is not None:
+        x = torch.where(emb_keep, x / (1.0 - p_drop), torch.zeros_like(x))
+    out = gru_stack(params, x, n_layers)
     return out @ params["dense.weight"].t() + params["dense.bias"]
 
 
-def forward_loss(params, items, masked_index, n_layers):
+def forward_loss(params, items, masked_index, n_layers, emb_keep=None, p_drop=0.0):
     """gru4rec.py:50-68."""
     pos_ids, neg_ids = items[:, 0], items[:, 1]
-    out = encode(params, pos_ids[:, :-1], n_layers)
+    out = encode(params, pos_ids[:, :-1], n_layers, emb_keep, p_drop)
     E = params["item_embedding.weight"]
     pos = (out * E[pos_ids[:, 1:]]).sum(-1)
     neg = (out * E[neg_ids[:, 1:]]).sum(-1)

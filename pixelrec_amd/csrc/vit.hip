@@ -10,7 +10,8 @@
 //                                       neither; the SASRec attention has its own fused kernels in attention.hip);
 //   * pxr_vit_embed_f32                 [class token | patch projections] + position embedding -> token matrix;
 //   * pxr_token_mean_f32 / pxr_token_mean_relu_bwd_f32   mean over the T tokens of relu(rec_fc(.)) and its gradient;
-//   * pxr_add_f32                       out = a + b (the two branches of a residual gradient).
+//   * pxr_add_f32                       out = a + b (the two branches of a residual gradient);
+//   * pxr_dropout_f32                   y = dropout(x) with the library's counter-hash mask (GRU4Rec's emb_dropout; its own backward).
 #include "pxr_common.h"
 
 namespace pxr {
@@ -250,6 +251,34 @@ extern "C" int pxr_token_mean_relu_bwd_f32(const float* dout, const float* act, 
   hipLaunchKernelGGL(token_mean_relu_bwd_kernel, dim3(grid_for(n * T * (D / 4))), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)dout, (const float4*)act, (float4*)dact, n, T, D / 4);
   return pxr_check_launch("pxr_token_mean_relu_bwd_f32");
+}
+
+// y[i] = keep(i) ? x[i] / (1 - p) : 0, keep = the counter hash of (seed + *step_dev, stream_id, i): calling it on the upstream
+// gradient regenerates the forward's mask (nothing is stored).  n % 4 == 0.
+namespace pxr {
+__global__ void __launch_bounds__(256) dropout_kernel(const float4* __restrict__ x, float4* __restrict__ y, int64_t n4, float inv_keep,
+                                                      uint32_t thr, uint64_t seed, uint32_t stream_id, const int64_t* step_dev) {
+  if (step_dev) seed += (uint64_t)step_dev[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 v = x[i];
+    const uint64_t e = (uint64_t)i * 4;
+    v.x = pxr_keep(seed, stream_id, e, thr) ? v.x * inv_keep : 0.f;
+    v.y = pxr_keep(seed, stream_id, e + 1, thr) ? v.y * inv_keep : 0.f;
+    v.z = pxr_keep(seed, stream_id, e + 2, thr) ? v.z * inv_keep : 0.f;
+    v.w = pxr_keep(seed, stream_id, e + 3, thr) ? v.w * inv_keep : 0.f;
+    y[i] = v;
+  }
+}
+}  // namespace pxr
+extern "C" int pxr_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                               void* stream) {
+  PXR_REQUIRE(x && y && n >= 0 && n % 4 == 0, "pxr_dropout_f32: bad args (n must be a multiple of 4)");
+  PXR_REQUIRE(p >= 0.f && p < 1.f, "pxr_dropout_f32: p must be in [0, 1)");
+  PXR_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "pxr_dropout_f32: operands must be 16-byte aligned");
+  if (n == 0) return PXR_OK;
+  hipLaunchKernelGGL(pxr::dropout_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)y, n / 4,
+                     1.0f / (1.0f - p), pxr_drop_threshold(p), seed, stream_id, step_dev);
+  return pxr_check_launch("pxr_dropout_f32");
 }
 
 extern "C" int pxr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "pxr_token_mean_f32": (_I, [_P, _P, _I64, _I, _I, _P]),
     "pxr_token_mean_relu_bwd_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "pxr_add_f32": (_I, [_P, _P, _P, _I64, _P]),
+    "pxr_dropout_f32": (_I, [_P, _P, _I64, _F, _U64, _U32, _P, _P]),
     "pxr_attn_rows_fwd_f32": (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _F, _U64, _U32, _P, _I, _P]),
     "pxr_attn_rows_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _U64, _U32, _P, _I, _P]),
     "pxr_split_planes_f32": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _P]),

@@ -19,7 +19,8 @@ of this build is SASRec.
 Contract kept: `input_type`; `__init__(config, dataload)` with the reference's keys (`embedding_size`, `hidden_size` as a
 multiplier, `num_layers`, `dropout_prob`); `forward((items [B, 2, L+1], masked_index [B, L])) -> loss`; `predict`;
 `compute_item_all`; `state_dict` keys `item_embedding.weight`, `gru_layers.weight_{ih,hh}_l{k}`, `dense.{weight,bias}`.
-Limit: `dropout_prob` must be 0 for training (the shipped IDNet/gru4rec.yaml value); a positive value raises.
+`dropout_prob` > 0: the embedding dropout of gru4rec.py:26,59 with the library's counter-hash mask (pxr_dropout_f32; the backward
+regenerates it) -- distributionally nn.Dropout, exactly reproducible in the oracle through oracle/dropout_rng.py.
 """
 from __future__ import annotations
 
@@ -83,15 +84,23 @@ class GRUBlock:
     def refresh_weight_planes(self):
         return None
 
+    EMB_DROP_STREAM = 0            # hash stream of the embedding dropout (SASRec's input-site id: the same place in the model)
+
+    def _emb_drop_seed(self) -> int:
+        return (self._drop_seed * 1000003) & 0xFFFFFFFFFFFFFFFF
+
     # ------------------------------------------------------------------------------------------ recurrent block
     def _encode(self, table, idx, idx_bstride, B, keymask, km_bstride, train: bool):
         """row ids into `table` -> dense(GRU(rows)) [B, L, E] (gru4rec.py:50-62 / :72-79).  idx: [B, idx_bstride] ids whose
         first L columns are the input sequence.  Internally time-major so that every step reads contiguous [B, .] slabs."""
         L, E, Hh = self.max_seq_length, self.embedding_size, self.gru_hidden
-        if train and self.dropout_prob > 0:
-            raise NotImplementedError("GRU4Rec: emb_dropout with dropout_prob > 0 is not built (IDNet/gru4rec.yaml ships 0)")
         ids_tm = idx.reshape(B, idx_bstride)[:, :L].t().contiguous()                     # [L, B]
         x = ops.embed_gather(table, ids_tm)                                              # [L, B, E]
+        drop = train and self.dropout_prob > 0
+        if drop:
+            # emb_dropout (gru4rec.py:26,59) with the library's counter-hash mask over the TIME-MAJOR [L, B, E] element index
+            # (stream id EMB_DROP_STREAM); the backward regenerates it from the same (seed, completed-step counter)
+            x = ops.dropout(x, self.dropout_prob, self._emb_drop_seed(), self.EMB_DROP_STREAM, self._drop_dev)
         dev = x.device
         layers = []
         for k in range(self.num_layers):
@@ -108,7 +117,7 @@ class GRUBlock:
             x = h
         out_tm = ops.linear_fwd(x, self._p("dense.w"), self._p("dense.b"))               # [L, B, E]
         out = out_tm.transpose(0, 1).contiguous()                                        # [B, L, E]: what the BPR head reads
-        return out, (dict(layers=layers, ids_tm=ids_tm) if train else None)
+        return out, (dict(layers=layers, ids_tm=ids_tm, drop=drop) if train else None)
 
     def _backward_core(self, grad_out, table):
         """Backward of SeqRecCore._forward_core for the recurrent block: fills the flat gradient buffer, hands the gradient
@@ -142,6 +151,8 @@ class GRUBlock:
             pend.append((dgi.view(L * B, 3 * Hh), a["x"].view(L * B, -1), g(f"gru.{k}.ih"), None))
             pend.append((dgh.view(L * B, 3 * Hh), hprev.view(L * B, Hh), g(f"gru.{k}.hh"), None))
             dh_out = ops.linear_bwd_input(dgi, Wih)                                      # [L, B, in]: the layer below / the rows
+        if s.get("drop"):
+            dh_out = ops.dropout(dh_out, self.dropout_prob, self._emb_drop_seed(), self.EMB_DROP_STREAM, self._drop_dev)
         dx0 = dh_out.transpose(0, 1).contiguous()                                        # [B, L, E]
         self._after_input_grads(dx0, coef, s)
         ops.grouped_linear_bwd_weight(pend)        # every weight (and the dense bias) gradient of the step: one launch

@@ -419,6 +419,16 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def dropout(x: torch.Tensor, p: float, seed: int, stream_id: int, step_dev=None) -> torch.Tensor:
+    """x / (1 - p) where the library's counter hash keeps the element, else 0 (pxr_dropout_f32); on the upstream gradient with the
+    same (seed, stream_id, step_dev) it is the backward of itself."""
+    _req(x, torch.float32, "x")
+    y = torch.empty_like(x)
+    _l.check(_l.load().pxr_dropout_f32(_l.ptr(x), _l.ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id),
+                                       _l.ptr(step_dev), _l.stream_ptr()), "pxr_dropout_f32")
+    return y
+
+
 def linear_bwd_input(dy: torch.Tensor, W: torch.Tensor, dgelu_pre: torch.Tensor | None = None,
                      add: torch.Tensor | None = None, mul: torch.Tensor | None = None):
     """dx = dy W, optionally times gelu'(pre) (from the saved pre-activation), times `mul` (gelu' saved by the forward),
@@ -453,9 +463,14 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor | Non
 
 
 def grouped_linear_bwd_weight(problems):
-    """problems: list of (dy2d [M,N], x2d [M,K], dW [N,K] out, db [N] out | None).  One launch for all of them."""
+    """problems: list of (dy2d [M,N], x2d [M,K], dW [N,K] out, db [N] out | None).  One launch for all of them (one per MULTI_MAX
+    of them: blocks deeper than 4 layers)."""
     import ctypes
 
+    if len(problems) > MULTI_MAX:
+        for lo in range(0, len(problems), MULTI_MAX):
+            grouped_linear_bwd_weight(problems[lo:lo + MULTI_MAX])
+        return
     L = _l.load()
     n = len(problems)
     P, I = ctypes.c_void_p * n, ctypes.c_int * n
@@ -472,18 +487,25 @@ def grouped_linear_bwd_weight(problems):
                  "pxr_grouped_linear_bwd_weight_f32")
 
 
+MULTI_MAX = 16      # matrices per pxr_split_planes_multi_f32 launch / plane segments per pxr_adamw_flat_tab_planes_f32 launch
+
+
 def split_planes_multi(mats, outs=None):
     """Several fp32 matrices -> Planes in ONE launch (pxr_split_planes_multi_f32); `outs`: existing Planes to overwrite."""
-    n = len(mats)
     if outs is None:
         outs = [Planes.alloc(m.shape[0], m.shape[1], m.device) for m in mats]
-    P, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
     for m in mats:
         assert m.dim() == 2 and m.stride(1) == 1 and m.dtype == torch.float32
-    _l.check(_l.load().pxr_split_planes_multi_f32(
-        n, P(*[m.data_ptr() for m in mats]), I64(*[m.shape[0] for m in mats]), I64(*[m.shape[1] for m in mats]),
-        I64(*[m.stride(0) for m in mats]), P(*[o.ptr().value for o in outs]), I64(*[o.ps for o in outs]),
-        I64(*[o.pr for o in outs]), _l.stream_ptr()), "pxr_split_planes_multi_f32")
+    # the entry point takes at most MULTI_MAX matrices per launch (its argument block is a fixed-size struct): deeper models
+    # (4 matrices per layer: n_layers >= 5) take one launch per group
+    for lo in range(0, len(mats), MULTI_MAX):
+        ms, os_ = mats[lo:lo + MULTI_MAX], outs[lo:lo + MULTI_MAX]
+        n = len(ms)
+        P, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+        _l.check(_l.load().pxr_split_planes_multi_f32(
+            n, P(*[m.data_ptr() for m in ms]), I64(*[m.shape[0] for m in ms]), I64(*[m.shape[1] for m in ms]),
+            I64(*[m.stride(0) for m in ms]), P(*[o.ptr().value for o in os_]), I64(*[o.ps for o in os_]),
+            I64(*[o.pr for o in os_]), _l.stream_ptr()), "pxr_split_planes_multi_f32")
     return outs
 
 
@@ -533,7 +555,11 @@ def linear_bwd_input_planes(dyp: Planes, Wp: Planes, add: torch.Tensor | None = 
 
 def grouped_dw_planes(problems, tile_hint=0):
     """problems: list of (dy Planes [T,N], x Planes [T,K], dW [N,K] out, db [N] out | None).  One launch for all of them
-    (pxr_grouped_dw_planes_f32)."""
+    (pxr_grouped_dw_planes_f32; one per MULTI_MAX of them: blocks deeper than 4 layers)."""
+    if len(problems) > MULTI_MAX:
+        for lo in range(0, len(problems), MULTI_MAX):
+            grouped_dw_planes(problems[lo:lo + MULTI_MAX], tile_hint)
+        return
     L = _l.load()
     n = len(problems)
     P, I, I64 = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
@@ -1129,6 +1155,10 @@ def adamw_flat_tab(p, g, m, v, hyper, step, beta1, beta2, eps, step_dev=None, pl
     Planes): weight matrices whose updated values are also written as planes by the same launch."""
     Lb = _l.load()
     segs = plane_segments or []
+    # the fused plane output serves MULTI_MAX matrices; the rest (models with more than 4 layers) are split from the updated flat
+    # buffer by a launch of their own right behind the optimizer's
+    late = segs[MULTI_MAX:]
+    segs = segs[:MULTI_MAX]
     n = len(segs)
     if n:
         P, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
@@ -1139,6 +1169,8 @@ def adamw_flat_tab(p, g, m, v, hyper, step, beta1, beta2, eps, step_dev=None, pl
     _l.check(Lb.pxr_adamw_flat_tab_planes_f32(_l.ptr(p), _l.ptr(g), _l.ptr(m), _l.ptr(v), p.numel(), _l.ptr(hyper), step,
                                               _l.ptr(step_dev), beta1, beta2, eps, *sa, _l.stream_ptr()),
              "pxr_adamw_flat_tab_f32")
+    if late:
+        split_planes_multi([p[o:o + r * c].view(r, c) for o, r, c, _ in late], [pl for _, _, _, pl in late])
 
 
 def counter_add(counter, delta=1):

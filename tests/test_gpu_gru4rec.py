@@ -90,19 +90,55 @@ def test_gru4rec_training_steps_follow_torch_adamw_on_the_oracle(table_update):
         assert err < 4e-5, (k, err)                                             # 4 steps of lr 1e-3 at the 1e-5-per-step budget
 
 
-def test_gru4rec_rejects_training_dropout_and_bad_shapes():
+def test_gru4rec_embedding_dropout_matches_the_oracle_with_the_library_mask():
+    """dropout_prob > 0 (reference gru4rec.py:26,59): loss and gradients of a training step against the oracle with the kernels'
+    counter-hash keep mask injected (oracle/dropout_rng.py; mask index = the time-major [L, B, E] element); evaluation never drops;
+    a second step draws a different mask (the completed-step counter is part of the seed)."""
+    from oracle import dropout_rng
     from pixelrec_amd.model import GRU4Rec
 
     class DL:
         item_num = N
 
-    cfg = dict(_config(), dropout_prob=0.3)
-    m = GRU4Rec(cfg, DL()).cuda().train()
-    with pytest.raises(NotImplementedError):
-        m((torch.from_numpy(G["items"]).cuda(), torch.from_numpy(G["masked_index"]).cuda()))
+    from oracle import gru4rec_oracle as GO
+
+    p_drop = 0.3
+    cfg = dict(_config(), dropout_prob=p_drop)
+    m = GRU4Rec(cfg, DL())
+    ref = {k[6:]: torch.from_numpy(G[k]).clone() for k in G.files if k.startswith("param/")}
+    m.load_state_dict(ref, strict=True)
+    m = m.cuda().train()
+    items, mask = torch.from_numpy(G["items"]), torch.from_numpy(G["masked_index"])
+    B = items.shape[0]
+    losses = []
+    for step in range(2):
+        seed = (m._emb_drop_seed() + step) & 0xFFFFFFFFFFFFFFFF
+        keep_tm = dropout_rng.keep_mask(seed, m.EMB_DROP_STREAM, (L, B, E), p_drop)             # time-major, as the kernel counts
+        keep = torch.from_numpy(np.ascontiguousarray(keep_tm.transpose(1, 0, 2)))
+        leaf = {k: v.clone().requires_grad_(True) for k, v in ref.items()}
+        loss_ref = GO.forward_loss(leaf, items, mask.float(), NL, emb_keep=keep, p_drop=p_drop)
+        loss_ref.backward()
+        loss = m((items.cuda(), mask.cuda()))
+        loss.backward()
+        losses.append(float(loss))
+        assert abs(float(loss) - float(loss_ref)) <= 3e-5 * max(1.0, abs(float(loss_ref)))
+        for name, prm in m.named_parameters():
+            g_ref = leaf[name].grad
+            if name == "item_embedding.weight":                                 # sparse table gradient: densify; padding row zeroed
+                sp = m.sparse_table_grad
+                n = int(sp.n)
+                got = torch.zeros_like(g_ref)
+                got[sp.idx[:n].cpu()] = sp.rows[:n].cpu()
+                g_ref = g_ref.clone(); g_ref[0].zero_()
+            else:
+                got = prm.grad.cpu()
+            assert (got - g_ref).abs().max().item() <= 5e-6 + 2e-4 * g_ref.abs().max().item(), (step, name)
+    assert losses[0] != losses[1]
     m.eval()
     with torch.no_grad():                                                       # evaluation never drops
-        assert np.isfinite(float(m((torch.from_numpy(G["items"]).cuda(), torch.from_numpy(G["masked_index"]).cuda()))))
+        l_eval = float(m((items.cuda(), mask.cuda())))
+    assert abs(l_eval - float(GO.forward_loss(ref, items, mask.float(), NL))) <= 3e-5 * max(1.0, abs(l_eval))
+    assert abs(l_eval - float(G["loss"])) < 5e-6
     with pytest.raises(ValueError):
         m((torch.zeros(2, 2, L, dtype=torch.int64).cuda(), torch.ones(2, L, dtype=torch.int64).cuda()))
 

@@ -242,3 +242,41 @@ def test_hidden_act_variants_match_reference_golden(act):
     m.eval()
     scores = m.predict(torch.from_numpy(z["eval.item_seq"]).cuda(), m.compute_item_all()).cpu().numpy()
     assert np.abs(scores - z[f"{act}.scores"]).max() <= 1e-4
+
+
+def test_five_layers_planes_mode_steps():
+    """n_layers = 5 => 20 weight matrices: more than one pxr_split_planes_multi_f32 / fused-plane AdamW launch holds (16).  Loss,
+    a weight gradient of the LAST layer and the parameters after two optimizer steps against the oracle's autograd + AdamW."""
+    from pixelrec_amd import ops
+    from pixelrec_amd.optim import PxrAdamW
+
+    meta = {"n_layers": 5, "H": 2, "D": 64, "inner": 128, "L": 12, "n_items": 300, "seed": 77}
+    m, p = _model(meta)
+    assert m._planes_on() or ops.gemm_mode() != "bf16x3" or not m.use_planes
+    g = torch.Generator().manual_seed(5)
+    B = 6
+    items = torch.randint(1, meta["n_items"], (B, 2, meta["L"] + 1), generator=g)
+    items[0, :, :4] = 0
+    mask = (items[:, 0, :-1] != 0).long()
+    cfg = oracle_cfg(meta)
+    ref = {k: v.clone() for k, v in p.items()}
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    m.train()
+    opt = PxrAdamW(m, lr=1e-4, weight_decay=0.1)       # (the reference's lr; Adam's first steps move every element by ~lr)
+    last = "trm_encoder.layer.4.feed_forward.dense_2.weight"
+    for step in range(1, 3):
+        loss_ref, grads = O.loss_and_grads(ref, items, mask, cfg)
+        opt.zero_grad()
+        loss = m((items.cuda(), mask.cuda()))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(loss_ref)) <= 3e-5 * max(1.0, abs(float(loss_ref)))
+        gl = dict(m.named_parameters())[last].grad
+        assert (gl.cpu() - grads[last]).abs().max().item() <= 5e-6 + 2e-4 * grads[last].abs().max().item()
+        opt.step()
+        for k in ref:
+            O.adamw_step(ref[k], grads[k], st[k][0], st[k][1], step, 1e-4)      # in place
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        for k in (last, "trm_encoder.layer.0.multi_head_attention.query.weight", "trm_encoder.layer.3.feed_forward.dense_1.weight",
+                  "position_embedding.weight"):
+            # (an element whose gradient is ~1e-8 moves by a fraction of lr that depends on the gradient's last bits)
+            assert (sd[k] - ref[k]).abs().max().item() <= 3e-5, (step, k)
