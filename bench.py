@@ -121,6 +121,16 @@ def cpu_baseline(batch, budget_s=20.0):
 
 
 def pixelnet_main(args):
+    out = pixelnet_run(args, args.steps, max(args.warmup, 2))
+    if out is not None:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def pixelnet_run(args, steps, warmup, init_dist=True, n_inst=3):
     """BASELINE configs[2] / [4]: one training step of MOSASRec (reference mosasrec.py:66-93) with the image encoder
     trained end to end (blocks >= tune_scale; reference load.py:90-120), both optimizer groups (trainer.py:74-96).
     Synthetic images already resident in HBM as fp32 pixel tensors; random-init weights of the named architecture."""
@@ -135,7 +145,7 @@ def pixelnet_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 and init_dist and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
@@ -170,14 +180,14 @@ def pixelnet_main(args):
         opt.step()
         return loss
 
-    for i in range(max(args.warmup, 2)):
+    for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -191,46 +201,59 @@ def pixelnet_main(args):
     # GEMM family of the step (ViT blocks + sequence block): HIP events around every launch of a few extra steps
     ev = []
     ops.GEMM_TIMING = ev
-    n_inst = min(args.steps, 3)
+    n_inst = min(steps, n_inst)
     for i in range(n_inst):
         step(i)
     ops.GEMM_TIMING = None
     torch.cuda.synchronize()
+    # where a step's device time goes (events on the compute stream around the four host-level phases of `step`)
+    ph_acc, n_ph = {}, min(steps, 3)
+    for i in range(n_ph):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        marks[0].record()
+        opt.zero_grad()
+        l_ = dp(pool[i % 2]); marks[1].record()
+        l_.backward(one); marks[2].record()
+        dp.sync_gradients(defer_flat=True); marks[3].record()
+        opt.step(); marks[4].record()
+        torch.cuda.synchronize()
+        for k, nm in enumerate(("forward (tower + sequence block + loss)", "backward (sequence block, trainable tower blocks, weight gradients)",
+                                "gradient exchange (enqueue; the flat all-reduces are joined in the optimizer)", "optimizer (both groups)")):
+            ph_acc[nm] = ph_acc.get(nm, 0.0) + marks[k].elapsed_time(marks[k + 1]) / n_ph
+    gsync = getattr(dp, "grad_sync", None)
     if rank != 0:
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        return
+        return None
     gem = [(s_.elapsed_time(e_) * 1e-3, w) for s_, e_, w, tag in ev if tag.startswith("gemm") or tag.startswith("grouped_dw")]
     g_s, g_fl = sum(x for x, _ in gem) or float("nan"), sum(w for _, w in gem)
     n_img = B * 2 * (L + 1)
     T = (image // patch) ** 2 + 1
     out = {"metric": f"user-sequences/sec, SASRec PixelNet + {args.encoder} end to end (training step: image encoder fwd, "
                      "bwd of the trainable blocks, sequence block, both AdamW groups)",
-           "value": world * B * args.steps / dt, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
-           "warmup": max(args.warmup, 2), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "value": world * B * steps / dt, "unit": "sequences/s", "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE.json configs[2]-shaped: SASRec PixelNet + {args.encoder}, train_batch_size {B}, "
                                   f"MAX_ITEM_LIST_LENGTH {L} ({n_img} images of {image}x{image} = {n_img * T} tokens per step), "
                                   f"emb {D}, tune_scale {tune} ({(391 if n_layers == 24 else 199) - tune} trainable encoder tensors)",
                       "batch_per_gpu": B, "global_batch": world * B, "seq_len": L, "images_per_step": n_img,
                       "parallelism": f"dp{world}", "hip_graph": False},
-           "images_per_s": world * n_img * args.steps / dt, "final_loss": float(loss.detach()),
+           "images_per_s": world * n_img * steps / dt, "final_loss": float(loss.detach()),
+           "data_parallel_phases": {"ms": ph_acc, "rccl_ranks": world if (gsync is not None and getattr(gsync, "active", False)) else 1,
+                                    "note": "eager steps, events on the compute stream; with one rank no collective is issued"},
            "roofline": {"bound": "mfma", "gemm_mode": ops.gemm_mode(),
-                        "kernel": "gemm_b3_kernel / gemm_kernel + grouped dW (bf16x3: v_mfma_f32_32x32x16_bf16 on the exact 3 x bf16 "
-                                  "split; f32: v_mfma_f32_32x32x2_f32 -- see gemm_mode): ViT blocks, batched "
-                                                   "attention contractions, rec_fc, sequence block",
+                        "kernel": "gemm_p3_kernel<P4Cfg 256x256 | 256x128> (ping-pong planes tiles, gemm_p4.cuh) + grouped_dw_p3_kernel "
+                                  "(v_mfma_f32_32x32x16_bf16 on the exact 3 x bf16 split, operands pre-split as planes): ViT blocks, "
+                                  "rec_fc, sequence block; f32 mode: gemm_kernel (v_mfma_f32_32x32x2_f32) -- see gemm_mode",
                         **mfma_roof(g_fl, g_s, ops.gemm_mode() == "bf16x3"), "traffic": _pixelnet_traffic(args.encoder, B),
                         "gemm_time_per_step_ms": g_s / max(n_inst, 1) * 1e3, "algorithmic_gflop_per_step": g_fl / max(n_inst, 1) / 1e9,
                         "launches_per_step": len(gem) / max(n_inst, 1),
-                        "note": "HIP events around every GEMM launch of extra eager steps (sum of durations; one stream); `traffic` = "
-                                "fabric bytes per GEMM-family launch from the separate rocprofv3 --pmc passes of this command "
-                                "(profiles/r03/pixelnet/pixelnet_gemm_traffic_summary.json; null for other shapes)"},
+                        "traffic_source": "profiles/r03/pixelnet/pixelnet_gemm_traffic_summary.json (separate rocprofv3 --pmc passes of "
+                                          "`bench.py --model pixelnet`, round 3's lockstep tiles; NOT measured in this run)",
+                        "note": "HIP events around every GEMM launch of extra eager steps (sum of durations; one stream)"},
            "cpu_baseline": None}
-    import ctypes
-    ctypes.CDLL(None).fflush(None)
-    print(json.dumps(out), flush=True)
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    del m, dp, opt, pool
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -582,12 +605,20 @@ def main():
         except Exception:
             traffic = None
     b3 = ops.gemm_mode() == "bf16x3"
+    planes_on = bool(b3 and getattr(model, "_planes_on", lambda: False)())
     roof = {"bound": "mfma",
-            "kernel": ("gemm_b3_kernel / grouped_dw_b3_kernel (v_mfma_f32_32x32x16_bf16 on an exact 3 x bf16 split of the fp32 "
-                       "operands, 6 products per multiply, fp32 accumulate; every nn.Linear fwd/bwd of the step)" if b3 else
+            "kernel": ("gemm_p3_kernel / grouped_dw_p3_kernel (v_mfma_f32_32x32x16_bf16 on an exact 3 x bf16 split of the fp32 operands "
+                       "that their producers wrote PRE-SPLIT as planes; 6 products per multiply, fp32 accumulate; every nn.Linear "
+                       "fwd/bwd of the step)" if planes_on else
+                       "gemm_b3_kernel / grouped_dw_b3_kernel (v_mfma_f32_32x32x16_bf16 on an exact 3 x bf16 split of the fp32 "
+                       "operands inside the main loop, 6 products per multiply, fp32 accumulate; every nn.Linear fwd/bwd of the step)"
+                       if b3 else
                        "gemm_kernel / grouped_dw_kernel (v_mfma_f32_32x32x2_f32; every nn.Linear fwd/bwd of the step)"),
-            "gemm_mode": ops.gemm_mode(),
+            "gemm_mode": ("planes" if planes_on else ops.gemm_mode()),
             **mfma_roof(g_fl, g_union, b3), "traffic": traffic,
+            "traffic_source": ("profiles/r03/pmc/gemm_traffic_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               "this command on the same kernels (read from the committed file, NOT measured in this run)"
+                               if traffic is not None else None),
             "launches_per_step": n_launch / max(n_inst, 1), "avg_kernel_us": g_union / max(n_launch, 1) * 1e6,
             "algorithmic_flops_per_step": g_fl / max(n_inst, 1),
             "gemm_time_per_step_us": g_union / max(n_inst, 1) * 1e6,
@@ -600,8 +631,7 @@ def main():
                     "host-bound); achieved = ALGORITHMIC fp32 flops / union of the launches' [start,end] intervals (= the sum "
                     "of durations in the default one-stream schedule), x 6 in bf16x3 mode = the bf16 products executed; peak = the "
                     "dense peak of the pipe the kernels run on (bf16 MFMA 2.5 PFLOP/s in bf16x3 mode, f32-input MFMA 157.3 "
-                    "TFLOP/s in f32 mode); `algorithmic_tflops` is the fp32-equivalent rate; `traffic` = HBM bytes per "
-                    "launch from the separate rocprofv3 --pmc pass of this command (profiles/r03/pmc)"}
+                    "TFLOP/s in f32 mode); `algorithmic_tflops` is the fp32-equivalent rate; `traffic`: see `traffic_source`"}
     hbm_kernels = per_tag(other_events, 1e9, "gbs")
 
     out = {
@@ -645,7 +675,7 @@ def main():
                                          "achieved": gf[0]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": gf[0]["gbs"] / HBM_PEAK_GBS, "avg_kernel_us": gf[0]["avg_kernel_us"],
                                          "note": "the gather as the step runs it: B*L table rows read + y + xhat written "
-                                                 "(3 x B*L*D*4 bytes)"}]
+                                                 "(3 x B*L*D*4 bytes) + the three bf16 planes of y in planes mode (6 B per element)"}]
 
     if not args.no_extras and world == 1 and B == 64 and not custom:
         # (0) the same step at throughput-oriented batch sizes (SURVEY.md §8d asks for B=64 AND 512 / 2048 per GPU)
@@ -684,6 +714,18 @@ def main():
                 step_b(eager=True)
             ops.GEMM_TIMING = None
             torch.cuda.synchronize()
+            fam = {}
+            for s_, e_, w, t in evs:
+                key = ("gemm fwd / dX (gemm_p3_kernel)" if t.startswith("gemm") else "grouped weight gradients" if t.startswith("grouped_dw")
+                       else "attention" if t.startswith("attn") else "layernorm (+ fused gather)" if t.startswith("ln_") else
+                       "table optimizer rows (adamw_rows)" if t.startswith("adamw_rows") else "other instrumented (loss, sort, segsum, flat optimizer)")
+                fam[key] = fam.get(key, 0.0) + s_.elapsed_time(e_) * 1e3 / 2
+            gfl = sum(w for _, _, w, t in evs if t.startswith("gemm") or t.startswith("grouped_dw")) / 2
+            gus = sum(v for k, v in fam.items() if k.startswith("gemm") or k.startswith("grouped"))
+            fam["everything not bracketed with events (attention, the other LayerNorm sites, loss, id sort, segment sums, "
+                "flat optimizer, launch gaps) = step time - the rows above"] = tb * 1e6 - sum(fam.values())
+            out["throughput_batches"][-1]["kernel_families_us_per_step"] = fam
+            out["throughput_batches"][-1]["gemm_family"] = {**mfma_roof(gfl, gus * 1e-6, b3), "us_per_step": gus}
             gl = [(s_.elapsed_time(e_) * 1e-3, w) for s_, e_, w, t in evs if t.startswith("ln_fwd_kernel<GATHER>")]
             if gl and "roofline_gather_fused" in out:
                 sec = sum(x for x, _ in gl) / len(gl)
@@ -720,10 +762,38 @@ def main():
         t_s = time_kernel(lambda: ops.gemm(True, True, 1024, N, D, last, L * D, table, D, scores, N, ops.EPI_NONE,
                                            use_ws=False), iters=10)
         fl = 2.0 * 1024 * N * D
-        out["roofline_scoring"] = {"bound": "mfma", "kernel": "gemm_b3_kernel<128,128,KC,KC>" if b3 else "gemm_kernel<128,128,KC,KC>",
-                                   **mfma_roof(fl, t_s, b3), "avg_kernel_us": t_s * 1e6,
-                                   "note": "409.6 MFLOP/user x 1024 users (algorithmic fp32 flops; gemm_mode " + ops.gemm_mode() + ")"}
+        out["roofline_scoring_literal"] = {"bound": "mfma", "kernel": "gemm_b3_kernel<128,128,KC,KC>" if b3 else "gemm_kernel<128,128,KC,KC>",
+                                           **mfma_roof(fl, t_s, b3), "avg_kernel_us": t_s * 1e6,
+                                           "note": "the literal scoring product (scores written: 1.6 GB), fp32 operands split inside the main "
+                                                   "loop; 409.6 MFLOP/user x 1024 users (algorithmic fp32 flops; gemm_mode " + ops.gemm_mode() + ")"}
+        # the path the PRODUCT evaluates with (trainer.evaluate): table split once per evaluation, then per batch of 1024 users the
+        # fused scoring + masks + top-10 whose main pass is score_thresh_p3_kernel on the planes; checked here against the literal
+        # sequence (GEMM -> the two -inf masks -> torch.topk) on the same operands
+        ev_b = synth.eval_batch(N, 1024, L, np.random.default_rng(3), zipf)
+        hu_t, hi_t = torch.from_numpy(ev_b[1]), torch.from_numpy(ev_b[2])
+        ptr, hitems = ops.history_csr(hu_t, hi_t, 1024, dev)
+        last2 = torch.as_strided(last, (1024, D), (L * D, 1)).contiguous()
+        scores[:, 0] = -float("inf")
+        scores[(hu_t.to(dev), hi_t.to(dev))] = -float("inf")
+        lit_v, lit_i = torch.topk(scores, 10, dim=-1)
         del scores
+        if b3 and ops.score_planes_supported(table):
+            t_sp = time_kernel(lambda: ops.split_planes(table), iters=3, warm=1)
+            tpl = ops.split_planes(table)
+            f_i, f_v = ops.score_topk(last2, D, 1024, table, 10, ptr, hitems, table_planes=tpl)
+            same_ids = bool(torch.equal(f_i, lit_i))
+            t_f = time_kernel(lambda: ops.score_topk(last2, D, 1024, table, 10, ptr, hitems, table_planes=tpl), iters=10)
+            out["roofline_scoring"] = {"bound": "mfma", "kernel": "score_thresh_p3_kernel (main pass of pxr_score_topk_planes_f32 on the pre-split "
+                                       "table; + sample pass score_topk_kernel, topk_tau, topk_cand_merge in the same call)",
+                                       **mfma_roof(fl, t_f, b3), "avg_call_us": t_f * 1e6, "identical_top10": same_ids,
+                                       "max_abs_value_diff_vs_literal": float((f_v - lit_v).abs().max()),
+                                       "table_split_us_once_per_evaluation": t_sp * 1e6,
+                                       "note": "the WHOLE fused scoring + history / padding masks + top-10 call per 1024 users x 400 001 items "
+                                               "(scores never reach HBM), timed end to end and priced as if all of it were the scoring product; "
+                                               "the main-pass kernel alone: profiles/r04 eval kernel stats"}
+            out["roofline_scoring_fused_topk"] = {"ms_per_1024_users": t_f * 1e3, "identical_top10": same_ids,
+                                                  "speedup_vs_literal_gemm_alone": t_s / t_f}
+            del tpl
         # (3) the dense AdamW table sweep (what `table_update="dense"` runs every step; the default lazy optimizer
         # replays untouched rows on demand instead): pure HBM streaming of p, m, v
         tm, tv = torch.zeros_like(table), torch.zeros_like(table)
@@ -771,11 +841,27 @@ def main():
                                         "step; the lazy figure includes catch-up + apply on the aged, non-repeating stream"}
         del opt_d
 
+    if not args.no_extras and world == 1 and not custom and B == 64:
+        # (5) BASELINE configs[2]-shaped PixelNet step (ViT-B/16 tower trained end to end, 352 images per step), a few steps: the
+        # line `bench.py --model pixelnet` prints, embedded so that the default run carries it
+        gstep = None
+        torch.cuda.empty_cache()
+        pa = argparse.Namespace(**{**vars(args), "encoder": "clip-vit-base-patch16", "batch": 64})
+        try:
+            px = pixelnet_run(pa, steps=5, warmup=2, init_dist=False, n_inst=2)
+            out["pixelnet"] = {"metric": px["metric"], "value": px["value"], "unit": px["unit"], "ms_per_step": px["ms_per_step"],
+                               "images_per_s": px["images_per_s"], "steps": px["steps"], "config": px["config"],
+                               "gemm_family": {k: px["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "gemm_time_per_step_ms",
+                                                                              "launches_per_step", "kernel")},
+                               "phases_ms": px["data_parallel_phases"]["ms"]}
+        except Exception as e:  # noqa: BLE001  (the headline line must not die with an extra)
+            out["pixelnet"] = {"error": f"{type(e).__name__}: {e}"}
+
     if args.emulate_world > 1 and world == 1 and not custom:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import world_projection
 
-        del gstep
+        gstep = None
         torch.cuda.empty_cache()
         out["world_projection"] = world_projection.project(args.emulate_world, B=B, log=lambda *_: None)
     if not args.no_cpu_baseline and world == 1:

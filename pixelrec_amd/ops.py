@@ -613,7 +613,8 @@ def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.
     # algorithmic bytes: B*L table rows read once + y (+ xhat when saved) written; the [B,2,L+1,D] gather of the
     # reference never exists (SURVEY.md §8d "fused" rule)
     yp = Planes.alloc(B * L, D, table.device) if planes else None
-    with _gemm_timer(4.0 * B * L * D * (3 if save else 2), "ln_fwd_kernel<GATHER> (gather + pos + LN + dropout)"):
+    # (+ the three bf16 planes of y, 6 B per element, when the kernel also writes them for the QKV GEMM)
+    with _gemm_timer(B * L * D * (4.0 * (3 if save else 2) + (6.0 if planes else 0.0)), "ln_fwd_kernel<GATHER> (gather + pos + LN + dropout)"):
         _l.check(Lb.pxr_input_ln_fwd_planes_f32(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
                                                 _l.ptr(beta), eps, B, L, D, _l.ptr(y), _l.ptr(xhat), _l.ptr(rstd), p_drop,
                                                 seed, stream_id, _l.ptr(step_dev), *_pl(yp), _l.stream_ptr()),
