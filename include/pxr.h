@@ -371,6 +371,22 @@ int pxr_score_topk_planes_f32(const float* users, int64_t ld_users, int B, const
                               const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx, float* topk_val,
                               void* ws, int64_t ws_bytes, void* stream);
 
+/* ... and with the pass over the catalogue on `products` = 3 (hi*hi + mid*hi + hi*mid) or 1 (hi*hi) of the six bf16 products
+ * (6: exactly the function above).  That pass only decides "score >= threshold": the threshold is lowered by a rigorous per-user
+ * bound on what the dropped products and the different rounding can change (c ||user||_2 max_i ||table[i]||_2), and the few
+ * survivors that can still reach the top K are re-scored with all six products in the full pass's own MFMA order -- ids and
+ * values are those of pxr_score_topk_planes_f32, bit for bit, at about half (3) of its MFMA work.  Needs both operands as planes
+ * and table_row_norm_max: DEVICE pointer to max_i ||table[i]||_2 (pxr_row_norm_max_f32, once per evaluation like the planes).
+ * Same reference path: model/IDNet/sasrec.py:112 + trainer/trainer.py:327-337 + evaluator/collector.py:131-139. */
+int pxr_score_topk_fast_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
+                            const void* users_planes, int64_t users_plane_stride, int64_t users_panel_rows,
+                            const void* table_planes, int64_t table_plane_stride, int64_t table_panel_rows,
+                            const float* table_row_norm_max, int products, const int32_t* hist_ptr, const int64_t* hist_items,
+                            int K, int64_t* topk_idx, float* topk_val, void* ws, int64_t ws_bytes, void* stream);
+/* out[0] (device float) = max_i ||x[i, :]||_2 of x [rows, cols] fp32 (row stride ldx, cols % 4 == 0): the item-table statistic of
+ * the function above (computed over what compute_item_all returns, model/IDNet/sasrec.py:115-117). */
+int pxr_row_norm_max_f32(const float* x, int64_t rows, int64_t cols, int64_t ldx, float* out, void* stream);
+
 /* ---- optimizer ---------------------------------------------------------------------------------------------- */
 /* torch.optim.AdamW update (trainer.py:102,125), step is 1-based.  n must be a multiple of 4. */
 int pxr_adamw_flat_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,

@@ -33,13 +33,17 @@ namespace pxr {
 
 // DMA_: where a wave issues its pieces of k block j + NS - 1:  0 = in L_j after the fragment reads;  1 = the A pieces in L_j, the B
 // pieces between the MFMAs of C_j;  2 = all of them between the MFMAs of C_j (one piece per product group);  3 = in L_j BEFORE the reads
-template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int NACC_, int DMA_ = 0>
+// NPL_: planes of each operand the loop stages and multiplies -- 3: all of them, the six products of gemm_p3 (the GEMMs); 2 (hi,
+// mid: hi*hi + mid*hi + hi*mid) and 1 (hi*hi) are the CHEAP passes of the top-k threshold search, whose survivors are re-scored
+// with all six products (score_topk.hip); they run on one accumulator set.
+template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int NACC_, int DMA_ = 0, int NPL_ = 3>
 struct P4Cfg {
-  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_, NACC = NACC_, DMA = DMA_;
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_, NACC = NACC_, DMA = DMA_, NPL = NPL_;
+  static_assert(NPL == 3 || NACC == 1, "the reduced-product passes use one accumulator set");
   static constexpr int G = WGM * WGN, NT = 64 * G, BK = 16;
   static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
   static constexpr int A_FR = BM / 32, B_FR = BN / 32;                      // 32-row fragment blocks per operand
-  static constexpr int A_PIECES = 3 * A_FR, B_PIECES = 3 * B_FR;            // 1 KiB pieces per k block
+  static constexpr int A_PIECES = NPL * A_FR, B_PIECES = NPL * B_FR;        // 1 KiB pieces per k block
   static constexpr int SLOT = (A_PIECES + B_PIECES) * 1024;
   static constexpr int RING_BYTES = NS * SLOT;
   // the epilogue stages the fp32 tile in LDS in passes of EPI_COLS columns ([BM][EPI_COLS + 4] floats, p4_row_epilogue)
@@ -47,7 +51,7 @@ struct P4Cfg {
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
   static constexpr bool PINGPONG = true;
   static_assert(G == 8, "two groups of four waves");
-  static_assert(A_FR % 2 == 0 && B_FR % 2 == 0, "each group issues half of an operand's pieces");
+  static_assert(A_PIECES % 2 == 0 && B_PIECES % 2 == 0, "each group issues half of an operand's pieces");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile = 32x32 blocks");
   static_assert(NS >= 3 && NS <= 8, "ring slots");
   static_assert(NACC == 1 || NACC == 2 || NACC == 3, "accumulator sets");
@@ -77,9 +81,9 @@ __device__ __forceinline__ void p4_wait_pieces(int c) {
 }
 
 // One operand's share of a wave's DMA batch.  FR = 32-row blocks of the tile along the operand's x, KC = flavour.
-template <int FR, bool KC>
+template <int FR, bool KC, int NPL = 3>
 struct P4Operand {
-  static constexpr int PG = 3 * FR / 2;          // pieces per wave group and k block
+  static constexpr int PG = NPL * FR / 2;        // pieces per wave group and k block
   static constexpr int MAXP = (PG + 3) / 4;      // ... per wave (waves with wi + 4 t >= PG skip piece t)
   bufrsrc rs;
   unsigned scal[MAXP];     // loop-invariant byte offset of each piece (plane, block, tile origin)
@@ -91,7 +95,7 @@ struct P4Operand {
     rs = make_rsrc(reinterpret_cast<const float*>(m.p), m.ps * 3 * 2);
 #pragma unroll
     for (int t = 0; t < MAXP; ++t) {
-      const int q = min(PG * grp + wi + 4 * t, 3 * FR - 1);
+      const int q = min(PG * grp + wi + 4 * t, NPL * FR - 1);
       const int pl = q / FR, blk = q % FR;
       unsigned o;
       if constexpr (KC) o = (unsigned)(pl * m.ps * 2) + (unsigned)((x0 + blk * 32) * 64);
@@ -171,17 +175,17 @@ struct P4FragOff {
 template <class Cfg, bool A_KC, bool B_KC>
 struct P4Loop {
   static constexpr int TM = Cfg::TM, TN = Cfg::TN, NS = Cfg::NS, PF = Cfg::NS - 1;
-  static constexpr int MAXA = P4Operand<Cfg::A_FR, A_KC>::MAXP, MAXB = P4Operand<Cfg::B_FR, B_KC>::MAXP;
+  static constexpr int MAXA = P4Operand<Cfg::A_FR, A_KC, Cfg::NPL>::MAXP, MAXB = P4Operand<Cfg::B_FR, B_KC, Cfg::NPL>::MAXP;
   // pieces of earlier-needed k blocks that may still be in flight when a wave certifies k block j + 1 at the end of L_j
   // (gemm_p4.cuh header, "RAW"): whole batches of the k blocks j + 2 .. issued so far, per operand
   static constexpr int KEEP_A = (Cfg::DMA == 2) ? PF - 2 : PF - 1;
   static constexpr int KEEP_B = (Cfg::DMA == 1 || Cfg::DMA == 2) ? PF - 2 : PF - 1;
   static_assert(KEEP_A >= 0 && KEEP_B >= 0, "pieces issued in the C segments need one more ring slot");
   struct Frag {
-    p3_bf16x8 a[TM][3], b[TN][3];
+    p3_bf16x8 a[TM][Cfg::NPL], b[TN][Cfg::NPL];
   };
-  P4Operand<Cfg::A_FR, A_KC> opA;
-  P4Operand<Cfg::B_FR, B_KC> opB;
+  P4Operand<Cfg::A_FR, A_KC, Cfg::NPL> opA;
+  P4Operand<Cfg::B_FR, B_KC, Cfg::NPL> opB;
   P4FragOff<A_KC> foA;
   P4FragOff<B_KC> foB;
   char* smem;
@@ -225,7 +229,7 @@ struct P4Loop {
   __device__ __forceinline__ void read_frag(Frag& f, int slot) const {
     const char* s = smem + slot * Cfg::SLOT;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < Cfg::NPL; ++p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) f.a[i][p] = foA.read(s + (p * Cfg::A_FR + wm * TM + i) * 1024);
 #pragma unroll
@@ -252,7 +256,13 @@ __device__ __forceinline__ void p4_mfma(const Frag& f, f32x16 (&accs)[Cfg::TM][C
     between(G);                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   }
-  if constexpr (Cfg::NACC == 3) {
+  if constexpr (Cfg::NPL == 1) {
+    PXR_P4_PROD(5, accs, 0, 0)
+  } else if constexpr (Cfg::NPL == 2) {
+    PXR_P4_PROD(5, accs, 1, 0)
+    PXR_P4_PROD(5, accs, 0, 1)
+    PXR_P4_PROD(5, accs, 0, 0)
+  } else if constexpr (Cfg::NACC == 3) {
     PXR_P4_PROD(0, accl, 2, 0)        // lo  * hi
     PXR_P4_PROD(1, accm, 1, 0)        // mid * hi
     PXR_P4_PROD(2, accs, 0, 0)        // hi  * hi

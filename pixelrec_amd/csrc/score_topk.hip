@@ -626,6 +626,326 @@ __global__ void __launch_bounds__(Sp4Cfg::NT) score_thresh_p4_kernel(ScoreTopkAr
     }
   });
 }
+
+// ---- "fewer products, exact results" (round 4): the threshold pass only has to DECIDE score >= tau, so it runs on a subset of
+// the six bf16 products -- NPL = 2 planes: hi*hi + mid*hi + hi*mid (error <= 2^-15 sum|u||v|), NPL = 1: hi*hi alone (<= 2^-8
+// sum|u||v|) -- with tau lowered by a rigorous per-user bound delta_u = c ||u||_2 max_i ||v_i||_2 (Cauchy-Schwarz; the table's
+// largest row norm is computed once per evaluation, pxr_row_norm_max_f32).  The survivors carry APPROXIMATE values; per user the
+// few that can still reach the top K (approximate value within 2 delta_u of the K-th best approximate value) are re-scored
+// with all six products through the SAME MFMA sequence as the full pass -- same k order, same three accumulator sets, same
+// final fold -- so ids AND values are bit-identical to the six-product schedule (tests/test_gpu_configs.py).
+// Tile: 256 items x 256 users, one accumulator set (128 registers), ping-pong k-block stream (gemm_p4_stream).
+constexpr int SPF_BM = 256, SPF_BN = 256;
+template <int NPL, int NS>
+using SpfCfg = P4Cfg<SPF_BM, SPF_BN, 4, 2, NS, 1, 0, NPL>;
+
+// NS = ring slots: the fewer products a k block carries, the shorter its slot-times and the more k blocks must be in flight to
+// cover the HBM latency of the table stream (NPL = 2: 32 KB per slot; NPL = 1: 16 KB)
+template <int NPL, int NS>
+__global__ void __launch_bounds__(512) score_thresh_fast_kernel(ScoreTopkArgs a, P3Mat table_p, P3Mat users_p) {
+  using Cfg = SpfCfg<NPL, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
+  const int rb = t % a.row_blocks, sp = t / a.row_blocks;
+  const int u0 = rb * SPF_BN;
+  const int tiles = (a.N + SPF_BM - 1) / SPF_BM;
+  const int per = (tiles + a.n_split - 1) / a.n_split;
+  const int tn0 = sp * per, tn1 = min(tiles, tn0 + per);
+  if (tn0 >= tn1) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  // one accumulator set leaves registers for the lane's thresholds (a global load per tile in front of the comparison would be a
+  // round trip on the critical path of BOTH wave groups: the other group waits at the barrier meanwhile)
+  float thr[Cfg::TN];
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int uj = u0 + wn * Cfg::WN + j * 32 + (int)(threadIdx.x & 31u);
+    thr[j] = uj < a.B ? a.tau[uj] : INFINITY;
+  }
+  gemm_p4_stream<Cfg>(table_p, users_p, a.D, tn0 * SPF_BM, u0, tn1 - tn0, smem, [&](int tile, const typename Cfg::Acc& accs) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int h = lane >> 5, r = lane & 31;
+    const int i0 = (tn0 + tile) * SPF_BM + wm * Cfg::WM + 4 * h;
+    // A lane owns one user per column block j and up to TM * 16 of its scores.  Appending survivor by survivor would cost one
+    // returning global atomic (a ~2 us round trip) per hit, serialised inside divergent code -- as long as the whole K loop of a
+    // tile in the reduced-product passes.  Instead: count the lane's hits per j, reserve their slots with ONE atomic per (lane, j)
+    // -- the TN atomics of a tile are in flight together -- then write.
+    int user[Cfg::TN], nh[Cfg::TN], base[Cfg::TN];
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) user[j] = u0 + wn * Cfg::WN + j * 32 + r;
+    unsigned hot = 0;                                     // bit (j * TM + i): block (i, j) holds a hit in SOME lane (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      nh[j] = 0;
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        float mx = accs.v[i][j][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, accs.v[i][j][e]);
+        if (!__any(mx >= thr[j])) continue;
+        hot |= 1u << (j * Cfg::TM + i);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int item = i0 + i * 32 + (e & 3) + 8 * (e >> 2);
+          nh[j] += (accs.v[i][j][e] >= thr[j] && item != 0 && item < a.N) ? 1 : 0;
+        }
+      }
+    }
+    if (hot == 0) return;
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) base[j] = nh[j] > 0 ? atomicAdd(&a.cand_cnt[user[j]], nh[j]) : 0;
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        if (!((hot >> (j * Cfg::TM + i)) & 1u)) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int item = i0 + i * 32 + (e & 3) + 8 * (e >> 2);
+          const float x = accs.v[i][j][e];
+          if (x >= thr[j] && item != 0 && item < a.N) {
+            if (base[j] < a.cand_cap) {
+              a.cand_val[(int64_t)user[j] * a.cand_cap + base[j]] = x;
+              a.cand_idx[(int64_t)user[j] * a.cand_cap + base[j]] = item;
+            }
+            ++base[j];
+          }
+        }
+      }
+    }
+  });
+}
+
+// tau'[u] = tau[u] - delta[u]: tau as topk_tau_kernel, delta[u] = c * ||users[u]||_2 * vmax[0]; cnt[u] = 0
+__global__ void __launch_bounds__(256) topk_tau_fast_kernel(const float* __restrict__ sample_val, int B, int K, const float* __restrict__ users,
+                                                            int64_t ld_users, int D, const float* __restrict__ vmax, float c,
+                                                            float* __restrict__ tau, float* __restrict__ delta, int* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + wave;
+  if (u >= B) return;
+  float ss = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float x = users[(int64_t)u * ld_users + k];
+    ss += x * x;
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) {
+    const float d = c * sqrtf(ss) * vmax[0];
+    const float t = sample_val[(int64_t)u * K + (K - 1)];
+    tau[u] = (t - fabsf(t) * 3.814697265625e-06f) - d;
+    delta[u] = d;
+    cnt[u] = 0;
+  }
+}
+
+// largest L2 norm of a row of x[rows, cols] -> out[0] (must be zeroed before the launch); one wave per row
+__global__ void __launch_bounds__(256) row_norm_max_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float best = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    float ss = 0.f;
+    for (int k = lane * 4; k < cols; k += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + k);
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    best = fmaxf(best, sqrtf(wave_sum(ss)));
+  }
+  if (lane == 0) atomicMax(reinterpret_cast<int*>(out), __float_as_int(best));     // non-negative floats order like their bits
+}
+
+// One wave per user: drop the history, find the K-th best APPROXIMATE value, re-score every candidate within 2 delta of it with the
+// six-product MFMA sequence of the full pass (32 candidates per group: A = their table rows gathered from the planes, B = the
+// user's row in every column), emit the K best by (exact value, ascending id).  The candidates live in registers (RS_CPL per lane;
+// a user with more than 64 * RS_CPL of them takes the same steps through global memory), the user's planes in LDS.
+constexpr int RS_MAX = 256;                 // shortlist slots per user
+constexpr int RS_CPL = 32;                  // candidates per lane held in registers
+constexpr int RS_DMAX = 1024;               // largest D whose user row is staged in LDS (3 planes x 2 B x D x 4 users = 24 KB)
+
+// best remaining (value, id) of a wave's candidates after (last_v, last_id), descending by value, ascending by id
+__device__ __forceinline__ void rs_wave_best(float& bv, int& bid) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bid, off, 64);
+    if (ov > bv || (ov == bv && oi < bid)) { bv = ov; bid = oi; }
+  }
+}
+
+__global__ void __launch_bounds__(256) topk_rescore_kernel(float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                           const int* __restrict__ cnt, int cap, int B, int K,
+                                                           const float* __restrict__ delta, P3Mat table_p, P3Mat users_p, int D,
+                                                           int64_t* __restrict__ out_idx, float* __restrict__ out_val, int32_t* status,
+                                                           const int* __restrict__ hist_ptr, const int64_t* __restrict__ hist_items) {
+  __shared__ int s_id[4][RS_MAX];
+  __shared__ float s_val[4][RS_MAX];
+  __shared__ __attribute__((aligned(16))) __bf16 s_user[4][3][RS_DMAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + wave;
+  if (u >= B) return;                      // (wave-uniform; no workgroup barrier below)
+  int n = cnt[u];
+  bool bad = (n > cap || n < K);
+  n = min(n, cap);
+  float* pv = cand_val + (int64_t)u * cap;
+  const int* pi = cand_idx + (int64_t)u * cap;
+  const bool lds_user = D <= RS_DMAX;
+  // the user's planes, k-contiguous per plane: chunk c (8 values) of the row at s_user[.][p][8 c]
+  if (lds_user) {
+    const int uswz = (u >> 2) & 3;
+    for (int c = lane; c < (D >> 3) * 3; c += 64) {
+      const int p = c / (D >> 3), ck = c - p * (D >> 3);            // chunk ck = 8 consecutive k of plane p
+      const int kt = ck >> 2, ch = ck & 3;
+      const p3_bf16x8 v = *reinterpret_cast<const p3_bf16x8*>(users_p.p + p * users_p.ps + ((int64_t)kt * users_p.pr + u) * 32 + ((ch ^ uswz) << 3));
+      *reinterpret_cast<p3_bf16x8*>(&s_user[wave][p][ck << 3]) = v;
+    }
+  }
+  const bool inreg = n <= 64 * RS_CPL;     // wave-uniform
+  float cv[RS_CPL];
+  int ci[RS_CPL];
+  const int hb = hist_ptr ? hist_ptr[u] : 0, he = hist_ptr ? hist_ptr[u + 1] : 0;
+  if (inreg) {
+#pragma unroll
+    for (int q = 0; q < RS_CPL; ++q) {
+      const int c = q * 64 + lane;
+      const bool ok = c < n;
+      cv[q] = ok ? pv[c] : -INFINITY;
+      ci[q] = ok ? pi[c] : 0x7fffffff;
+    }
+    for (int p = hb; p < he; ++p) {
+      const int hid = (int)hist_items[p];
+#pragma unroll
+      for (int q = 0; q < RS_CPL; ++q)
+        if (ci[q] == hid) cv[q] = -INFINITY;
+    }
+  } else if (he > hb) {
+    for (int c = lane; c < n; c += 64) {
+      const int64_t id = pi[c];
+      bool seen = false;
+      for (int p = hb; p < he; ++p) seen |= (hist_items[p] == id);
+      if (seen) pv[c] = -INFINITY;
+    }
+  }
+  // K-th best approximate value (ties by id, as the final selection)
+  float last_v = INFINITY;
+  int last_id = -1;
+  for (int k = 0; k < K; ++k) {
+    float bv = -INFINITY;
+    int bid = 0x7fffffff;
+    if (inreg) {
+#pragma unroll
+      for (int q = 0; q < RS_CPL; ++q) {
+        const float v = cv[q];
+        const int id = ci[q];
+        const bool remaining = (v < last_v) || (v == last_v && id > last_id);
+        if (remaining && (v > bv || (v == bv && id < bid))) { bv = v; bid = id; }
+      }
+    } else {
+      for (int c = lane; c < n; c += 64) {
+        const float v = pv[c];
+        const int id = pi[c];
+        const bool remaining = (v < last_v) || (v == last_v && id > last_id);
+        if (remaining && (v > bv || (v == bv && id < bid))) { bv = v; bid = id; }
+      }
+    }
+    rs_wave_best(bv, bid);
+    last_v = bv;
+    last_id = bid;
+  }
+  const float cut = last_v - 2.0f * delta[u];          // (K-th best approx = -inf when fewer than K candidates: everything stays)
+  // shortlist
+  int ns = 0;
+  if (inreg) {
+#pragma unroll
+    for (int q = 0; q < RS_CPL; ++q) {
+      const bool in = cv[q] >= cut && cv[q] > -INFINITY;
+      const unsigned long long m = __ballot(in);
+      if (in) {
+        const int pos = ns + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < RS_MAX) s_id[wave][pos] = ci[q];
+      }
+      ns += __popcll(m);
+    }
+  } else {
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int c = c0 + lane;
+      const bool in = c < n && pv[c] >= cut && pv[c] > -INFINITY;
+      const unsigned long long m = __ballot(in);
+      if (in) {
+        const int pos = ns + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < RS_MAX) s_id[wave][pos] = pi[c];
+      }
+      ns += __popcll(m);
+    }
+  }
+  if (ns > RS_MAX) { bad = true; ns = RS_MAX; }
+  if (bad && status && lane == 0) atomicOr(status, PXR_STATUS_TOPK_OVERFLOW);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // exact re-scoring, 32 shortlist entries per group
+  const int r = lane & 31, h = lane >> 5;
+  const __bf16* ub = users_p.p + ((int64_t)u << 5);
+  const int uswz = (u >> 2) & 3;
+  const int nkt = D >> 5;
+  for (int g0 = 0; g0 < ns; g0 += 32) {
+    const int item = (g0 + r < ns) ? s_id[wave][g0 + r] : 1;
+    const __bf16* tb = table_p.p + ((int64_t)item << 5);
+    const int iswz = (item >> 2) & 3;
+    f32x16 accs, accm, accl;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accs[e] = 0.f; accm[e] = 0.f; accl[e] = 0.f; }
+#pragma unroll 4
+    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        p3_bf16x8 a[3], b[3];
+        const int64_t ao = (int64_t)kt * table_p.pr * 32 + ((((kb << 1) | h) ^ iswz) << 3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const p3_bf16x8*>(tb + p * table_p.ps + ao);
+        if (lds_user) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const p3_bf16x8*>(&s_user[wave][p][(kt << 5) + (((kb << 1) | h) << 3)]);
+        } else {
+          const int64_t bo = (int64_t)kt * users_p.pr * 32 + ((((kb << 1) | h) ^ uswz) << 3);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const p3_bf16x8*>(ub + p * users_p.ps + bo);
+        }
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], accl, 0, 0, 0);
+        accm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], accm, 0, 0, 0);
+        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], accs, 0, 0, 0);
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], accl, 0, 0, 0);
+        accm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], accm, 0, 0, 0);
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], accl, 0, 0, 0);
+      }
+    }
+    if (r == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (g0 + row < ns) s_val[wave][g0 + row] = accs[e] + (accm[e] + accl[e]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // the K best of the shortlist by exact value
+  last_v = INFINITY;
+  last_id = -1;
+  for (int k = 0; k < K; ++k) {
+    float bv = -INFINITY;
+    int bid = 0x7fffffff;
+    for (int c = lane; c < ns; c += 64) {
+      const float v = s_val[wave][c];
+      const int id = s_id[wave][c];
+      const bool remaining = (v < last_v) || (v == last_v && id > last_id);
+      if (remaining && (v > bv || (v == bv && id < bid))) { bv = v; bid = id; }
+    }
+    rs_wave_best(bv, bid);
+    if (lane == 0) {
+      const bool ok = bid != 0x7fffffff;
+      out_val[(int64_t)u * K + k] = ok ? bv : -INFINITY;
+      out_idx[(int64_t)u * K + k] = ok ? (int64_t)bid : (int64_t)-1;
+    }
+    last_v = bv;
+    last_id = bid;
+  }
+}
 }  // namespace pxr
 
 using namespace pxr;
@@ -648,14 +968,15 @@ extern "C" int64_t pxr_score_topk_ws_bytes(int B, int N, int K) {
   const int kt = pick_kt(K);
   if (kt == 0) return -1;
   if (use_thresh(N))   // sample lists (variant-1 layout) | sample top-K (idx, val) | tau | cnt | candidate values | ids
-    return lists_bytes(B, N, kt, 2) + a256((int64_t)B * K * 8) + a256((int64_t)B * K * 4) + 2 * a256((int64_t)B * 4) +
-           2 * a256((int64_t)B * ST4_CAP * 4) + 256;
+    return lists_bytes(B, N, kt, 2) + a256((int64_t)B * K * 8) + a256((int64_t)B * K * 4) + 3 * a256((int64_t)B * 4) +
+           2 * a256((int64_t)B * ST4_CAP * 4) + 256;                     // (+ delta, the reduced-product schedule's margin)
   const int64_t cand = (int64_t)pick_split(B, N) * lists_per_split() * kt;
   return (int64_t)B * cand * 8 + 256;
 }
 
 static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, float* topk_val, void* ws, hipStream_t st,
-                             const P3Mat* table_p = nullptr, const P3Mat* users_p = nullptr) {
+                             const P3Mat* table_p = nullptr, const P3Mat* users_p = nullptr, int products = 6,
+                             const float* table_norm_max = nullptr) {
   char* w = (char*)ws;
   const int64_t lb = lists_bytes(a.B, a.N, kt, 2) / 2;
   a.part_val = (float*)w;              a.part_idx = (int*)(w + lb);         w += 2 * lb;
@@ -664,7 +985,9 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
   float* tau = (float*)w;              w += a256((int64_t)a.B * 4);
   int* cnt = (int*)w;                  w += a256((int64_t)a.B * 4);
   float* cval = (float*)w;             w += a256((int64_t)a.B * ST4_CAP * 4);
-  int* cidx = (int*)w;
+  int* cidx = (int*)w;                 w += a256((int64_t)a.B * ST4_CAP * 4);
+  float* delta = (float*)w;
+  const bool fast = table_p != nullptr && products != 6 && table_norm_max != nullptr;
   const dim3 grid(a.row_blocks * a.n_split);
   // pass 1: lists over a SAMPLE of the tiles (one workgroup per sampled tile and row block) -> K-th best value per user
   const int n_split_full = a.n_split;
@@ -679,11 +1002,57 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
   const int64_t cand = (int64_t)a.n_split * 2 * kt;
   hipLaunchKernelGGL(topk_merge_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, (const float*)a.part_val,
                      (const int*)a.part_idx, a.B, (int)cand, K, s_idx, s_val);
-  hipLaunchKernelGGL(topk_tau_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, (const float*)s_val, a.B, K, tau, cnt);
+  if (fast)      // tau lowered by the rigorous margin of the reduced-product pass (see score_thresh_fast_kernel)
+    hipLaunchKernelGGL(topk_tau_fast_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, (const float*)s_val, a.B, K, a.users, a.ld_users, a.D,
+                       table_norm_max, products == 3 ? 6.1035156e-05f /* 2^-14 */ : 4.1015625e-03f /* 1.05 * 2^-8 */, tau, delta, cnt);
+  else
+    hipLaunchKernelGGL(topk_tau_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, (const float*)s_val, a.B, K, tau, cnt);
   // pass 2: every tile at full GEMM speed, survivors appended
   a.n_split = n_split_full;
   a.tile_stride = 1; a.tau = tau; a.cand_cnt = cnt; a.cand_val = cval; a.cand_idx = cidx; a.cand_cap = ST4_CAP;
   bool hist_in_merge = false;
+  if (fast) {
+    // ring depth: measuring knob PXR_TOPK_NS (defaults = the measured best, tools/eval_bench.py)
+    const int env_ns = getenv("PXR_TOPK_NS") ? atoi(getenv("PXR_TOPK_NS")) : 0;
+    const int tiles256 = (a.N + SPF_BM - 1) / SPF_BM;
+    a.row_blocks = (a.B + SPF_BN - 1) / SPF_BN;
+    int nsp = (256 + a.row_blocks - 1) / a.row_blocks;
+    if (nsp > tiles256) nsp = tiles256;
+    if (nsp < 1) nsp = 1;
+    a.n_split = nsp;
+    const dim3 fgrid(a.row_blocks * a.n_split);
+#define PXR_FAST(NPL_, NS_)                                                                                                   \
+  do {                                                                                                                        \
+    auto kern = score_thresh_fast_kernel<NPL_, NS_>;                                                                          \
+    constexpr int lds = SpfCfg<NPL_, NS_>::RING_BYTES;                                                                        \
+    static bool attr = false;                                                                                                 \
+    if (!attr) {                                                                                                              \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { \
+        (void)hipGetLastError();                                                                                              \
+        pxr_set_error("pxr_score_topk_fast_f32: cannot reserve %d bytes of LDS", lds);                                        \
+        return PXR_ERR_LAUNCH;                                                                                                \
+      }                                                                                                                       \
+      attr = true;                                                                                                            \
+    }                                                                                                                         \
+    hipLaunchKernelGGL(kern, fgrid, dim3(512), lds, st, a, *table_p, *users_p);                                               \
+  } while (0)
+    if (products == 3) {
+      if (env_ns == 3) PXR_FAST(2, 3);
+      else if (env_ns == 5) PXR_FAST(2, 5);
+      else PXR_FAST(2, 4);
+    } else {
+      if (env_ns == 3) PXR_FAST(1, 3);
+      else if (env_ns == 4) PXR_FAST(1, 4);
+      else if (env_ns == 6) PXR_FAST(1, 6);
+      else PXR_FAST(1, 8);
+    }
+#undef PXR_FAST
+    int rc = pxr_check_launch("pxr_score_topk_fast_f32(threshold pass)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(topk_rescore_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, cval, (const int*)cidx, (const int*)cnt, ST4_CAP, a.B, K,
+                       (const float*)delta, *table_p, *users_p, a.D, topk_idx, topk_val, pxr_status_word(), a.hist_ptr, a.hist_items);
+    return pxr_check_launch("pxr_score_topk_fast_f32(re-scoring)");
+  }
   if (table_p != nullptr) {
     // planes: 256-item tiles, one workgroup per CU, every CU the same number of tiles.  Default: round 3's lockstep stream with
     // the history bitmap; PXR_SCORE_P4=1 (read per call: a measuring / test knob): the ping-pong stream (score_thresh_p4_kernel),
@@ -740,6 +1109,13 @@ extern "C" int pxr_score_topk_f32(const float* users, int64_t ld_users, int B, c
   return pxr_score_topk_planes_f32(users, ld_users, B, table, N, D, nullptr, 0, 0, nullptr, 0, 0, hist_ptr, hist_items, K, topk_idx,
                                    topk_val, ws, ws_bytes, stream);
 }
+extern "C" int pxr_score_topk_fast_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
+                                       const void* users_planes, int64_t users_plane_stride, int64_t users_panel_rows,
+                                       const void* table_planes, int64_t table_plane_stride, int64_t table_panel_rows,
+                                       const float* table_row_norm_max, int products, const int32_t* hist_ptr,
+                                       const int64_t* hist_items, int K, int64_t* topk_idx, float* topk_val, void* ws, int64_t ws_bytes,
+                                       void* stream);
+
 // The same with the operands ALSO given as planes (include/pxr.h "pre-split operands"; both NULL: the plain function): on
 // catalogues that take the threshold schedule the main pass -- every item tile -- runs on the planes (gemm_p3_stream); the
 // sample pass keeps the fp32 operands.  The table's planes are made once per evaluation (pxr_split_planes_f32).
@@ -748,6 +1124,22 @@ extern "C" int pxr_score_topk_planes_f32(const float* users, int64_t ld_users, i
                                          const void* table_planes, int64_t table_plane_stride, int64_t table_panel_rows,
                                          const int32_t* hist_ptr, const int64_t* hist_items, int K, int64_t* topk_idx,
                                          float* topk_val, void* ws, int64_t ws_bytes, void* stream) {
+  return pxr_score_topk_fast_f32(users, ld_users, B, table, N, D, users_planes, users_plane_stride, users_panel_rows, table_planes,
+                                 table_plane_stride, table_panel_rows, nullptr, 6, hist_ptr, hist_items, K, topk_idx, topk_val, ws,
+                                 ws_bytes, stream);
+}
+// ... and with the threshold pass on `products` = 3 or 1 of the six bf16 products (6: the function above): needs the planes and
+// table_row_norm_max (device pointer to max_i ||table[i]||_2, pxr_row_norm_max_f32, once per evaluation).  Results are the
+// six-product schedule's, bit for bit (the survivors are re-scored with all six products).
+extern "C" int pxr_score_topk_fast_f32(const float* users, int64_t ld_users, int B, const float* table, int N, int D,
+                                       const void* users_planes, int64_t users_plane_stride, int64_t users_panel_rows,
+                                       const void* table_planes, int64_t table_plane_stride, int64_t table_panel_rows,
+                                       const float* table_row_norm_max, int products, const int32_t* hist_ptr,
+                                       const int64_t* hist_items, int K, int64_t* topk_idx, float* topk_val, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+  PXR_REQUIRE(products == 6 || products == 3 || products == 1, "pxr_score_topk_fast_f32: products must be 6, 3 or 1");
+  PXR_REQUIRE(products == 6 || (table_row_norm_max && users_planes && table_planes),
+              "pxr_score_topk_fast_f32: the reduced-product pass needs both planes and the table's largest row norm");
   PXR_REQUIRE(users && table && topk_idx && topk_val && ws, "pxr_score_topk_f32: null pointer");
   PXR_REQUIRE((users_planes == nullptr) == (table_planes == nullptr), "pxr_score_topk_planes_f32: give both planes or neither");
   PXR_REQUIRE(!users_planes || (D % 32 == 0 && p3_mat_ok(users_planes, users_plane_stride, users_panel_rows, B, D) &&
@@ -770,7 +1162,7 @@ extern "C" int pxr_score_topk_planes_f32(const float* users, int64_t ld_users, i
     if (users_planes && pxr_get_gemm_mode()) {
       const P3Mat tp{reinterpret_cast<__bf16*>(const_cast<void*>(table_planes)), table_plane_stride, table_panel_rows};
       const P3Mat up{reinterpret_cast<__bf16*>(const_cast<void*>(users_planes)), users_plane_stride, users_panel_rows};
-      return score_topk_thresh(a, K, kt, topk_idx, topk_val, ws, (hipStream_t)stream, &tp, &up);
+      return score_topk_thresh(a, K, kt, topk_idx, topk_val, ws, (hipStream_t)stream, &tp, &up, products, table_row_norm_max);
     }
     return score_topk_thresh(a, K, kt, topk_idx, topk_val, ws, (hipStream_t)stream);
   }
@@ -804,4 +1196,16 @@ extern "C" int pxr_score_topk_planes_f32(const float* users, int64_t ld_users, i
   hipLaunchKernelGGL(topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)a.part_val,
                      (const int*)a.part_idx, B, (int)cand, K, topk_idx, topk_val);
   return pxr_check_launch("pxr_score_topk_f32(merge)");
+}
+
+// out[0] = max_i ||x[i, :]||_2 (x [rows, cols] fp32, row stride ldx, cols % 4 == 0): the table statistic behind the margin of the
+// reduced-product top-k pass.  out is a device float (zeroed here, on the stream).
+extern "C" int pxr_row_norm_max_f32(const float* x, int64_t rows, int64_t cols, int64_t ldx, float* out, void* stream) {
+  PXR_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && cols < (1ll << 31), "pxr_row_norm_max_f32: bad args");
+  PXR_REQUIRE((((uintptr_t)x) & 15) == 0, "pxr_row_norm_max_f32: x must be 16-byte aligned");
+  if (hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return pxr_check_launch("pxr_row_norm_max_f32(memset)");
+  if (rows == 0) return PXR_OK;
+  const int64_t blocks = rows < 4096 * 4 ? (rows + 3) / 4 : 4096;
+  hipLaunchKernelGGL(row_norm_max_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, rows, (int)cols, ldx, out);
+  return pxr_check_launch("pxr_row_norm_max_f32");
 }

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "pxr_score_topk_ws_bytes": (_I64, [_I, _I, _I]),
     "pxr_score_topk_f32": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I64, _P]),
     "pxr_score_topk_planes_f32": (_I, [_P, _I64, _I, _P, _I, _I, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _I, _P, _P, _P, _I64, _P]),
+    "pxr_score_topk_fast_f32": (_I, [_P, _I64, _I, _P, _I, _I, _P, _I64, _I64, _P, _I64, _I64, _P, _I, _P, _P, _I, _P, _P, _P, _I64, _P]),
+    "pxr_row_norm_max_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
     "pxr_adamw_flat_f32": (_I, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),
     "pxr_slot_fill_i32": (_I, [_P, _I64, ctypes.c_int32, _P]),
     "pxr_adamw_table_f32": (_I, [_P, _P, _P, _I64, _I, _P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _P]),

@@ -1062,11 +1062,29 @@ def score_planes_supported(table: torch.Tensor) -> bool:
     return gemm_mode() == "bf16x3" and D % 32 == 0 and ((N + 31) // 32 * 32) * D * 6 < 0x7FFFFFF0
 
 
+def row_norm_max(x: torch.Tensor) -> torch.Tensor:
+    """max_i ||x[i]||_2 as a 1-element device tensor (pxr_row_norm_max_f32): the table statistic of the reduced-product top-k."""
+    _req(x, torch.float32, "x", contiguous=False)
+    assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _l.check(_l.load().pxr_row_norm_max_f32(_l.ptr(x), x.shape[0], x.shape[1], x.stride(0), _l.ptr(out), _l.stream_ptr()),
+             "pxr_row_norm_max_f32")
+    return out
+
+
+def topk_products() -> int:
+    """bf16 products of the top-k threshold pass: PXR_TOPK_PRODUCTS = 6 | 3 | 1 (default 3; results are identical, see pxr.h)."""
+    v = int(os.environ.get("PXR_TOPK_PRODUCTS", "3"))
+    return v if v in (1, 3, 6) else 3
+
+
 def score_topk(users: torch.Tensor, ld_users: int, B: int, table: torch.Tensor, K: int, hist_ptr=None,
-               hist_items=None, table_planes: Planes | None = None):
+               hist_items=None, table_planes: Planes | None = None, table_norm_max: torch.Tensor | None = None):
     """Fused full-catalog scoring + masking + top-K (see pxr.h).  `users` may be a strided view (row stride
     ld_users floats).  Returns (topk_idx int64 [B,K], topk_val fp32 [B,K]).  table_planes: split_planes(table), made once
-    per evaluation -- the main pass over the catalogue then runs on pre-split operands (pxr_score_topk_planes_f32)."""
+    per evaluation -- the main pass over the catalogue then runs on pre-split operands (pxr_score_topk_planes_f32);
+    table_norm_max: row_norm_max(table), made with them -- that pass then runs on topk_products() of the six bf16 products and the
+    survivors are re-scored exactly (pxr_score_topk_fast_f32): same ids, same bits."""
     Lb = _l.load()
     _req(users, torch.float32, "users", contiguous=False); _req(table, torch.float32, "table")
     N, D = table.shape
@@ -1081,9 +1099,11 @@ def score_topk(users: torch.Tensor, ld_users: int, B: int, table: torch.Tensor, 
     if table_planes is not None:
         u2 = torch.as_strided(users, (B, D), (ld_users, 1))
         up = split_planes(u2)
-    _l.check(Lb.pxr_score_topk_planes_f32(_l.ptr(users), ld_users, B, _l.ptr(table), N, D, *_pl(up), *_pl(table_planes),
-                                          _l.ptr(hist_ptr), _l.ptr(hist_items), K, _l.ptr(idx), _l.ptr(val), _l.ptr(ws),
-                                          ws_bytes, _l.stream_ptr()), "pxr_score_topk_f32")
+    products = topk_products() if (table_planes is not None and table_norm_max is not None) else 6
+    _l.check(Lb.pxr_score_topk_fast_f32(_l.ptr(users), ld_users, B, _l.ptr(table), N, D, *_pl(up), *_pl(table_planes),
+                                        _l.ptr(table_norm_max) if products != 6 else None, products,
+                                        _l.ptr(hist_ptr), _l.ptr(hist_items), K, _l.ptr(idx), _l.ptr(val), _l.ptr(ws),
+                                        ws_bytes, _l.stream_ptr()), "pxr_score_topk_f32")
     return idx, val
 
 

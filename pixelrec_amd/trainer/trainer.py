@@ -344,14 +344,17 @@ class Trainer:
             self.item_feature = self.model.module.compute_item_all()
         # the fused scoring's main pass reads the item vectors as pre-split planes: made once per evaluation (0.4 ms for
         # 400 K x 512), reused by every batch of users
-        self._item_planes = None
+        self._item_planes = self._item_norm_max = None
         use_p = self.config["eval_planes"]
         if self.fused_topk and (use_p is None or bool(use_p)) and ops.score_planes_supported(self.item_feature.data):
             buf = getattr(self, "_item_planes_buf", None)
             N_, D_ = self.item_feature.shape
             if buf is None or (buf.rows, buf.cols) != (N_, D_) or buf.buf.device != self.item_feature.device:
                 buf = self._item_planes_buf = ops.Planes.alloc(N_, D_, self.item_feature.device)
-            self._item_planes = ops.split_planes(self.item_feature.data.contiguous(), buf)
+            feat = self.item_feature.data.contiguous()
+            self._item_planes = ops.split_planes(feat, buf)
+            # ... and the largest row norm: the margin of the threshold pass on 3 of the 6 bf16 products (ops.score_topk)
+            self._item_norm_max = ops.row_norm_max(feat)
 
     @torch.no_grad()
     def _full_sort_batch_eval(self, batched_data):
@@ -379,7 +382,7 @@ class Trainer:
         if history_index is not None:
             ptr, items = ops.history_csr(history_index[0], history_index[1], B, self.device)
         idx, _ = ops.score_topk(last, L * D, B, self.item_feature.data, max(self.config["topk"]), ptr, items,
-                                table_planes=getattr(self, "_item_planes", None))
+                                table_planes=getattr(self, "_item_planes", None), table_norm_max=getattr(self, "_item_norm_max", None))
         return idx, positive_i
 
     def distributed_concat(self, tensor, num_total_examples):

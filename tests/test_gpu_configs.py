@@ -69,6 +69,18 @@ def test_fused_topk_full_eval_shape():
         finally:
             os.environ.pop("PXR_SCORE_P4", None)
         assert torch.equal(idx_p, idx) and torch.equal(val_p, val), f"planes top-k (PXR_SCORE_P4={p4}) differs"
+    # the threshold pass on 3 / 1 of the 6 bf16 products + exact re-scoring of the survivors: the SAME ids and bits
+    vmax = ops.row_norm_max(table)
+    assert abs(float(vmax) - float(table.norm(dim=1).max())) <= 1e-5 * float(vmax)
+    for products in ("3", "1", "6"):
+        os.environ["PXR_TOPK_PRODUCTS"] = products
+        try:
+            idx_f, val_f = ops.score_topk(users, D, B, table, K, ptr, items, table_planes=tp, table_norm_max=vmax)
+        finally:
+            os.environ.pop("PXR_TOPK_PRODUCTS", None)
+        assert torch.equal(idx_f, idx), f"{products}-product top-k: ids differ"
+        assert torch.equal(val_f, val), f"{products}-product top-k: values differ by {(val_f - val).abs().max().item()}"
+    ops.raise_on_bad_indices() if hasattr(ops, "raise_on_bad_indices") else None
 
 
 # ------------------------------------------------------------------------------------------------ configs[2] / [4]

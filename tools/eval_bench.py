@@ -50,3 +50,18 @@ if tp is not None:
     json.dump({"literal_ms": tl, "fused_ms": tf, "fused_planes_ms": tp3, "table_split_ms": t_split, "alg_tflops_fused_planes": fl / tp3 / 1e9,
                "bf16_pipe_frac_fused_planes": pipe(tp3), "bf16_pipe_frac_fused": pipe(tf), "identical_top10": bool(torch.equal(i1, i3))},
               open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "eval_bench.json"), "w"), indent=1)
+    # the threshold pass on 3 / 1 of the 6 bf16 products, survivors re-scored exactly (pxr_score_topk_fast_f32)
+    vmax = ops.row_norm_max(table)
+    t_norm = timeit(lambda: ops.row_norm_max(table), iters=5)
+    res = {}
+    for prod in (6, 3, 1):
+        os.environ["PXR_TOPK_PRODUCTS"] = str(prod)
+        fn = lambda: ops.score_topk(users, D, B, table, 10, ptr, items, table_planes=tp, table_norm_max=vmax)
+        ip, vp = fn()
+        same = bool(torch.equal(ip, i3) and torch.equal(vp, v3))
+        tq = timeit(fn)
+        res[prod] = {"ms": tq, "identical_ids_and_values": same}
+        print(f"threshold pass on {prod} product(s): {tq:.2f} ms   identical ids AND values: {same}")
+    os.environ.pop("PXR_TOPK_PRODUCTS", None)
+    print(f"row_norm_max (once per evaluation): {t_norm:.2f} ms")
+    json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "eval_bench_products.json"), "w"), indent=1)

@@ -252,8 +252,19 @@ int main(int argc, char** argv) {
     const bool n256 = s.N % 256 == 0;
 #define RUN(NAME, DBG, ...) run<__VA_ARGS__, true, true, DBG>(NAME, g, iters, Cref, diffbuf)
     RUN("p4 256x128 ns3 acc3 dma0", 0, P4Cfg<256, 128, 4, 2, 3, 3, 0>);
-    RUN("p4 256x128 ns3 acc3 dma0 plainstore", 64, P4Cfg<256, 128, 4, 2, 3, 3, 0>);
-    RUN("p4 256x128 ns4 acc3 dma0", 0, P4Cfg<256, 128, 4, 2, 4, 3, 0>);
+    RUN("p4 256x128 ns3 acc3 nostore", 32, P4Cfg<256, 128, 4, 2, 3, 3, 0>);
+    RUN("p4 256x256 ns3 acc1 npl3 nostore", 32, P4Cfg<256, 256, 4, 2, 3, 1, 0, 3>);
+    RUN("p4 256x256 ns4 acc1 npl2 nostore", 32, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
+    RUN("p4 256x256 ns4 acc1 npl2 nostore nomfma", 36, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
+    RUN("p4 256x256 ns4 acc1 npl2 nostore nodma", 34, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
+    RUN("p4 256x256 ns4 acc1 npl2 nostore noreads", 48, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
+    RUN("p4 256x256 ns4 acc1 npl2 nostore nodma noreads", 50, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
+    RUN("p4 256x256 ns8 acc1 npl1 nostore", 32, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
+    RUN("p4 256x256 ns8 acc1 npl1 nostore nomfma", 36, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
+    RUN("p4 256x256 ns8 acc1 npl1 nostore nodma", 34, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
+    RUN("p4 256x256 ns8 acc1 npl1 nostore noreads", 48, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
+    RUN("p4 256x256 ns8 acc1 npl1 nostore nodma noreads nomfma", 54, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
+    RUN("p4 256x256 ns8 acc1 npl1 nostore nostagger", 33, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
     RUN("p3 128x128 s3 4 waves (2 WG/CU)", 0, P3Cfg<128, 128, 2, 2, 3>);
     // zero-filled operands: the same instruction stream at the clock the power budget allows without data toggling
     CK(hipMemset(Ap.p, 0, (size_t)Ap.m.ps * 6)); CK(hipMemset(Bp.p, 0, (size_t)Bp.m.ps * 6));
