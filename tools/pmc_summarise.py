@@ -29,7 +29,7 @@ def main():
     res = {}
     for k, cs in acc.items():
         if not any(t in k for t in ("gemm", "grouped_dw", "score_topk", "adamw", "ln_", "attn", "embed", "segsum", "bpr",
-                                    "sort", "merge", "flash", "vit")):
+                                    "sort", "merge", "flash", "vit", "score_thresh", "rescore", "tower", "split_planes")):
             continue
         res[k] = {c: v[0] / v[1] for c, v in cs.items()}
         res[k]["launches"] = max(v[1] for v in cs.values())
