@@ -258,12 +258,17 @@ __global__ void __launch_bounds__(Cfg::NT) grouped_dw_p3_kernel(const P3DwGroup 
   typename Cfg::Acc accs;
   f32x16 ones_acc[Cfg::TM];
   const bool do_bias = (P.db != nullptr) && (tn == 0);      // block-uniform
-  if (do_bias) gemm_p3_mainloop<Cfg, false, false, EARLY, true>(accs, P.dy, P.x, kpad, m0, n0, smem, ones_acc);
-  else gemm_p3_mainloop<Cfg, false, false, EARLY, false>(accs, P.dy, P.x, kpad, m0, n0, smem);
+  if constexpr (Cfg::PINGPONG) {
+    if (do_bias) gemm_p4_mainloop<Cfg, false, false, true>(accs, P.dy, P.x, kpad, m0, n0, smem, ones_acc);
+    else gemm_p4_mainloop<Cfg, false, false, false>(accs, P.dy, P.x, kpad, m0, n0, smem);
+  } else {
+    if (do_bias) gemm_p3_mainloop<Cfg, false, false, EARLY, true>(accs, P.dy, P.x, kpad, m0, n0, smem, ones_acc);
+    else gemm_p3_mainloop<Cfg, false, false, EARLY, false>(accs, P.dy, P.x, kpad, m0, n0, smem);
+  }
   float* dW = P.dW;
   const int64_t ldw = P.K;
   const bool vec_ok = (P.K % 8 == 0);
-  p3_row_epilogue<Cfg>(accs, smem, P.N, P.K, m0, n0, [&](int, int row, int col, int nv, float (&v)[8]) {
+  auto store = [&](int, int row, int col, int nv, float (&v)[8]) {
     float* cp = dW + (int64_t)row * ldw + col;
     if (vec_ok && nv == 8) {
       *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -273,7 +278,9 @@ __global__ void __launch_bounds__(Cfg::NT) grouped_dw_p3_kernel(const P3DwGroup 
       for (int e = 0; e < 8; ++e)
         if (e < nv) cp[e] = v[e];
     }
-  });
+  };
+  if constexpr (Cfg::PINGPONG) p4_row_epilogue<Cfg>(accs, smem, P.N, P.K, m0, n0, [](int, int, int, int) {}, store);
+  else p3_row_epilogue<Cfg>(accs, smem, P.N, P.K, m0, n0, store);
   if (do_bias) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN, h = lane >> 5, r = lane & 31;
@@ -503,7 +510,13 @@ extern "C" int pxr_grouped_dw_planes_f32(int n, const void* const* dy, const int
     t128 += (int64_t)((N[i] + 127) / 128) * ((K[i] + 127) / 128);
   }
   hipStream_t st = (hipStream_t)stream;
-  if (tile_hint == 0) tile_hint = t128 >= 192 ? 412812831 : 406406431;
+  // 256x128 ping-pong tiles (two accumulator sets: the bias column sums need the third set's registers) when they fill >= 192 CUs
+  // in ONE round (the ViT tower's blocks: 216 tiles); 128x128 lockstep tiles when those do; 64x64 below
+  int64_t t256 = 0;
+  for (int i = 0; i < n; ++i) t256 += (int64_t)((N[i] + 255) / 256) * ((K[i] + 127) / 128);
+  static const int env_p4dw = getenv("PXR_P4_DW") ? atoi(getenv("PXR_P4_DW")) : 1;
+  if (tile_hint == 0) tile_hint = (env_p4dw && ((t256 >= 192 && t256 <= 256) || t256 >= 512)) ? 425612832 : (t128 >= 192 ? 412812831 : 406406431);
+  if (tile_hint == 425612832) return launch_dw_p3<P4Cfg<256, 128, 4, 2, 3, 2>, false>(g, st);
   if (tile_hint == 812812830) return launch_dw_p3<P3Cfg<128, 128, 2, 4, 3>, false>(g, st);
   if (tile_hint == 412812831) return launch_dw_p3<P3Cfg<128, 128, 2, 2, 3>, true>(g, st);
   if (tile_hint == 412812830) return launch_dw_p3<P3Cfg<128, 128, 2, 2, 3>, false>(g, st);

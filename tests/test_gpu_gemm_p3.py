@@ -67,7 +67,7 @@ def test_input_gradient_flavour(tile, M, N, K):
             assert torch.equal(dx, dx0)
 
 
-@pytest.mark.parametrize("tile", [0, 412812831, 812812830, 406406431])
+@pytest.mark.parametrize("tile", [0, 412812831, 812812830, 406406431, 425612832])
 def test_grouped_weight_gradient_and_bias(tile):
     from pixelrec_amd import ops
 
@@ -88,7 +88,10 @@ def test_grouped_weight_gradient_and_bias(tile):
     for (_, _, dW, db), (_, _, dW0, db0), (rW, rb, T) in zip(pl, probs, refs):
         assert (dW.double().cpu() - rW).abs().max().item() <= _tol(rW, T)
         assert (db.double().cpu() - rb).abs().max().item() <= 2e-6 * (T ** 0.5) * float(rb.abs().max()) + 1e-7
-        assert torch.equal(dW, dW0)                # same products, same order as grouped_dw_b3_kernel
+        if tile in NOT_BIT_IDENTICAL:              # (two accumulator sets: same products, different rounding points)
+            assert (dW - dW0).abs().max().item() <= 0.05 * _tol(rW, T)
+        else:
+            assert torch.equal(dW, dW0)            # same products, same order as grouped_dw_b3_kernel
 
 
 def test_producers_write_the_planes_of_their_fp32_output():
