@@ -573,8 +573,8 @@ extern "C" int pxr_counter_add_i64(int64_t* counter, int64_t delta, void* stream
 // now (its scalars are in the table): used for the rows of the NEXT batch, so that its forward finds them current.
 // max_blocks > 0 caps the grid (grid-stride loop inside): a thin launch for side-stream work.
 // PXR_LAZY_REPLAY=exact: replay missed steps with the dense sweep's own arithmetic (lazy == dense bit for bit for gaps <= 256)
-static bool lazy_replay_fast() {
-  const char* e = getenv("PXR_LAZY_REPLAY");
+static bool lazy_replay_fast() {      // read per launch ON PURPOSE: the test suite switches modes inside one process (a getenv is
+  const char* e = getenv("PXR_LAZY_REPLAY");   // ~50 ns against a 3 us launch; under hipGraph replay it is not called at all)
   return !(e && strcmp(e, "exact") == 0);
 }
 static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blocks, int D, void* stream, const char* who) {
@@ -586,13 +586,16 @@ static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blo
   // Replayed steps per row before the closed form takes over.  Exact mode: 256 (the bit-identity window of the tests).  Fast
   // mode: 128 -- the Adam terms dropped beyond it sum to < 31.6 lr rho^128 / (1 - rho) = 4.7e-4 lr (rho = b1 / sqrt(b2) = 0.90045;
   // 4.7e-8 at lr 1e-4, against the 1e-5 parity budget), and the rows at the cap are the ones that set the kernel's duration.
-  const char* w = getenv("PXR_LAZY_WINDOW");
-  a.window = w ? atoi(w) : (a.fast ? PXR_LAZY_EXACT / 2 : PXR_LAZY_EXACT);
-  if (a.window < 0 || a.window > PXR_LAZY_EXACT) a.window = PXR_LAZY_EXACT;
+  static const int env_window = getenv("PXR_LAZY_WINDOW") ? atoi(getenv("PXR_LAZY_WINDOW")) : -1;
+  a.window = env_window >= 0 ? env_window : (a.fast ? PXR_LAZY_EXACT / 2 : PXR_LAZY_EXACT);
+  // (0 would turn the whole replay into the closed form, which drops every Adam term: at least one replayed step)
+  if (a.window < 1) a.window = 1;
+  if (a.window > PXR_LAZY_EXACT) a.window = PXR_LAZY_EXACT;
   hipStream_t st = (hipStream_t)stream;
   // 2 elements per lane up to D = 2048 (a 512-wide row = 4 waves), 4 beyond (block size caps at 1024 threads)
   int epl = D <= 2048 ? 2 : 4;
-  if (const char* e = getenv("PXR_ROWS_EPL")) { if (atoi(e) == 4 && D % 4 == 0) epl = 4; }    // measuring knob
+  static const int env_epl = getenv("PXR_ROWS_EPL") ? atoi(getenv("PXR_ROWS_EPL")) : 0;       // measuring knob
+  if (env_epl == 4 && D % 4 == 0) epl = 4;
   const int lpr = ((D / epl + 63) / 64) * 64;          // lanes per row
   const int tl = lpr <= 64 ? 64 : (lpr <= 128 ? 128 : (lpr <= 256 ? 256 : (lpr <= 512 ? 512 : 1024)));
   const int rpb = tl >= 256 ? 1 : 256 / tl;          // == the kernel's RPB

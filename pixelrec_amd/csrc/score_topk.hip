@@ -342,7 +342,9 @@ __global__ void __launch_bounds__(256) topk_tau_kernel(const float* __restrict__
   // score equal to the K-th best up to summation order must still pass `x >= tau`, so tau is lowered by 2^-18 |tau|
   // (thousands of ulps: it only admits a few more candidates, the merge below decides)
   const float t = sample_val[(int64_t)u * K + (K - 1)];
-  tau[u] = t - fabsf(t) * 3.814697265625e-06f;
+  // (a non-finite K-th sample value -- +inf scores, NaN embeddings -- must not become a NaN threshold that rejects everything:
+  // -inf admits every item, the candidate buffer then overflows and the host raises THAT)
+  tau[u] = isfinite(t) ? t - fabsf(t) * 3.814697265625e-06f : -INFINITY;
   cnt[u] = 0;
 }
 
@@ -359,8 +361,8 @@ __global__ void __launch_bounds__(256) topk_cand_merge_kernel(float* __restrict_
   const int u = blockIdx.x * 4 + wave;
   if (u >= B) return;
   int n = cnt[u];
-  if (n > cap || n < K) {    // dropped candidates, or fewer than K survivors (idx -1 in the output): both are errors the host raises
-    if (status && lane == 0) atomicOr(status, PXR_STATUS_TOPK_OVERFLOW);
+  if (n > cap || n < K) {    // dropped candidates, or fewer than K survivors (idx -1 in the output): two different errors the host raises
+    if (status && lane == 0) atomicOr(status, n > cap ? PXR_STATUS_TOPK_OVERFLOW : PXR_STATUS_TOPK_UNDERFLOW);
     n = min(n, cap);
   }
   float* pv = cand_val + (int64_t)u * cap;
@@ -732,7 +734,7 @@ __global__ void __launch_bounds__(256) topk_tau_fast_kernel(const float* __restr
   if (lane == 0) {
     const float d = c * sqrtf(ss) * vmax[0];
     const float t = sample_val[(int64_t)u * K + (K - 1)];
-    tau[u] = (t - fabsf(t) * 3.814697265625e-06f) - d;
+    tau[u] = (isfinite(t) && isfinite(d)) ? (t - fabsf(t) * 3.814697265625e-06f) - d : -INFINITY;
     delta[u] = d;
     cnt[u] = 0;
   }
@@ -783,7 +785,8 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(float* __restrict__ c
   const int u = blockIdx.x * 4 + wave;
   if (u >= B) return;                      // (wave-uniform; no workgroup barrier below)
   int n = cnt[u];
-  bool bad = (n > cap || n < K);
+  bool bad = n > cap;
+  if (n < K && status && lane == 0) atomicOr(status, PXR_STATUS_TOPK_UNDERFLOW);
   n = min(n, cap);
   float* pv = cand_val + (int64_t)u * cap;
   const int* pi = cand_idx + (int64_t)u * cap;

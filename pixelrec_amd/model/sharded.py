@@ -16,8 +16,12 @@ rows only (PxrAdamW sizes itself from `item_embedding.weight`).  Per training st
      (pair_cap = |U_r| / W x slack per pair), against W x cap rows for
   3. the older `row_exchange = "reduce_scatter"`: all-gather of the W full id lists, every rank serves a [W, cap, D] block that
      is zero wherever it is not the owner, reduce-scatter(SUM) -- exactly one non-zero contribution per slot, so the sum is
-     exact.  Kept as the fallback without a capacity bound (a batch whose hits pile up on one owner beyond pair_cap sets a
-     status bit that raises at the next check; nothing is dropped silently).
+     exact.  Kept as the fallback without a capacity bound.  A batch whose hits pile up on one owner beyond pair_cap sets a
+     device status bit (PXR_STATUS_SHARD_OVERFLOW) and the surplus rows are served as ZERO embeddings until the host reads
+     that word: `ops.raise_on_bad_indices` -- the Trainer calls it once per epoch, so up to an epoch of steps can apply
+     updates computed from those zero rows before the RuntimeError surfaces (nothing is dropped unnoticed, but it is not
+     caught within the step).  Loops that drive ShardedDataParallel directly should call `check_overflow()` (below) at their
+     own host synchronisation points, or use `row_exchange = "reduce_scatter"`.
      Either way the forward / backward kernels then run on the [cap + 1, D] block with the batch re-indexed onto it
      (`pxr_ids_to_compact_i64`): same kernels, same arithmetic as the replicated model;
   4. the sparse gradient (global ids, rows) is exchanged and merged exactly as in the replicated mode
@@ -153,6 +157,11 @@ class ShardedSASRec(SASRec):
         if W == 1:
             return cap
         return min(cap, (int(cap / W * self.pair_slack) + 64 + 63) // 64 * 64)
+
+    def check_overflow(self):
+        """Host check (synchronises) of the status word: raises if a pair of the all-to-all row exchange overflowed since the last
+        check.  The Trainer's once-per-epoch `ops.raise_on_bad_indices` is the same check; call this where a custom loop syncs."""
+        ops.raise_on_bad_indices(self.item_embedding.weight.device)
 
     def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
         """send[o] goes to rank o; returns recv with recv[q] = what rank q sent here.  send: [W, ...] contiguous."""

@@ -107,6 +107,9 @@ def raise_on_bad_indices(device=None):
     if v & 4:
         raise RuntimeError("fused scoring + top-k: the per-user candidate buffer of the threshold pass overflowed "
                            "(results may miss items); set PXR_TOPK_VARIANT=2")
+    if v & 32:
+        raise RuntimeError("fused scoring + top-k: a user ended with fewer than K candidates above its threshold (non-finite scores "
+                           "or embeddings?); the affected rows of the result hold id -1")
     if v & 16:
         raise RuntimeError("row-sharded table: one rank owned more of a batch's hit rows than the per-pair request capacity "
                            "(ShardedSASRec.pair_slack); rows were dropped -- raise the slack or use row_exchange='reduce_scatter'")

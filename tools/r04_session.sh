@@ -18,8 +18,9 @@ if has gemmtest; then
   tail -n 8 "$OUT/pytest_gemm_p3.log"
 fi
 if has tests; then
-  ( time timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -15 ) > "$OUT/pytest_gpu.log" 2>&1
-  tail -n 8 "$OUT/pytest_gpu.log"
+  ( time timeout 2400 python -m pytest tests -m gpu -v 2>&1 | grep -v "amdgpu.ids\|socket.cpp" ) > "$OUT/pytest_gpu_full.log" 2>&1
+  grep -v "PASSED\|^$" "$OUT/pytest_gpu_full.log" | cut -c1-400 | tail -n 60 > "$OUT/pytest_gpu.log"
+  grep -c PASSED "$OUT/pytest_gpu_full.log"; grep "PASSED" "$OUT/pytest_gpu_full.log" | tail -2 | cut -c1-200; tail -n 40 "$OUT/pytest_gpu.log"
 fi
 if has vitgemm; then
   timeout 300 python tools/vit_gemm_bench.py > "$OUT/vit_gemm_bench.log" 2>&1; cat "$OUT/vit_gemm_bench.log"
