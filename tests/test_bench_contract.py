@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the line the last GPU session committed (profiles/r03/bench_default_line.json):
+"""The bench.py output contract, checked on the line the last GPU session committed (profiles/r04/bench_default_line.json):
 every key the driver parses is there with the right type, the metric/config are BASELINE.json's, and the derived
 fields are consistent with each other.  (bench.py itself needs an MI355X: this guards the schema on CPU.)"""
 import json
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    text = open(os.path.join(ROOT, "profiles", "r03", "bench_default_line.json")).read().strip().splitlines()
+    text = open(os.path.join(ROOT, "profiles", "r04", "bench_default_line.json")).read().strip().splitlines()
     assert len(text) == 1, "bench.py prints ONE JSON line"
     return json.loads(text[0])
 
@@ -44,8 +44,12 @@ def test_roofline_and_cpu_baseline_objects():
     assert r["traffic"] is None or r["traffic"] > 0
     # round 3: priced against the pipe the kernels run on -- in bf16x3 mode the dense bf16 MFMA peak with the 6 bf16 products
     # per fp32 multiply counted as executed work; the fp32-equivalent view travels beside it
-    assert r["gemm_mode"] in ("bf16x3", "f32")
-    if r["gemm_mode"] == "bf16x3":
+    assert r["gemm_mode"] in ("planes", "bf16x3", "f32")
+    # round 4: the line names the kernels the trace shows, and says where `traffic` comes from (a committed PMC file, not this run)
+    if r["gemm_mode"] == "planes":
+        assert "gemm_p3_kernel" in r["kernel"] and "grouped_dw_p3_kernel" in r["kernel"]
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+    if r["gemm_mode"] in ("planes", "bf16x3"):
         assert r["peak"] == 2500.0 and "bf16" in r["pipe"]
         assert math.isclose(r["achieved"], 6.0 * r["algorithmic_tflops"], rel_tol=1e-6)
         assert math.isclose(r["algorithmic_over_f32_mfma_peak"], r["algorithmic_tflops"] / 157.3, rel_tol=1e-3)
@@ -60,3 +64,27 @@ def test_roofline_and_cpu_baseline_objects():
     assert d["roofline_gather"]["frac"] >= 0.70
     sc = d["roofline_scoring"]
     assert sc["peak"] == 2500.0 and 0 < sc["frac"] <= 1 and sc["algorithmic_over_f32_mfma_peak"] >= 0.60
+    # round 4: measured on the path the product evaluates with (fused top-k on the pre-split table), with the result checked in the run
+    assert "score_thresh_p3_kernel" in sc["kernel"] and sc["identical_top10"] is True
+    ft = d["roofline_scoring_fused_topk"]
+    assert ft["identical_top10"] is True and ft["identical_ids_and_values_to_six_product_schedule"] is True
+    assert ft["products_in_threshold_pass"] in (1, 3, 6) and 0 < ft["ms_per_1024_users"] <= ft["six_product_schedule_ms"] * 1.05
+
+
+def test_round4_extras_travel_with_the_default_line():
+    d = _line()
+    # the PixelNet (BASELINE configs[2]-shaped) step, a few steps of it
+    px = d["pixelnet"]
+    assert "error" not in px, px
+    assert px["unit"] == "sequences/s" and px["ms_per_step"] > 0 and px["config"]["images_per_step"] == 352
+    assert 0 < px["gemm_family"]["frac"] <= 1 and set(px["phases_ms"]) and all(v >= 0 for v in px["phases_ms"].values())
+    # per-family device time of the step at the throughput-oriented batch sizes
+    bs = {t["batch_per_gpu"]: t for t in d["throughput_batches"]}
+    assert set(bs) == {512, 2048}
+    for t in bs.values():
+        fam = t["kernel_families_us_per_step"]
+        assert any(k.startswith("gemm") for k in fam) and any(k.startswith("grouped") for k in fam)
+        assert abs(sum(fam.values()) - t["ms_per_step"] * 1e3) <= 1e-3 * t["ms_per_step"] * 1e3      # the rows add up to the step
+        assert 0 < t["gemm_family"]["frac"] <= 1
+    # the fused gather is priced with the plane bytes it writes
+    assert "planes" in d["roofline_gather_fused"][0]["note"]
