@@ -121,7 +121,10 @@ class CLIPVisionEncoder(nn.Module):
         self.hidden = hidden
 
     def forward(self, pixel_values):
-        return (self.vision_model(pixel_values),)
+        # (last_hidden_state, pooler_output) like HF: pooler_output = post_layernorm(class token); with post_layernorm swapped for
+        # Identity (methods 'mean' / 'cls', load.py:112,116) it is the class token itself and nobody reads it
+        last = self.vision_model(pixel_values)
+        return (last, self.vision_model.post_layernorm(last[:, 0, :]))
 
 
 ENCODER_SHAPES = {
@@ -182,6 +185,19 @@ class ClsItemEncoder(_ItemEncoderBase):
         return self.rec_fc(x[:, 0, :])
 
 
+class PoolItemEncoder(_ItemEncoderBase):
+    """rec_fc on HF's `pooler_output` = post_layernorm(class token) (layers.py:130-137; load.py:119-120 keeps post_layernorm a
+    parameter of the model for this method -- indices 197, 198 of CLIP ViT-B: trainable at the shipped tune_scale)."""
+    native_method = "pool"
+
+    def forward(self, x):
+        if x.is_cuda:
+            from . import vit_native
+
+            return vit_native.run(self, x)
+        return self.rec_fc(self.item_encoder(x)[1])
+
+
 def _load_pretrained_backbone(model, name, config):
     """fine_tune_arg.pre_trained (the shipped default, overall/ViT.yaml): the reference calls
     CLIPVisionModel.from_pretrained('openai/<name>') (load.py:94).  Same here, restricted to what is on local disk (no
@@ -234,8 +250,9 @@ def load_model(config):
         elif not pre_trained:
             param.data.normal_(mean=0.0, std=0.02)                      # load.py:104-108
     method = ft.get("method", "mean")
-    cls = {"mean": MeanItemEncoder, "cls": ClsItemEncoder}.get(method)
+    cls = {"mean": MeanItemEncoder, "cls": ClsItemEncoder, "pool": PoolItemEncoder}.get(method)
     if cls is None:
-        raise NotImplementedError(f"fine_tune_arg.method={method!r} (built: mean, cls)")
-    model.vision_model.post_layernorm = nn.Identity()                   # load.py:112,116
+        raise NotImplementedError(f"fine_tune_arg.method={method!r} (built: mean, cls, pool)")
+    if method != "pool":
+        model.vision_model.post_layernorm = nn.Identity()               # load.py:112,116 (the 'pool' branch, :119-120, keeps it)
     return cls(model, model.hidden, config["embedding_size"], ft.get("activation", "relu"), ft.get("dnn_layers"))

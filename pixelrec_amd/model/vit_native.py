@@ -81,7 +81,8 @@ class NativeTower:
             flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = flat[off:off + n].view(p.shape)
             views[name] = (off, n, tuple(p.shape))
-            if p.requires_grad and "post_layernorm" not in name:     # post_layernorm: unused by 'mean'/'cls' (load.py:112)
+            # post_layernorm: unused by 'mean' / 'cls' (load.py:112), the pooled head's LayerNorm under 'pool'
+            if p.requires_grad and ("post_layernorm" not in name or self.enc.native_method == "pool"):
                 p.grad = gflat[off:off + n].view(p.shape)
                 if segs and segs[-1][1] == off:
                     segs[-1] = (segs[-1][0], off + pad4(n))
@@ -306,11 +307,16 @@ class NativeTower:
             raise NotImplementedError("native image encoder: rec_fc activation must be relu or none (overall/ViT.yaml: relu)")
         W, b = self.view("rec_fc.0.weight"), self.view("rec_fc.0.bias")
         head_in = x if e.native_method == "mean" else x[:, 0, :].contiguous()
+        xh_p = rs_p = None
+        if e.native_method == "pool":            # pooler_output: post_layernorm of the class token (HF CLIPVisionTransformer)
+            y_p, xh_p, rs_p = ops.ln_residual_fwd(head_in.view(n, 1, -1), None, self.view(vm + "post_layernorm.weight"),
+                                                  self.view(vm + "post_layernorm.bias"), 1e-5, save=need_grad)
+            head_in = y_p.view(n, -1)
         act = ops.linear_epi(head_in, W, b, ops.EPI_BIAS_RELU) if act_relu else ops.linear_fwd(head_in, W, b)
         out = ops.token_mean(act) if e.native_method == "mean" else act
         saved = None
         if need_grad:
-            saved = dict(n=n, first=first, blocks=blocks, x_last=x, head_in=head_in, act=act, act_relu=act_relu,
+            saved = dict(n=n, first=first, blocks=blocks, x_last=x, head_in=head_in, act=act, act_relu=act_relu, xh_p=xh_p, rs_p=rs_p,
                          patches=patches if keep0 else None, xh0=xh0, rs0=rs0)
         return out, saved
 
@@ -374,6 +380,10 @@ class NativeTower:
             defer.flush()
             return
         dxl = ops.linear_bwd_input(dact, self.view("rec_fc.0.weight"))
+        if e.native_method == "pool":
+            dxl, _ = ops.ln_bwd(0, dxl.view(n, 1, H), saved["xh_p"], saved["rs_p"], self.view(vm + "post_layernorm.weight"),
+                                G(vm + "post_layernorm.weight"), G(vm + "post_layernorm.bias"), defer=defer)
+            dxl = dxl.view(n, H)
         if e.native_method == "mean":
             dx = dxl.view(n, T, H)
         else:

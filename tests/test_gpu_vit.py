@@ -108,7 +108,7 @@ def test_vit_epilogues_and_small_kernels():
     assert torch.equal(ops.add(a2, b2), a2 + b2)
 
 
-@pytest.mark.parametrize("method,tune", [("mean", 5 + 16 * 2), ("mean", 0), ("cls", 5 + 16)])
+@pytest.mark.parametrize("method,tune", [("mean", 5 + 16 * 2), ("mean", 0), ("cls", 5 + 16), ("pool", 5 + 16)])
 def test_native_encoder_matches_torch_tower(method, tune):
     """Forward, every trainable gradient and three VisualAdamW steps of the native encoder against the torch restatement
     of the same tower under autograd + torch.optim.AdamW (tiny 3-block tower; full widths: tests/test_gpu_configs.py)."""
@@ -134,8 +134,9 @@ def test_native_encoder_matches_torch_tower(method, tune):
         w = torch.randn(4, 24) * 1e4
         out = enc(x.cuda())
         (out * w.cuda()).sum().backward()
-        tower = ref.item_encoder(x)[0]
-        ref_out = torch.mean(ref.rec_fc(tower), dim=1) if method == "mean" else ref.rec_fc(tower[:, 0, :])
+        tower, pooled = ref.item_encoder(x)
+        ref_out = (torch.mean(ref.rec_fc(tower), dim=1) if method == "mean" else
+                   ref.rec_fc(pooled) if method == "pool" else ref.rec_fc(tower[:, 0, :]))
         assert (out.detach().cpu() - ref_out).abs().max().item() < 2e-5
         topt.zero_grad()
         (ref_out * w).sum().backward()
@@ -169,6 +170,7 @@ def test_native_encoder_matches_torch_tower(method, tune):
         assert diff.max().item() < (3e-4 if "patch_embedding" in n else 1e-4), n
     with torch.no_grad():
         x = torch.randn(2, 3, 64, 64)
-        tower = ref.item_encoder(x)[0]
-        ref_out = torch.mean(ref.rec_fc(tower), dim=1) if method == "mean" else ref.rec_fc(tower[:, 0, :])
+        tower, pooled = ref.item_encoder(x)
+        ref_out = (torch.mean(ref.rec_fc(tower), dim=1) if method == "mean" else
+                   ref.rec_fc(pooled) if method == "pool" else ref.rec_fc(tower[:, 0, :]))
         assert (enc(x.cuda()).cpu() - ref_out).abs().max().item() < 1e-4
