@@ -664,15 +664,41 @@ __global__ void __launch_bounds__(512) score_thresh_fast_kernel(ScoreTopkArgs a,
     const int uj = u0 + wn * Cfg::WN + j * 32 + (int)(threadIdx.x & 31u);
     thr[j] = uj < a.B ? a.tau[uj] : INFINITY;
   }
+  // Survivors of a tile are STASHED (up to two per lane and column block) and their slots reserved with one returning atomic per
+  // (lane, block) whose result is not consumed before the NEXT tile's comparison, a whole K loop later: the atomic's round trip
+  // (~2 us, which both wave groups would otherwise spend at the barrier) disappears behind the stream.  The atomic is issued from
+  // inline asm so that the compiler neither waits for it (it would drain the DMA ring with a vmcnt(0)) nor counts it: by the
+  // time it is used, at least one counted wait of the stream (all but the youngest `keep` operations retired) lies behind it --
+  // for reductions shorter than the ring that is forced below.  A lane with more than two hits in a block (a 1e-5 event on the
+  // north-star shape) sends its wave through the blocking path for that block.
+  int pn[Cfg::TN], pbase[Cfg::TN], pit[Cfg::TN][2];
+  float pval[Cfg::TN][2];
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) { pn[j] = 0; pbase[j] = 0; pit[j][0] = pit[j][1] = 0; pval[j][0] = pval[j][1] = 0.f; }
+  const bool short_k = (a.D / 16) <= NS + 1;
+  auto flush = [&]() {
+    if (short_k) p3_wait_vm<0>();
+    const int r = (int)(threadIdx.x & 31u);
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      if (pn[j] > 0) {
+        const int user = u0 + wn * Cfg::WN + j * 32 + r;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k < pn[j] && pbase[j] + k < a.cand_cap) {
+            a.cand_val[(int64_t)user * a.cand_cap + pbase[j] + k] = pval[j][k];
+            a.cand_idx[(int64_t)user * a.cand_cap + pbase[j] + k] = pit[j][k];
+          }
+      }
+      pn[j] = 0;
+    }
+  };
   gemm_p4_stream<Cfg>(table_p, users_p, a.D, tn0 * SPF_BM, u0, tn1 - tn0, smem, [&](int tile, const typename Cfg::Acc& accs) {
+    flush();                                              // the previous tile's survivors: their slots were reserved a K loop ago
     const int lane = (int)(threadIdx.x & 63u);
     const int h = lane >> 5, r = lane & 31;
     const int i0 = (tn0 + tile) * SPF_BM + wm * Cfg::WM + 4 * h;
-    // A lane owns one user per column block j and up to TM * 16 of its scores.  Appending survivor by survivor would cost one
-    // returning global atomic (a ~2 us round trip) per hit, serialised inside divergent code -- as long as the whole K loop of a
-    // tile in the reduced-product passes.  Instead: count the lane's hits per j, reserve their slots with ONE atomic per (lane, j)
-    // -- the TN atomics of a tile are in flight together -- then write.
-    int user[Cfg::TN], nh[Cfg::TN], base[Cfg::TN];
+    int user[Cfg::TN], nh[Cfg::TN];
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) user[j] = u0 + wn * Cfg::WN + j * 32 + r;
     unsigned hot = 0;                                     // bit (j * TM + i): block (i, j) holds a hit in SOME lane (wave-uniform)
@@ -689,33 +715,50 @@ __global__ void __launch_bounds__(512) score_thresh_fast_kernel(ScoreTopkArgs a,
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int item = i0 + i * 32 + (e & 3) + 8 * (e >> 2);
-          nh[j] += (accs.v[i][j][e] >= thr[j] && item != 0 && item < a.N) ? 1 : 0;
+          const float x = accs.v[i][j][e];
+          if (x >= thr[j] && item != 0 && item < a.N) {
+            if (nh[j] == 0) { pval[j][0] = x; pit[j][0] = item; }
+            else if (nh[j] == 1) { pval[j][1] = x; pit[j][1] = item; }
+            ++nh[j];
+          }
         }
       }
     }
     if (hot == 0) return;
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) base[j] = nh[j] > 0 ? atomicAdd(&a.cand_cnt[user[j]], nh[j]) : 0;
-#pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
+      if (!__any(nh[j] > 0)) continue;
+      if (!__any(nh[j] > 2)) {
+        if (nh[j] > 0) {
+          int* cp = &a.cand_cnt[user[j]];
+          asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pbase[j]) : "v"(cp), "v"(nh[j]) : "memory");
+        }
+        pn[j] = nh[j];
+      } else {
+        // blocking path: reserve, then walk the block column again and write
+        int base = nh[j] > 0 ? atomicAdd(&a.cand_cnt[user[j]], nh[j]) : 0;
 #pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) {
-        if (!((hot >> (j * Cfg::TM + i)) & 1u)) continue;
+        for (int i = 0; i < Cfg::TM; ++i) {
+          if (!((hot >> (j * Cfg::TM + i)) & 1u)) continue;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int item = i0 + i * 32 + (e & 3) + 8 * (e >> 2);
-          const float x = accs.v[i][j][e];
-          if (x >= thr[j] && item != 0 && item < a.N) {
-            if (base[j] < a.cand_cap) {
-              a.cand_val[(int64_t)user[j] * a.cand_cap + base[j]] = x;
-              a.cand_idx[(int64_t)user[j] * a.cand_cap + base[j]] = item;
+          for (int e = 0; e < 16; ++e) {
+            const int item = i0 + i * 32 + (e & 3) + 8 * (e >> 2);
+            const float x = accs.v[i][j][e];
+            if (x >= thr[j] && item != 0 && item < a.N) {
+              if (base < a.cand_cap) {
+                a.cand_val[(int64_t)user[j] * a.cand_cap + base] = x;
+                a.cand_idx[(int64_t)user[j] * a.cand_cap + base] = item;
+              }
+              ++base;
             }
-            ++base[j];
           }
         }
+        pn[j] = 0;
       }
     }
   });
+  p3_wait_vm<0>();                                        // the last tile's reservations
+  flush();
 }
 
 // tau'[u] = tau[u] - delta[u]: tau as topk_tau_kernel, delta[u] = c * ||users[u]||_2 * vmax[0]; cnt[u] = 0

@@ -105,8 +105,9 @@ def raise_on_bad_indices(device=None):
     if v & 1:
         raise IndexError("index out of range in self (an item id outside [0, item_num) reached an embedding gather)")
     if v & 4:
-        raise RuntimeError("fused scoring + top-k: the per-user candidate buffer of the threshold pass overflowed "
-                           "(results may miss items); set PXR_TOPK_VARIANT=2")
+        raise RuntimeError("fused scoring + top-k: the per-user candidate buffer of the threshold pass overflowed (results may miss "
+                           "items); with PXR_TOPK_PRODUCTS=1 first go back to 3 or 6 (a tighter threshold margin admits fewer "
+                           "candidates), else set PXR_TOPK_VARIANT=2 (register lists, no candidate buffer)")
     if v & 32:
         raise RuntimeError("fused scoring + top-k: a user ended with fewer than K candidates above its threshold (non-finite scores "
                            "or embeddings?); the affected rows of the result hold id -1")
