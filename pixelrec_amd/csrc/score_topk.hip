@@ -630,14 +630,26 @@ __global__ void __launch_bounds__(Sp4Cfg::NT) score_thresh_p4_kernel(ScoreTopkAr
 }
 
 // ---- "fewer products, exact results" (round 4): the threshold pass only has to DECIDE score >= tau, so it runs on a subset of
-// the six bf16 products -- NPL = 2 planes: hi*hi + mid*hi + hi*mid (error <= 2^-15 sum|u||v|), NPL = 1: hi*hi alone (<= 2^-8
-// sum|u||v|) -- with tau lowered by a rigorous per-user bound delta_u = c ||u||_2 max_i ||v_i||_2 (Cauchy-Schwarz; the table's
+// the six bf16 products -- NPL = 2 planes: hi*hi + mid*hi + hi*mid (error <= 2^-13.7 sum|u||v| at K = 512), NPL = 1: hi*hi alone
+// (<= 1.03 * 2^-7 sum|u||v|; both derived at spf_margin below) -- with tau lowered by a rigorous per-user bound delta_u = c ||u||_2 max_i ||v_i||_2 (Cauchy-Schwarz; the table's
 // largest row norm is computed once per evaluation, pxr_row_norm_max_f32).  The survivors carry APPROXIMATE values; per user the
 // few that can still reach the top K (approximate value within 2 delta_u of the K-th best approximate value) are re-scored
 // with all six products through the SAME MFMA sequence as the full pass -- same k order, same three accumulator sets, same
 // final fold -- so ids AND values are bit-identical to the six-product schedule (tests/test_gpu_configs.py).
 // Tile: 256 items x 256 users, one accumulator set (128 registers), ping-pong k-block stream (gemm_p4_stream).
 constexpr int SPF_BM = 256, SPF_BN = 256;
+// The margin constants: |six-product value - reduced-product value| <= c * sum_k |u_k| |v_k| <= c ||u||_2 ||v||_2.
+// With x = hi + mid + lo (bf16 RNE: |x - hi| <= 2^-8 |x|, so |mid| <= 2^-8 (1 + 2^-8) |x|, |lo| <= 2^-16 |x|, |hi| <= (1 + 2^-8) |x|):
+//   one product:    dropped mid*hi + hi*mid + hi*lo + lo*hi + mid*mid <= (2 * 2^-8 (1 + 2^-8)^2 + 3.03 * 2^-16) |u||v| = 1.013 * 2^-7 |u||v|
+//   three products: dropped hi*lo + lo*hi + mid*mid <= 3.03 * 2^-16 |u||v| = 2^-14.4 |u||v|
+// plus the two sums' own fp32 accumulation error, <= (MFMA accumulations x <= 4 internal roundings each) * 2^-24 sum|u||v|: 2^-16.9
+// for the three-set six-product sum, 2^-15.4 for 96 accumulations into one set (K = 512; both grow with K / 16, hence the K factor
+// below).  c = the sum with a 1.5x margin, evaluated for the reduction length at hand.
+__host__ __device__ inline float spf_margin(int products, int D) {
+  const float acc = (D / 16.0f) * (4.0f * 4.0f + 4.0f * 3.0f) * 5.9604645e-08f;      // (six-product + three-product chains) * 2^-24
+  const float dropped = products == 3 ? 3.03f * 1.52587890625e-05f : 1.013f * 7.8125e-03f + 3.03f * 1.52587890625e-05f;
+  return 1.5f * (dropped + acc);
+}
 template <int NPL, int NS>
 using SpfCfg = P4Cfg<SPF_BM, SPF_BN, 4, 2, NS, 1, 0, NPL>;
 
@@ -1050,7 +1062,7 @@ static int score_topk_thresh(ScoreTopkArgs a, int K, int kt, int64_t* topk_idx, 
                      (const int*)a.part_idx, a.B, (int)cand, K, s_idx, s_val);
   if (fast)      // tau lowered by the rigorous margin of the reduced-product pass (see score_thresh_fast_kernel)
     hipLaunchKernelGGL(topk_tau_fast_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, (const float*)s_val, a.B, K, a.users, a.ld_users, a.D,
-                       table_norm_max, products == 3 ? 6.1035156e-05f /* 2^-14 */ : 4.1015625e-03f /* 1.05 * 2^-8 */, tau, delta, cnt);
+                       table_norm_max, spf_margin(products, a.D), tau, delta, cnt);
   else
     hipLaunchKernelGGL(topk_tau_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, (const float*)s_val, a.B, K, tau, cnt);
   // pass 2: every tile at full GEMM speed, survivors appended
