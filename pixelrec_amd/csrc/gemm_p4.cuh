@@ -56,7 +56,7 @@ struct P4Cfg {
   static_assert(NS >= 3 && NS <= 8, "ring slots");
   static_assert(NACC == 1 || NACC == 2 || NACC == 3, "accumulator sets");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-  static_assert(BN % EPI_COLS == 0 && (64 * G) % (EPI_COLS / 8) == 0 && BM % (64 * G / (EPI_COLS / 8)) == 0, "epilogue chunk map");
+  static constexpr bool EPI_OK = BN % EPI_COLS == 0 && (64 * G) % (EPI_COLS / 8) == 0 && BM % (64 * G / (EPI_COLS / 8)) == 0;   // p4_row_epilogue's chunk map
   struct Acc {
     f32x16 v[TM][TN];
   };
@@ -511,6 +511,7 @@ struct P4ChunkMap {
 };
 template <class Cfg, class Pre, class Fn>
 __device__ __forceinline__ void p4_row_epilogue(const typename Cfg::Acc& accs, char* smem, int M, int N, int m0, int n0, Pre&& pre, Fn&& fn) {
+  static_assert(Cfg::EPI_OK, "epilogue chunk map");
   float* t = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN, h = lane >> 5, r = lane & 31;

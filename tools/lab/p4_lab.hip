@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(Cfg::NT) lab_kernel(const LabArgs g) {
   typename Cfg::Acc accs;
   lab_mainloop<Cfg, A_KC, B_KC, DBG>(accs, g, m0, n0, smem);
   constexpr bool nostore = (DBG & 32) != 0;
-  if constexpr (Cfg::BM * Cfg::EPI_LD * 4 <= Cfg::LDS_BYTES) {
+  if constexpr (Cfg::BM * Cfg::EPI_LD * 4 <= Cfg::LDS_BYTES && (!Cfg::PINGPONG || Cfg::BN <= 128)) {
     p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, [&](int, int row, int col, int nv, float (&v)[8]) {
       if (nostore && v[0] != 1.2345e38f) return;
       float* cp = g.C + (int64_t)row * g.N + col;
@@ -221,6 +221,10 @@ int main(int argc, char** argv) {
   const char* only = argc > 2 ? argv[2] : "";
   struct Shape { const char* name; int M, N, K; };
   const Shape shapes[] = {
+      {"seq fc1 (B=64)", 3200, 1024, 512},
+      {"seq qkv (B=64)", 3200, 1536, 512},
+      {"seq out (B=64)", 3200, 512, 512},
+      {"seq fc2 (B=64)", 3200, 512, 1024},
       {"scoring  items x users", 400128, 1024, 512},
       {"vit fc1", 69344, 3072, 768},
       {"vit fc2", 69344, 768, 3072},
@@ -252,6 +256,7 @@ int main(int argc, char** argv) {
     const bool n256 = s.N % 256 == 0;
 #define RUN(NAME, DBG, ...) run<__VA_ARGS__, true, true, DBG>(NAME, g, iters, Cref, diffbuf)
     RUN("p4 256x128 ns3 acc3 dma0", 0, P4Cfg<256, 128, 4, 2, 3, 3, 0>);
+    if (s.M > 4096)
     RUN("p4 256x128 ns3 acc3 nostore", 32, P4Cfg<256, 128, 4, 2, 3, 3, 0>);
     RUN("p4 256x256 ns3 acc1 npl3 nostore", 32, P4Cfg<256, 256, 4, 2, 3, 1, 0, 3>);
     RUN("p4 256x256 ns4 acc1 npl2 nostore", 32, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
@@ -265,6 +270,17 @@ int main(int argc, char** argv) {
     RUN("p4 256x256 ns8 acc1 npl1 nostore noreads", 48, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
     RUN("p4 256x256 ns8 acc1 npl1 nostore nodma noreads nomfma", 54, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
     RUN("p4 256x256 ns8 acc1 npl1 nostore nostagger", 33, P4Cfg<256, 256, 4, 2, 8, 1, 0, 1>);
+    if (s.M <= 4096) {
+      run<P3Cfg<128, 64, 2, 2, 2>, true, true, 0>("p3 128x64 s2 (product, N>=1024)", g, iters, Cref, diffbuf);
+      run<P3Cfg<64, 64, 2, 2, 3>, true, true, 0>("p3 64x64 s3 (product, N<1024; non-early)", g, iters, Cref, diffbuf);
+      RUN("p4 128x128 wg2x4 ns3 acc3", 0, P4Cfg<128, 128, 2, 4, 3, 3, 0>);
+      RUN("p4 128x128 wg4x2 ns3 acc3", 0, P4Cfg<128, 128, 4, 2, 3, 3, 0>);
+      RUN("p4 128x128 wg2x4 ns4 acc3", 0, P4Cfg<128, 128, 2, 4, 4, 3, 0>);
+      RUN("p4 128x192 wg4x2 ns3 acc3", 0, P4Cfg<128, 192, 4, 2, 3, 3, 0>);
+      RUN("p4 128x64 wg4x2 ns3 acc3", 0, P4Cfg<128, 64, 4, 2, 3, 3, 0>);
+      RUN("p4 64x128 wg2x4 ns3 acc3", 0, P4Cfg<64, 128, 2, 4, 3, 3, 0>);
+      RUN("p4 128x128 wg2x4 ns3 acc3 nostore", 32, P4Cfg<128, 128, 2, 4, 3, 3, 0>);
+    }
     RUN("p3 128x128 s3 4 waves (2 WG/CU)", 0, P3Cfg<128, 128, 2, 2, 3>);
     // zero-filled operands: the same instruction stream at the clock the power budget allows without data toggling
     CK(hipMemset(Ap.p, 0, (size_t)Ap.m.ps * 6)); CK(hipMemset(Bp.p, 0, (size_t)Bp.m.ps * 6));
