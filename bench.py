@@ -37,8 +37,8 @@ B3_PRODUCTS = 6.0           # bf16 products issued per fp32 multiply in GEMM mod
 
 
 def _pixelnet_traffic(encoder, B):
-    """HBM/fabric bytes per GEMM-family launch of the shipped PixelNet shape (PMC passes of tools/r03_final.sh), else None."""
-    f = os.path.join(ROOT, "profiles", "r03", "pixelnet", "pixelnet_gemm_traffic_summary.json")
+    """HBM/fabric bytes per GEMM-family launch of the shipped PixelNet shape (PMC passes of tools/r04_session.sh, stage pixelpmc), else None."""
+    f = os.path.join(ROOT, "profiles", "r04", "pixelnet", "pixelnet_gemm_traffic_summary.json")
     if encoder != "clip-vit-base-patch16" or B != 16 or not os.path.exists(f):
         return None
     try:
@@ -247,8 +247,8 @@ def pixelnet_run(args, steps, warmup, init_dist=True, n_inst=3):
                         **mfma_roof(g_fl, g_s, ops.gemm_mode() == "bf16x3"), "traffic": _pixelnet_traffic(args.encoder, B),
                         "gemm_time_per_step_ms": g_s / max(n_inst, 1) * 1e3, "algorithmic_gflop_per_step": g_fl / max(n_inst, 1) / 1e9,
                         "launches_per_step": len(gem) / max(n_inst, 1),
-                        "traffic_source": "profiles/r03/pixelnet/pixelnet_gemm_traffic_summary.json (separate rocprofv3 --pmc passes of "
-                                          "`bench.py --model pixelnet`, round 3's lockstep tiles; NOT measured in this run)",
+                        "traffic_source": "profiles/r04/pixelnet/pixelnet_gemm_traffic_summary.json (separate rocprofv3 --pmc passes of "
+                                          "`bench.py --model pixelnet` on this round's ping-pong tiles; NOT measured in this run)",
                         "note": "HIP events around every GEMM launch of extra eager steps (sum of durations; one stream)"},
            "cpu_baseline": None}
     del m, dp, opt, pool
@@ -598,7 +598,7 @@ def main():
 
     per_kernel = per_tag(gemm_events, 1e12, "tflops")
     traffic = None
-    tr_file = os.path.join(ROOT, "profiles", "r03", "pmc", "gemm_traffic_summary.json")
+    tr_file = os.path.join(ROOT, "profiles", "r04", "pmc", "gemm_traffic_summary.json")
     if os.path.exists(tr_file) and not custom and B == 64:
         try:
             traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
@@ -616,7 +616,7 @@ def main():
                        "gemm_kernel / grouped_dw_kernel (v_mfma_f32_32x32x2_f32; every nn.Linear fwd/bwd of the step)"),
             "gemm_mode": ("planes" if planes_on else ops.gemm_mode()),
             **mfma_roof(g_fl, g_union, b3), "traffic": traffic,
-            "traffic_source": ("profiles/r03/pmc/gemm_traffic_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+            "traffic_source": ("profiles/r04/pmc/gemm_traffic_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                "this command on the same kernels (read from the committed file, NOT measured in this run)"
                                if traffic is not None else None),
             "launches_per_step": n_launch / max(n_inst, 1), "avg_kernel_us": g_union / max(n_launch, 1) * 1e6,

@@ -63,3 +63,26 @@ if has evaltest; then
   timeout 300 python tools/eval_bench.py > "$OUT/eval_bench.log" 2>&1; grep -v amdgpu.ids "$OUT/eval_bench.log" | tail
   PXR_SCORE_P4=0 timeout 300 python tools/eval_bench.py > "$OUT/eval_bench_p4off.log" 2>&1; grep -v amdgpu.ids "$OUT/eval_bench_p4off.log" | tail
 fi
+cd /tmp && export TMPDIR=/tmp
+if has pixelpmc; then
+  Q=$OUT/pmc_pixelnet; mkdir -p "$Q"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$Q" -o $c -- python $REPO/bench.py --model pixelnet --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-gemm-events > "$Q/${c}_stdout.log" 2>&1
+  done
+  find "$Q" -name "*.db" -delete
+  python $REPO/tools/pmc_summarise.py "$Q/summary.json" $(ls "$Q"/*counter_collection.csv) > /dev/null 2>&1
+  python $REPO/tools/gemm_traffic.py "$Q/summary.json" "$OUT/pixelnet_gemm_traffic_summary.json" "round 4, PixelNet ViT-B/16 B=16 step, ping-pong tiles" > "$OUT/pixelnet_gemm_traffic.log" 2>&1
+  rm -f "$Q"/*kernel_trace.csv "$Q"/*counter_collection.csv
+  cat "$OUT/pixelnet_gemm_traffic.log"
+fi
+if has pmc64; then
+  Q=$OUT/pmc64; mkdir -p "$Q"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$Q" -o $c -- python $REPO/bench.py --steps 10 --warmup 2 --age-steps 20 --no-cpu-baseline --no-extras --no-gemm-events --no-graph > "$Q/${c}_stdout.log" 2>&1
+  done
+  find "$Q" -name "*.db" -delete
+  python $REPO/tools/pmc_summarise.py "$Q/summary.json" $(ls "$Q"/*counter_collection.csv) > /dev/null 2>&1
+  python $REPO/tools/gemm_traffic.py "$Q/summary.json" "$OUT/gemm_traffic_summary.json" "round 4 code, planes GEMM mode, B=64" > "$OUT/gemm_traffic.log" 2>&1
+  rm -f "$Q"/*kernel_trace.csv "$Q"/*counter_collection.csv
+  cat "$OUT/gemm_traffic.log"
+fi
