@@ -197,6 +197,30 @@ int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A, int64_t a_
 /* up to 16 matrices in one launch (host arrays of n entries): the weight matrices of the block after an optimizer step */
 int pxr_split_planes_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
                                void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows, void* stream);
+/* ---- the TWO-plane fp16 operand format ("h2", csrc/planes.cuh): x 2^e = hi + lo, both fp16, 22 significant bits; a product
+ * needs three MFMAs (v_mfma_f32_32x32x16_f16) instead of the six of the 3 x bf16 split -- same accuracy, half the matrix-pipe
+ * work (profiles/r04/lab/h2_lab_run1.log).  fp16 has a finite range: the producer of an operand picks the power of two 2^e
+ * (exact) that places its values in it and the GEMM undoes it; a value that still leaves the range sets bit 64 of the status
+ * word (pxr_set_status_word) instead of silently becoming inf.  Same panel layout as the bf16 planes, planes 0 and 1.
+ * Used by the forward-only blocks of the image tower (reference: the frozen CLIP blocks of code/REC/model/load.py:90-120).
+ *   pxr_split_h2_multi_f32   up to 16 matrices, matrix i multiplied by 2^scale_exp[i] first
+ *   pxr_gemm_h2_f32          C = epilogue(2^-(a_exp+b_exp) A~ B~^T), B~ [N][K]; epilogue NONE | BIAS | BIAS_GELU | BIAS_ADD |
+ *                            BIAS_QGELU | BIAS_RELU; c_fmt 0: output planes as three bf16 planes, 1: as two fp16 planes (unit scale)
+ *   pxr_ln_residual_fwd_h2_f32 / pxr_tower_attn_fwd_h2_f32: the plane-writing producers with h2 planes (unit scale) */
+int pxr_split_h2_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
+                           void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows, const int* scale_exp,
+                           void* stream);
+int pxr_gemm_h2_f32(int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows, int a_exp, const void* B,
+                    int64_t b_plane_stride, int64_t b_panel_rows, int b_exp, float* C, int64_t ldc, int epilogue,
+                    const float* bias, float* aux, int64_t ldaux, void* c_planes, int64_t c_plane_stride, int64_t c_panel_rows,
+                    int c_fmt, int act, int tile_hint, void* stream);
+int pxr_ln_residual_fwd_h2_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps, int rows,
+                               int D, float* y, float* xhat, float* rstd, void* y_planes, int64_t y_plane_stride,
+                               int64_t y_panel_rows, void* stream);
+int pxr_tower_attn_fwd_h2_f32(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads, int T, int d,
+                              float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t ctx_plane_stride,
+                              int64_t ctx_panel_rows, float* lse, void* stream);
+
 /* Producers that write their output straight as planes (same arguments as the functions they extend + the planes matrix;
  * planes == NULL: exactly the plain function).  LayerNorm sites: y as planes; LayerNorm backward (residual sites): the
  * gradient the next GEMMs read (dx when given, else dz); attention: ctx as the [B*L, H*d] matrix (ctx may then be NULL),

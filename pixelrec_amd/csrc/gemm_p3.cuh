@@ -47,7 +47,8 @@ struct P3Cfg {
   static constexpr int A_PIECES = 3 * BM / 16, B_PIECES = 3 * BN / 16;   // 1 KiB DMA pieces per K tile
   static constexpr int A_PPW = A_PIECES / G, B_PPW = B_PIECES / G, PPW = A_PPW + B_PPW;
   static constexpr int EPI_LD = BN + 4;                               // floats per row of the epilogue's LDS tile
-  static constexpr bool PINGPONG = false;                             // (gemm_p4.cuh's configurations say true)
+  static constexpr bool PINGPONG = false;
+  static constexpr bool HALF = false;      // (gemm_p4.cuh: operands as two fp16 planes)                             // (gemm_p4.cuh's configurations say true)
   static_assert(A_PIECES % G == 0 && B_PIECES % G == 0, "DMA pieces must divide evenly among the waves");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile = 32x32 blocks");
   static_assert(STAGES >= 2 && STAGES <= 6, "2..6 LDS stages");

@@ -77,6 +77,9 @@ struct P3Args {
   int64_t ldaux;
   int tiles_m, tiles_n, n_fastest, act, dbg;
   int group_m;             // > 1: tiles are walked in groups of group_m row tiles x all column tiles (see gemm_p3_kernel)
+  float acc_scale;         // fp16 two-plane operands (Cfg::HALF): 2^-(eA + eB), undoes the operands' power-of-two scales
+  int cp_fmt;              // format of the output planes: PXR_PLANES_BF16X3 | PXR_PLANES_H2
+  int32_t* status;         // status word (fp16 range check of h2 output planes) or null
 };
 
 template <class Cfg, bool PP>
@@ -136,6 +139,15 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
   typename Cfg::Acc accs;
   if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, true, B_KC>(accs, g.A, g.B, g.K, m0, n0, smem);
   else gemm_p3_mainloop<Cfg, true, B_KC, EARLY>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
+  if constexpr (Cfg::HALF) {
+    const float sc = g.acc_scale;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs.v[i][j][e] *= sc;
+  }
   auto chunk = [&](int it, int row, int col, int nv, float (&v)[8]) {
     float bv[8], av[8], ao[8];
     const bool vec = vec_ok && nv == 8;
@@ -188,7 +200,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
           if (e < nv) cp[e] = v[e];
       }
     }
-    if (g.Cp.p != nullptr) p3_store8(g.Cp, row, col, v);      // (output planes: N % 32 == 0, chunks are whole)
+    if (g.Cp.p != nullptr) px_store8(g.Cp, g.cp_fmt, g.status, row, col, v);      // (output planes: N % 32 == 0, chunks are whole)
   };
   if constexpr (PP) {
     p4_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0,
@@ -324,6 +336,9 @@ struct SplitMulti {
   const float* x[16]; int64_t ldx[16]; int rows[16], cols8[16]; P3Mat out[16];
   int64_t begin[17];
   int n;
+  int fmt;                 // PXR_PLANES_BF16X3 | PXR_PLANES_H2 (all matrices of the launch)
+  float scale[16];         // h2: the power of two each matrix is multiplied by before the split
+  int32_t* status;
 };
 __global__ void __launch_bounds__(256) split_planes_multi_kernel(const SplitMulti m) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -338,8 +353,13 @@ __global__ void __launch_bounds__(256) split_planes_multi_kernel(const SplitMult
   const float* src = m.x[pi] + row * m.ldx[pi] + c;
   const float4 a = *reinterpret_cast<const float4*>(src);
   const float4 b = *reinterpret_cast<const float4*>(src + 4);
-  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  p3_store8(m.out[pi], row, c, v);
+  float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  if (m.fmt == PXR_PLANES_H2) {
+    const float sc = m.scale[pi];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= sc;
+  }
+  px_store8(m.out[pi], m.fmt, m.status, row, c, v);
 }
 
 template <class Cfg, bool B_KC, int EPI, bool EARLY>
@@ -382,6 +402,21 @@ static int epi_p3(int b_kc, int epilogue, P3Args& g, hipStream_t st) {
   }
 #undef PXR_P3
   pxr_set_error("pxr_gemm_planes_f32: flavour b_kc=%d / epilogue %d is not instantiated", b_kc, epilogue);
+  return PXR_ERR_BAD_ARG;
+}
+
+// the forward flavours of the fp16 two-plane GEMM (weights k-contiguous)
+template <class Cfg>
+static int epi_h2(int epilogue, P3Args& g, hipStream_t st) {
+  switch (epilogue) {
+    case EPI_NONE: return launch_p3<Cfg, true, EPI_NONE, false>(g, st);
+    case EPI_BIAS: return launch_p3<Cfg, true, EPI_BIAS, false>(g, st);
+    case EPI_BIAS_GELU: return launch_p3<Cfg, true, EPI_BIAS_GELU, false>(g, st);
+    case EPI_BIAS_ADD: return launch_p3<Cfg, true, EPI_BIAS_ADD, false>(g, st);
+    case EPI_BIAS_QGELU: return launch_p3<Cfg, true, EPI_BIAS_QGELU, false>(g, st);
+    case EPI_BIAS_RELU: return launch_p3<Cfg, true, EPI_BIAS_RELU, false>(g, st);
+  }
+  pxr_set_error("pxr_gemm_h2_f32: epilogue %d is not instantiated", epilogue);
   return PXR_ERR_BAD_ARG;
 }
 
@@ -428,6 +463,83 @@ extern "C" int pxr_split_planes_multi_f32(int n, const float* const* x, const in
   return pxr_check_launch("pxr_split_planes_multi_f32");
 }
 
+// The same into the TWO-plane fp16 format (planes.cuh "h2"): matrix i is multiplied by 2^scale_exp[i] first (exact; the caller
+// picks the exponent that puts max |x| 2^e near 2^14 and hands it to pxr_gemm_h2_f32).  A scaled value beyond the fp16 range sets
+// PXR_STATUS_H2_RANGE.  plane_stride: elements between the two planes (only two are written).
+extern "C" int pxr_split_h2_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
+                                      void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows,
+                                      const int* scale_exp, void* stream) {
+  PXR_REQUIRE(n >= 1 && n <= 16 && x && rows && cols && ldx && planes && plane_stride && panel_rows && scale_exp, "pxr_split_h2_multi_f32: bad args");
+  SplitMulti m{};
+  m.n = n;
+  m.fmt = PXR_PLANES_H2;
+  m.status = pxr_status_word();
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    PXR_REQUIRE(x[i] && planes[i] && rows[i] > 0 && rows[i] < (1ll << 31) && cols[i] > 0 && cols[i] % 32 == 0 && ldx[i] % 4 == 0 &&
+                    (((uintptr_t)x[i]) & 15) == 0 && p3_mat_ok(planes[i], plane_stride[i], panel_rows[i], rows[i], cols[i]),
+                "pxr_split_h2_multi_f32: matrix %d is bad", i);
+    PXR_REQUIRE(scale_exp[i] >= -60 && scale_exp[i] <= 60, "pxr_split_h2_multi_f32: scale exponent %d of matrix %d", scale_exp[i], i);
+    m.x[i] = x[i]; m.ldx[i] = ldx[i]; m.rows[i] = (int)rows[i]; m.cols8[i] = (int)(cols[i] / 8);
+    m.out[i] = P3Mat{reinterpret_cast<__bf16*>(planes[i]), plane_stride[i], panel_rows[i]};
+    m.scale[i] = ldexpf(1.0f, scale_exp[i]);
+    m.begin[i] = total;
+    total += rows[i] * (cols[i] / 8);
+  }
+  m.begin[n] = total;
+  PXR_REQUIRE((total + 255) / 256 < (1ll << 31), "pxr_split_h2_multi_f32: too large");
+  hipLaunchKernelGGL(split_planes_multi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m);
+  return pxr_check_launch("pxr_split_h2_multi_f32");
+}
+
+// C[M,N] = epilogue(2^-(a_exp + b_exp) * (A~ B~^T)) with both operands as TWO fp16 planes (A~ = A 2^a_exp, B~ = B 2^b_exp, [N][K]
+// k-contiguous): three products per multiply on v_mfma_f32_32x32x16_f16 -- 22 significant bits per operand, the accuracy of the
+// six-product bf16x3 GEMM at half its matrix-pipe work (profiles/r04/lab/h2_lab_run1.log).  Forward flavours only (epilogue:
+// EPI_NONE | EPI_BIAS | EPI_BIAS_GELU | EPI_BIAS_ADD | EPI_BIAS_QGELU | EPI_BIAS_RELU); output as fp32 and / or planes in either
+// format (c_fmt: 0 = three bf16 planes, 1 = two fp16 planes at unit scale).  Ping-pong tiles only (gemm_p4.cuh): meant for the tall
+// GEMMs of the image tower.
+extern "C" int pxr_gemm_h2_f32(int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows, int a_exp,
+                               const void* B, int64_t b_plane_stride, int64_t b_panel_rows, int b_exp, float* C, int64_t ldc,
+                               int epilogue, const float* bias, float* aux, int64_t ldaux, void* c_planes, int64_t c_plane_stride,
+                               int64_t c_panel_rows, int c_fmt, int act, int tile_hint, void* stream) {
+  PXR_REQUIRE(A && B && (C || c_planes), "pxr_gemm_h2_f32: null operand");
+  PXR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && K % 32 == 0, "pxr_gemm_h2_f32: K must be a multiple of 32");
+  PXR_REQUIRE(a_panel_rows % 16 == 0 && b_panel_rows % 16 == 0 && a_plane_stride % 8 == 0 && b_plane_stride % 8 == 0,
+              "pxr_gemm_h2_f32: panel rows must be multiples of 16, plane strides of 8 elements");
+  PXR_REQUIRE(a_panel_rows >= M && b_panel_rows >= N && a_plane_stride >= a_panel_rows * K && b_plane_stride >= b_panel_rows * K,
+              "pxr_gemm_h2_f32: operand planes smaller than the matrices");
+  PXR_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)c_planes | (uintptr_t)aux | (uintptr_t)bias) & 15) == 0,
+              "pxr_gemm_h2_f32: operands must be 16-byte aligned");
+  PXR_REQUIRE(a_plane_stride * 4 < 0x7FFFFFF0ll && b_plane_stride * 4 < 0x7FFFFFF0ll, "pxr_gemm_h2_f32: an operand's two planes must span less than 2 GiB");
+  PXR_REQUIRE(!c_planes || (N % 32 == 0 && c_panel_rows % 16 == 0 && c_panel_rows >= M), "pxr_gemm_h2_f32: output planes need N %% 32 == 0");
+  PXR_REQUIRE(c_fmt == PXR_PLANES_BF16X3 || c_fmt == PXR_PLANES_H2, "pxr_gemm_h2_f32: c_fmt");
+  PXR_REQUIRE(a_exp >= -60 && a_exp <= 60 && b_exp >= -60 && b_exp <= 60, "pxr_gemm_h2_f32: scale exponents");
+  PXR_REQUIRE(aux || !(epilogue == EPI_BIAS_ADD || epilogue == EPI_BIAS_GELU), "pxr_gemm_h2_f32: epilogue %d reads / writes aux", epilogue);
+  PXR_REQUIRE(bias || epilogue == EPI_NONE, "pxr_gemm_h2_f32: epilogue %d needs a bias", epilogue);
+  if (M == 0 || N == 0) return PXR_OK;
+  P3Args g;
+  g.A = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(A)), a_plane_stride, a_panel_rows};
+  g.B = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(B)), b_plane_stride, b_panel_rows};
+  g.Cp = P3Mat{reinterpret_cast<__bf16*>(c_planes), c_plane_stride, c_panel_rows};
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.act = act;
+  g.acc_scale = ldexpf(1.0f, -(a_exp + b_exp));
+  g.cp_fmt = c_fmt;
+  g.status = pxr_status_word();
+  hipStream_t st = (hipStream_t)stream;
+  // tiles: 2 | BM | BN | ring slots | accumulator sets.  256x256 (one set) when it costs no more rounds of 256 workgroups than
+  // 256x128 (two sets: hi*hi apart from the cross terms)
+  if (tile_hint == 0) {
+    const int64_t t128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128), t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    static const int env_sq = getenv("PXR_H2_SQUARE") ? atoi(getenv("PXR_H2_SQUARE")) : 1;
+    tile_hint = (env_sq && N >= 256 && 2 * ((t256 + 255) / 256) <= (t128 + 255) / 256) ? 225625641 : 225612842;
+  }
+  if (tile_hint == 225625641) return epi_h2<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>>(epilogue, g, st);
+  if (tile_hint == 225612842) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>>(epilogue, g, st);
+  if (tile_hint == 225612841) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 1, 0, 2, true>>(epilogue, g, st);
+  pxr_set_error("pxr_gemm_h2_f32: tile %d is not instantiated", tile_hint);
+  return PXR_ERR_BAD_ARG;
+}
+
 extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows,
                                    const void* B, int64_t b_plane_stride, int64_t b_panel_rows, float* C, int64_t ldc,
                                    int epilogue, const float* bias, float* aux, int64_t ldaux, void* c_planes,
@@ -442,12 +554,16 @@ extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A,
   PXR_REQUIRE(a_plane_stride * 6 < 0x7FFFFFF0ll && b_plane_stride * 6 < 0x7FFFFFF0ll,
               "pxr_gemm_planes_f32: an operand's three planes must span less than 2 GiB");
   PXR_REQUIRE(!c_planes || (N % 32 == 0 && c_panel_rows % 16 == 0 && c_panel_rows >= M), "pxr_gemm_planes_f32: output planes need N %% 32 == 0");
+  PXR_REQUIRE(aux || !(epilogue == EPI_ADD || epilogue == EPI_MUL || epilogue == EPI_BIAS_ADD || epilogue == EPI_BIAS_GELU ||
+                       epilogue == EPI_BIAS_GELU_GRAD || epilogue == EPI_BIAS_QGELU_GRAD || epilogue == EPI_BIAS_ACT_GRAD),
+              "pxr_gemm_planes_f32: epilogue %d reads / writes aux", epilogue);
   if (M == 0 || N == 0) return PXR_OK;
   P3Args g;
   g.A = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(A)), a_plane_stride, a_panel_rows};
   g.B = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(B)), b_plane_stride, b_panel_rows};
   g.Cp = P3Mat{reinterpret_cast<__bf16*>(c_planes), c_plane_stride, c_panel_rows};
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.act = act;
+  g.acc_scale = 1.0f; g.cp_fmt = PXR_PLANES_BF16X3; g.status = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // tile_hint digits: waves | BM (3) | BN (3) | stages | early fragment reads.  Heuristic (tools/p3_sweep.py on MI355X):
   // 256x128 tiles when they fill the chip more than twice; at M = B*L ~ 3200 tokens 128x64 (two workgroups per CU) for wide

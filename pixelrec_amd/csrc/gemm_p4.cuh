@@ -36,10 +36,14 @@ namespace pxr {
 // NPL_: planes of each operand the loop stages and multiplies -- 3: all of them, the six products of gemm_p3 (the GEMMs); 2 (hi,
 // mid: hi*hi + mid*hi + hi*mid) and 1 (hi*hi) are the CHEAP passes of the top-k threshold search, whose survivors are re-scored
 // with all six products (score_topk.hip); they run on one accumulator set.
-template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int NACC_, int DMA_ = 0, int NPL_ = 3>
+// HALF_: the operands are TWO fp16 planes (planes.cuh "h2": 22 significant bits) multiplied with three products (lo*hi, hi*lo, hi*hi on
+// v_mfma_f32_32x32x16_f16) -- half the matrix-pipe work of the six bf16 products; NACC 1 (one set, small terms first) or 2 (hi*hi apart).
+template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int NACC_, int DMA_ = 0, int NPL_ = 3, bool HALF_ = false>
 struct P4Cfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_, NACC = NACC_, DMA = DMA_, NPL = NPL_;
-  static_assert(NPL == 3 || NACC == 1, "the reduced-product passes use one accumulator set");
+  static constexpr bool HALF = HALF_;
+  static_assert(NPL == 3 || NACC == 1 || (HALF && NACC == 2), "the reduced-product passes use one accumulator set");
+  static_assert(!HALF || NPL == 2, "the fp16 format has two planes");
   static constexpr int G = WGM * WGN, NT = 64 * G, BK = 16;
   static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
   static constexpr int A_FR = BM / 32, B_FR = BN / 32;                      // 32-row fragment blocks per operand
@@ -92,7 +96,7 @@ struct P4Operand {
   unsigned kstep;          // KC: bytes per 32-wide K tile (= 2 k blocks);  XC: 1024 per k block
   // m: the matrix; x0: tile origin along x; piece0: index of this operand's first piece inside a slot
   __device__ __forceinline__ void init(const P3Mat& m, int x0, int grp, int wi, int piece0) {
-    rs = make_rsrc(reinterpret_cast<const float*>(m.p), m.ps * 3 * 2);
+    rs = make_rsrc(reinterpret_cast<const float*>(m.p), m.ps * NPL * 2);      // the planes this loop reads, nothing behind them
 #pragma unroll
     for (int t = 0; t < MAXP; ++t) {
       const int q = min(PG * grp + wi + 4 * t, NPL * FR - 1);
@@ -256,7 +260,21 @@ __device__ __forceinline__ void p4_mfma(const Frag& f, f32x16 (&accs)[Cfg::TM][C
     between(G);                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   }
-  if constexpr (Cfg::NPL == 1) {
+#define PXR_P4_PRODH(G, ACC, PA, PB)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(p3_f16x8, f.a[i][PA]),                \
+                                                         __builtin_bit_cast(p3_f16x8, f.b[j][PB]), ACC[i][j], 0, 0, 0);
+  if constexpr (Cfg::HALF) {
+    if constexpr (Cfg::NACC == 2) {
+      PXR_P4_PRODH(0, accm, 1, 0)       // lo * hi
+      PXR_P4_PRODH(1, accs, 0, 0)       // hi * hi
+      PXR_P4_PRODH(2, accm, 0, 1)       // hi * lo
+    } else {
+      PXR_P4_PRODH(0, accs, 1, 0)
+      PXR_P4_PRODH(1, accs, 0, 1)
+      PXR_P4_PRODH(2, accs, 0, 0)
+    }
+  } else if constexpr (Cfg::NPL == 1) {
     PXR_P4_PROD(5, accs, 0, 0)
   } else if constexpr (Cfg::NPL == 2) {
     PXR_P4_PROD(5, accs, 1, 0)
@@ -285,6 +303,7 @@ __device__ __forceinline__ void p4_mfma(const Frag& f, f32x16 (&accs)[Cfg::TM][C
     PXR_P4_PROD(5, accs, 0, 0)
   }
 #undef PXR_P4_PROD
+#undef PXR_P4_PRODH
 }
 
 // acc tile (m0, n0) = A_op x B_op over k in [0, K) (K % 32 == 0), operands as planes.

@@ -39,7 +39,8 @@ struct LnFwdArgs {
   uint64_t seed;
   const int64_t* step_dev;  // optional device counter added to the seed (hipGraph replays advance it on the device)
   int32_t* status;          // GATHER: device status word (bad-index flag) or null
-  P3Mat yp;                 // optional: y also as bf16x3 planes (the next GEMM's operand format, planes.cuh); p == null: none
+  P3Mat yp;                 // optional: y also as planes (the next GEMM's operand format, planes.cuh); p == null: none
+  int yp_fmt;               // PXR_PLANES_BF16X3 | PXR_PLANES_H2 (two fp16 planes; a value beyond the fp16 range flags `status`)
 };
 
 // RPW = rows per wave.  RPW = 2 (large batches): both rows' ids and table rows are requested before either is reduced,
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
           }
         }
         if (a.y) *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
-        if (a.yp.p) p3_store4(a.yp, row, c, y);
+        if (a.yp.p) px_store4(a.yp, a.yp_fmt, a.status, row, c, y);
       }
     }
   }
@@ -400,6 +401,24 @@ extern "C" int pxr_ln_residual_fwd_planes_f32(const float* x, const float* res, 
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
   a.yp = P3Mat{reinterpret_cast<__bf16*>(y_planes), y_plane_stride, y_panel_rows};
+  return launch_ln_fwd<false>(a, (hipStream_t)stream);
+}
+// the same with y as TWO fp16 planes (planes.cuh "h2", unit scale): the operand of pxr_gemm_h2_f32 -- the forward-only blocks of
+// the image tower.  A LayerNorm output beyond the fp16 range sets PXR_STATUS_H2_RANGE in the registered status word.
+extern "C" int pxr_ln_residual_fwd_h2_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                                          int rows, int D, float* y, float* xhat, float* rstd, void* y_planes,
+                                          int64_t y_plane_stride, int64_t y_panel_rows, void* stream) {
+  PXR_REQUIRE(x && gamma && beta && y_planes, "pxr_ln_residual_fwd_h2_f32: null pointer");
+  PXR_REQUIRE(p3_mat_ok(y_planes, y_plane_stride, y_panel_rows, rows, D), "pxr_ln_residual_fwd_h2_f32: bad planes");
+  PXR_REQUIRE(D > 0 && D % 4 == 0 && rows >= 0, "pxr_ln_residual_fwd_h2_f32: bad shape");
+  if (rows == 0) return PXR_OK;
+  LnFwdArgs a{};
+  a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xhat = xhat; a.rstd = rstd;
+  a.rows = rows; a.D = D; a.L = 1; a.eps = eps;
+  a.drop_thr = pxr_drop_threshold(0.f);
+  a.status = pxr_status_word();
+  a.yp = P3Mat{reinterpret_cast<__bf16*>(y_planes), y_plane_stride, y_panel_rows};
+  a.yp_fmt = PXR_PLANES_H2;
   return launch_ln_fwd<false>(a, (hipStream_t)stream);
 }
 

@@ -63,6 +63,67 @@ __device__ __forceinline__ void p3_store4(const P3Mat& m, int64_t r, int c, cons
   *reinterpret_cast<p3_u32x2*>(dst + m.ps) = p3_u32x2{m0, m1};
   *reinterpret_cast<p3_u32x2*>(dst + 2 * m.ps) = p3_u32x2{l0, l1};
 }
+// ---- the TWO-plane fp16 format ("h2"): x * 2^e = hi + lo + d with hi = fp16_rne(x 2^e), lo = fp16_rne(x 2^e - hi) (the remainder is
+// exact in fp32), |d| <= max(2^-22 |x 2^e|, 2^-25) -- 22 significant bits in two planes, so a product needs three MFMAs (hi*hi,
+// lo*hi, hi*lo; the dropped lo*lo is 2^-22 relative) instead of the six of the 3 x bf16 split.  fp16 has 5 exponent bits: the
+// producer picks the power-of-two scale 2^e (exact) that puts its values inside [2^-24, 65504]; consumers undo it in their
+// epilogue.  Same panel layout as the bf16 planes (2-byte elements), planes 0 and 1 of a P3Mat.
+typedef _Float16 p3_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 p3_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void h2_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const p3_f32x2 v = {a, b};
+  const p3_f16x2 h = __builtin_convertvector(v, p3_f16x2);
+  const p3_f32x2 r1 = v - __builtin_convertvector(h, p3_f32x2);
+  const p3_f16x2 l = __builtin_convertvector(r1, p3_f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// store 8 consecutive values (already scaled) into the two fp16 planes: one 16-byte store per plane
+__device__ __forceinline__ void h2_store8(const P3Mat& m, int64_t r, int c, const float (&v)[8]) {
+  p3_u32x4 p[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h, l;
+    h2_split2(v[2 * j], v[2 * j + 1], h, l);
+    p[0][j] = h; p[1][j] = l;
+  }
+  __bf16* dst = m.p + p3_chunk_index(m.pr, r, c);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) *reinterpret_cast<p3_u32x4*>(dst + q * m.ps) = p[q];
+}
+__device__ __forceinline__ void h2_store4(const P3Mat& m, int64_t r, int c, const float4& v) {
+  unsigned h0, l0, h1, l1;
+  h2_split2(v.x, v.y, h0, l0);
+  h2_split2(v.z, v.w, h1, l1);
+  __bf16* dst = m.p + p3_chunk_index(m.pr, r, c & ~7) + (c & 4);
+  *reinterpret_cast<p3_u32x2*>(dst) = p3_u32x2{h0, h1};
+  *reinterpret_cast<p3_u32x2*>(dst + m.ps) = p3_u32x2{l0, l1};
+}
+// ---- format-dispatching stores (fmt: 0 = three bf16 planes, 1 = two fp16 planes; wave-uniform).  The fp16 format has a finite
+// range: a value beyond it sets PXR_STATUS_H2_RANGE in the status word (the host raises at its next check) instead of silently
+// becoming inf.  `scale` (a power of two, h2 only) is applied before the split.
+#define PXR_PLANES_BF16X3 0
+#define PXR_PLANES_H2 1
+__device__ __forceinline__ void px_store8(const P3Mat& m, int fmt, int32_t* status, int64_t r, int c, const float (&v)[8]) {
+  if (fmt == PXR_PLANES_H2) {
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[e]));
+    if (!(mx <= 65504.f) && status) atomicOr(status, PXR_STATUS_H2_RANGE);     // (NaN lands here too)
+    h2_store8(m, r, c, v);
+  } else {
+    p3_store8(m, r, c, v);
+  }
+}
+__device__ __forceinline__ void px_store4(const P3Mat& m, int fmt, int32_t* status, int64_t r, int c, const float4& v) {
+  if (fmt == PXR_PLANES_H2) {
+    const float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (!(mx <= 65504.f) && status) atomicOr(status, PXR_STATUS_H2_RANGE);
+    h2_store4(m, r, c, v);
+  } else {
+    p3_store4(m, r, c, v);
+  }
+}
 static inline bool p3_mat_ok(const void* p, int64_t ps, int64_t pr, int64_t rows, int64_t cols) {
   return p == nullptr || (cols % 32 == 0 && pr % 32 == 0 && pr >= rows && ps >= pr * cols && ps % 8 == 0 && ((uintptr_t)p & 15) == 0);
 }

@@ -31,6 +31,7 @@ int32_t* pxr_status_word(void);
 #define PXR_STATUS_GEMM_TIMEOUT 8    /* a stream-K GEMM worker gave up waiting for a partial tile (results are wrong) */
 #define PXR_STATUS_ROWS_OVERFLOW 2   /* a rank's unique-row count exceeded the capacity of a reduced row exchange */
 #define PXR_STATUS_TOPK_UNDERFLOW 32 /* a user of the two-pass top-k ended with fewer than K candidates (non-finite scores / thresholds?) */
+#define PXR_STATUS_H2_RANGE 64       /* a producer of fp16 two-plane operands (planes.cuh "h2") met a value outside the fp16 range */
 #define PXR_STATUS_SHARD_OVERFLOW 16 /* row-sharded table: more hit rows owned by ONE rank than the per-pair request capacity */
 
 static inline int pxr_check_launch(const char* what) {

@@ -40,6 +40,8 @@ struct TowerAttnArgs {
   int64_t ld;
   float* ctx; int64_t ld_ctx;                       // fp32 context [images*T, ld_ctx] (head h at column 64 h) or null
   P3Mat op;                                         // context as planes of the [images*T, heads*64] matrix, or p == null
+  int op_fmt;                                       // PXR_PLANES_BF16X3 | PXR_PLANES_H2 (planes.cuh)
+  int32_t* status;                                  // status word for the fp16 range check of the h2 format, or null
   float* lse;                                       // [images*heads, T] natural-log sum of exp of the scaled scores, or null
   int heads, T;
   float scale_log2;                                 // head_size^-0.5 * log2(e)
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(NW * 64) tower_attn_fwd_kernel(TowerAttnArgs a
           *reinterpret_cast<ta_f32x4*>(dst) = ta_f32x4{v8[0], v8[1], v8[2], v8[3]};
           *reinterpret_cast<ta_f32x4*>(dst + 4) = ta_f32x4{v8[4], v8[5], v8[6], v8[7]};
         }
-        if (a.op.p) p3_store8(a.op, orow, col, v8);
+        if (a.op.p) px_store8(a.op, a.op_fmt, a.status, orow, col, v8);
       }
     }
 }
@@ -611,9 +613,24 @@ extern "C" int pxr_tower_attn_supported(int T, int d) { return (d == TA_D && T >
 // ctx[b*T + t, 64 h .. 64 h + 63] = softmax_t'(scale * q_t . k_t') v_t'   per (image b, head h); no mask, no dropout.
 // q/k/v: fp32, element (b, t, h, c) at p[(b*T + t)*ld + 64 h + c] (the fused projection output is passed with three base
 // pointers).  Outputs: ctx fp32 and/or ctx planes (planes.cuh) -- at least one; lse optional ([images*heads, T]).
+static int tower_attn_fwd_impl(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads, int T, int d,
+                               float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t c_ps, int64_t c_pr, int c_fmt,
+                               float* lse, void* stream);
 extern "C" int pxr_tower_attn_fwd_f32(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads,
                                       int T, int d, float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t c_ps,
                                       int64_t c_pr, float* lse, void* stream) {
+  return tower_attn_fwd_impl(q, k, v, ld, images, heads, T, d, scale, ctx, ld_ctx, ctx_planes, c_ps, c_pr, PXR_PLANES_BF16X3, lse, stream);
+}
+// the same with the context planes in the two-plane fp16 format (planes.cuh "h2", unit scale; the operand of pxr_gemm_h2_f32)
+extern "C" int pxr_tower_attn_fwd_h2_f32(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads,
+                                         int T, int d, float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t c_ps,
+                                         int64_t c_pr, float* lse, void* stream) {
+  PXR_REQUIRE(ctx_planes, "pxr_tower_attn_fwd_h2_f32: no planes");
+  return tower_attn_fwd_impl(q, k, v, ld, images, heads, T, d, scale, ctx, ld_ctx, ctx_planes, c_ps, c_pr, PXR_PLANES_H2, lse, stream);
+}
+static int tower_attn_fwd_impl(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads, int T, int d,
+                               float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t c_ps, int64_t c_pr, int c_fmt,
+                               float* lse, void* stream) {
   PXR_REQUIRE(q && k && v && images >= 0 && heads > 0, "pxr_tower_attn_fwd_f32: bad args");
   PXR_REQUIRE(pxr_tower_attn_supported(T, d), "pxr_tower_attn_fwd_f32: head size %d / %d tokens not supported (64, <= %d)", d,
               T, 32 * TA_MAXW);
@@ -628,6 +645,8 @@ extern "C" int pxr_tower_attn_fwd_f32(const float* q, const float* k, const floa
   a.q = q; a.k = k; a.v = v; a.ld = ld;
   a.ctx = ctx; a.ld_ctx = ld_ctx;
   a.op = P3Mat{(__bf16*)ctx_planes, c_ps, c_pr};
+  a.op_fmt = c_fmt;
+  a.status = pxr_status_word();
   a.lse = lse;
   a.heads = heads; a.T = T;
   a.scale_log2 = scale * 1.4426950408889634f;

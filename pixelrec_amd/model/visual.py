@@ -133,6 +133,7 @@ ENCODER_SHAPES = {
     "clip-vit-base-patch16": (768, 12, 12, 3072, 224, 16),     # BASELINE configs[2]
     "clip-vit-large-patch14": (1024, 24, 16, 4096, 224, 14),   # BASELINE configs[4]
     "clip-vit-tiny-test": (64, 3, 4, 128, 64, 32),     # unit tests only
+    "clip-vit-tiny64-test": (128, 3, 2, 256, 64, 16),  # unit tests only: head size 64 (the fused tower attention / fp16 planes path)
 }
 
 
@@ -232,7 +233,7 @@ def load_model(config):
     tune_scale = ft.get("tune_scale", 0)
     pre_trained = ft.get("pre_trained", True)
     model = CLIPVisionEncoder(*ENCODER_SHAPES[name])
-    if name != "clip-vit-tiny-test":
+    if not name.endswith("-test"):
         err = _load_pretrained_backbone(model, name, config)
         if err is not None and not config["pretrain_path"]:
             if not ft.get("allow_random_backbone", False):

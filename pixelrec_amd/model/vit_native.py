@@ -146,24 +146,33 @@ class NativeTower:
         return ctx, (S if keep else None)
 
     # ---- planes mode (csrc/gemm_p3.cuh): the blocks that only run FORWARD (the frozen front of the tower: 10 of 12 blocks at
-    # the shipped tune_scale, every block at inference) take their GEMM operands as pre-split bf16x3 planes -- LayerNorm and
-    # the fc1 epilogue write them, the frozen weights are split once.  Same products as GEMM mode bf16x3, bit for bit.
+    # the shipped tune_scale, every block at inference) take their GEMM operands as pre-split planes -- LayerNorm, the fused
+    # attention and the fc1 epilogue write them, the frozen weights are split once.  FROZEN blocks: two fp16 planes, three
+    # products per multiply (_h2_block); the others: three bf16 planes, the same products as GEMM mode bf16x3, bit for bit.
     def _planes_on(self):
         H, heads, d, T, _ = self._shape()
         return (os.environ.get("PXR_PLANES", "1") != "0" and ops.gemm_mode() == "bf16x3" and H % 32 == 0
                 and self.view(f"item_encoder.vision_model.encoder.layers.0.mlp.fc1.weight").shape[0] % 32 == 0)
 
-    def _block_weight_planes(self, i):
+    def _h2_block(self, i):
+        """Whether block i runs on the TWO-plane fp16 operands (csrc/planes.cuh "h2": three MFMAs per multiply instead of six, the
+        same 2^-22-grade accuracy -- profiles/r04/lab/h2_lab_run1.log): the FROZEN blocks, whose weights are split (and their
+        power-of-two scales chosen) once, when the fused attention serves the shape.  PXR_TOWER_H2=0: bf16x3 everywhere."""
+        H, heads, d, T, _ = self._shape()
+        return (os.environ.get("PXR_TOWER_H2", "1") != "0" and i < self.first_trainable_block()
+                and ops.tower_attn_supported(T, d))
+
+    def _block_weight_planes(self, i, h2=False):
         """(qkv, out_proj, fc1, fc2) planes of block i: one split launch; kept for frozen blocks (ensure_packed /
         load_state_dict drop the cache), redone at every forward for trainable ones."""
-        wp = self._wplanes.get(i)
+        wp = self._wplanes.get((i, h2))
         if wp is None:
             vm = "item_encoder.vision_model."
             P = lambda s_, **kw: self.view(f"{vm}encoder.layers.{i}.{s_}", **kw)
             wp = ops.split_planes_multi([P("self_attn.k_proj.weight", span=3), P("self_attn.out_proj.weight"),
-                                         P("mlp.fc1.weight"), P("mlp.fc2.weight")])
+                                         P("mlp.fc1.weight"), P("mlp.fc2.weight")], h2=h2)
             if i < self.first_trainable_block():
-                self._wplanes[i] = wp            # only FROZEN blocks are cached: a trainable block's weights move every step
+                self._wplanes[(i, h2)] = wp      # only FROZEN blocks are cached: a trainable block's weights move every step
         return wp
 
     def drop_weight_planes(self, trainable_only: bool = False):
@@ -171,7 +180,7 @@ class NativeTower:
         (they are only ever used by inference forwards between training steps)."""
         if trainable_only:
             first = self.first_trainable_block()
-            self._wplanes = {i: v for i, v in self._wplanes.items() if i < first}
+            self._wplanes = {k: v for k, v in self._wplanes.items() if k[0] < first}
         else:
             self._wplanes = {}
 
@@ -183,8 +192,10 @@ class NativeTower:
         H, heads, d, T, _ = self._shape()
         n = x.shape[0]
         M = n * T
-        Wqkv, Wo, W1, W2 = W = self._block_weight_planes(i)
-        _, xh1, rs1, h1p = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=keep, planes=True, want_y=False)
+        h2 = (not keep) and self._h2_block(i)
+        pf = "h2" if h2 else True          # format of the activation planes this block's producers write
+        Wqkv, Wo, W1, W2 = W = self._block_weight_planes(i, h2)
+        _, xh1, rs1, h1p = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=keep, planes=pf, want_y=False)
         qkv = torch.empty(n, T, 3 * H, dtype=torch.float32, device=x.device)
         ops.gemm_planes(h1p, Wqkv, qkv.view(M, 3 * H), ops.EPI_BIAS, bias=P("self_attn.k_proj.bias", span=3))
         S = ctx = lse = None
@@ -193,14 +204,14 @@ class NativeTower:
             # fused: no score matrix, the context leaves as planes; a trainable block also keeps the fp32 context and the
             # log-sum-exp its fused backward recomputes the probabilities from
             ctx, ctxp, lse = ops.tower_attn_fwd(qkv.view(M, 3 * H), n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=fused_bwd,
-                                                planes=True, lse=fused_bwd)
+                                                planes=pf, lse=fused_bwd)
         else:
             ctx, S = self._attn_fwd(qkv, n, T, heads, d, keep)
             ctxp = ops.split_planes(ctx.view(M, H))
         x2 = torch.empty_like(x)
         ops.gemm_planes(ctxp, Wo, x2.view(M, H), ops.EPI_BIAS_ADD, bias=P("self_attn.out_proj.bias"), aux=x.view(M, H))
-        _, xh2, rs2, h2p = ops.ln_residual_fwd(x2, None, P("layer_norm2.weight"), P("layer_norm2.bias"), 1e-5, save=keep, planes=True, want_y=False)
-        fp = ops.Planes.alloc(M, W1.rows, x.device)
+        _, xh2, rs2, h2p = ops.ln_residual_fwd(x2, None, P("layer_norm2.weight"), P("layer_norm2.bias"), 1e-5, save=keep, planes=pf, want_y=False)
+        fp = ops.Planes.alloc(M, W1.rows, x.device, fmt=int(h2))
         gq = torch.empty(M, W1.rows, dtype=torch.float32, device=x.device) if keep else None
         ops.gemm_planes(h2p, W1, None, ops.EPI_BIAS_QGELU_GRAD if keep else ops.EPI_BIAS_QGELU, bias=P("mlp.fc1.bias"), aux=gq, Cp=fp)
         x3 = torch.empty_like(x)

@@ -111,6 +111,10 @@ def raise_on_bad_indices(device=None):
     if v & 32:
         raise RuntimeError("fused scoring + top-k: a user ended with fewer than K candidates above its threshold (non-finite scores "
                            "or embeddings?); the affected rows of the result hold id -1")
+    if v & 64:
+        raise RuntimeError("image tower on fp16 two-plane operands: an activation or a scaled weight left the fp16 range "
+                           "(|x| > 65504) -- the affected item vectors are inf / nan; set PXR_TOWER_H2=0 (the six-product bf16x3 "
+                           "GEMMs have fp32's range)")
     if v & 16:
         raise RuntimeError("row-sharded table: one rank owned more of a batch's hit rows than the per-pair request capacity "
                            "(ShardedSASRec.pair_slack); rows were dropped -- raise the slack or use row_exchange='reduce_scatter'")
@@ -159,16 +163,17 @@ def gemm(a_kc: bool, b_kc: bool, M: int, N: int, K: int, A, lda, B, ldb, C, ldc,
 
 
 class Planes:
-    """An fp32 matrix [rows, cols] pre-split into three bf16 planes in PANEL layout (include/pxr.h, csrc/gemm_p3.cuh): the
-    operand format of gemm_planes.  `buf` is a flat bf16 tensor; `off` / `pr` / `ps` are the element offset of plane 0, the
-    rows per panel and the plane stride, so row / column ranges are views of the same buffer."""
-    __slots__ = ("buf", "rows", "cols", "pr", "ps", "off")
+    """An fp32 matrix [rows, cols] pre-split into planes in PANEL layout (include/pxr.h, csrc/planes.cuh): the operand format of
+    gemm_planes.  fmt 0: three bf16 planes (x = hi + mid + lo exactly); fmt 1 ("h2"): two fp16 planes of x * 2^exp (22 significant
+    bits; the forward-only blocks of the image tower).  `buf` is a flat 2-byte-element tensor; `off` / `pr` / `ps` are the element
+    offset of plane 0, the rows per panel and the plane stride, so row / column ranges are views of the same buffer."""
+    __slots__ = ("buf", "rows", "cols", "pr", "ps", "off", "fmt", "exp")
 
-    def __init__(self, buf, rows, cols, pr, ps, off=0):
-        self.buf, self.rows, self.cols, self.pr, self.ps, self.off = buf, rows, cols, pr, ps, off
+    def __init__(self, buf, rows, cols, pr, ps, off=0, fmt=0, exp=0):
+        self.buf, self.rows, self.cols, self.pr, self.ps, self.off, self.fmt, self.exp = buf, rows, cols, pr, ps, off, fmt, exp
 
     @staticmethod
-    def alloc(rows: int, cols: int, device) -> "Planes":
+    def alloc(rows: int, cols: int, device, fmt: int = 0) -> "Planes":
         if cols % 32:
             raise _l.PxrError(f"planes need a multiple of 32 columns, got {cols}")
         pr = (rows + 31) // 32 * 32
@@ -176,6 +181,8 @@ class Planes:
         # rows past `rows` of a panel are read by edge tiles and, when the rows are a GEMM's reduction dimension (weight
         # gradients), multiplied in: they must be zero.  Producers never write them, so one fill at allocation is enough.
         mk = torch.empty if pr == rows else torch.zeros
+        if fmt:
+            return Planes(mk(2 * ps, dtype=torch.float16, device=device), rows, cols, pr, ps, fmt=1)
         return Planes(mk(3 * ps, dtype=torch.bfloat16, device=device), rows, cols, pr, ps)
 
     def ptr(self):
@@ -183,23 +190,24 @@ class Planes:
 
     def row_range(self, r0: int, r1: int) -> "Planes":
         assert r0 % 16 == 0 and r0 <= r1 <= self.rows
-        return Planes(self.buf, r1 - r0, self.cols, self.pr, self.ps, self.off + 32 * r0)
+        return Planes(self.buf, r1 - r0, self.cols, self.pr, self.ps, self.off + 32 * r0, self.fmt, self.exp)
 
     def col_range(self, c0: int, c1: int) -> "Planes":
         assert c0 % 32 == 0 and c1 % 32 == 0 and c0 <= c1 <= self.cols
-        return Planes(self.buf, self.rows, c1 - c0, self.pr, self.ps, self.off + (c0 // 32) * self.pr * 32)
+        return Planes(self.buf, self.rows, c1 - c0, self.pr, self.ps, self.off + (c0 // 32) * self.pr * 32, self.fmt, self.exp)
 
     def to_dense(self) -> torch.Tensor:
-        """fp32 [rows, cols] = hi + mid + lo (exact).  For tests; not on the product path."""
+        """fp32 [rows, cols] = the sum of the planes (exact for fmt 0; x rounded to 22 bits for fmt 1).  For tests; not on the
+        product path."""
         dev = self.buf.device
         r = torch.arange(self.rows, device=dev).view(-1, 1)
         c = torch.arange(self.cols, device=dev).view(1, -1)
         idx = ((c // 32) * self.pr + r) * 32 + ((((c // 8) % 4) ^ ((r // 4) % 4)) * 8) + c % 8 + self.off
         out = None
-        for q in range(3):
+        for q in range(2 if self.fmt else 3):
             t = self.buf[(idx + q * self.ps).reshape(-1)].view(self.rows, self.cols).float()
             out = t if out is None else out + t
-        return out
+        return out * (2.0 ** -self.exp) if self.fmt else out
 
 
 def split_planes(x: torch.Tensor, out: Planes | None = None) -> Planes:
@@ -222,6 +230,18 @@ def gemm_planes(Ap: Planes, Bp: Planes, C: torch.Tensor | None, epilogue=EPI_NON
     N = Bp.rows if b_kc else Bp.cols
     assert (Bp.cols if b_kc else Bp.rows) == K
     assert C is None or C.shape == (M, N)
+    if Ap.fmt or Bp.fmt:
+        # two fp16 planes per operand, three products per multiply (pxr_gemm_h2_f32; forward flavours only)
+        if not (Ap.fmt and Bp.fmt and b_kc):
+            raise _l.PxrError("gemm_planes: fp16 two-plane operands need BOTH operands in that format and a k-contiguous B")
+        device_status(Ap.buf.device)      # the producers' fp16 range check reports through the status word
+        with _gemm_timer(2.0 * M * N * K, "gemm_p3_kernel<P4Cfg<..., HALF>> (fp16 two-plane operands, 3 products)"):
+            _l.check(_l.load().pxr_gemm_h2_f32(M, N, K, Ap.ptr(), Ap.ps, Ap.pr, Ap.exp, Bp.ptr(), Bp.ps, Bp.pr, Bp.exp, _l.ptr(C),
+                                               C.stride(0) if C is not None else 0, epilogue, _l.ptr(bias), _l.ptr(aux),
+                                               aux.stride(0) if aux is not None else 0, *_pl(Cp),
+                                               Cp.fmt if Cp is not None else 0, act, tile_hint, _l.stream_ptr()), "pxr_gemm_h2_f32")
+        return C
+    assert Cp is None or Cp.fmt == 0, "the bf16x3 GEMMs write bf16x3 planes"
     with _gemm_timer(2.0 * M * N * K):
         _l.check(_l.load().pxr_gemm_planes_f32(int(b_kc), M, N, K, Ap.ptr(), Ap.ps, Ap.pr, Bp.ptr(), Bp.ps, Bp.pr, _l.ptr(C),
                                                C.stride(0) if C is not None else 0, epilogue, _l.ptr(bias), _l.ptr(aux),
@@ -318,12 +338,16 @@ def tower_attn_fwd(qkv: torch.Tensor, n: int, T: int, heads: int, d: int, q_off:
     ld = qkv.shape[-1]
     H = heads * d
     out = torch.empty(n, T, H, dtype=torch.float32, device=qkv.device) if ctx else None
-    op = Planes.alloc(n * T, H, qkv.device) if planes else None
+    h2 = planes == "h2"               # context planes in the two-plane fp16 format (the operand of the h2 out-projection GEMM)
+    op = Planes.alloc(n * T, H, qkv.device, fmt=int(h2)) if planes else None
     ls = torch.empty(n * heads, T, dtype=torch.float32, device=qkv.device) if lse else None
     cp = _l.c_void_p
     base = qkv.data_ptr()
+    fn = _l.load().pxr_tower_attn_fwd_h2_f32 if h2 else _l.load().pxr_tower_attn_fwd_f32
+    if h2:
+        device_status(qkv.device)
     with _gemm_timer(4.0 * T * T * d * n * heads, "tower_attn_fwd_kernel (fused QK^T / softmax / PV of a tower block)"):
-        _l.check(_l.load().pxr_tower_attn_fwd_f32(cp(base + 4 * q_off), cp(base + 4 * k_off), cp(base + 4 * v_off), ld, n, heads, T,
+        _l.check(fn(cp(base + 4 * q_off), cp(base + 4 * k_off), cp(base + 4 * v_off), ld, n, heads, T,
                                                   d, float(scale), _l.ptr(out) if ctx else None, H, *_pl(op),
                                                   _l.ptr(ls) if lse else None, _l.stream_ptr()), "pxr_tower_attn_fwd_f32")
     return out, op, ls
@@ -494,12 +518,40 @@ def grouped_linear_bwd_weight(problems):
 MULTI_MAX = 16      # matrices per pxr_split_planes_multi_f32 launch / plane segments per pxr_adamw_flat_tab_planes_f32 launch
 
 
-def split_planes_multi(mats, outs=None):
-    """Several fp32 matrices -> Planes in ONE launch (pxr_split_planes_multi_f32); `outs`: existing Planes to overwrite."""
-    if outs is None:
-        outs = [Planes.alloc(m.shape[0], m.shape[1], m.device) for m in mats]
+def h2_exponent(max_abs: float) -> int:
+    """The power-of-two exponent e that puts max_abs * 2^e into [2^13, 2^14): a factor 4 below the fp16 maximum, 38 binades above
+    its smallest subnormal (csrc/planes.cuh "h2")."""
+    import math
+
+    if not (max_abs > 0.0) or math.isinf(max_abs):
+        return 0
+    return max(-60, min(60, 14 - math.frexp(max_abs)[1]))
+
+
+def split_planes_multi(mats, outs=None, h2: bool = False):
+    """Several fp32 matrices -> Planes in ONE launch (pxr_split_planes_multi_f32); `outs`: existing Planes to overwrite.
+    h2=True: the two-plane fp16 format, each matrix scaled by its own power of two (h2_exponent of its max |x|: ONE host
+    synchronisation for all of them -- meant for weights that are split once)."""
     for m in mats:
         assert m.dim() == 2 and m.stride(1) == 1 and m.dtype == torch.float32
+    if h2:
+        assert outs is None
+        mx = torch.stack([m.abs().max() for m in mats]).tolist()
+        outs = [Planes.alloc(m.shape[0], m.shape[1], m.device, fmt=1) for m in mats]
+        device_status(mats[0].device)
+        for lo in range(0, len(mats), MULTI_MAX):
+            ms, os_ = mats[lo:lo + MULTI_MAX], outs[lo:lo + MULTI_MAX]
+            n = len(ms)
+            for o, v in zip(os_, mx[lo:lo + MULTI_MAX]):
+                o.exp = h2_exponent(float(v))
+            P, I64, I32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+            _l.check(_l.load().pxr_split_h2_multi_f32(
+                n, P(*[m.data_ptr() for m in ms]), I64(*[m.shape[0] for m in ms]), I64(*[m.shape[1] for m in ms]),
+                I64(*[m.stride(0) for m in ms]), P(*[o.ptr().value for o in os_]), I64(*[o.ps for o in os_]),
+                I64(*[o.pr for o in os_]), I32(*[o.exp for o in os_]), _l.stream_ptr()), "pxr_split_h2_multi_f32")
+        return outs
+    if outs is None:
+        outs = [Planes.alloc(m.shape[0], m.shape[1], m.device) for m in mats]
     # the entry point takes at most MULTI_MAX matrices per launch (its argument block is a fixed-size struct): deeper models
     # (4 matrices per layer: n_layers >= 5) take one launch per group
     for lo in range(0, len(mats), MULTI_MAX):
@@ -638,6 +690,13 @@ def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, s
     y = torch.empty_like(x) if want_y else None
     xhat = torch.empty_like(x) if save else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    if planes == "h2":                # y as two fp16 planes (no dropout at these sites: the image tower)
+        assert p_drop == 0.0
+        yp = Planes.alloc(rows, D, x.device, fmt=1)
+        device_status(x.device)
+        _l.check(Lb.pxr_ln_residual_fwd_h2_f32(_l.ptr(x), _l.ptr(res), _l.ptr(gamma), _l.ptr(beta), eps, rows, D, _l.ptr(y),
+                                               _l.ptr(xhat), _l.ptr(rstd), *_pl(yp), _l.stream_ptr()), "pxr_ln_residual_fwd_h2_f32")
+        return (y, xhat, rstd, yp)
     yp = Planes.alloc(rows, D, x.device) if planes else None
     _l.check(Lb.pxr_ln_residual_fwd_planes_f32(_l.ptr(x), _l.ptr(res), _l.ptr(gamma), _l.ptr(beta), eps, rows, D, _l.ptr(y),
                                                _l.ptr(xhat), _l.ptr(rstd), p_drop, seed, stream_id, _l.ptr(step_dev),

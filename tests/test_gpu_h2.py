@@ -1,0 +1,176 @@
+"""The TWO-plane fp16 operand format ("h2", csrc/planes.cuh) and its GEMM (pxr_gemm_h2_f32: three products per multiply on
+v_mfma_f32_32x32x16_f16) -- the forward-only blocks of the image tower: against fp64, against the six-product bf16x3 GEMM on the
+same operands (no worse), the producers that write h2 planes themselves (LayerNorm, fused tower attention, GEMM epilogues), the
+fp16 range flag, and the tower end to end (h2 on vs off, and against the torch restatement)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H2_TILES = [0, 225625641, 225612842, 225612841]
+
+
+def _rel_rms(got, ref):
+    return float(((got.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+
+
+@pytest.mark.parametrize("tile", H2_TILES)
+@pytest.mark.parametrize("M,N,K,ws", [(1000, 768, 256, 0.05), (300, 256, 64, 1.0), (64, 32, 32, 1e-6), (2049, 512, 160, 300.0),
+                                      (130, 8, 64, 0.02)])
+def test_h2_gemm_matches_fp64_as_well_as_the_six_product_gemm(tile, M, N, K, ws):
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * ws, torch.randn(N, generator=g) * ws
+    xs, Ws, bs = x.cuda(), W.cuda(), b.cuda()
+    xh, Wh = ops.split_planes_multi([xs, Ws], h2=True)
+    assert xh.fmt == 1 and Wh.fmt == 1
+    assert 2 ** 13 <= float(Ws.abs().max()) * 2.0 ** Wh.exp < 2 ** 14            # the scale the host picked
+    # the planes hold the operand to 22 bits
+    assert (xh.to_dense() - xs).abs().max().item() <= 2.0 ** -21 * float(xs.abs().max())
+    assert (Wh.to_dense() - Ws).abs().max().item() <= 2.0 ** -21 * float(Ws.abs().max())
+    y = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_planes(xh, Wh, y, ops.EPI_BIAS, bias=bs, tile_hint=tile)
+    ref = x.double() @ W.double().t() + b.double()
+    e_h2 = _rel_rms(y.cpu(), ref)
+    y6 = torch.empty(M, N, device="cuda")
+    ops.gemm_planes(ops.split_planes(xs), ops.split_planes(Ws), y6, ops.EPI_BIAS, bias=bs)
+    e_6 = _rel_rms(y6.cpu(), ref)
+    # 22-bit operands, fp32 accumulation: 2^-21 of the result's scale; and never materially worse than the six-product kernel
+    assert e_h2 < 2.0 ** -20, (e_h2, e_6)
+    assert e_h2 < 4.0 * e_6 + 2.0 ** -23, (e_h2, e_6)
+    assert (y.double().cpu() - ref).abs().max().item() <= 4e-6 * (K ** 0.5) * float(ref.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("c_fmt", [0, 1])
+def test_h2_gemm_epilogues_and_output_planes(c_fmt):
+    from pixelrec_amd import ops
+
+    M, N, K = 777, 256, 128
+    g = torch.Generator().manual_seed(3)
+    x, W, b, res = (torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) * 0.1).cuda(), torch.randn(N, generator=g).cuda(),
+                    torch.randn(M, N, generator=g).cuda())
+    xh, Wh = ops.split_planes_multi([x, W], h2=True)
+    pre = x.double() @ W.double().t() + b.double()
+    refs = {ops.EPI_NONE: x.double() @ W.double().t(), ops.EPI_BIAS: pre, ops.EPI_BIAS_ADD: pre + res.double(),
+            ops.EPI_BIAS_QGELU: pre * torch.sigmoid(1.702 * pre), ops.EPI_BIAS_RELU: torch.relu(pre),
+            ops.EPI_BIAS_GELU: torch.nn.functional.gelu(pre)}
+    for epi, ref in refs.items():
+        y = torch.full((M, N), float("nan"), device="cuda")
+        yp = ops.Planes.alloc(M, N, "cuda", fmt=c_fmt)
+        aux = res if epi == ops.EPI_BIAS_ADD else (torch.empty(M, N, device="cuda") if epi == ops.EPI_BIAS_GELU else None)
+        ops.gemm_planes(xh, Wh, y, epi, bias=None if epi == ops.EPI_NONE else b, aux=aux, Cp=yp)
+        assert (y.double() - ref).abs().max().item() < 2e-5, epi
+        if epi == ops.EPI_BIAS_GELU:
+            assert (aux.double() - pre).abs().max().item() < 2e-5        # the erf-GELU flavour also writes the pre-activation
+        if c_fmt == 0:
+            assert torch.equal(yp.to_dense(), y)                      # three bf16 planes: exact
+        else:
+            assert (yp.to_dense() - y).abs().max().item() <= 2.0 ** -21 * float(y.abs().max()) + 2.0 ** -24
+        # planes only (what the fc1 of a forward-only block does)
+        yp2 = ops.Planes.alloc(M, N, "cuda", fmt=c_fmt)
+        ops.gemm_planes(xh, Wh, None, epi, bias=None if epi == ops.EPI_NONE else b, aux=aux, Cp=yp2)
+        assert torch.equal(yp2.to_dense(), yp.to_dense())
+
+
+def test_mixed_formats_are_refused():
+    from pixelrec_amd import ops
+    from pixelrec_amd.lib import PxrError
+
+    x, W = torch.randn(64, 32).cuda(), torch.randn(32, 32).cuda()
+    xh0, Wh0 = ops.split_planes_multi([x, W], h2=True)
+    with pytest.raises(PxrError):                   # an epilogue that writes aux without one: refused, not a device fault
+        ops.gemm_planes(xh0, Wh0, torch.empty(64, 32, device="cuda"), ops.EPI_BIAS_GELU, bias=torch.zeros(32, device="cuda"))
+    (xh,) = ops.split_planes_multi([x], h2=True)
+    with pytest.raises(PxrError):
+        ops.gemm_planes(xh, ops.split_planes(W), torch.empty(64, 32, device="cuda"))
+    with pytest.raises(PxrError):
+        ops.gemm_planes(ops.split_planes(x), ops.split_planes_multi([W], h2=True)[0], torch.empty(64, 32, device="cuda"))
+
+
+def test_producers_write_h2_planes():
+    """LayerNorm and the fused tower attention writing their output as h2 planes = a 22-bit rounding of their fp32 output."""
+    from pixelrec_amd import ops
+
+    torch.manual_seed(0)
+    rows, D = 333, 128
+    x, gam, bet = torch.randn(rows, D).cuda() * 3, torch.randn(D).cuda(), torch.randn(D).cuda()
+    y, _, _, yp = ops.ln_residual_fwd(x, None, gam, bet, 1e-5, save=False, planes="h2", want_y=True)
+    y0, _, _ = ops.ln_residual_fwd(x, None, gam, bet, 1e-5, save=False)
+    assert torch.equal(y, y0) and yp.fmt == 1 and yp.exp == 0
+    assert (yp.to_dense() - y).abs().max().item() <= 2.0 ** -21 * float(y.abs().max())
+    n, T, heads, d = 3, 50, 2, 64
+    H = heads * d
+    qkv = torch.randn(n * T, 3 * H).cuda()
+    ctx, cp, _ = ops.tower_attn_fwd(qkv, n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=True, planes="h2")
+    ctx0, cp0, _ = ops.tower_attn_fwd(qkv, n, T, heads, d, 2 * H, 0, H, d ** -0.5, ctx=True, planes=True)
+    assert torch.equal(ctx, ctx0) and cp.fmt == 1 and cp0.fmt == 0
+    assert torch.equal(cp0.to_dense(), ctx0.view(n * T, H))
+    assert (cp.to_dense() - ctx.view(n * T, H)).abs().max().item() <= 2.0 ** -21 * float(ctx.abs().max())
+
+
+def test_fp16_range_is_flagged_not_silent():
+    from pixelrec_amd import ops
+
+    ops.raise_on_bad_indices("cuda")                      # clear
+    x = torch.randn(64, 64).cuda()
+    gam, bet = torch.full((64,), 1e5).cuda(), torch.zeros(64).cuda()            # LayerNorm output ~ 1e5 > 65504
+    ops.ln_residual_fwd(x, None, gam, bet, 1e-5, save=False, planes="h2", want_y=False)
+    with pytest.raises(RuntimeError, match="fp16"):
+        ops.raise_on_bad_indices("cuda")
+    ops.ln_residual_fwd(x, None, gam * 1e-5, bet, 1e-5, save=False, planes="h2", want_y=False)
+    ops.raise_on_bad_indices("cuda")                      # in range: no flag
+
+
+@pytest.mark.parametrize("method", ["mean", "cls"])
+def test_tower_with_frozen_blocks_on_h2(method, monkeypatch):
+    """A 3-block tower with head size 64 (the fused attention serves it): blocks 0-1 frozen -> fp16 planes, block 2 trainable ->
+    bf16x3.  Output and gradients against the torch restatement, and against the same tower with PXR_TOWER_H2=0."""
+    import copy
+
+    from pixelrec_amd import ops
+    from pixelrec_amd.model import visual
+
+    torch.manual_seed(7)
+    cfg = {"encoder_name": "clip-vit-tiny64-test", "encoder_source": "transformers", "embedding_size": 32, "pretrain_path": None,
+           "fine_tune_arg": {"tune_scale": 5 + 16 * 2, "pre_trained": False, "activation": "relu", "dnn_layers": [], "method": method}}
+    enc = visual.load_model(cfg)
+    for p in enc.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    ref = copy.deepcopy(enc)
+    enc = enc.cuda()
+    tower = enc._native
+    tower.ensure_packed()
+    assert tower.first_trainable_block() == 2
+    if ops.gemm_mode() == "bf16x3":
+        assert tower._h2_block(0) and tower._h2_block(1) and not tower._h2_block(2)
+    x = torch.randn(5, 3, 64, 64)
+    w = torch.randn(5, 32)
+    out = enc(x.cuda())
+    (out * w.cuda()).sum().backward()
+    if ops.gemm_mode() == "bf16x3" and tower._planes_on():
+        assert {k[1] for k in tower._wplanes} == {True}              # the frozen blocks' cached weight planes are h2
+    towr, pooled = ref.item_encoder(x)
+    ref_out = torch.mean(ref.rec_fc(towr), dim=1) if method == "mean" else ref.rec_fc(towr[:, 0, :])
+    assert (out.detach().cpu() - ref_out).abs().max().item() < 2e-5
+    (ref_out * w).sum().backward()
+    gmax = max(q.grad.abs().max().item() for q in ref.parameters() if q.grad is not None)
+    for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        if q.grad is not None:      # (the key bias has a mathematically zero gradient: the floor is relative to the largest one)
+            assert (p.grad.cpu() - q.grad).abs().max().item() <= 3e-4 * max(q.grad.abs().max().item(), 1e-5 * gmax), n
+    g_h2 = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    monkeypatch.setenv("PXR_TOWER_H2", "0")
+    tower.drop_weight_planes()
+    out0 = enc(x.cuda())
+    (out0 * w.cuda()).sum().backward()
+    assert (out0 - out).abs().max().item() < 5e-6                    # two roundings of the same fp32 computation
+    for n, p in enc.named_parameters():
+        if p.grad is not None:
+            assert (p.grad - g_h2[n]).abs().max().item() <= 1e-4 * max(float(g_h2[n].abs().max()), 1e-5 * gmax), n
+    ops.raise_on_bad_indices("cuda")
+    with torch.no_grad():                                            # inference: every block is forward-only; the trainable one stays bf16x3
+        monkeypatch.setenv("PXR_TOWER_H2", "1")
+        tower.drop_weight_planes()
+        o1 = enc(x.cuda())
+        assert (o1.cpu() - ref_out).abs().max().item() < 2e-5

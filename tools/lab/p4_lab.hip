@@ -1,7 +1,7 @@
 // p4_lab.hip -- standalone A/B harness for the big-tile planes GEMM main loops (gemm_p3.cuh lockstep vs gemm_p4.cuh ping-pong).
 // Not part of the product: builds to an executable (tools/lab/build.sh), runs a matrix of (variant, shape, dbg) on one GPU and
 // prints TF/s (six bf16 products per fp32 multiply counted) + the difference from the gemm_p3 result on the same operands.
-//   usage: p4_lab [iters]
+//   usage: p4_lab [iters] [shape-substring] [h2]      (h2: the fp16 two-plane experiment)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -73,6 +73,31 @@ __global__ void mismatch_kernel(const float* a, const float* b, int64_t n, unsig
       atomicAdd(out, 1ull);
       atomicMin(out + 1, (unsigned long long)i);
     }
+}
+
+
+// ---- fp16 two-plane ("h2") experiment: split with a power-of-two scale, sampled fp64 check ------------------------------------
+__global__ void split_h2_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols8, P3Mat out, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols8) return;
+  const int64_t row = i / cols8;
+  const int c = (int)(i % cols8) * 8;
+  const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
+  const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
+  const float v[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
+  h2_store8(out, row, c, v);
+}
+// sample s -> element (i, j) of C; out[0] += err^2, out[1] += ref^2, out[2] = max err (as double bits via atomicMax on u64)
+__global__ void sample_err_kernel(const float* A, const float* B, const float* C, int M, int N, int K, double cscale, int ns, double* out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  const int i = (int)(pxr_hash32(77u, 1, (uint64_t)s) % (uint32_t)M), j = (int)(pxr_hash32(77u, 2, (uint64_t)s) % (uint32_t)N);
+  double r = 0.0;
+  for (int k = 0; k < K; ++k) r += (double)A[(int64_t)i * K + k] * (double)B[(int64_t)j * K + k];
+  const double e = fabs((double)C[(int64_t)i * N + j] * cscale - r);
+  atomicAdd(out, e * e);
+  atomicAdd(out + 1, r * r);
+  atomicMax(reinterpret_cast<unsigned long long*>(out + 2), (unsigned long long)__double_as_longlong(e));
 }
 
 struct LabArgs {
@@ -162,6 +187,31 @@ static Planes make_planes(const float* x, int64_t R, int64_t C, bool transposed)
   return P;
 }
 
+
+static Planes make_planes_h2(const float* x, int64_t R, int64_t C, float scale) {
+  const int64_t pr = (R + 31) / 32 * 32, ps = pr * C;
+  Planes P;
+  CK(hipMalloc(&P.p, (size_t)ps * 2 * 2 + 4096));
+  CK(hipMemset(P.p, 0, (size_t)ps * 2 * 2 + 4096));
+  P.m = P3Mat{P.p, ps, pr};
+  const int64_t n = R * (C / 8);
+  hipLaunchKernelGGL(split_h2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, x, C, R, (int)(C / 8), P.m, scale);
+  CK(hipDeviceSynchronize());
+  return P;
+}
+static void sample_err(const char* what, const float* A, const float* B, const float* C, int M, int N, int K, double cscale) {
+  double* d;
+  CK(hipMalloc(&d, 24));
+  CK(hipMemset(d, 0, 24));
+  const int ns = 16384;
+  hipLaunchKernelGGL(sample_err_kernel, dim3(ns / 256), dim3(256), 0, 0, A, B, C, M, N, K, cscale, ns, d);
+  double h[3];
+  CK(hipMemcpy(h, d, 24, hipMemcpyDeviceToHost));
+  printf("    %-30s vs fp64 on %d samples: rms err %.3e  max err %.3e  (rms |c| %.3e; rms err / rms c = 2^%.1f)\n", what, ns, sqrt(h[0] / ns), h[2],
+         sqrt(h[1] / ns), log2(sqrt(h[0] / h[1])));
+  CK(hipFree(d));
+}
+
 template <class Cfg, bool A_KC, bool B_KC, int DBG = 0>
 static float run(const char* name, LabArgs g, int iters, const float* ref, float* diffbuf, bool quiet = false) {
   g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
@@ -234,6 +284,66 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&diffbuf, 8));
   unsigned long long* clk;
   CK(hipMalloc(&clk, 16));
+
+  if (argc > 3 && !strcmp(argv[3], "h2")) {
+    // the fp16 two-plane product against the six-product bf16 one: time, clock, error against fp64
+    struct H2Shape { const char* name; int M, N, K; float sa, sb; int ea, eb; };
+    const H2Shape hs[] = {
+        {"vit fc1", 69344, 3072, 768, 1.0f, 0.05f, 0, 8},
+        {"vit fc2", 69344, 768, 3072, 1.0f, 0.05f, 0, 8},
+        {"vit qkv", 69344, 2304, 768, 1.0f, 0.05f, 0, 8},
+        {"scoring  items x users", 400128, 1024, 512, 0.05f, 1.0f, 8, 0},
+        {"tiny-b (1e-6 weights, unscaled: fp16 subnormals)", 8192, 1024, 512, 1.0f, 1e-6f, 0, 0},
+        {"tiny-b scaled 2^16", 8192, 1024, 512, 1.0f, 1e-6f, 0, 16},
+    };
+    for (const H2Shape& s : hs) {
+      if (only[0] && !strstr(s.name, only)) continue;
+      printf("== %s  M=%d N=%d K=%d\n", s.name, s.M, s.N, s.K);
+      float *A, *B, *C;
+      CK(hipMalloc(&A, (size_t)s.M * s.K * 4));
+      CK(hipMalloc(&B, (size_t)s.N * s.K * 4));
+      CK(hipMalloc(&C, (size_t)s.M * s.N * 4));
+      hipLaunchKernelGGL(fill_normal, dim3((unsigned)(((int64_t)s.M * s.K + 255) / 256)), dim3(256), 0, 0, A, (int64_t)s.M * s.K, 11u, s.sa);
+      hipLaunchKernelGGL(fill_normal, dim3((unsigned)(((int64_t)s.N * s.K + 255) / 256)), dim3(256), 0, 0, B, (int64_t)s.N * s.K, 12u, s.sb);
+      CK(hipDeviceSynchronize());
+      LabArgs g{};
+      g.M = s.M; g.N = s.N; g.K = s.K; g.clk = clk; g.C = C;
+      {
+        Planes Ap = make_planes(A, s.M, s.K, false), Bp = make_planes(B, s.N, s.K, false);
+        g.A = Ap.m; g.B = Bp.m;
+        run<P3Cfg<256, 128, 4, 2, 2>, true, true>("bf16x3 p3 256x128 lockstep", g, iters, nullptr, diffbuf);
+        sample_err("bf16x3 six products (3 sets)", A, B, C, s.M, s.N, s.K, 1.0);
+        run<P4Cfg<256, 128, 4, 2, 3, 3, 0>, true, true>("bf16x3 p4 256x128 acc3", g, iters, nullptr, diffbuf);
+        if (s.N % 256 == 0) {
+          run<P4Cfg<256, 256, 4, 2, 3, 1, 0, 3>, true, true, 64>("bf16x3 p4 256x256 acc1", g, iters, nullptr, diffbuf);
+          sample_err("bf16x3 six products (1 set)", A, B, C, s.M, s.N, s.K, 1.0);
+        }
+        CK(hipFree(Ap.p)); CK(hipFree(Bp.p));
+      }
+      {
+        Planes Ap = make_planes_h2(A, s.M, s.K, ldexpf(1.0f, s.ea)), Bp = make_planes_h2(B, s.N, s.K, ldexpf(1.0f, s.eb));
+        g.A = Ap.m; g.B = Bp.m;
+        const double cs = ldexp(1.0, -(s.ea + s.eb));
+        run<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>, true, true>("h2 p4 256x128 ns4 acc2", g, iters, nullptr, diffbuf);
+        sample_err("h2 three products (2 sets)", A, B, C, s.M, s.N, s.K, cs);
+        run<P4Cfg<256, 128, 4, 2, 4, 1, 0, 2, true>, true, true>("h2 p4 256x128 ns4 acc1", g, iters, nullptr, diffbuf);
+        sample_err("h2 three products (1 set)", A, B, C, s.M, s.N, s.K, cs);
+        run<P4Cfg<256, 128, 4, 2, 6, 1, 0, 2, true>, true, true>("h2 p4 256x128 ns6 acc1", g, iters, nullptr, diffbuf);
+        if (s.N % 256 == 0) {
+          run<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>, true, true, 64>("h2 p4 256x256 ns4 acc1", g, iters, nullptr, diffbuf);
+          sample_err("h2 three products (1 set, 256x256)", A, B, C, s.M, s.N, s.K, cs);
+          run<P4Cfg<256, 256, 4, 2, 3, 1, 0, 2, true>, true, true, 64>("h2 p4 256x256 ns3 acc1", g, iters, nullptr, diffbuf);
+          run<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>, true, true, 32 + 64>("h2 p4 256x256 ns4 acc1 nostore", g, iters, nullptr, diffbuf);
+          run<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>, true, true, 32 + 4>("h2 p4 256x256 ns4 acc1 nostore nomfma", g, iters, nullptr, diffbuf);
+        }
+        CK(hipMemset(Ap.p, 0, (size_t)Ap.m.ps * 4)); CK(hipMemset(Bp.p, 0, (size_t)Bp.m.ps * 4));
+        run<P4Cfg<256, 128, 4, 2, 4, 1, 0, 2, true>, true, true>("h2 p4 256x128 ns4 acc1  ZERO operands", g, iters, nullptr, diffbuf);
+        CK(hipFree(Ap.p)); CK(hipFree(Bp.p));
+      }
+      CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
+    }
+    return 0;
+  }
   for (const Shape& s : shapes) {
     if (only[0] && !strstr(s.name, only)) continue;
     printf("== %s  M=%d N=%d K=%d\n", s.name, s.M, s.N, s.K);
