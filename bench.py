@@ -47,18 +47,30 @@ def _pixelnet_traffic(encoder, B):
         return None
 
 
-def mfma_roof(alg_flops, seconds, b3):
+def mfma_roof(alg_flops, seconds, b3, executed_flops=None):
     """`achieved`/`peak`/`frac` of an MFMA-bound kernel against the pipe it RUNS on ("if a bf16-split scheme is
-    used quote that peak instead").  bf16x3: achieved = the 6 bf16 products per algorithmic fp32 multiply actually executed,
-    peak = the dense bf16 MFMA peak; f32: algorithmic fp32 flops against the f32-input MFMA peak.  The algorithmic rate and
-    its ratio to the f32-input peak travel as side fields (that ratio is NOT a roofline in bf16x3 mode: it can exceed 1)."""
+    used quote that peak instead").  bf16x3: achieved = the 16-bit products actually executed (6 per algorithmic fp32 multiply
+    on the 3 x bf16 split; `executed_flops` when some launches ran the 3-product fp16 two-plane kernels -- fp16 and bf16 MFMAs
+    share the dense peak), peak = that peak; f32: algorithmic fp32 flops against the f32-input MFMA peak.  The algorithmic rate
+    and its ratio to the f32-input peak travel as side fields (that ratio is NOT a roofline in bf16x3 mode: it can exceed 1)."""
     alg = alg_flops / seconds / 1e12
     if b3:
-        return {"achieved": B3_PRODUCTS * alg, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                "frac": B3_PRODUCTS * alg / MFMA_BF16_PEAK_TF, "pipe": "bf16 MFMA, 6 products per fp32 multiply",
-                "algorithmic_tflops": alg, "algorithmic_over_f32_mfma_peak": alg / MFMA_F32_PEAK_TF}
+        ex = (executed_flops / seconds / 1e12) if executed_flops is not None else B3_PRODUCTS * alg
+        r = {"achieved": ex, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ex / MFMA_BF16_PEAK_TF,
+             "pipe": "bf16 MFMA, 6 products per fp32 multiply", "algorithmic_tflops": alg,
+             "algorithmic_over_f32_mfma_peak": alg / MFMA_F32_PEAK_TF}
+        if executed_flops is not None:
+            r["pipe"] = ("bf16 / fp16 MFMA (same dense peak): 6 products per fp32 multiply on the 3 x bf16 split, 3 on the fp16 "
+                         "two-plane operands (forward-only tower blocks)")
+            r["products_per_multiply"] = ex / alg if alg else None
+        return r
     return {"achieved": alg, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg / MFMA_F32_PEAK_TF,
             "pipe": "f32-input MFMA", "algorithmic_tflops": alg, "algorithmic_over_f32_mfma_peak": alg / MFMA_F32_PEAK_TF}
+
+
+def executed_products(tag):
+    """16-bit MFMA products per algorithmic fp32 multiply of a GEMM launch, from the kernel tag ops.py records."""
+    return 3.0 if "HALF" in tag else B3_PRODUCTS
 
 
 def model_config(p_drop=0.1):
@@ -223,8 +235,10 @@ def pixelnet_run(args, steps, warmup, init_dist=True, n_inst=3):
     gsync = getattr(dp, "grad_sync", None)
     if rank != 0:
         return None
-    gem = [(s_.elapsed_time(e_) * 1e-3, w) for s_, e_, w, tag in ev if tag.startswith("gemm") or tag.startswith("grouped_dw")]
-    g_s, g_fl = sum(x for x, _ in gem) or float("nan"), sum(w for _, w in gem)
+    gem = [(s_.elapsed_time(e_) * 1e-3, w, tag) for s_, e_, w, tag in ev if tag.startswith("gemm") or tag.startswith("grouped_dw")]
+    g_s, g_fl = sum(x for x, _, _ in gem) or float("nan"), sum(w for _, w, _ in gem)
+    g_ex = sum(w * executed_products(tag) for _, w, tag in gem)
+    h2_s, h2_fl = sum(x for x, _, tag in gem if "HALF" in tag), sum(w for _, w, tag in gem if "HALF" in tag)
     n_img = B * 2 * (L + 1)
     T = (image // patch) ** 2 + 1
     out = {"metric": f"user-sequences/sec, SASRec PixelNet + {args.encoder} end to end (training step: image encoder fwd, "
@@ -241,10 +255,20 @@ def pixelnet_run(args, steps, warmup, init_dist=True, n_inst=3):
            "data_parallel_phases": {"ms": ph_acc, "rccl_ranks": world if (gsync is not None and getattr(gsync, "active", False)) else 1,
                                     "note": "eager steps, events on the compute stream; with one rank no collective is issued"},
            "roofline": {"bound": "mfma", "gemm_mode": ops.gemm_mode(),
-                        "kernel": "gemm_p3_kernel<P4Cfg 256x256 | 256x128> (ping-pong planes tiles, gemm_p4.cuh) + grouped_dw_p3_kernel "
-                                  "(v_mfma_f32_32x32x16_bf16 on the exact 3 x bf16 split, operands pre-split as planes): ViT blocks, "
-                                  "rec_fc, sequence block; f32 mode: gemm_kernel (v_mfma_f32_32x32x2_f32) -- see gemm_mode",
-                        **mfma_roof(g_fl, g_s, ops.gemm_mode() == "bf16x3"), "traffic": _pixelnet_traffic(args.encoder, B),
+                        "kernel": "gemm_p3_kernel<P4Cfg 256x256 | 256x128> (ping-pong planes tiles, gemm_p4.cuh) + grouped_dw_p3_kernel: "
+                                  "v_mfma_f32_32x32x16_bf16 on the exact 3 x bf16 split (6 products per multiply; trainable ViT blocks, "
+                                  "rec_fc, sequence block) and v_mfma_f32_32x32x16_f16 on two fp16 planes (3 products; the frozen ViT "
+                                  "blocks, `fp16_two_plane`), operands pre-split as planes; f32 mode: gemm_kernel "
+                                  "(v_mfma_f32_32x32x2_f32) -- see gemm_mode",
+                        **mfma_roof(g_fl, g_s, ops.gemm_mode() == "bf16x3", g_ex if h2_fl else None),
+                        "fp16_two_plane": ({"gemm_time_per_step_ms": h2_s / max(n_inst, 1) * 1e3,
+                                            "algorithmic_gflop_per_step": h2_fl / max(n_inst, 1) / 1e9,
+                                            "achieved": 3.0 * h2_fl / h2_s / 1e12, "frac": 3.0 * h2_fl / h2_s / 1e12 / MFMA_BF16_PEAK_TF,
+                                            "algorithmic_tflops": h2_fl / h2_s / 1e12,
+                                            "note": "the launches on fp16 two-plane operands alone (3 products per multiply executed); "
+                                                    "PXR_TOWER_H2=0 puts them back on the six-product bf16x3 kernels"}
+                                           if h2_fl else None),
+                        "traffic": _pixelnet_traffic(args.encoder, B),
                         "gemm_time_per_step_ms": g_s / max(n_inst, 1) * 1e3, "algorithmic_gflop_per_step": g_fl / max(n_inst, 1) / 1e9,
                         "launches_per_step": len(gem) / max(n_inst, 1),
                         "traffic_source": "profiles/r04/pixelnet/pixelnet_gemm_traffic_summary.json (separate rocprofv3 --pmc passes of "

@@ -342,6 +342,17 @@ static int sk_scratch_for(hipStream_t st, SkScratch* out) {
   return PXR_OK;
 }
 
+// the flag block of a stream (SK_MAX_WORKERS zero-initialised words that every user leaves zeroed): shared with the split-K weight
+// gradient launch of gemm_p3.hip, which runs on the same stream as any stream-K GEMM that could use it (never concurrently)
+int pxr_stream_flags(hipStream_t st, unsigned** flags, int* n_flags) {
+  SkScratch sc{};
+  const int rc = sk_scratch_for(st, &sc);
+  if (rc != PXR_OK) return rc;
+  *flags = sc.flags;
+  *n_flags = SK_MAX_WORKERS;
+  return PXR_OK;
+}
+
 // Where stream-K pays (tools/sk_sweep.py, M = 3200 tokens, us per launch, tile-per-workgroup -> stream-K with 768 workers):
 //   N=512 K=1536 (dX of the QKV projection) 58.0 -> 52.9;  N=512 K=1024 40.7 -> 38.5 / 37.3 -> 38.8;
 //   N=512 K=512 21.3 -> 24.9;  N=1024 K=512 45.6 -> 48.3;  N=1536 K=512 46.3 -> 51.8.

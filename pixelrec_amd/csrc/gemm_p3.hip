@@ -253,11 +253,20 @@ struct P3DwProblem {
 struct P3DwGroup {
   P3DwProblem p[DW_MAX];
   int n, total_tiles;
+  unsigned* flags;         // KS == 2: one zero-initialised word per tile (left zeroed)
+  unsigned* status;
 };
-template <class Cfg, bool EARLY>
+int pxr_stream_flags(hipStream_t st, unsigned** flags, int* n_flags);      // gemm_f32.hip
+// KS == 2 (split-K, ping-pong tiles only): two workgroups per tile, each reducing HALF of the tokens -- the launches whose tiles fill
+// half the chip or less (the sequence block's four matrices per layer: 128 tiles of 256x128) run on all of it.  The first half STORES
+// its tile and raises the tile's flag; the second half (the next logical index: dispatched later, normally on the same XCD) waits for
+// it, ADDS its own sum and lowers the flag -- a fixed order (deterministic bits), no zero-filled output, no atomics on the data.
+template <class Cfg, bool EARLY, int KS = 1>
 __global__ void __launch_bounds__(Cfg::NT) grouped_dw_p3_kernel(const P3DwGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = xcd_remap(blockIdx.x, g.total_tiles);
+  static_assert(KS == 1 || (KS == 2 && Cfg::PINGPONG), "split-K: the ping-pong tiles");
+  const int tl = xcd_remap(blockIdx.x, KS * g.total_tiles);
+  const int t = tl / KS, half = tl % KS;
   int pi = 0;
 #pragma unroll 1
   for (int i = 1; i < g.n; ++i)
@@ -270,7 +279,27 @@ __global__ void __launch_bounds__(Cfg::NT) grouped_dw_p3_kernel(const P3DwGroup 
   typename Cfg::Acc accs;
   f32x16 ones_acc[Cfg::TM];
   const bool do_bias = (P.db != nullptr) && (tn == 0);      // block-uniform
-  if constexpr (Cfg::PINGPONG) {
+  if constexpr (KS == 2) {
+    // tokens [0, k0) | [k0, kpad), k0 a multiple of 32: a row range of both planes matrices (32 elements per panel row)
+    const int k0 = (kpad / 64) * 32;
+    const int kb = half ? k0 : 0, kl = half ? kpad - k0 : k0;
+    const P3Mat dyh{P.dy.p + (int64_t)kb * 32, P.dy.ps, P.dy.pr}, xh{P.x.p + (int64_t)kb * 32, P.x.ps, P.x.pr};
+    if (do_bias) gemm_p4_mainloop<Cfg, false, false, true>(accs, dyh, xh, kl, m0, n0, smem, ones_acc);
+    else gemm_p4_mainloop<Cfg, false, false, false>(accs, dyh, xh, kl, m0, n0, smem);
+    if (half) {
+      if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(&g.flags[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1u << 22)) {        // ~seconds: never in a healthy launch; flag it instead of hanging the GPU
+            if (g.status) atomicOr(g.status, (unsigned)PXR_STATUS_GEMM_TIMEOUT);
+            break;
+          }
+        }
+      }
+      __syncthreads();                       // (the loads below bypass the caches: no acquire fence -- an agent-scope fence is a full
+    }                                        //  L2 write-back + invalidate per wave, ~100 us per launch at 256 workgroups: measured)
+  } else if constexpr (Cfg::PINGPONG) {
     if (do_bias) gemm_p4_mainloop<Cfg, false, false, true>(accs, P.dy, P.x, kpad, m0, n0, smem, ones_acc);
     else gemm_p4_mainloop<Cfg, false, false, false>(accs, P.dy, P.x, kpad, m0, n0, smem);
   } else {
@@ -280,15 +309,40 @@ __global__ void __launch_bounds__(Cfg::NT) grouped_dw_p3_kernel(const P3DwGroup 
   float* dW = P.dW;
   const int64_t ldw = P.K;
   const bool vec_ok = (P.K % 8 == 0);
+  // split-K hand-over: the first half's stores and the second half's loads of the partial tile go THROUGH the caches (sc1 | sc0:
+  // write-through / bypass, as the stream-K partials of gemm_f32.hip), so the pair needs no fence whichever XCDs it runs on
+  constexpr int COH = (1 << 4) | 1;
+  const bool add = (KS == 2) && half;          // the second half of a split tile adds to what the first one stored
+  const bool publish = (KS == 2) && !half;
+  const bufrsrc rsw = make_rsrc(dW, (int64_t)P.N * P.K * 4);
   auto store = [&](int, int row, int col, int nv, float (&v)[8]) {
     float* cp = dW + (int64_t)row * ldw + col;
+    const unsigned off = (unsigned)(((int64_t)row * ldw + col) * 4);
     if (vec_ok && nv == 8) {
-      *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      if (add) {
+        const auto a = __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, COH), b = __builtin_amdgcn_raw_buffer_load_b128(rsw, off + 16, 0, COH);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(a[e]); v[4 + e] += __uint_as_float(b[e]); }
+      }
+      if (publish) {
+        p3_u32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = __float_as_uint(v[e]); b[e] = __float_as_uint(v[4 + e]); }
+        __builtin_amdgcn_raw_buffer_store_b128(a, rsw, off, 0, COH);
+        __builtin_amdgcn_raw_buffer_store_b128(b, rsw, off + 16, 0, COH);
+      } else {
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        if (e < nv) cp[e] = v[e];
+        if (e < nv) {
+          float o = v[e];
+          if (add) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsw, off + 4 * e, 0, COH));
+          if (publish) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rsw, off + 4 * e, 0, COH);
+          else cp[e] = o;
+        }
     }
   };
   if constexpr (Cfg::PINGPONG) p4_row_epilogue<Cfg>(accs, smem, P.N, P.K, m0, n0, [](int, int, int, int) {}, store);
@@ -302,13 +356,28 @@ __global__ void __launch_bounds__(Cfg::NT) grouped_dw_p3_kernel(const P3DwGroup 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = m0 + wm * Cfg::WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (row < P.N) P.db[row] = ones_acc[i][e];
+          if (row < P.N) {
+            float o = ones_acc[i][e];
+            if constexpr (KS == 2) {
+              const bufrsrc rsb = make_rsrc(P.db, (int64_t)P.N * 4);
+              if (add) o += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsb, (unsigned)row * 4u, 0, COH));
+              if (publish) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rsb, (unsigned)row * 4u, 0, COH);
+              else P.db[row] = o;
+            } else {
+              P.db[row] = o;
+            }
+          }
         }
     }
   }
+  if constexpr (KS == 2) {
+    __builtin_amdgcn_s_waitcnt(0);           // every lane's stores acknowledged at the coherence point (first half); loads consumed
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&g.flags[t], half ? 0u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
-template <class Cfg, bool EARLY>
+template <class Cfg, bool EARLY, int KS = 1>
 static int launch_dw_p3(P3DwGroup& g, hipStream_t st) {
   int tiles = 0;
   for (int i = 0; i < g.n; ++i) {
@@ -317,7 +386,17 @@ static int launch_dw_p3(P3DwGroup& g, hipStream_t st) {
     tiles += g.p[i].tiles_m * ((g.p[i].K + Cfg::BN - 1) / Cfg::BN);
   }
   g.total_tiles = tiles;
-  auto kern = grouped_dw_p3_kernel<Cfg, EARLY>;
+  if constexpr (KS == 2) {
+    int n_flags = 0;
+    const int rc = pxr_stream_flags(st, &g.flags, &n_flags);
+    if (rc != PXR_OK) return rc;
+    if (tiles > n_flags) {
+      pxr_set_error("pxr_grouped_dw_planes_f32: split-K launch with %d tiles (max %d)", tiles, n_flags);
+      return PXR_ERR_BAD_ARG;
+    }
+    g.status = (unsigned*)pxr_status_word();
+  }
+  auto kern = grouped_dw_p3_kernel<Cfg, EARLY, KS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
@@ -327,7 +406,7 @@ static int launch_dw_p3(P3DwGroup& g, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, st, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(KS * tiles)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, g);
   return pxr_check_launch("pxr_grouped_dw_planes_f32");
 }
 
@@ -526,12 +605,13 @@ extern "C" int pxr_gemm_h2_f32(int M, int N, int K, const void* A, int64_t a_pla
   g.cp_fmt = c_fmt;
   g.status = pxr_status_word();
   hipStream_t st = (hipStream_t)stream;
-  // tiles: 2 | BM | BN | ring slots | accumulator sets.  256x256 (one set) when it costs no more rounds of 256 workgroups than
-  // 256x128 (two sets: hi*hi apart from the cross terms)
+  // tiles: 2 | BM | BN | ring slots | accumulator sets.  256x256 (one set) when its rounds of 256 workgroups, each 1.75x as long as
+  // a round of 256x128 tiles (two sets: hi*hi apart from the cross terms; measured: profiles/r04/lab/h2_lab_run1.log -- the square
+  // tile reads half as many LDS bytes per MFMA), cost no more
   if (tile_hint == 0) {
     const int64_t t128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128), t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     static const int env_sq = getenv("PXR_H2_SQUARE") ? atoi(getenv("PXR_H2_SQUARE")) : 1;
-    tile_hint = (env_sq && N >= 256 && 2 * ((t256 + 255) / 256) <= (t128 + 255) / 256) ? 225625641 : 225612842;
+    tile_hint = (env_sq && N >= 256 && 7 * ((t256 + 255) / 256) <= 4 * ((t128 + 255) / 256)) ? 225625641 : 225612842;
   }
   if (tile_hint == 225625641) return epi_h2<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>>(epilogue, g, st);
   if (tile_hint == 225612842) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>>(epilogue, g, st);
@@ -631,7 +711,16 @@ extern "C" int pxr_grouped_dw_planes_f32(int n, const void* const* dy, const int
   int64_t t256 = 0;
   for (int i = 0; i < n; ++i) t256 += (int64_t)((N[i] + 255) / 256) * ((K[i] + 127) / 128);
   static const int env_p4dw = getenv("PXR_P4_DW") ? atoi(getenv("PXR_P4_DW")) : 1;
-  if (tile_hint == 0) tile_hint = (env_p4dw && ((t256 >= 192 && t256 <= 256) || t256 >= 512)) ? 425612832 : (t128 >= 192 ? 412812831 : 406406431);
+  // ... and the same tiles with the token reduction split in two (grouped_dw_p3_kernel KS = 2) when the tiles fill at most half of
+  // the chip and the reduction is long enough to pay for the second ramp (the sequence block: 128 tiles, >= 3200 tokens)
+  static const int env_splitk = getenv("PXR_DW_SPLITK") ? atoi(getenv("PXR_DW_SPLITK")) : 1;
+  int t_min = T[0];
+  for (int i = 1; i < n; ++i) t_min = T[i] < t_min ? T[i] : t_min;
+  if (tile_hint == 0) {
+    if (env_p4dw && env_splitk && t256 >= 96 && t256 <= 128 && t_min >= 2048) tile_hint = 425612822;
+    else tile_hint = (env_p4dw && ((t256 >= 192 && t256 <= 256) || t256 >= 512)) ? 425612832 : (t128 >= 192 ? 412812831 : 406406431);
+  }
+  if (tile_hint == 425612822) return launch_dw_p3<P4Cfg<256, 128, 4, 2, 3, 2>, false, 2>(g, st);
   if (tile_hint == 425612832) return launch_dw_p3<P4Cfg<256, 128, 4, 2, 3, 2>, false>(g, st);
   if (tile_hint == 812812830) return launch_dw_p3<P3Cfg<128, 128, 2, 4, 3>, false>(g, st);
   if (tile_hint == 412812831) return launch_dw_p3<P3Cfg<128, 128, 2, 2, 3>, true>(g, st);
