@@ -204,16 +204,32 @@ int pxr_split_planes_multi_f32(int n, const float* const* x, const int64_t* rows
  * word (pxr_set_status_word) instead of silently becoming inf.  Same panel layout as the bf16 planes, planes 0 and 1.
  * Used by the forward-only blocks of the image tower (reference: the frozen CLIP blocks of code/REC/model/load.py:90-120).
  *   pxr_split_h2_multi_f32   up to 16 matrices, matrix i multiplied by 2^scale_exp[i] first
- *   pxr_gemm_h2_f32          C = epilogue(2^-(a_exp+b_exp) A~ B~^T), B~ [N][K]; epilogue NONE | BIAS | BIAS_GELU | BIAS_ADD |
- *                            BIAS_QGELU | BIAS_RELU; c_fmt 0: output planes as three bf16 planes, 1: as two fp16 planes (unit scale)
+ *   pxr_gemm_h2_f32          C = epilogue(2^-(a_exp+b_exp) A~ B~), B~ [N][K] (b_kc: forward; epilogue NONE | BIAS | BIAS_GELU |
+ *                            BIAS_ADD | BIAS_QGELU | BIAS_QGELU_GRAD | BIAS_RELU) or [K][N] (input gradient; NONE | ADD | MUL);
+ *                            exponents immediate or read from *_exp_dev; c_fmt 0: output planes as three bf16 planes, 1: as two
+ *                            fp16 planes holding C 2^(*c_exp_dev) (unit scale when null)
  *   pxr_ln_residual_fwd_h2_f32 / pxr_tower_attn_fwd_h2_f32: the plane-writing producers with h2 planes (unit scale) */
 int pxr_split_h2_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
                            void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows, const int* scale_exp,
                            void* stream);
-int pxr_gemm_h2_f32(int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows, int a_exp, const void* B,
-                    int64_t b_plane_stride, int64_t b_panel_rows, int b_exp, float* C, int64_t ldc, int epilogue,
-                    const float* bias, float* aux, int64_t ldaux, void* c_planes, int64_t c_plane_stride, int64_t c_panel_rows,
-                    int c_fmt, int act, int tile_hint, void* stream);
+int pxr_gemm_h2_f32(int b_kc, int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows, int a_exp,
+                    const int* a_exp_dev, const void* B, int64_t b_plane_stride, int64_t b_panel_rows, int b_exp,
+                    const int* b_exp_dev, float* C, int64_t ldc, int epilogue, const float* bias, float* aux, int64_t ldaux,
+                    void* c_planes, int64_t c_plane_stride, int64_t c_panel_rows, int c_fmt, const int* c_exp_dev, int act,
+                    int tile_hint, void* stream);
+/* the weight gradients of pxr_grouped_dw_planes_f32 from h2 operands (exponents per problem: immediate, or read from *_exp_dev[i]) */
+int pxr_grouped_dw_h2_f32(int n, const void* const* dy, const int64_t* dy_plane_stride, const int64_t* dy_panel_rows,
+                          const int* dy_exp, const int* const* dy_exp_dev, const void* const* x, const int64_t* x_plane_stride,
+                          const int64_t* x_panel_rows, const int* x_exp, const int* const* x_exp_dev, float* const* dW,
+                          float* const* db, const int* T, const int* N, const int* K, int tile_hint, void* stream);
+/* h2 split with the scale chosen ON THE DEVICE (tensors that change every step): per matrix max |x| -> stats[2 i] (col_stats: also
+ * the largest column sum of |x| -> stats[2 i + 1]) and e = 14 - ceil(log2 max) -> exps[i]; no host synchronisation.
+ * pxr_h2_bound_exp: *exp_out = 15 - ceil(log2(a_max[0] * b_colsum[0] * factor)) -- the exponent of an input gradient that leaves
+ * a GEMM epilogue as planes before its maximum can be known (|dy W| <= max |dy| * max column sum of |W|). */
+int pxr_h2_split_auto_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
+                                void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows, int col_stats,
+                                float* stats, int* exps, void* stream);
+int pxr_h2_bound_exp(const float* a_max, const float* b_colsum, float factor, int* exp_out, void* stream);
 int pxr_ln_residual_fwd_h2_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps, int rows,
                                int D, float* y, float* xhat, float* rstd, void* y_planes, int64_t y_plane_stride,
                                int64_t y_panel_rows, void* stream);

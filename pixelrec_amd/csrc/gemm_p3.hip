@@ -77,7 +77,12 @@ struct P3Args {
   int64_t ldaux;
   int tiles_m, tiles_n, n_fastest, act, dbg;
   int group_m;             // > 1: tiles are walked in groups of group_m row tiles x all column tiles (see gemm_p3_kernel)
-  float acc_scale;         // fp16 two-plane operands (Cfg::HALF): 2^-(eA + eB), undoes the operands' power-of-two scales
+  // fp16 two-plane operands (Cfg::HALF): the operands hold A 2^a_exp and B 2^b_exp; the exponents are immediates or, when the
+  // pointer is given, read from device memory (a producer chose them on the device: gradients, weights re-split every step)
+  int a_exp, b_exp;
+  const int* a_exp_dev;
+  const int* b_exp_dev;
+  const int* c_exp_dev;    // h2 output planes hold C 2^(*c_exp_dev) (null: unit scale)
   int cp_fmt;              // format of the output planes: PXR_PLANES_BF16X3 | PXR_PLANES_H2
   int32_t* status;         // status word (fp16 range check of h2 output planes) or null
 };
@@ -139,8 +144,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
   typename Cfg::Acc accs;
   if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, true, B_KC>(accs, g.A, g.B, g.K, m0, n0, smem);
   else gemm_p3_mainloop<Cfg, true, B_KC, EARLY>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
+  float c_scale = 1.0f;
   if constexpr (Cfg::HALF) {
-    const float sc = g.acc_scale;
+    const int ea = g.a_exp_dev ? *g.a_exp_dev : g.a_exp, eb = g.b_exp_dev ? *g.b_exp_dev : g.b_exp;
+    const float sc = ldexpf(1.0f, -(ea + eb));
+    if (g.c_exp_dev) c_scale = ldexpf(1.0f, *g.c_exp_dev);
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -200,7 +208,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
           if (e < nv) cp[e] = v[e];
       }
     }
-    if (g.Cp.p != nullptr) px_store8(g.Cp, g.cp_fmt, g.status, row, col, v);      // (output planes: N % 32 == 0, chunks are whole)
+    if (g.Cp.p != nullptr) {                                   // (output planes: N % 32 == 0, chunks are whole)
+      if constexpr (Cfg::HALF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= c_scale;             // (after the fp32 / aux stores: those stay unscaled)
+      }
+      px_store8(g.Cp, g.cp_fmt, g.status, row, col, v);
+    }
   };
   if constexpr (PP) {
     p4_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0,
@@ -249,6 +263,9 @@ struct P3DwProblem {
   float* db;
   int T, N, K;              // tokens, out features, in features
   int tile_begin, tiles_m;
+  int dy_exp, x_exp;        // fp16 two-plane operands (Cfg::HALF): the planes hold dY 2^dy_exp, X 2^x_exp (immediate or from the device)
+  const int* dy_exp_dev;
+  const int* x_exp_dev;
 };
 struct P3DwGroup {
   P3DwProblem p[DW_MAX];
@@ -305,6 +322,21 @@ __global__ void __launch_bounds__(Cfg::NT) grouped_dw_p3_kernel(const P3DwGroup 
   } else {
     if (do_bias) gemm_p3_mainloop<Cfg, false, false, EARLY, true>(accs, P.dy, P.x, kpad, m0, n0, smem, ones_acc);
     else gemm_p3_mainloop<Cfg, false, false, EARLY, false>(accs, P.dy, P.x, kpad, m0, n0, smem);
+  }
+  if constexpr (Cfg::HALF) {
+    const int ey = P.dy_exp_dev ? *P.dy_exp_dev : P.dy_exp, ex = P.x_exp_dev ? *P.x_exp_dev : P.x_exp;
+    const float sc = ldexpf(1.0f, -(ey + ex)), sb = ldexpf(1.0f, -ey);
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs.v[i][j][e] *= sc;
+      if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ones_acc[i][e] *= sb;
+      }
+    }
   }
   float* dW = P.dW;
   const int64_t ldw = P.K;
@@ -484,18 +516,27 @@ static int epi_p3(int b_kc, int epilogue, P3Args& g, hipStream_t st) {
   return PXR_ERR_BAD_ARG;
 }
 
-// the forward flavours of the fp16 two-plane GEMM (weights k-contiguous)
+// the flavours of the fp16 two-plane GEMM: forward (weights k-contiguous) and input gradient (weights x-contiguous)
 template <class Cfg>
-static int epi_h2(int epilogue, P3Args& g, hipStream_t st) {
-  switch (epilogue) {
-    case EPI_NONE: return launch_p3<Cfg, true, EPI_NONE, false>(g, st);
-    case EPI_BIAS: return launch_p3<Cfg, true, EPI_BIAS, false>(g, st);
-    case EPI_BIAS_GELU: return launch_p3<Cfg, true, EPI_BIAS_GELU, false>(g, st);
-    case EPI_BIAS_ADD: return launch_p3<Cfg, true, EPI_BIAS_ADD, false>(g, st);
-    case EPI_BIAS_QGELU: return launch_p3<Cfg, true, EPI_BIAS_QGELU, false>(g, st);
-    case EPI_BIAS_RELU: return launch_p3<Cfg, true, EPI_BIAS_RELU, false>(g, st);
+static int epi_h2(int b_kc, int epilogue, P3Args& g, hipStream_t st) {
+  if (b_kc) {
+    switch (epilogue) {
+      case EPI_NONE: return launch_p3<Cfg, true, EPI_NONE, false>(g, st);
+      case EPI_BIAS: return launch_p3<Cfg, true, EPI_BIAS, false>(g, st);
+      case EPI_BIAS_GELU: return launch_p3<Cfg, true, EPI_BIAS_GELU, false>(g, st);
+      case EPI_BIAS_ADD: return launch_p3<Cfg, true, EPI_BIAS_ADD, false>(g, st);
+      case EPI_BIAS_QGELU: return launch_p3<Cfg, true, EPI_BIAS_QGELU, false>(g, st);
+      case EPI_BIAS_QGELU_GRAD: return launch_p3<Cfg, true, EPI_BIAS_QGELU_GRAD, false>(g, st);
+      case EPI_BIAS_RELU: return launch_p3<Cfg, true, EPI_BIAS_RELU, false>(g, st);
+    }
+  } else {
+    switch (epilogue) {
+      case EPI_NONE: return launch_p3<Cfg, false, EPI_NONE, false>(g, st);
+      case EPI_ADD: return launch_p3<Cfg, false, EPI_ADD, false>(g, st);
+      case EPI_MUL: return launch_p3<Cfg, false, EPI_MUL, false>(g, st);
+    }
   }
-  pxr_set_error("pxr_gemm_h2_f32: epilogue %d is not instantiated", epilogue);
+  pxr_set_error("pxr_gemm_h2_f32: flavour b_kc=%d / epilogue %d is not instantiated", b_kc, epilogue);
   return PXR_ERR_BAD_ARG;
 }
 
@@ -577,31 +618,36 @@ extern "C" int pxr_split_h2_multi_f32(int n, const float* const* x, const int64_
 // EPI_NONE | EPI_BIAS | EPI_BIAS_GELU | EPI_BIAS_ADD | EPI_BIAS_QGELU | EPI_BIAS_RELU); output as fp32 and / or planes in either
 // format (c_fmt: 0 = three bf16 planes, 1 = two fp16 planes at unit scale).  Ping-pong tiles only (gemm_p4.cuh): meant for the tall
 // GEMMs of the image tower.
-extern "C" int pxr_gemm_h2_f32(int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows, int a_exp,
-                               const void* B, int64_t b_plane_stride, int64_t b_panel_rows, int b_exp, float* C, int64_t ldc,
-                               int epilogue, const float* bias, float* aux, int64_t ldaux, void* c_planes, int64_t c_plane_stride,
-                               int64_t c_panel_rows, int c_fmt, int act, int tile_hint, void* stream) {
+extern "C" int pxr_gemm_h2_f32(int b_kc, int M, int N, int K, const void* A, int64_t a_plane_stride, int64_t a_panel_rows, int a_exp,
+                               const int* a_exp_dev, const void* B, int64_t b_plane_stride, int64_t b_panel_rows, int b_exp,
+                               const int* b_exp_dev, float* C, int64_t ldc, int epilogue, const float* bias, float* aux,
+                               int64_t ldaux, void* c_planes, int64_t c_plane_stride, int64_t c_panel_rows, int c_fmt,
+                               const int* c_exp_dev, int act, int tile_hint, void* stream) {
   PXR_REQUIRE(A && B && (C || c_planes), "pxr_gemm_h2_f32: null operand");
   PXR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && K % 32 == 0, "pxr_gemm_h2_f32: K must be a multiple of 32");
+  PXR_REQUIRE(b_kc || N % 32 == 0, "pxr_gemm_h2_f32: an x-contiguous B needs N %% 32 == 0");
   PXR_REQUIRE(a_panel_rows % 16 == 0 && b_panel_rows % 16 == 0 && a_plane_stride % 8 == 0 && b_plane_stride % 8 == 0,
               "pxr_gemm_h2_f32: panel rows must be multiples of 16, plane strides of 8 elements");
-  PXR_REQUIRE(a_panel_rows >= M && b_panel_rows >= N && a_plane_stride >= a_panel_rows * K && b_plane_stride >= b_panel_rows * K,
+  PXR_REQUIRE(a_panel_rows >= M && a_plane_stride >= a_panel_rows * K &&
+                  (b_kc ? (b_panel_rows >= N && b_plane_stride >= b_panel_rows * K) : (b_panel_rows >= K && b_plane_stride >= b_panel_rows * N)),
               "pxr_gemm_h2_f32: operand planes smaller than the matrices");
   PXR_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)c_planes | (uintptr_t)aux | (uintptr_t)bias) & 15) == 0,
               "pxr_gemm_h2_f32: operands must be 16-byte aligned");
   PXR_REQUIRE(a_plane_stride * 4 < 0x7FFFFFF0ll && b_plane_stride * 4 < 0x7FFFFFF0ll, "pxr_gemm_h2_f32: an operand's two planes must span less than 2 GiB");
   PXR_REQUIRE(!c_planes || (N % 32 == 0 && c_panel_rows % 16 == 0 && c_panel_rows >= M), "pxr_gemm_h2_f32: output planes need N %% 32 == 0");
   PXR_REQUIRE(c_fmt == PXR_PLANES_BF16X3 || c_fmt == PXR_PLANES_H2, "pxr_gemm_h2_f32: c_fmt");
+  PXR_REQUIRE(!c_exp_dev || (c_planes && c_fmt == PXR_PLANES_H2), "pxr_gemm_h2_f32: an output exponent needs h2 output planes");
   PXR_REQUIRE(a_exp >= -60 && a_exp <= 60 && b_exp >= -60 && b_exp <= 60, "pxr_gemm_h2_f32: scale exponents");
-  PXR_REQUIRE(aux || !(epilogue == EPI_BIAS_ADD || epilogue == EPI_BIAS_GELU), "pxr_gemm_h2_f32: epilogue %d reads / writes aux", epilogue);
-  PXR_REQUIRE(bias || epilogue == EPI_NONE, "pxr_gemm_h2_f32: epilogue %d needs a bias", epilogue);
+  PXR_REQUIRE(aux || !(epilogue == EPI_BIAS_ADD || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_QGELU_GRAD || epilogue == EPI_ADD ||
+                       epilogue == EPI_MUL), "pxr_gemm_h2_f32: epilogue %d reads / writes aux", epilogue);
+  PXR_REQUIRE(bias || !b_kc || epilogue == EPI_NONE, "pxr_gemm_h2_f32: epilogue %d needs a bias", epilogue);
   if (M == 0 || N == 0) return PXR_OK;
   P3Args g;
   g.A = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(A)), a_plane_stride, a_panel_rows};
   g.B = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(B)), b_plane_stride, b_panel_rows};
   g.Cp = P3Mat{reinterpret_cast<__bf16*>(c_planes), c_plane_stride, c_panel_rows};
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.act = act;
-  g.acc_scale = ldexpf(1.0f, -(a_exp + b_exp));
+  g.a_exp = a_exp; g.b_exp = b_exp; g.a_exp_dev = a_exp_dev; g.b_exp_dev = b_exp_dev; g.c_exp_dev = c_exp_dev;
   g.cp_fmt = c_fmt;
   g.status = pxr_status_word();
   hipStream_t st = (hipStream_t)stream;
@@ -613,9 +659,9 @@ extern "C" int pxr_gemm_h2_f32(int M, int N, int K, const void* A, int64_t a_pla
     static const int env_sq = getenv("PXR_H2_SQUARE") ? atoi(getenv("PXR_H2_SQUARE")) : 1;
     tile_hint = (env_sq && N >= 256 && 7 * ((t256 + 255) / 256) <= 4 * ((t128 + 255) / 256)) ? 225625641 : 225612842;
   }
-  if (tile_hint == 225625641) return epi_h2<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>>(epilogue, g, st);
-  if (tile_hint == 225612842) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>>(epilogue, g, st);
-  if (tile_hint == 225612841) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 1, 0, 2, true>>(epilogue, g, st);
+  if (tile_hint == 225625641) return epi_h2<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>>(b_kc, epilogue, g, st);
+  if (tile_hint == 225612842) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>>(b_kc, epilogue, g, st);
+  if (tile_hint == 225612841) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 1, 0, 2, true>>(b_kc, epilogue, g, st);
   pxr_set_error("pxr_gemm_h2_f32: tile %d is not instantiated", tile_hint);
   return PXR_ERR_BAD_ARG;
 }
@@ -643,7 +689,7 @@ extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A,
   g.B = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(B)), b_plane_stride, b_panel_rows};
   g.Cp = P3Mat{reinterpret_cast<__bf16*>(c_planes), c_plane_stride, c_panel_rows};
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.act = act;
-  g.acc_scale = 1.0f; g.cp_fmt = PXR_PLANES_BF16X3; g.status = nullptr;
+  g.a_exp = g.b_exp = 0; g.a_exp_dev = g.b_exp_dev = g.c_exp_dev = nullptr; g.cp_fmt = PXR_PLANES_BF16X3; g.status = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // tile_hint digits: waves | BM (3) | BN (3) | stages | early fragment reads.  Heuristic (tools/p3_sweep.py on MI355X):
   // 256x128 tiles when they fill the chip more than twice; at M = B*L ~ 3200 tokens 128x64 (two workgroups per CU) for wide
@@ -680,6 +726,44 @@ extern "C" int pxr_gemm_planes_f32(int b_kc, int M, int N, int K, const void* A,
   if (tile_hint == 425612832) return epi_p3<P4Cfg<256, 128, 4, 2, 3, 2>, false>(b_kc, epilogue, g, st);
   if (tile_hint == 425625631) return epi_p3<P4Cfg<256, 256, 4, 2, 3, 1>, false>(b_kc, epilogue, g, st);
   pxr_set_error("pxr_gemm_planes_f32: tile %d is not instantiated", tile_hint);
+  return PXR_ERR_BAD_ARG;
+}
+
+// The same from fp16 two-plane operands (planes.cuh "h2"): dW = 2^-(dy_exp + x_exp) dY~^T X~, three products per multiply.  The
+// exponents of problem i are dy_exp[i] / x_exp[i], or *dy_exp_dev[i] / *x_exp_dev[i] where that pointer is not null.
+extern "C" int pxr_grouped_dw_h2_f32(int n, const void* const* dy, const int64_t* dy_plane_stride, const int64_t* dy_panel_rows,
+                                     const int* dy_exp, const int* const* dy_exp_dev, const void* const* x,
+                                     const int64_t* x_plane_stride, const int64_t* x_panel_rows, const int* x_exp,
+                                     const int* const* x_exp_dev, float* const* dW, float* const* db, const int* T, const int* N,
+                                     const int* K, int tile_hint, void* stream) {
+  PXR_REQUIRE(n >= 1 && n <= DW_MAX && dy && x && dW && db && T && N && K && dy_plane_stride && dy_panel_rows && x_plane_stride &&
+                  x_panel_rows && dy_exp && x_exp && dy_exp_dev && x_exp_dev, "pxr_grouped_dw_h2_f32: bad args (n=%d, max %d)", n, DW_MAX);
+  P3DwGroup g{};
+  g.n = n;
+  int64_t t256 = 0;
+  int t_min = T[0];
+  for (int i = 0; i < n; ++i) {
+    PXR_REQUIRE(dy[i] && x[i] && dW[i] && T[i] > 0 && N[i] > 0 && K[i] > 0 && N[i] % 32 == 0 && K[i] % 32 == 0,
+                "pxr_grouped_dw_h2_f32: problem %d has a bad shape (N and K must be multiples of 32)", i);
+    PXR_REQUIRE(dy_panel_rows[i] % 32 == 0 && x_panel_rows[i] % 32 == 0 && dy_panel_rows[i] >= T[i] && x_panel_rows[i] >= T[i],
+                "pxr_grouped_dw_h2_f32: problem %d: panel rows must be multiples of 32 >= T", i);
+    PXR_REQUIRE((((uintptr_t)dy[i] | (uintptr_t)x[i] | (uintptr_t)dW[i]) & 15) == 0, "pxr_grouped_dw_h2_f32: unaligned operand");
+    PXR_REQUIRE(dy_plane_stride[i] * 4 < 0x7FFFFFF0ll && x_plane_stride[i] * 4 < 0x7FFFFFF0ll, "pxr_grouped_dw_h2_f32: planes too large");
+    PXR_REQUIRE(dy_exp[i] >= -60 && dy_exp[i] <= 60 && x_exp[i] >= -60 && x_exp[i] <= 60, "pxr_grouped_dw_h2_f32: scale exponents");
+    P3DwProblem& P = g.p[i];
+    P.dy = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(dy[i])), dy_plane_stride[i], dy_panel_rows[i]};
+    P.x = P3Mat{reinterpret_cast<__bf16*>(const_cast<void*>(x[i])), x_plane_stride[i], x_panel_rows[i]};
+    P.dW = dW[i]; P.db = db[i]; P.T = T[i]; P.N = N[i]; P.K = K[i];
+    P.dy_exp = dy_exp[i]; P.x_exp = x_exp[i]; P.dy_exp_dev = dy_exp_dev[i]; P.x_exp_dev = x_exp_dev[i];
+    t256 += (int64_t)((N[i] + 255) / 256) * ((K[i] + 127) / 128);
+    t_min = T[i] < t_min ? T[i] : t_min;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  static const int env_splitk = getenv("PXR_DW_SPLITK") ? atoi(getenv("PXR_DW_SPLITK")) : 1;
+  if (tile_hint == 0) tile_hint = (env_splitk && t256 >= 64 && t256 <= 128 && t_min >= 2048) ? 225612822 : 225612842;
+  if (tile_hint == 225612842) return launch_dw_p3<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>, false>(g, st);
+  if (tile_hint == 225612822) return launch_dw_p3<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>, false, 2>(g, st);
+  pxr_set_error("pxr_grouped_dw_h2_f32: tile %d is not instantiated", tile_hint);
   return PXR_ERR_BAD_ARG;
 }
 

@@ -384,7 +384,16 @@ __device__ __forceinline__ void gemm_p4_mainloop(typename Cfg::Acc& acc_out, con
       } else {
         p4_mfma<Cfg, false>(f, accs, accm, accl, P4NoHook());
       }
-      if constexpr (ONES) {
+      if constexpr (ONES && Cfg::HALF) {
+        p3_f16x8 ones_h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones_h[e] = (_Float16)1.0f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            ones_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(p3_f16x8, f.a[i][p]), ones_h, ones_acc[i], 0, 0, 0);
+      } else if constexpr (ONES) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll

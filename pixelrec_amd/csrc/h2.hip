@@ -1,0 +1,163 @@
+// h2.hip -- producers of the TWO-plane fp16 operand format (planes.cuh "h2") whose power-of-two scale is chosen ON THE DEVICE:
+// tensors that change every step (the gradients of a backward pass, the weights of trainable blocks), where a host-side maximum
+// would cost a synchronisation per tensor.
+//
+//   pxr_h2_split_auto_multi_f32   per matrix: max |x| (and, for weights, the largest column sum of |w|) by atomic maxima, then the
+//                                 split with e = 14 - ceil(log2 max): max |x| 2^e in [2^13, 2^14); e and the statistics stay in
+//                                 device memory, the GEMMs read e from there (pxr_gemm_h2_f32 / pxr_grouped_dw_h2_f32 *_exp_dev)
+//   pxr_h2_bound_exp              the exponent of a tensor that is written as planes BEFORE its maximum can be known (an input
+//                                 gradient leaving a GEMM epilogue): from the rigorous bound
+//                                     |sum_k dy[t,k] w[k,j] f| <= max |dy| * max_j sum_k |w[k,j]| * max |f|
+//                                 e = 15 - ceil(log2 bound): no overflow whatever the data; the bound is loose by the usual
+//                                 sqrt(K)-vs-K factor (2^5 .. 2^6 for the tower), which costs that many of fp16's 30 binades of
+//                                 headroom below 2^15, not accuracy of the values that matter (see DESIGN.md "fp16 two-plane")
+#include "gemm_p3.cuh"
+
+namespace pxr {
+
+// non-negative floats order like their bit patterns: atomicMax on the int view (NaN: larger than everything -> propagates as "huge")
+__device__ __forceinline__ void h2_atomic_max(float* p, float v) { atomicMax(reinterpret_cast<int*>(p), __float_as_int(v)); }
+
+// e with max_abs * 2^e in [2^(top-1), 2^top)
+__device__ __forceinline__ int h2_exp_for(float max_abs, int top) {
+  if (!(max_abs > 0.f) || isinf(max_abs)) return 0;
+  int ex;
+  (void)frexpf(max_abs, &ex);          // max_abs = f 2^ex, f in [0.5, 1)
+  const int e = top - ex;
+  return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+
+// stat[0] = max |x|   (four independent 16-byte loads in flight per thread: the tensors are hundreds of MB)
+__global__ void __launch_bounds__(256) h2_max_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols4, float* stat) {
+  const int64_t n = rows * cols4, stride = (int64_t)gridDim.x * 256;
+  float m = 0.f;
+  bool bad = false;
+  auto take = [&](const float4& v) {
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+  };
+  auto at = [&](int64_t i) { return *reinterpret_cast<const float4*>(x + (i / cols4) * ldx + (i % cols4) * 4); };
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const float4 a = at(i), b = at(i + stride), c = at(i + 2 * stride), d = at(i + 3 * stride);
+    take(a); take(b); take(c); take(d);
+  }
+  for (; i < n; i += stride) take(at(i));
+  if (bad) m = __int_as_float(0x7f800000);       // NaN -> inf
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) h2_atomic_max(stat, m);
+}
+// stat[0] = max |w|, stat[1] = max over columns j of sum_k |w[k][j]|   (w [rows][cols]).  A workgroup owns 32 columns: 8 row lanes x
+// 32 columns of threads walk the rows (128-byte coalesced segments), the 8 partial sums of a column are added in a fixed order
+// (deterministic: the exponent derived from the bound must not depend on the launch)
+__global__ void __launch_bounds__(256) h2_colstat_kernel(const float* __restrict__ w, int64_t ldw, int rows, int cols, float* stat) {
+  __shared__ float ps[8][33], pm[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cx;
+  float m = 0.f, s0 = 0.f, s1 = 0.f;
+  bool bad = false;
+  if (j < cols) {
+    int k = ry;
+    for (; k + 8 < rows; k += 16) {
+      const float a = fabsf(w[(int64_t)k * ldw + j]), b = fabsf(w[(int64_t)(k + 8) * ldw + j]);
+      m = fmaxf(m, fmaxf(a, b)); s0 += a; s1 += b;
+      bad |= (a != a) | (b != b);
+    }
+    if (k < rows) {
+      const float a = fabsf(w[(int64_t)k * ldw + j]);
+      m = fmaxf(m, a); s0 += a;
+      bad |= (a != a);
+    }
+  }
+  if (bad) { m = __int_as_float(0x7f800000); s0 = m; }
+  ps[ry][cx] = s0 + s1; pm[ry][cx] = m;
+  __syncthreads();
+  if (ry == 0) {
+    float s = 0.f, mm = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s += ps[q][cx]; mm = fmaxf(mm, pm[q][cx]); }
+    if (mm > 0.f) { h2_atomic_max(stat, mm); h2_atomic_max(stat + 1, s); }
+  }
+}
+
+struct H2SplitAuto {
+  const float* x[16]; int64_t ldx[16]; int rows[16], cols8[16]; P3Mat out[16];
+  int64_t begin[17];
+  int n;
+  const float* stats;      // [n][2]
+  int* exps;               // [n]
+  int32_t* status;
+};
+__global__ void __launch_bounds__(256) h2_split_auto_kernel(const H2SplitAuto m) {
+  if (blockIdx.x == 0 && threadIdx.x < m.n) m.exps[threadIdx.x] = h2_exp_for(m.stats[2 * threadIdx.x], 14);
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m.begin[m.n]) return;
+  int pi = 0;
+#pragma unroll 1
+  for (int k = 1; k < m.n; ++k)
+    if (i >= m.begin[k]) pi = k;
+  const float sc = ldexpf(1.0f, h2_exp_for(m.stats[2 * pi], 14));
+  const int64_t li = i - m.begin[pi];
+  const int64_t row = li / m.cols8[pi];
+  const int c = (int)(li % m.cols8[pi]) * 8;
+  const float* src = m.x[pi] + row * m.ldx[pi] + c;
+  const float4 a = *reinterpret_cast<const float4*>(src);
+  const float4 b = *reinterpret_cast<const float4*>(src + 4);
+  const float v[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, b.x * sc, b.y * sc, b.z * sc, b.w * sc};
+  px_store8(m.out[pi], PXR_PLANES_H2, m.status, row, c, v);
+}
+
+__global__ void h2_bound_exp_kernel(const float* a_max, const float* b_colsum, float factor, int* exp_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *exp_out = h2_exp_for(a_max[0] * b_colsum[0] * factor, 15);
+}
+
+}  // namespace pxr
+
+using namespace pxr;
+
+extern "C" int pxr_h2_split_auto_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
+                                           void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows, int col_stats,
+                                           float* stats, int* exps, void* stream) {
+  PXR_REQUIRE(n >= 1 && n <= 16 && x && rows && cols && ldx && planes && plane_stride && panel_rows && stats && exps,
+              "pxr_h2_split_auto_multi_f32: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  H2SplitAuto m{};
+  m.n = n;
+  m.stats = stats; m.exps = exps; m.status = pxr_status_word();
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    PXR_REQUIRE(x[i] && planes[i] && rows[i] > 0 && rows[i] < (1ll << 31) && cols[i] > 0 && cols[i] % 32 == 0 && ldx[i] % 4 == 0 &&
+                    (((uintptr_t)x[i]) & 15) == 0 && p3_mat_ok(planes[i], plane_stride[i], panel_rows[i], rows[i], cols[i]),
+                "pxr_h2_split_auto_multi_f32: matrix %d is bad", i);
+    m.x[i] = x[i]; m.ldx[i] = ldx[i]; m.rows[i] = (int)rows[i]; m.cols8[i] = (int)(cols[i] / 8);
+    m.out[i] = P3Mat{reinterpret_cast<__bf16*>(planes[i]), plane_stride[i], panel_rows[i]};
+    m.begin[i] = total;
+    total += rows[i] * (cols[i] / 8);
+  }
+  m.begin[n] = total;
+  PXR_REQUIRE((total + 255) / 256 < (1ll << 31), "pxr_h2_split_auto_multi_f32: too large");
+  if (hipMemsetAsync(stats, 0, (size_t)n * 2 * sizeof(float), st) != hipSuccess) {
+    (void)hipGetLastError();
+    pxr_set_error("pxr_h2_split_auto_multi_f32: cannot clear the statistics");
+    return PXR_ERR_LAUNCH;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (col_stats) {
+      hipLaunchKernelGGL(h2_colstat_kernel, dim3((unsigned)((cols[i] + 31) / 32)), dim3(256), 0, st, x[i], ldx[i], (int)rows[i], (int)cols[i],
+                         stats + 2 * i);
+    } else {
+      const int64_t work = rows[i] * (cols[i] / 4);
+      const int64_t blocks = (work + 255) / 256;
+      hipLaunchKernelGGL(h2_max_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, x[i], ldx[i], rows[i], (int)(cols[i] / 4),
+                         stats + 2 * i);
+    }
+  }
+  hipLaunchKernelGGL(h2_split_auto_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, m);
+  return pxr_check_launch("pxr_h2_split_auto_multi_f32");
+}
+
+extern "C" int pxr_h2_bound_exp(const float* a_max, const float* b_colsum, float factor, int* exp_out, void* stream) {
+  PXR_REQUIRE(a_max && b_colsum && exp_out && factor > 0.f, "pxr_h2_bound_exp: bad args");
+  hipLaunchKernelGGL(h2_bound_exp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a_max, b_colsum, factor, exp_out);
+  return pxr_check_launch("pxr_h2_bound_exp");
+}

@@ -154,13 +154,18 @@ class NativeTower:
         return (os.environ.get("PXR_PLANES", "1") != "0" and ops.gemm_mode() == "bf16x3" and H % 32 == 0
                 and self.view(f"item_encoder.vision_model.encoder.layers.0.mlp.fc1.weight").shape[0] % 32 == 0)
 
-    def _h2_block(self, i):
+    def _h2_block(self, i, train=False):
         """Whether block i runs on the TWO-plane fp16 operands (csrc/planes.cuh "h2": three MFMAs per multiply instead of six, the
-        same 2^-22-grade accuracy -- profiles/r04/lab/h2_lab_run1.log): the FROZEN blocks, whose weights are split (and their
-        power-of-two scales chosen) once, when the fused attention serves the shape.  PXR_TOWER_H2=0: bf16x3 everywhere."""
+        same 2^-22-grade accuracy -- profiles/r04/lab/h2_lab_run1.log), when the fused attention serves the shape.  Frozen blocks
+        (weights split once, scales chosen on the host): PXR_TOWER_H2 (default on).  Blocks whose weights move (forward AND
+        backward of a training step, `train`; their inference forwards too): PXR_TOWER_H2_TRAIN (default on) -- every scale is
+        then chosen on the device (ops.split_h2_auto / ops.h2_bound_exp)."""
         H, heads, d, T, _ = self._shape()
-        return (os.environ.get("PXR_TOWER_H2", "1") != "0" and i < self.first_trainable_block()
-                and ops.tower_attn_supported(T, d))
+        if not ops.tower_attn_supported(T, d) or os.environ.get("PXR_TOWER_H2", "1") == "0":
+            return False
+        if i < self.first_trainable_block() and not train:
+            return True
+        return os.environ.get("PXR_TOWER_H2_TRAIN", "1") != "0" and os.environ.get("PXR_TOWER_ATTN_BWD", "1") != "0"
 
     def _block_weight_planes(self, i, h2=False):
         """(qkv, out_proj, fc1, fc2) planes of block i: one split launch; kept for frozen blocks (ensure_packed /
@@ -169,9 +174,13 @@ class NativeTower:
         if wp is None:
             vm = "item_encoder.vision_model."
             P = lambda s_, **kw: self.view(f"{vm}encoder.layers.{i}.{s_}", **kw)
-            wp = ops.split_planes_multi([P("self_attn.k_proj.weight", span=3), P("self_attn.out_proj.weight"),
-                                         P("mlp.fc1.weight"), P("mlp.fc2.weight")], h2=h2)
-            if i < self.first_trainable_block():
+            mats = [P("self_attn.k_proj.weight", span=3), P("self_attn.out_proj.weight"), P("mlp.fc1.weight"), P("mlp.fc2.weight")]
+            frozen = i < self.first_trainable_block()
+            if h2 and not frozen:
+                wp = ops.split_h2_auto(mats, col_stats=True)      # scales on the device: no host synchronisation per step
+            else:
+                wp = ops.split_planes_multi(mats, h2=h2)
+            if frozen:
                 self._wplanes[(i, h2)] = wp      # only FROZEN blocks are cached: a trainable block's weights move every step
         return wp
 
@@ -192,7 +201,7 @@ class NativeTower:
         H, heads, d, T, _ = self._shape()
         n = x.shape[0]
         M = n * T
-        h2 = (not keep) and self._h2_block(i)
+        h2 = self._h2_block(i, train=keep)
         pf = "h2" if h2 else True          # format of the activation planes this block's producers write
         Wqkv, Wo, W1, W2 = W = self._block_weight_planes(i, h2)
         _, xh1, rs1, h1p = ops.ln_residual_fwd(x, None, P("layer_norm1.weight"), P("layer_norm1.bias"), 1e-5, save=keep, planes=pf, want_y=False)
@@ -216,7 +225,7 @@ class NativeTower:
         ops.gemm_planes(h2p, W1, None, ops.EPI_BIAS_QGELU_GRAD if keep else ops.EPI_BIAS_QGELU, bias=P("mlp.fc1.bias"), aux=gq, Cp=fp)
         x3 = torch.empty_like(x)
         ops.gemm_planes(fp, W2, x3.view(M, H), ops.EPI_BIAS_ADD, bias=P("mlp.fc2.bias"), aux=x2.view(M, H))
-        saved = dict(planes=True, W=W, xh1=xh1, rs1=rs1, h1p=h1p, qkv=qkv, P=S, ctx=ctx, lse=lse, ctxp=ctxp, xh2=xh2, rs2=rs2,
+        saved = dict(planes=True, h2=h2, W=W, xh1=xh1, rs1=rs1, h1p=h1p, qkv=qkv, P=S, ctx=ctx, lse=lse, ctxp=ctxp, xh2=xh2, rs2=rs2,
                      h2p=h2p, gq=gq, fp=fp) if keep else None
         return x3, saved
 
@@ -233,15 +242,18 @@ class NativeTower:
         ld, Tp, bh = 3 * H, (T + 3) & ~3, n * heads
         Wqkv, Wo, W1, W2 = s["W"]
         lead = (n, T)
-        dx3p = ops.split_planes(dx3.view(M, H))
+        # fp16 two-plane operands (s["h2"]): each gradient is split with a scale found on the device; the one that leaves a GEMM
+        # epilogue as planes (du) takes its scale from the bound |dx3 W2| * max |quick_gelu'| (= 1.0998)
+        split = (lambda t: ops.split_h2_auto([t])[0]) if s.get("h2") else ops.split_planes
+        dx3p = split(dx3.view(M, H))
         pend = [(dx3p, s["fp"], G("mlp.fc2.weight"), G("mlp.fc2.bias"))]
-        _, dup = ops.linear_bwd_input_planes(dx3p, W2, mul=s["gq"], want_fp32=False, want_planes=True)   # x quick_gelu'
+        _, dup = ops.linear_bwd_input_planes(dx3p, W2, mul=s["gq"], want_fp32=False, want_planes=True, mul_bound=1.1)   # x quick_gelu'
         pend.append((dup, s["h2p"], G("mlp.fc1.weight"), G("mlp.fc1.bias")))
         dh2, _ = ops.linear_bwd_input_planes(dup, W1, lead_shape=lead)
         dz2, _ = ops.ln_bwd(0, dh2, s["xh2"], s["rs2"], P("layer_norm2.weight"), G("layer_norm2.weight"),
                             G("layer_norm2.bias"), defer=defer)
         dx2 = ops.add(dx3, dz2)
-        dx2p = ops.split_planes(dx2.view(M, H))
+        dx2p = split(dx2.view(M, H))
         pend.append((dx2p, s["ctxp"], G("self_attn.out_proj.weight"), G("self_attn.out_proj.bias")))
         dctx, _ = ops.linear_bwd_input_planes(dx2p, Wo, lead_shape=lead)
         if s["P"] is None:          # the forward ran the fused attention: so does the backward
@@ -249,7 +261,7 @@ class NativeTower:
                                       2 * H, 0, H, d ** -0.5).view(n, T, ld)
         else:
             dqkv = self._attn_bwd(s["qkv"], s["P"], dctx, n, T, heads, d)
-        dqkvp = ops.split_planes(dqkv.view(M, ld))
+        dqkvp = split(dqkv.view(M, ld))
         pend.append((dqkvp, s["h1p"], G("self_attn.k_proj.weight", span=3), G("self_attn.k_proj.bias", span=3)))
         dh1, _ = ops.linear_bwd_input_planes(dqkvp, Wqkv, lead_shape=lead)
         dz1, _ = ops.ln_bwd(0, dh1, s["xh1"], s["rs1"], P("layer_norm1.weight"), G("layer_norm1.weight"),

@@ -167,10 +167,13 @@ class Planes:
     gemm_planes.  fmt 0: three bf16 planes (x = hi + mid + lo exactly); fmt 1 ("h2"): two fp16 planes of x * 2^exp (22 significant
     bits; the forward-only blocks of the image tower).  `buf` is a flat 2-byte-element tensor; `off` / `pr` / `ps` are the element
     offset of plane 0, the rows per panel and the plane stride, so row / column ranges are views of the same buffer."""
-    __slots__ = ("buf", "rows", "cols", "pr", "ps", "off", "fmt", "exp")
+    __slots__ = ("buf", "rows", "cols", "pr", "ps", "off", "fmt", "exp", "exp_dev", "stats")
 
-    def __init__(self, buf, rows, cols, pr, ps, off=0, fmt=0, exp=0):
+    def __init__(self, buf, rows, cols, pr, ps, off=0, fmt=0, exp=0, exp_dev=None, stats=None):
         self.buf, self.rows, self.cols, self.pr, self.ps, self.off, self.fmt, self.exp = buf, rows, cols, pr, ps, off, fmt, exp
+        # fmt 1 with a scale chosen on the device (split_h2_auto / a bound): int32 [1] holding the exponent (then `exp` is unused)
+        # and float32 [2] = (max |x|, for weights the largest column sum of |x|)
+        self.exp_dev, self.stats = exp_dev, stats
 
     @staticmethod
     def alloc(rows: int, cols: int, device, fmt: int = 0) -> "Planes":
@@ -190,11 +193,12 @@ class Planes:
 
     def row_range(self, r0: int, r1: int) -> "Planes":
         assert r0 % 16 == 0 and r0 <= r1 <= self.rows
-        return Planes(self.buf, r1 - r0, self.cols, self.pr, self.ps, self.off + 32 * r0, self.fmt, self.exp)
+        return Planes(self.buf, r1 - r0, self.cols, self.pr, self.ps, self.off + 32 * r0, self.fmt, self.exp, self.exp_dev, self.stats)
 
     def col_range(self, c0: int, c1: int) -> "Planes":
         assert c0 % 32 == 0 and c1 % 32 == 0 and c0 <= c1 <= self.cols
-        return Planes(self.buf, self.rows, c1 - c0, self.pr, self.ps, self.off + (c0 // 32) * self.pr * 32, self.fmt, self.exp)
+        return Planes(self.buf, self.rows, c1 - c0, self.pr, self.ps, self.off + (c0 // 32) * self.pr * 32, self.fmt, self.exp,
+                      self.exp_dev, self.stats)
 
     def to_dense(self) -> torch.Tensor:
         """fp32 [rows, cols] = the sum of the planes (exact for fmt 0; x rounded to 22 bits for fmt 1).  For tests; not on the
@@ -207,7 +211,9 @@ class Planes:
         for q in range(2 if self.fmt else 3):
             t = self.buf[(idx + q * self.ps).reshape(-1)].view(self.rows, self.cols).float()
             out = t if out is None else out + t
-        return out * (2.0 ** -self.exp) if self.fmt else out
+        if self.fmt:
+            out = out * (2.0 ** -(int(self.exp_dev.item()) if self.exp_dev is not None else self.exp))
+        return out
 
 
 def split_planes(x: torch.Tensor, out: Planes | None = None) -> Planes:
@@ -231,15 +237,17 @@ def gemm_planes(Ap: Planes, Bp: Planes, C: torch.Tensor | None, epilogue=EPI_NON
     assert (Bp.cols if b_kc else Bp.rows) == K
     assert C is None or C.shape == (M, N)
     if Ap.fmt or Bp.fmt:
-        # two fp16 planes per operand, three products per multiply (pxr_gemm_h2_f32; forward flavours only)
-        if not (Ap.fmt and Bp.fmt and b_kc):
-            raise _l.PxrError("gemm_planes: fp16 two-plane operands need BOTH operands in that format and a k-contiguous B")
+        # two fp16 planes per operand, three products per multiply (pxr_gemm_h2_f32)
+        if not (Ap.fmt and Bp.fmt):
+            raise _l.PxrError("gemm_planes: fp16 two-plane operands need BOTH operands in that format")
         device_status(Ap.buf.device)      # the producers' fp16 range check reports through the status word
         with _gemm_timer(2.0 * M * N * K, "gemm_p3_kernel<P4Cfg<..., HALF>> (fp16 two-plane operands, 3 products)"):
-            _l.check(_l.load().pxr_gemm_h2_f32(M, N, K, Ap.ptr(), Ap.ps, Ap.pr, Ap.exp, Bp.ptr(), Bp.ps, Bp.pr, Bp.exp, _l.ptr(C),
-                                               C.stride(0) if C is not None else 0, epilogue, _l.ptr(bias), _l.ptr(aux),
-                                               aux.stride(0) if aux is not None else 0, *_pl(Cp),
-                                               Cp.fmt if Cp is not None else 0, act, tile_hint, _l.stream_ptr()), "pxr_gemm_h2_f32")
+            _l.check(_l.load().pxr_gemm_h2_f32(int(b_kc), M, N, K, Ap.ptr(), Ap.ps, Ap.pr, Ap.exp, _l.ptr(Ap.exp_dev), Bp.ptr(), Bp.ps,
+                                               Bp.pr, Bp.exp, _l.ptr(Bp.exp_dev), _l.ptr(C), C.stride(0) if C is not None else 0,
+                                               epilogue, _l.ptr(bias), _l.ptr(aux), aux.stride(0) if aux is not None else 0, *_pl(Cp),
+                                               Cp.fmt if Cp is not None else 0,
+                                               _l.ptr(Cp.exp_dev) if (Cp is not None and Cp.fmt) else None, act, tile_hint,
+                                               _l.stream_ptr()), "pxr_gemm_h2_f32")
         return C
     assert Cp is None or Cp.fmt == 0, "the bf16x3 GEMMs write bf16x3 planes"
     with _gemm_timer(2.0 * M * N * K):
@@ -528,6 +536,43 @@ def h2_exponent(max_abs: float) -> int:
     return max(-60, min(60, 14 - math.frexp(max_abs)[1]))
 
 
+def split_h2_auto(mats, col_stats: bool = False):
+    """fp32 matrices -> h2 Planes whose power-of-two scales are chosen ON THE DEVICE (pxr_h2_split_auto_multi_f32): no host
+    synchronisation -- gradients, weights that an optimizer step just moved.  Each result carries `exp_dev` (int32 [1]) and
+    `stats` (float32 [2]: max |x|; with col_stats also the largest column sum of |x|, what h2_bound_exp needs of a weight)."""
+    outs = []
+    for lo in range(0, len(mats), MULTI_MAX):
+        ms = mats[lo:lo + MULTI_MAX]
+        n = len(ms)
+        for m in ms:
+            assert m.dim() == 2 and m.stride(1) == 1 and m.dtype == torch.float32
+        dev = ms[0].device
+        device_status(dev)
+        os_ = [Planes.alloc(m.shape[0], m.shape[1], dev, fmt=1) for m in ms]
+        stats = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        exps = torch.empty(n, dtype=torch.int32, device=dev)
+        P, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+        _l.check(_l.load().pxr_h2_split_auto_multi_f32(
+            n, P(*[m.data_ptr() for m in ms]), I64(*[m.shape[0] for m in ms]), I64(*[m.shape[1] for m in ms]),
+            I64(*[m.stride(0) for m in ms]), P(*[o.ptr().value for o in os_]), I64(*[o.ps for o in os_]), I64(*[o.pr for o in os_]),
+            int(col_stats), _l.ptr(stats), _l.ptr(exps), _l.stream_ptr()), "pxr_h2_split_auto_multi_f32")
+        for i, o in enumerate(os_):
+            o.exp_dev, o.stats = exps[i:i + 1], stats[i]
+        outs += os_
+    return outs
+
+
+def h2_bound_exp(dy: Planes, W: Planes, factor: float = 1.0) -> torch.Tensor:
+    """int32 [1] on the device: the exponent e with |dy W| * factor * 2^e < 2^15 for EVERY element, from max |dy| and the largest
+    column sum of |W| (both gathered by split_h2_auto) -- for an input gradient a GEMM epilogue writes as planes before its own
+    maximum can be known (pxr_h2_bound_exp)."""
+    assert dy.stats is not None and W.stats is not None
+    out = torch.empty(1, dtype=torch.int32, device=dy.buf.device)
+    _l.check(_l.load().pxr_h2_bound_exp(_l.ptr(dy.stats), ctypes.c_void_p(W.stats.data_ptr() + 4), float(factor), _l.ptr(out),
+                                        _l.stream_ptr()), "pxr_h2_bound_exp")
+    return out
+
+
 def split_planes_multi(mats, outs=None, h2: bool = False):
     """Several fp32 matrices -> Planes in ONE launch (pxr_split_planes_multi_f32); `outs`: existing Planes to overwrite.
     h2=True: the two-plane fp16 format, each matrix scaled by its own power of two (h2_exponent of its max |x|: ONE host
@@ -590,16 +635,26 @@ def linear_fwd_planes(xp: Planes, Wp: Planes, b, gelu: bool = False, save_grad: 
 
 
 def linear_bwd_input_planes(dyp: Planes, Wp: Planes, add: torch.Tensor | None = None, mul: torch.Tensor | None = None,
-                            want_fp32: bool = True, want_planes: bool = False, lead_shape=None):
-    """linear_bwd_input from planes: dx = dy W (dyp [M,N], Wp [N,K]) (+ add | * mul).  Returns (dx | None, dx Planes | None)."""
+                            want_fp32: bool = True, want_planes: bool = False, lead_shape=None, mul_bound: float = 1.0):
+    """linear_bwd_input from planes: dx = dy W (dyp [M,N], Wp [N,K]) (+ add | * mul).  Returns (dx | None, dx Planes | None).
+    h2 operands (both from split_h2_auto): `mul_bound` >= max |mul| enters the bound that fixes the output planes' scale."""
     M, N, K = dyp.rows, dyp.cols, Wp.cols
     assert Wp.rows == N
     dev = dyp.buf.device
     shape = tuple(lead_shape) + (K,) if lead_shape is not None else (M, K)
     dx = torch.empty(shape, dtype=torch.float32, device=dev) if want_fp32 else None
-    dxp = Planes.alloc(M, K, dev) if want_planes else None
     aux = mul if mul is not None else add
     epi = EPI_MUL if mul is not None else (EPI_ADD if add is not None else EPI_NONE)
+    if dyp.fmt:
+        # fp16 two-plane operands; the output planes' scale comes from the bound |dy W| * mul_bound (h2_bound_exp)
+        dxp = None
+        if want_planes:
+            dxp = Planes.alloc(M, K, dev, fmt=1)
+            dxp.exp_dev = h2_bound_exp(dyp, Wp, mul_bound)
+        gemm_planes(dyp, Wp, dx.view(M, K) if dx is not None else None, epi, aux=aux.view(M, K) if aux is not None else None, b_kc=False,
+                    Cp=dxp)
+        return dx, dxp
+    dxp = Planes.alloc(M, K, dev) if want_planes else None
     tag = ("gemm_p3_kernel<KC,XC,EPI_MUL> (dX x saved gelu')" if mul is not None else
            "gemm_p3_kernel<KC,XC,EPI_ADD> (dX + residual grad)" if add is not None else "gemm_p3_kernel<KC,XC,EPI_NONE> (dX)")
     with _gemm_timer(2.0 * M * N * K, tag):
@@ -621,6 +676,21 @@ def grouped_dw_planes(problems, tile_hint=0):
     P, I, I64 = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
     for dy, x, _, _ in problems:
         assert dy.rows == x.rows
+    if any(p[0].fmt or p[1].fmt for p in problems):
+        if not all(p[0].fmt and p[1].fmt for p in problems):
+            raise _l.PxrError("grouped_dw_planes: fp16 two-plane operands need every operand of the launch in that format")
+        edev = lambda pl: (pl.exp_dev.data_ptr() if pl.exp_dev is not None else None)
+        flops = sum(2.0 * p[0].rows * p[0].cols * p[1].cols for p in problems)
+        with _gemm_timer(flops, "grouped_dw_p3_kernel<P4Cfg<..., HALF>> (all dW + db of a block, fp16 two-plane operands)"):
+            _l.check(L.pxr_grouped_dw_h2_f32(
+                n, P(*[p[0].ptr().value for p in problems]), I64(*[p[0].ps for p in problems]), I64(*[p[0].pr for p in problems]),
+                I(*[p[0].exp for p in problems]), P(*[edev(p[0]) for p in problems]),
+                P(*[p[1].ptr().value for p in problems]), I64(*[p[1].ps for p in problems]), I64(*[p[1].pr for p in problems]),
+                I(*[p[1].exp for p in problems]), P(*[edev(p[1]) for p in problems]),
+                P(*[p[2].data_ptr() for p in problems]), P(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems]),
+                I(*[p[0].rows for p in problems]), I(*[p[0].cols for p in problems]), I(*[p[1].cols for p in problems]), tile_hint,
+                _l.stream_ptr()), "pxr_grouped_dw_h2_f32")
+        return
     args = (P(*[p[0].ptr().value for p in problems]), I64(*[p[0].ps for p in problems]), I64(*[p[0].pr for p in problems]),
             P(*[p[1].ptr().value for p in problems]), I64(*[p[1].ps for p in problems]), I64(*[p[1].pr for p in problems]),
             P(*[p[2].data_ptr() for p in problems]), P(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems]),

@@ -123,9 +123,11 @@ def test_fp16_range_is_flagged_not_silent():
 
 
 @pytest.mark.parametrize("method", ["mean", "cls"])
-def test_tower_with_frozen_blocks_on_h2(method, monkeypatch):
-    """A 3-block tower with head size 64 (the fused attention serves it): blocks 0-1 frozen -> fp16 planes, block 2 trainable ->
-    bf16x3.  Output and gradients against the torch restatement, and against the same tower with PXR_TOWER_H2=0."""
+def test_tower_on_h2(method, monkeypatch):
+    """A 3-block tower with head size 64 (the fused attention serves it), blocks 0-1 frozen, block 2 trainable: (a) everything on
+    fp16 planes -- the frozen blocks with host-chosen scales, the trainable one (forward, input and weight gradients) with scales
+    chosen on the device; (b) only the frozen blocks; (c) none (bf16x3).  Output and gradients of each against the torch
+    restatement, and of (a) / (b) against (c)."""
     import copy
 
     from pixelrec_amd import ops
@@ -143,34 +145,83 @@ def test_tower_with_frozen_blocks_on_h2(method, monkeypatch):
     tower = enc._native
     tower.ensure_packed()
     assert tower.first_trainable_block() == 2
-    if ops.gemm_mode() == "bf16x3":
-        assert tower._h2_block(0) and tower._h2_block(1) and not tower._h2_block(2)
     x = torch.randn(5, 3, 64, 64)
     w = torch.randn(5, 32)
-    out = enc(x.cuda())
-    (out * w.cuda()).sum().backward()
-    if ops.gemm_mode() == "bf16x3" and tower._planes_on():
-        assert {k[1] for k in tower._wplanes} == {True}              # the frozen blocks' cached weight planes are h2
     towr, pooled = ref.item_encoder(x)
     ref_out = torch.mean(ref.rec_fc(towr), dim=1) if method == "mean" else ref.rec_fc(towr[:, 0, :])
-    assert (out.detach().cpu() - ref_out).abs().max().item() < 2e-5
     (ref_out * w).sum().backward()
     gmax = max(q.grad.abs().max().item() for q in ref.parameters() if q.grad is not None)
-    for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
-        if q.grad is not None:      # (the key bias has a mathematically zero gradient: the floor is relative to the largest one)
-            assert (p.grad.cpu() - q.grad).abs().max().item() <= 3e-4 * max(q.grad.abs().max().item(), 1e-5 * gmax), n
-    g_h2 = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
-    monkeypatch.setenv("PXR_TOWER_H2", "0")
-    tower.drop_weight_planes()
-    out0 = enc(x.cuda())
-    (out0 * w.cuda()).sum().backward()
-    assert (out0 - out).abs().max().item() < 5e-6                    # two roundings of the same fp32 computation
-    for n, p in enc.named_parameters():
-        if p.grad is not None:
-            assert (p.grad - g_h2[n]).abs().max().item() <= 1e-4 * max(float(g_h2[n].abs().max()), 1e-5 * gmax), n
-    ops.raise_on_bad_indices("cuda")
-    with torch.no_grad():                                            # inference: every block is forward-only; the trainable one stays bf16x3
+    results = {}
+    for name, h2, h2t in (("all", "1", "1"), ("frozen", "1", "0"), ("none", "0", "0")):
+        monkeypatch.setenv("PXR_TOWER_H2", h2)
+        monkeypatch.setenv("PXR_TOWER_H2_TRAIN", h2t)
+        tower.drop_weight_planes()
+        if ops.gemm_mode() == "bf16x3":
+            assert tower._h2_block(0) == (h2 == "1") and tower._h2_block(2, train=True) == (h2t == "1")
+        out = enc(x.cuda())
+        (out * w.cuda()).sum().backward()
+        if ops.gemm_mode() == "bf16x3" and tower._planes_on():
+            assert {k[1] for k in tower._wplanes} == {h2 == "1"}     # the frozen blocks' cached weight planes
+        assert (out.detach().cpu() - ref_out).abs().max().item() < 2e-5, name
+        for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+            if q.grad is not None:  # (the key bias has a mathematically zero gradient: the floor is relative to the largest one)
+                assert (p.grad.cpu() - q.grad).abs().max().item() <= 3e-4 * max(q.grad.abs().max().item(), 1e-5 * gmax), (name, n)
+        results[name] = (out.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None})
+        ops.raise_on_bad_indices("cuda")                             # no fp16 range flag
+    for name in ("all", "frozen"):
+        assert (results[name][0] - results["none"][0]).abs().max().item() < 5e-6       # roundings of the same fp32 computation
+        for n, gr in results["none"][1].items():
+            assert (results[name][1][n] - gr).abs().max().item() <= 1e-4 * max(float(gr.abs().max()), 1e-5 * gmax), (name, n)
+    with torch.no_grad():                                            # inference: every block is forward-only
         monkeypatch.setenv("PXR_TOWER_H2", "1")
+        monkeypatch.setenv("PXR_TOWER_H2_TRAIN", "1")
         tower.drop_weight_planes()
         o1 = enc(x.cuda())
         assert (o1.cpu() - ref_out).abs().max().item() < 2e-5
+
+
+def test_device_chosen_scales_and_the_input_gradient_bound():
+    """split_h2_auto: exponent and statistics on the device; the dX GEMM flavours (KC x XC) and the grouped weight gradient on h2
+    operands against fp64; output planes of an input gradient scaled by the bound (never out of range, 22-bit accurate)."""
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    T, N, K = 1500, 256, 128
+    dy = (torch.randn(T, N, generator=g) * 3e-4).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    x = torch.randn(T, K, generator=g).cuda()
+    mul = (torch.rand(T, K, generator=g) * 1.1).cuda()
+    dyp, = ops.split_h2_auto([dy])
+    Wp, = ops.split_h2_auto([W], col_stats=True)
+    xp, = ops.split_h2_auto([x])
+    assert 2 ** 13 <= float(dy.abs().max()) * 2.0 ** int(dyp.exp_dev.item()) < 2 ** 14
+    assert abs(float(dyp.stats[0]) - float(dy.abs().max())) == 0.0
+    assert abs(float(Wp.stats[1]) - float(W.abs().sum(0).max())) <= 1e-5 * float(Wp.stats[1])
+    assert (dyp.to_dense() - dy).abs().max().item() <= 2.0 ** -21 * float(dy.abs().max())
+    ref = dy.double() @ W.double()
+    for epi, aux, r in ((ops.EPI_NONE, None, ref), (ops.EPI_ADD, x, ref + x.double()), (ops.EPI_MUL, mul, ref * mul.double())):
+        dx = torch.full((T, K), float("nan"), device="cuda")
+        ops.gemm_planes(dyp, Wp, dx, epi, aux=aux, b_kc=False)
+        assert (dx.double() - r).abs().max().item() <= 4e-6 * (N ** 0.5) * float(r.abs().max()) + 1e-12, epi
+    dxf, dxp = ops.linear_bwd_input_planes(dyp, Wp, mul=mul, want_fp32=True, want_planes=True, mul_bound=1.1)
+    e = int(dxp.exp_dev.item())
+    assert float(dxf.abs().max()) * 2.0 ** e < 2 ** 15                       # the bound holds ...
+    assert float(dxf.abs().max()) * 2.0 ** e > 2 ** 4                        # ... and is not absurdly loose (K = 256: 2^-11 at worst)
+    assert (dxp.to_dense() - dxf).abs().max().item() <= 2.0 ** -20 * float(dxf.abs().max())
+    # weight gradient dW = dy^T x (+ db) from h2 operands with device exponents, against fp64 and the six-product kernel
+    dW, db = torch.full((N, K), float("nan"), device="cuda"), torch.full((N,), float("nan"), device="cuda")
+    ops.grouped_dw_planes([(dyp, xp, dW, db)])
+    rW, rb = dy.double().t() @ x.double(), dy.double().sum(0)
+    assert (dW.double() - rW).abs().max().item() <= 4e-6 * (T ** 0.5) * float(rW.abs().max())
+    assert (db.double() - rb).abs().max().item() <= 4e-6 * (T ** 0.5) * float(rb.abs().max()) + 1e-12
+    dW6, db6 = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+    ops.grouped_dw_planes([(ops.split_planes(dy), ops.split_planes(x), dW6, db6)])
+    e_h2 = float(((dW.double() - rW).pow(2).mean() / rW.pow(2).mean()).sqrt())
+    e_6 = float(((dW6.double() - rW).pow(2).mean() / rW.pow(2).mean()).sqrt())
+    assert e_h2 < 2.0 ** -20 and e_h2 < 4 * e_6 + 2.0 ** -23, (e_h2, e_6)
+    for tile in (225612842, 225612822):                                      # (the split-K variant: deterministic bits)
+        dW2, db2 = torch.full_like(dW, float("nan")), torch.full_like(db, float("nan"))
+        ops.grouped_dw_planes([(dyp, xp, dW2, db2)], tile_hint=tile)
+        assert (dW2.double() - rW).abs().max().item() <= 4e-6 * (T ** 0.5) * float(rW.abs().max())
+        assert (db2.double() - rb).abs().max().item() <= 4e-6 * (T ** 0.5) * float(rb.abs().max()) + 1e-12
+    ops.raise_on_bad_indices("cuda")
