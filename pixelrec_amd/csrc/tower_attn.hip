@@ -77,7 +77,9 @@ __device__ __forceinline__ void ta_load(TaStage (&st)[(TA_ITEMS + NT - 1) / NT],
   }
 }
 
-template <int NT>
+// H2: the operands are split into TWO fp16 planes (planes.cuh "h2", unit scale: q, k, v are O(1) projections, p <= 1) and multiplied
+// with three products on v_mfma_f32_32x32x16_f16 instead of six on the bf16 pipe -- the blocks whose GEMMs run on h2 operands
+template <int NT, bool H2>
 __device__ __forceinline__ void ta_store(const TaStage (&st)[(TA_ITEMS + NT - 1) / NT], __bf16* sK, __bf16* sV) {
   constexpr int ITER = (TA_ITEMS + NT - 1) / NT;
 #pragma unroll
@@ -89,13 +91,14 @@ __device__ __forceinline__ void ta_store(const TaStage (&st)[(TA_ITEMS + NT - 1)
       p3_u32x4 p[3];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        unsigned h, m, l;
-        p3_split2(v[2 * e], v[2 * e + 1], h, m, l);
+        unsigned h, m, l = 0;
+        if constexpr (H2) h2_split2(v[2 * e], v[2 * e + 1], h, m);
+        else p3_split2(v[2 * e], v[2 * e + 1], h, m, l);
         p[0][e] = h; p[1][e] = m; p[2][e] = l;
       }
       __bf16* dst = sK + key * TA_KLD + c;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<p3_u32x4*>(dst + q * TA_KPLANE) = p[q];
+      for (int q = 0; q < (H2 ? 2 : 3); ++q) *reinterpret_cast<p3_u32x4*>(dst + q * TA_KPLANE) = p[q];
     } else if (item < TA_ITEMS) {
       // keys 4 kg .. 4 kg + 3 of dh c .. c + 3, transposed: per dh one 8-byte run of 4 keys.  Key groups are stored in the
       // order the P^T fragments hold them: inside a 16-key step  [0-3 | 8-11 | 4-7 | 12-15]  (slot group = kg with its two
@@ -107,12 +110,17 @@ __device__ __forceinline__ void ta_store(const TaStage (&st)[(TA_ITEMS + NT - 1)
       const TaStage& t = st[it];
 #define PXR_TA_VROW(i, f)                                                            \
   {                                                                                  \
-    unsigned h0, m0, l0, h1, m1, l1;                                                 \
-    p3_split2(t.r0.f, t.r1.f, h0, m0, l0);                                           \
-    p3_split2(t.r2.f, t.r3.f, h1, m1, l1);                                           \
+    unsigned h0, m0, l0 = 0, h1, m1, l1 = 0;                                         \
+    if constexpr (H2) {                                                              \
+      h2_split2(t.r0.f, t.r1.f, h0, m0);                                             \
+      h2_split2(t.r2.f, t.r3.f, h1, m1);                                             \
+    } else {                                                                         \
+      p3_split2(t.r0.f, t.r1.f, h0, m0, l0);                                         \
+      p3_split2(t.r2.f, t.r3.f, h1, m1, l1);                                         \
+    }                                                                                \
     *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD) = p3_u32x2{h0, h1};             \
     *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD + TA_VPLANE) = p3_u32x2{m0, m1}; \
-    *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD + 2 * TA_VPLANE) = p3_u32x2{l0, l1}; \
+    if constexpr (!H2) *reinterpret_cast<p3_u32x2*>(dst + (i) * TA_VLD + 2 * TA_VPLANE) = p3_u32x2{l0, l1}; \
   }
       PXR_TA_VROW(0, x) PXR_TA_VROW(1, y) PXR_TA_VROW(2, z) PXR_TA_VROW(3, w)
 #undef PXR_TA_VROW
@@ -141,9 +149,28 @@ __device__ __forceinline__ void ta_split8(const float (&v)[8], ta_bf16x8 (&out)[
 #pragma unroll
   for (int q = 0; q < 3; ++q) out[q] = __builtin_bit_cast(ta_bf16x8, p[q]);
 }
+// the fp16 two-plane flavour: (a0 + a1)(b0 + b1) without a1 b1 (2^-22 relative), small terms first; out[2] unused
+__device__ __forceinline__ void ta_mma3h(ta_f32x16& acc, const ta_bf16x8 (&a)[3], const ta_bf16x8 (&b)[3]) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(p3_f16x8, a[1]), __builtin_bit_cast(p3_f16x8, b[0]), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(p3_f16x8, a[0]), __builtin_bit_cast(p3_f16x8, b[1]), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(p3_f16x8, a[0]), __builtin_bit_cast(p3_f16x8, b[0]), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void ta_split8h(const float (&v)[8], ta_bf16x8 (&out)[3]) {
+  p3_u32x4 p[2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned h, l;
+    h2_split2(v[2 * e], v[2 * e + 1], h, l);
+    p[0][e] = h; p[1][e] = l;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) out[q] = __builtin_bit_cast(ta_bf16x8, p[q]);
+  out[2] = out[1];
+}
 
-template <int NW>
+template <int NW, bool H2 = false>
 __global__ void __launch_bounds__(NW * 64) tower_attn_fwd_kernel(TowerAttnArgs a) {
+  constexpr int NP = H2 ? 2 : 3;
   constexpr int NT = NW * 64;
   constexpr int ITER = (TA_ITEMS + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) __bf16 sK[2][3 * TA_KPLANE];
@@ -169,10 +196,11 @@ __global__ void __launch_bounds__(NW * 64) tower_attn_fwd_kernel(TowerAttnArgs a
       ta_f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
       if (ok) { x0 = *reinterpret_cast<const ta_f32x4*>(src + ks * 16); x1 = *reinterpret_cast<const ta_f32x4*>(src + ks * 16 + 4); }
       const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-      ta_split8(v, qf[ks]);
+      if constexpr (H2) ta_split8h(v, qf[ks]);
+      else ta_split8(v, qf[ks]);
     }
   }
-  ta_store<NT>(st, sK[0], sV[0]);
+  ta_store<NT, H2>(st, sK[0], sV[0]);
   __syncthreads();
 
   ta_f32x16 accO[2];
@@ -194,8 +222,9 @@ __global__ void __launch_bounds__(NW * 64) tower_attn_fwd_kernel(TowerAttnArgs a
     for (int ks = 0; ks < 4; ++ks) {
       ta_bf16x8 kf[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) kf[q] = *reinterpret_cast<const ta_bf16x8*>(kb + q * TA_KPLANE + ks * 16);
-      ta_mma6(s, kf, qf[ks]);
+      for (int q = 0; q < NP; ++q) kf[q] = *reinterpret_cast<const ta_bf16x8*>(kb + q * TA_KPLANE + ks * 16);
+      if constexpr (H2) ta_mma3h(s, kf, qf[ks]);
+      else ta_mma6(s, kf, qf[ks]);
     }
     // ---- online softmax of the lane's 16 keys: key(e) = 32 c + (e & 3) + 8 (e >> 2) + 4 hh
     float mx = -INFINITY;
@@ -228,17 +257,19 @@ __global__ void __launch_bounds__(NW * 64) tower_attn_fwd_kernel(TowerAttnArgs a
       const float pv[8] = {s[8 * ks2], s[8 * ks2 + 1], s[8 * ks2 + 2], s[8 * ks2 + 3],
                            s[8 * ks2 + 4], s[8 * ks2 + 5], s[8 * ks2 + 6], s[8 * ks2 + 7]};
       ta_bf16x8 pf[3];
-      ta_split8(pv, pf);
+      if constexpr (H2) ta_split8h(pv, pf);
+      else ta_split8(pv, pf);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         ta_bf16x8 vf[3];
         const __bf16* vb = sV[buf] + (j * 32 + r) * TA_VLD + ks2 * 16 + hh * 8;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) vf[q] = *reinterpret_cast<const ta_bf16x8*>(vb + q * TA_VPLANE);
-        ta_mma6(accO[j], vf, pf);
+        for (int q = 0; q < NP; ++q) vf[q] = *reinterpret_cast<const ta_bf16x8*>(vb + q * TA_VPLANE);
+        if constexpr (H2) ta_mma3h(accO[j], vf, pf);
+        else ta_mma6(accO[j], vf, pf);
       }
     }
-    if (c + 1 < nchunk) ta_store<NT>(st, sK[buf ^ 1], sV[buf ^ 1]);
+    if (c + 1 < nchunk) ta_store<NT, H2>(st, sK[buf ^ 1], sV[buf ^ 1]);
     __syncthreads();
   }
 
@@ -652,8 +683,16 @@ static int tower_attn_fwd_impl(const float* q, const float* k, const float* v, i
   a.scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)(images * heads));
   hipStream_t s = (hipStream_t)stream;
+  // h2 context planes = a block whose GEMMs run on fp16 two-plane operands: so do the two contractions here (PXR_TOWER_ATTN_H2=0:
+  // only the output format changes, the contractions stay on the six bf16 products)
+  static const int env_h2 = getenv("PXR_TOWER_ATTN_H2") ? atoi(getenv("PXR_TOWER_ATTN_H2")) : 1;
+  const bool h2_math = (c_fmt == PXR_PLANES_H2) && env_h2;
   switch ((T + 31) / 32) {
-#define PXR_TA_CASE(NW) case NW: hipLaunchKernelGGL(tower_attn_fwd_kernel<NW>, grid, dim3(NW * 64), 0, s, a); break;
+#define PXR_TA_CASE(NW)                                                                                           \
+  case NW:                                                                                                        \
+    if (h2_math) hipLaunchKernelGGL((tower_attn_fwd_kernel<NW, true>), grid, dim3(NW * 64), 0, s, a);             \
+    else hipLaunchKernelGGL((tower_attn_fwd_kernel<NW, false>), grid, dim3(NW * 64), 0, s, a);                    \
+    break;
     PXR_TA_CASE(1) PXR_TA_CASE(2) PXR_TA_CASE(3) PXR_TA_CASE(4) PXR_TA_CASE(5) PXR_TA_CASE(6) PXR_TA_CASE(7) PXR_TA_CASE(8)
     PXR_TA_CASE(9)
 #undef PXR_TA_CASE
