@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(256) h2_max_kernel(const float* __restrict__ x
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
   };
-  auto at = [&](int64_t i) { return *reinterpret_cast<const float4*>(x + (i / cols4) * ldx + (i % cols4) * 4); };
+  const bool flat = (ldx == (int64_t)cols4 * 4);      // contiguous rows: no 64-bit division per load
+  auto at = [&](int64_t i) { return *reinterpret_cast<const float4*>(flat ? x + i * 4 : x + (i / cols4) * ldx + (i % cols4) * 4); };
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   for (; i + 3 * stride < n; i += 4 * stride) {
     const float4 a = at(i), b = at(i + stride), c = at(i + 2 * stride), d = at(i + 3 * stride);

@@ -193,7 +193,7 @@ class NativeTower:
         else:
             self._wplanes = {}
 
-    def _block_fwd_planes(self, i, x, keep=False):
+    def _block_fwd_planes(self, i, x, keep=False, out_planes=False):
         """One block on the planes GEMMs.  keep=True (a trainable block of a training step) also returns what its backward
         needs -- activations as planes where the weight-gradient / input-gradient GEMMs read them."""
         vm = "item_encoder.vision_model."
@@ -224,7 +224,10 @@ class NativeTower:
         gq = torch.empty(M, W1.rows, dtype=torch.float32, device=x.device) if keep else None
         ops.gemm_planes(h2p, W1, None, ops.EPI_BIAS_QGELU_GRAD if keep else ops.EPI_BIAS_QGELU, bias=P("mlp.fc1.bias"), aux=gq, Cp=fp)
         x3 = torch.empty_like(x)
-        ops.gemm_planes(fp, W2, x3.view(M, H), ops.EPI_BIAS_ADD, bias=P("mlp.fc2.bias"), aux=x2.view(M, H))
+        # out_planes (the LAST block when the head's Linear runs on h2 operands): its output also leaves as h2 planes, unit scale
+        x3p = ops.Planes.alloc(M, H, x.device, fmt=1) if (out_planes and h2) else None
+        ops.gemm_planes(fp, W2, x3.view(M, H), ops.EPI_BIAS_ADD, bias=P("mlp.fc2.bias"), aux=x2.view(M, H), Cp=x3p)
+        self._last_out_planes = x3p
         saved = dict(planes=True, h2=h2, W=W, xh1=xh1, rs1=rs1, h1p=h1p, qkv=qkv, P=S, ctx=ctx, lse=lse, ctxp=ctxp, xh2=xh2, rs2=rs2,
                      h2p=h2p, gq=gq, fp=fp) if keep else None
         return x3, saved
@@ -284,9 +287,10 @@ class NativeTower:
         ops.gemm_batched(False, False, T, d, T, dP, 0, Tp, qkv, 2 * H, ld, dqkv, 0, ld, bh, heads, sP, sQ, sQ)  # dK = dS^T Q
         return dqkv
 
-    def _block_fwd(self, i, x, keep):
+    def _block_fwd(self, i, x, keep, out_planes=False):
+        self._last_out_planes = None
         if self._planes_on() and (not keep or os.environ.get("PXR_TOWER_TRAIN_PLANES", "1") != "0"):
-            return self._block_fwd_planes(i, x, keep)
+            return self._block_fwd_planes(i, x, keep, out_planes)
         vm = "item_encoder.vision_model."
         P = lambda s, **kw: self.view(f"{vm}encoder.layers.{i}.{s}", **kw)
         H, heads, d, T, _ = self._shape()
@@ -321,11 +325,18 @@ class NativeTower:
                                           1e-5, save=keep0)
         n_layers = len(e.item_encoder.vision_model.encoder.layers)
         blocks = []
-        for i in range(n_layers):
-            x, s = self._block_fwd(i, x, keep=need_grad and i >= first)
-            blocks.append(s)
-        # head: rec_fc (Linear + activation) on every token then the token mean, or on the class token only
         act_relu = isinstance(e.rec_fc[1], torch.nn.ReLU)
+        # opt-in (PXR_TOWER_H2_HEAD=1): the head's Linear over every token (method 'mean') on fp16 two-plane operands too -- the last
+        # block writes its output as planes, the weight is split with a device-chosen scale.  Measured on MI355X (ViT-B/16, 69 344
+        # tokens): 65.5 -> 66.2 ms per step -- the statistics pass over the head's gradient costs more than three products save on a
+        # 768 x 512 weight; off by default.
+        head_h2 = (e.native_method == "mean" and act_relu and os.environ.get("PXR_TOWER_H2_HEAD", "0") == "1"
+                   and self.view("rec_fc.0.weight").shape[0] % 32 == 0)
+        for i in range(n_layers):
+            x, s = self._block_fwd(i, x, keep=need_grad and i >= first, out_planes=head_h2 and i == n_layers - 1)
+            blocks.append(s)
+        xp_last = getattr(self, "_last_out_planes", None) if n_layers else None
+        # head: rec_fc (Linear + activation) on every token then the token mean, or on the class token only
         if not act_relu and not isinstance(e.rec_fc[1], torch.nn.Identity):
             raise NotImplementedError("native image encoder: rec_fc activation must be relu or none (overall/ViT.yaml: relu)")
         W, b = self.view("rec_fc.0.weight"), self.view("rec_fc.0.bias")
@@ -335,12 +346,18 @@ class NativeTower:
             y_p, xh_p, rs_p = ops.ln_residual_fwd(head_in.view(n, 1, -1), None, self.view(vm + "post_layernorm.weight"),
                                                   self.view(vm + "post_layernorm.bias"), 1e-5, save=need_grad)
             head_in = y_p.view(n, -1)
-        act = ops.linear_epi(head_in, W, b, ops.EPI_BIAS_RELU) if act_relu else ops.linear_fwd(head_in, W, b)
+        Wp = None
+        if xp_last is not None:
+            Wp, = ops.split_h2_auto([W], col_stats=True)
+            act = torch.empty(n, T, W.shape[0], dtype=torch.float32, device=x.device)
+            ops.gemm_planes(xp_last, Wp, act.view(n * T, -1), ops.EPI_BIAS_RELU, bias=b)
+        else:
+            act = ops.linear_epi(head_in, W, b, ops.EPI_BIAS_RELU) if act_relu else ops.linear_fwd(head_in, W, b)
         out = ops.token_mean(act) if e.native_method == "mean" else act
         saved = None
         if need_grad:
             saved = dict(n=n, first=first, blocks=blocks, x_last=x, head_in=head_in, act=act, act_relu=act_relu, xh_p=xh_p, rs_p=rs_p,
-                         patches=patches if keep0 else None, xh0=xh0, rs0=rs0)
+                         patches=patches if keep0 else None, xh0=xh0, rs0=rs0, head_planes=(xp_last, Wp) if Wp is not None else None)
         return out, saved
 
     # ------------------------------------------------------------------------------------------ backward
@@ -397,12 +414,21 @@ class NativeTower:
             dact = torch.where(act > 0, d_out, torch.zeros_like(d_out)) if saved["act_relu"] else d_out
             M = n
         D = dact.shape[-1]
-        ops.grouped_linear_bwd_weight([(dact.view(M, D), head_in.view(M, H), G("rec_fc.0.weight"), G("rec_fc.0.bias"))])
+        hp = saved.get("head_planes")
+        dactp = None
+        if hp is not None:       # the head ran on h2 operands: so do its weight and input gradients
+            dactp, = ops.split_h2_auto([dact.view(M, D)])
+            ops.grouped_dw_planes([(dactp, hp[0], G("rec_fc.0.weight"), G("rec_fc.0.bias"))])
+        else:
+            ops.grouped_linear_bwd_weight([(dact.view(M, D), head_in.view(M, H), G("rec_fc.0.weight"), G("rec_fc.0.bias"))])
         n_layers = len(e.item_encoder.vision_model.encoder.layers)
         if first >= n_layers:                    # only rec_fc trains
             defer.flush()
             return
-        dxl = ops.linear_bwd_input(dact, self.view("rec_fc.0.weight"))
+        if dactp is not None:
+            dxl, _ = ops.linear_bwd_input_planes(dactp, hp[1], lead_shape=(n, T))
+        else:
+            dxl = ops.linear_bwd_input(dact, self.view("rec_fc.0.weight"))
         if e.native_method == "pool":
             dxl, _ = ops.ln_bwd(0, dxl.view(n, 1, H), saved["xh_p"], saved["rs_p"], self.view(vm + "post_layernorm.weight"),
                                 G(vm + "post_layernorm.weight"), G(vm + "post_layernorm.bias"), defer=defer)
