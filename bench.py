@@ -256,10 +256,10 @@ def pixelnet_run(args, steps, warmup, init_dist=True, n_inst=3):
                                     "note": "eager steps, events on the compute stream; with one rank no collective is issued"},
            "roofline": {"bound": "mfma", "gemm_mode": ops.gemm_mode(),
                         "kernel": "gemm_p3_kernel<P4Cfg 256x256 | 256x128> (ping-pong planes tiles, gemm_p4.cuh) + grouped_dw_p3_kernel: "
-                                  "v_mfma_f32_32x32x16_bf16 on the exact 3 x bf16 split (6 products per multiply; trainable ViT blocks, "
-                                  "rec_fc, sequence block) and v_mfma_f32_32x32x16_f16 on two fp16 planes (3 products; the frozen ViT "
-                                  "blocks, `fp16_two_plane`), operands pre-split as planes; f32 mode: gemm_kernel "
-                                  "(v_mfma_f32_32x32x2_f32) -- see gemm_mode",
+                                  "v_mfma_f32_32x32x16_f16 on two fp16 planes per operand (3 products per multiply: every ViT block -- "
+                                  "forward, input and weight gradients; `fp16_two_plane`) and v_mfma_f32_32x32x16_bf16 on the exact "
+                                  "3 x bf16 split (6 products: rec_fc, sequence block), operands pre-split as planes; f32 mode: "
+                                  "gemm_kernel (v_mfma_f32_32x32x2_f32) -- see gemm_mode",
                         **mfma_roof(g_fl, g_s, ops.gemm_mode() == "bf16x3", g_ex if h2_fl else None),
                         "fp16_two_plane": ({"gemm_time_per_step_ms": h2_s / max(n_inst, 1) * 1e3,
                                             "algorithmic_gflop_per_step": h2_fl / max(n_inst, 1) / 1e9,

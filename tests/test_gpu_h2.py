@@ -159,9 +159,10 @@ def test_tower_on_h2(method, monkeypatch):
     (ref_out * w).sum().backward()
     gmax = max(q.grad.abs().max().item() for q in ref.parameters() if q.grad is not None)
     results = {}
-    for name, h2, h2t in (("all", "1", "1"), ("frozen", "1", "0"), ("none", "0", "0")):
+    for name, h2, h2t in (("all", "1", "1"), ("all+head", "1", "1"), ("frozen", "1", "0"), ("none", "0", "0")):
         monkeypatch.setenv("PXR_TOWER_H2", h2)
         monkeypatch.setenv("PXR_TOWER_H2_TRAIN", h2t)
+        monkeypatch.setenv("PXR_TOWER_H2_HEAD", "1" if name == "all+head" else "0")   # (the opt-in head Linear on h2 operands)
         tower.drop_weight_planes()
         if ops.gemm_mode() == "bf16x3":
             assert tower._h2_block(0) == (h2 == "1") and tower._h2_block(2, train=True) == (h2t == "1")
@@ -175,7 +176,7 @@ def test_tower_on_h2(method, monkeypatch):
                 assert (p.grad.cpu() - q.grad).abs().max().item() <= 3e-4 * max(q.grad.abs().max().item(), 1e-5 * gmax), (name, n)
         results[name] = (out.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None})
         ops.raise_on_bad_indices("cuda")                             # no fp16 range flag
-    for name in ("all", "frozen"):
+    for name in ("all", "all+head", "frozen"):
         assert (results[name][0] - results["none"][0]).abs().max().item() < 5e-6       # roundings of the same fp32 computation
         for n, gr in results["none"][1].items():
             assert (results[name][1][n] - gr).abs().max().item() <= 1e-4 * max(float(gr.abs().max()), 1e-5 * gmax), (name, n)
