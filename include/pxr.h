@@ -205,10 +205,11 @@ int pxr_split_planes_multi_f32(int n, const float* const* x, const int64_t* rows
  * Used by the forward-only blocks of the image tower (reference: the frozen CLIP blocks of code/REC/model/load.py:90-120).
  *   pxr_split_h2_multi_f32   up to 16 matrices, matrix i multiplied by 2^scale_exp[i] first
  *   pxr_gemm_h2_f32          C = epilogue(2^-(a_exp+b_exp) A~ B~), B~ [N][K] (b_kc: forward; epilogue NONE | BIAS | BIAS_GELU |
- *                            BIAS_ADD | BIAS_QGELU | BIAS_QGELU_GRAD | BIAS_RELU) or [K][N] (input gradient; NONE | ADD | MUL);
+ *                            BIAS_GELU_GRAD | BIAS_ACT_GRAD | BIAS_ADD | BIAS_QGELU | BIAS_QGELU_GRAD | BIAS_RELU) or [K][N] (input gradient; NONE | ADD | MUL);
  *                            exponents immediate or read from *_exp_dev; c_fmt 0: output planes as three bf16 planes, 1: as two
  *                            fp16 planes holding C 2^(*c_exp_dev) (unit scale when null)
- *   pxr_ln_residual_fwd_h2_f32 / pxr_tower_attn_fwd_h2_f32: the plane-writing producers with h2 planes (unit scale) */
+ *   pxr_ln_residual_fwd_h2_f32 / pxr_input_ln_fwd_h2_f32 / pxr_attn_fwd_h2_f32 / pxr_tower_attn_fwd_h2_f32: the plane-writing
+ *                            producers (same arguments as their *_planes_f32 versions) with h2 planes, unit scale */
 int pxr_split_h2_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
                            void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows, const int* scale_exp,
                            void* stream);
@@ -231,8 +232,17 @@ int pxr_h2_split_auto_multi_f32(int n, const float* const* x, const int64_t* row
                                 float* stats, int* exps, void* stream);
 int pxr_h2_bound_exp(const float* a_max, const float* b_colsum, float factor, int* exp_out, void* stream);
 int pxr_ln_residual_fwd_h2_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps, int rows,
-                               int D, float* y, float* xhat, float* rstd, void* y_planes, int64_t y_plane_stride,
-                               int64_t y_panel_rows, void* stream);
+                               int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed, uint32_t stream_id,
+                               const int64_t* step_dev, void* y_planes, int64_t y_plane_stride, int64_t y_panel_rows,
+                               void* stream);
+int pxr_input_ln_fwd_h2_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride, const float* pos,
+                            const float* gamma, const float* beta, float eps, int B, int L, int D, float* y, float* xhat,
+                            float* rstd, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                            void* y_planes, int64_t y_plane_stride, int64_t y_panel_rows, void* stream);
+int pxr_attn_fwd_h2_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask, int64_t km_bstride,
+                        int B, int H, int L, int d, float* ctx, int64_t ld_ctx, float* probs, float p_drop, uint64_t seed,
+                        uint32_t stream_id, const int64_t* step_dev, void* ctx_planes, int64_t ctx_plane_stride,
+                        int64_t ctx_panel_rows, void* stream);
 int pxr_tower_attn_fwd_h2_f32(const float* q, const float* k, const float* v, int64_t ld, int64_t images, int heads, int T, int d,
                               float scale, float* ctx, int64_t ld_ctx, void* ctx_planes, int64_t ctx_plane_stride,
                               int64_t ctx_panel_rows, float* lse, void* stream);

@@ -46,6 +46,8 @@ struct AttnArgs {
   // column ranges (starting at pcol[0..2]) of one [B*L, .] matrix.  With planes the fp32 outputs may be null.
   P3Mat op;
   int pcol[3];
+  int op_fmt;               // PXR_PLANES_BF16X3 | PXR_PLANES_H2 (the forward's ctx planes; planes.cuh)
+  int32_t* status;          // status word for the fp16 range check of h2 planes, or null
 };
 
 // stage tile[row][0..w) <- src[(row)*ld + 0..w) for row < L; all threads of the block, float4 accesses
@@ -327,7 +329,8 @@ __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TN], float* out, i
 // consecutive columns of a row = one 16-byte store per plane.  ALL threads of the workgroup must call it (two barriers).
 template <int TN, int NT>
 __device__ __forceinline__ void store_acc_planes(const f32x16 (&acc)[TN], bool mine, float* tile, int m_base, int n_base, int L,
-                                                 int w, int lane, const P3Mat& P, int64_t row0, int col0) {
+                                                 int w, int lane, const P3Mat& P, int64_t row0, int col0, int fmt = PXR_PLANES_BF16X3,
+                                                 int32_t* status = nullptr) {
   const int h = lane >> 5, r = lane & 31;
   if (mine) {
 #pragma unroll
@@ -343,7 +346,7 @@ __device__ __forceinline__ void store_acc_planes(const f32x16 (&acc)[TN], bool m
     const float4 x0 = *reinterpret_cast<const float4*>(tile + row * ATT_KLD + c8);
     const float4 x1 = *reinterpret_cast<const float4*>(tile + row * ATT_KLD + c8 + 4);
     const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    p3_store8(P, row0 + row, col0 + c8, v);
+    px_store8(P, fmt, status, row0 + row, col0 + c8, v);
   }
   __syncthreads();
 }
@@ -585,14 +588,14 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_mfma1_kernel(AttnArgs a) {
     zero_acc<2>(accO);
     if (wn * 64 < d) lds_mma<true, false, 2>(accO, sS, ATT_SLD, sV, ATT_KLD, wm * 32, wn * 64, 64, lane);
     if (a.ctx) store_acc<2>(accO, ctx, a.ld_ctx, wm * 32, wn * 64, L, d, lane);
-    if (a.op.p) store_acc_planes<2, NT>(accO, wn * 64 < d, sQ, wm * 32, wn * 64, L, d, lane, a.op, (int64_t)b * L, h * d);
+    if (a.op.p) store_acc_planes<2, NT>(accO, wn * 64 < d, sQ, wm * 32, wn * 64, L, d, lane, a.op, (int64_t)b * L, h * d, a.op_fmt, a.status);
   } else {
     const int wm = wave >> 2, wn = wave & 3;
     f32x16 accO[1];
     zero_acc<1>(accO);
     if (wn * 32 < d) lds_mma<true, false, 1>(accO, sS, ATT_SLD, sV, ATT_KLD, wm * 32, wn * 32, 64, lane);
     if (a.ctx) store_acc<1>(accO, ctx, a.ld_ctx, wm * 32, wn * 32, L, d, lane);
-    if (a.op.p) store_acc_planes<1, NT>(accO, wn * 32 < d, sQ, wm * 32, wn * 32, L, d, lane, a.op, (int64_t)b * L, h * d);
+    if (a.op.p) store_acc_planes<1, NT>(accO, wn * 32 < d, sQ, wm * 32, wn * 32, L, d, lane, a.op, (int64_t)b * L, h * d, a.op_fmt, a.status);
   }
 }
 
@@ -950,10 +953,30 @@ extern "C" int pxr_attn_fwd_f32(const float* q, const float* k, const float* v, 
 }
 // the same with ctx (the [B*L, H*d] matrix) additionally -- or, ctx == NULL, only -- written as bf16x3 planes: the operand
 // format of the output projection that follows (layers.py:613).  Shapes: pxr_attn_planes_supported.
+static int attn_fwd_planes_impl(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
+                                int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx, float* probs, float p_drop,
+                                uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ctx_planes,
+                                int64_t ctx_plane_stride, int64_t ctx_panel_rows, int c_fmt, void* stream);
 extern "C" int pxr_attn_fwd_planes_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
                                        int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx,
                                        float* probs, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
                                        void* ctx_planes, int64_t ctx_plane_stride, int64_t ctx_panel_rows, void* stream) {
+  return attn_fwd_planes_impl(q, k, v, ld, keymask, km_bstride, B, H, L, d, ctx, ld_ctx, probs, p_drop, seed, stream_id, step_dev,
+                              ctx_planes, ctx_plane_stride, ctx_panel_rows, PXR_PLANES_BF16X3, stream);
+}
+// ... with the ctx planes in the two-plane fp16 format (planes.cuh "h2", unit scale): the operand of pxr_gemm_h2_f32
+extern "C" int pxr_attn_fwd_h2_f32(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
+                                   int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx, float* probs,
+                                   float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ctx_planes,
+                                   int64_t ctx_plane_stride, int64_t ctx_panel_rows, void* stream) {
+  PXR_REQUIRE(ctx_planes, "pxr_attn_fwd_h2_f32: no planes");
+  return attn_fwd_planes_impl(q, k, v, ld, keymask, km_bstride, B, H, L, d, ctx, ld_ctx, probs, p_drop, seed, stream_id, step_dev,
+                              ctx_planes, ctx_plane_stride, ctx_panel_rows, PXR_PLANES_H2, stream);
+}
+static int attn_fwd_planes_impl(const float* q, const float* k, const float* v, int64_t ld, const int64_t* keymask,
+                                int64_t km_bstride, int B, int H, int L, int d, float* ctx, int64_t ld_ctx, float* probs, float p_drop,
+                                uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ctx_planes,
+                                int64_t ctx_plane_stride, int64_t ctx_panel_rows, int c_fmt, void* stream) {
   PXR_REQUIRE(q && k && v && keymask && (ctx || ctx_planes), "pxr_attn_fwd_f32: null pointer");
   PXR_REQUIRE(!ctx_planes || (pxr_attn_planes_supported(L, d) && p3_mat_ok(ctx_planes, ctx_plane_stride, ctx_panel_rows, (int64_t)B * L, (int64_t)H * d)),
               "pxr_attn_fwd_planes_f32: planes are not available for this shape (L=%d, d=%d)", L, d);
@@ -965,6 +988,8 @@ extern "C" int pxr_attn_fwd_planes_f32(const float* q, const float* k, const flo
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.keymask = keymask; a.km_bstride = km_bstride;
   a.ctx = ctx; a.ld_ctx = ld_ctx; a.probs = probs; a.B = B; a.H = H; a.L = L; a.d = d;
   a.op = P3Mat{reinterpret_cast<__bf16*>(ctx_planes), ctx_plane_stride, ctx_panel_rows};
+  a.op_fmt = c_fmt;
+  a.status = pxr_status_word();
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;

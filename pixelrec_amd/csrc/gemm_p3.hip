@@ -524,6 +524,8 @@ static int epi_h2(int b_kc, int epilogue, P3Args& g, hipStream_t st) {
       case EPI_NONE: return launch_p3<Cfg, true, EPI_NONE, false>(g, st);
       case EPI_BIAS: return launch_p3<Cfg, true, EPI_BIAS, false>(g, st);
       case EPI_BIAS_GELU: return launch_p3<Cfg, true, EPI_BIAS_GELU, false>(g, st);
+      case EPI_BIAS_GELU_GRAD: return launch_p3<Cfg, true, EPI_BIAS_GELU_GRAD, false>(g, st);
+      case EPI_BIAS_ACT_GRAD: return launch_p3<Cfg, true, EPI_BIAS_ACT_GRAD, false>(g, st);
       case EPI_BIAS_ADD: return launch_p3<Cfg, true, EPI_BIAS_ADD, false>(g, st);
       case EPI_BIAS_QGELU: return launch_p3<Cfg, true, EPI_BIAS_QGELU, false>(g, st);
       case EPI_BIAS_QGELU_GRAD: return launch_p3<Cfg, true, EPI_BIAS_QGELU_GRAD, false>(g, st);
@@ -639,7 +641,8 @@ extern "C" int pxr_gemm_h2_f32(int b_kc, int M, int N, int K, const void* A, int
   PXR_REQUIRE(!c_exp_dev || (c_planes && c_fmt == PXR_PLANES_H2), "pxr_gemm_h2_f32: an output exponent needs h2 output planes");
   PXR_REQUIRE(a_exp >= -60 && a_exp <= 60 && b_exp >= -60 && b_exp <= 60, "pxr_gemm_h2_f32: scale exponents");
   PXR_REQUIRE(aux || !(epilogue == EPI_BIAS_ADD || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_QGELU_GRAD || epilogue == EPI_ADD ||
-                       epilogue == EPI_MUL), "pxr_gemm_h2_f32: epilogue %d reads / writes aux", epilogue);
+                       epilogue == EPI_MUL || epilogue == EPI_BIAS_GELU_GRAD || epilogue == EPI_BIAS_ACT_GRAD),
+              "pxr_gemm_h2_f32: epilogue %d reads / writes aux", epilogue);
   PXR_REQUIRE(bias || !b_kc || epilogue == EPI_NONE, "pxr_gemm_h2_f32: epilogue %d needs a bias", epilogue);
   if (M == 0 || N == 0) return PXR_OK;
   P3Args g;

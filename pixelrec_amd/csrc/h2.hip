@@ -81,6 +81,12 @@ __global__ void __launch_bounds__(256) h2_colstat_kernel(const float* __restrict
   }
 }
 
+// (a kernel, not hipMemsetAsync: inside a captured step the memset node was seen to run out of order with the atomic maxima that
+// follow it -- intermittently zeroing finished statistics; a kernel node is ordered like every other launch of the stream)
+__global__ void h2_zero_kernel(float* p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
 struct H2SplitAuto {
   const float* x[16]; int64_t ldx[16]; int rows[16], cols8[16]; P3Mat out[16];
   int64_t begin[17];
@@ -137,11 +143,7 @@ extern "C" int pxr_h2_split_auto_multi_f32(int n, const float* const* x, const i
   }
   m.begin[n] = total;
   PXR_REQUIRE((total + 255) / 256 < (1ll << 31), "pxr_h2_split_auto_multi_f32: too large");
-  if (hipMemsetAsync(stats, 0, (size_t)n * 2 * sizeof(float), st) != hipSuccess) {
-    (void)hipGetLastError();
-    pxr_set_error("pxr_h2_split_auto_multi_f32: cannot clear the statistics");
-    return PXR_ERR_LAUNCH;
-  }
+  hipLaunchKernelGGL(h2_zero_kernel, dim3(1), dim3(64), 0, st, stats, 2 * n);
   for (int i = 0; i < n; ++i) {
     if (col_stats) {
       hipLaunchKernelGGL(h2_colstat_kernel, dim3((unsigned)((cols[i] + 31) / 32)), dim3(256), 0, st, x[i], ldx[i], (int)rows[i], (int)cols[i],

@@ -403,23 +403,46 @@ extern "C" int pxr_ln_residual_fwd_planes_f32(const float* x, const float* res, 
   a.yp = P3Mat{reinterpret_cast<__bf16*>(y_planes), y_plane_stride, y_panel_rows};
   return launch_ln_fwd<false>(a, (hipStream_t)stream);
 }
-// the same with y as TWO fp16 planes (planes.cuh "h2", unit scale): the operand of pxr_gemm_h2_f32 -- the forward-only blocks of
-// the image tower.  A LayerNorm output beyond the fp16 range sets PXR_STATUS_H2_RANGE in the registered status word.
+// the same with y as TWO fp16 planes (planes.cuh "h2", unit scale): the operand of pxr_gemm_h2_f32 -- the image tower, the sequence
+// block of large batches.  A LayerNorm output beyond the fp16 range sets PXR_STATUS_H2_RANGE in the registered status word.
 extern "C" int pxr_ln_residual_fwd_h2_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps,
-                                          int rows, int D, float* y, float* xhat, float* rstd, void* y_planes,
-                                          int64_t y_plane_stride, int64_t y_panel_rows, void* stream) {
+                                          int rows, int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed,
+                                          uint32_t stream_id, const int64_t* step_dev, void* y_planes, int64_t y_plane_stride,
+                                          int64_t y_panel_rows, void* stream) {
   PXR_REQUIRE(x && gamma && beta && y_planes, "pxr_ln_residual_fwd_h2_f32: null pointer");
   PXR_REQUIRE(p3_mat_ok(y_planes, y_plane_stride, y_panel_rows, rows, D), "pxr_ln_residual_fwd_h2_f32: bad planes");
   PXR_REQUIRE(D > 0 && D % 4 == 0 && rows >= 0, "pxr_ln_residual_fwd_h2_f32: bad shape");
+  PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_ln_residual_fwd_h2_f32: bad dropout p");
   if (rows == 0) return PXR_OK;
   LnFwdArgs a{};
   a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xhat = xhat; a.rstd = rstd;
   a.rows = rows; a.D = D; a.L = 1; a.eps = eps;
-  a.drop_thr = pxr_drop_threshold(0.f);
+  a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  a.step_dev = step_dev;
   a.status = pxr_status_word();
   a.yp = P3Mat{reinterpret_cast<__bf16*>(y_planes), y_plane_stride, y_panel_rows};
   a.yp_fmt = PXR_PLANES_H2;
   return launch_ln_fwd<false>(a, (hipStream_t)stream);
+}
+extern "C" int pxr_input_ln_fwd_h2_f32(const float* table, int64_t n_table, const int64_t* idx, int64_t idx_bstride,
+                                       const float* pos, const float* gamma, const float* beta, float eps, int B, int L, int D,
+                                       float* y, float* xhat, float* rstd, float p_drop, uint64_t seed, uint32_t stream_id,
+                                       const int64_t* step_dev, void* y_planes, int64_t y_plane_stride, int64_t y_panel_rows,
+                                       void* stream) {
+  PXR_REQUIRE(table && idx && pos && gamma && beta && y && y_planes, "pxr_input_ln_fwd_h2_f32: null pointer");
+  PXR_REQUIRE(p3_mat_ok(y_planes, y_plane_stride, y_panel_rows, (int64_t)B * L, D), "pxr_input_ln_fwd_h2_f32: bad planes");
+  PXR_REQUIRE(D > 0 && D % 4 == 0 && B >= 0 && L > 0, "pxr_input_ln_fwd_h2_f32: bad shape");
+  PXR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "pxr_input_ln_fwd_h2_f32: bad dropout p");
+  if (B == 0) return PXR_OK;
+  LnFwdArgs a{};
+  a.table = table; a.idx = idx; a.pos = pos; a.gamma = gamma; a.beta = beta; a.y = y; a.xhat = xhat; a.rstd = rstd;
+  a.idx_bstride = idx_bstride; a.n_table = n_table; a.rows = B * L; a.D = D; a.L = L; a.eps = eps;
+  a.status = pxr_status_word();
+  a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
+  a.step_dev = step_dev;
+  a.yp = P3Mat{reinterpret_cast<__bf16*>(y_planes), y_plane_stride, y_panel_rows};
+  a.yp_fmt = PXR_PLANES_H2;
+  return launch_ln_fwd<true>(a, (hipStream_t)stream);
 }
 
 extern "C" int pxr_ln_bwd_partial_rows(int rows) {

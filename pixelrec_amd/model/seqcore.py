@@ -243,6 +243,17 @@ class SeqRecCore(BaseModel):
         return (self.use_planes and ops.gemm_mode() == "bf16x3" and self.hidden_size % 32 == 0
                 and self.inner_size % 32 == 0)
 
+    def _h2_on(self, B: int) -> bool:
+        """Whether a forward over B sequences runs its GEMMs on TWO fp16 planes per operand (csrc/planes.cuh "h2": three MFMAs per
+        multiply instead of six at the same 2^-22-grade accuracy).  The format has a finite range, so every operand that is not an
+        O(1) activation gets a power-of-two scale found on the device -- extra passes over the weights and the gradients
+        (ops.split_h2_auto) that only pay when the GEMMs are large, and the h2 GEMMs only have the 256-row ping-pong tiles:
+        PXR_SEQ_H2 = auto (default: from PXR_SEQ_H2_MIN_TOKENS = 16384 tokens per step, i.e. 328 sequences of 50) | 1 | 0."""
+        mode = os.environ.get("PXR_SEQ_H2", "auto")
+        if mode == "0" or not self._planes_on() or not ops.attn_planes_supported(self.max_seq_length, self.hidden_size // self.n_heads):
+            return False
+        return mode == "1" or B * self.max_seq_length >= int(os.environ.get("PXR_SEQ_H2_MIN_TOKENS", "16384"))
+
     _W_NAMES = (("q.w", 3, "qkv"), ("o.w", 1, "o"), ("f1.w", 1, "f1"), ("f2.w", 1, "f2"))
 
     _wplanes_fresh = False
@@ -252,6 +263,12 @@ class SeqRecCore(BaseModel):
 
     def _weight_mats(self):
         return [self._p(f"{i}.{n}", span=sp) for i in range(self.n_layers) for n, sp, _ in self._W_NAMES]
+
+    def _weight_planes_h2(self):
+        """The weight matrices as h2 planes, scales (and the column statistics the input-gradient bound needs) found on the device."""
+        mats = self._weight_mats()
+        keys = [f"{i}.{k}" for i in range(self.n_layers) for _, _, k in self._W_NAMES]
+        return dict(zip(keys, ops.split_h2_auto(mats, col_stats=True)))
 
     def _weight_planes(self, train: bool = False):
         """The block's weight matrices as planes.  Re-split from the flat parameter buffer (ONE launch) at the start of every
@@ -299,25 +316,27 @@ class SeqRecCore(BaseModel):
         pa = self.attn_dropout_prob if train else 0.0
         seed = (self._drop_seed * 1000003) & 0xFFFFFFFFFFFFFFFF
         sdv = self._drop_dev if train else None
-        saved = {"seed": seed, "ph": ph, "pa": pa, "layers": [], "planes": True} if train else None
-        wp = self._weight_planes(train)
+        h2m = self._h2_on(B)
+        pf = "h2" if h2m else True        # format of the activation planes the producers write
+        saved = {"seed": seed, "ph": ph, "pa": pa, "layers": [], "planes": True, "h2": h2m} if train else None
+        wp = self._weight_planes_h2() if h2m else self._weight_planes(train)
         h, xhat0, rstd0, hp = ops.input_ln_fwd(table, idx, idx_bstride, B, L, self._p("pos"), self._p("ln0.w"),
-                                               self._p("ln0.b"), eps, ph, seed, 0, save=train, step_dev=sdv, planes=True)
+                                               self._p("ln0.b"), eps, ph, seed, 0, save=train, step_dev=sdv, planes=pf)
         if train:
             saved["xhat0"], saved["rstd0"], saved["wp"] = xhat0, rstd0, wp
         for i in range(self.n_layers):
             qkv, _, _ = ops.linear_fwd_planes(hp, wp[f"{i}.qkv"], self._p(f"{i}.q.b", span=3), lead_shape=(B, L))
             ctxp, probs = ops.attn_fwd(qkv, keymask, km_bstride, B, H, L, d, pa, seed, 1 + 3 * i, save=train, step_dev=sdv,
-                                       planes=True)
+                                       planes=pf)
             a, _, _ = ops.linear_fwd_planes(ctxp, wp[f"{i}.o"], self._p(f"{i}.o.b"), lead_shape=(B, L))
             h1, xhat1, rstd1, h1p = ops.ln_residual_fwd(a, h, self._p(f"{i}.ln1.w"), self._p(f"{i}.ln1.b"), eps, ph, seed,
-                                                        2 + 3 * i, save=train, step_dev=sdv, planes=True)
+                                                        2 + 3 * i, save=train, step_dev=sdv, planes=pf)
             _, fp, u = ops.linear_fwd_planes(h1p, wp[f"{i}.f1"], self._p(f"{i}.f1.b"), gelu=True, save_grad=train,
                                              act=self.hidden_act, want_fp32=False, want_planes=True, lead_shape=(B, L))
             f2, _, _ = ops.linear_fwd_planes(fp, wp[f"{i}.f2"], self._p(f"{i}.f2.b"), lead_shape=(B, L))
             last = i == self.n_layers - 1
             r = ops.ln_residual_fwd(f2, h1, self._p(f"{i}.ln2.w"), self._p(f"{i}.ln2.b"), eps, ph, seed, 3 + 3 * i,
-                                    save=train, step_dev=sdv, planes=not last)
+                                    save=train, step_dev=sdv, planes=(pf if not last else False))
             h2, xhat2, rstd2 = r[0], r[1], r[2]
             if train:
                 saved["layers"].append(dict(h_in=hp, qkv=qkv, probs=probs, ctx=ctxp, xhat1=xhat1, rstd1=rstd1, h1=h1p,
@@ -441,22 +460,36 @@ class SeqRecCore(BaseModel):
             # every GEMM operand as planes: the gradients that only GEMMs read (du, dqkv) exist as planes only
             wp = s["wp"]
             pend = []
+            h2m = bool(s.get("h2"))
+
+            def ln_bwd_planes(*args, **kw):
+                """(dz, gradient the next GEMMs read as planes).  h2: the LayerNorm backward writes fp32, the split finds the
+                gradient's power-of-two scale on the device (ops.split_h2_auto)."""
+                if not h2m:
+                    dz, _, gp = ops.ln_bwd(*args, planes=True, **kw)
+                    return dz, gp
+                dz, dx = ops.ln_bwd(*args, **kw)
+                return dz, ops.split_h2_auto([(dx if dx is not None else dz).view(T, D)])[0]
+
             for i in reversed(range(self.n_layers)):
                 a = s["layers"][i]
-                dz2, _, dxf2p = ops.ln_bwd(0, dh, a["xhat2"], a["rstd2"], self._p(f"{i}.ln2.w"), g(f"{i}.ln2.w"),
-                                           g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer,
-                                           planes=True)
+                dz2, dxf2p = ln_bwd_planes(0, dh, a["xhat2"], a["rstd2"], self._p(f"{i}.ln2.w"), g(f"{i}.ln2.w"),
+                                           g(f"{i}.ln2.b"), ph, seed, 3 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer)
                 pend.append((dxf2p, a["f"], g(f"{i}.f2.w"), g(f"{i}.f2.b")))
+                # (h2: du leaves the epilogue as planes scaled by the bound |dxf2 W2| * max |act'|: erf-GELU 1.13, the others <= 1.1)
                 _, dup = ops.linear_bwd_input_planes(dxf2p, wp[f"{i}.f2"], mul=a["u"].view(T, -1), want_fp32=False,
-                                                     want_planes=True)
+                                                     want_planes=True, mul_bound=1.13)
                 pend.append((dup, a["h1"], g(f"{i}.f1.w"), g(f"{i}.f1.b")))
                 dh1, _ = ops.linear_bwd_input_planes(dup, wp[f"{i}.f1"], add=dz2.view(T, D), lead_shape=(B, L))
-                dz1, _, dxap = ops.ln_bwd(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
-                                          g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer,
-                                          planes=True)
+                dz1, dxap = ln_bwd_planes(0, dh1, a["xhat1"], a["rstd1"], self._p(f"{i}.ln1.w"), g(f"{i}.ln1.w"),
+                                          g(f"{i}.ln1.b"), ph, seed, 2 + 3 * i, need_dx=ph > 0, step_dev=sdv, defer=defer)
                 pend.append((dxap, a["ctx"], g(f"{i}.o.w"), g(f"{i}.o.b")))
                 dctx, _ = ops.linear_bwd_input_planes(dxap, wp[f"{i}.o"], lead_shape=(B, L))
-                dqkvp = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv, planes=True)
+                if h2m:
+                    dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv)
+                    dqkvp = ops.split_h2_auto([dqkv.view(T, 3 * D)])[0]
+                else:
+                    dqkvp = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv, planes=True)
                 pend.append((dqkvp, a["h_in"], g(f"{i}.q.w", 3), g(f"{i}.q.b", 3)))
                 dh, _ = ops.linear_bwd_input_planes(dqkvp, wp[f"{i}.qkv"], add=dz1.view(T, D), lead_shape=(B, L))
             dx0, _ = ops.ln_bwd(1, dh, s["xhat0"], s["rstd0"], self._p("ln0.w"), g("ln0.w"), g("ln0.b"), ph, seed, 0,

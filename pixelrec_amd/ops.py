@@ -618,7 +618,7 @@ def linear_fwd_planes(xp: Planes, Wp: Planes, b, gelu: bool = False, save_grad: 
     dev = xp.buf.device
     shape = tuple(lead_shape) + (N,) if lead_shape is not None else (M, N)
     y = torch.empty(shape, dtype=torch.float32, device=dev) if want_fp32 else None
-    yp = Planes.alloc(M, N, dev) if want_planes else None
+    yp = Planes.alloc(M, N, dev, fmt=xp.fmt) if want_planes else None
     aux, epi, code = None, EPI_BIAS, 0
     if act is not None and act != "gelu":
         epi, code = EPI_BIAS_ACT_GRAD, ACT_CODES[act]
@@ -626,6 +626,10 @@ def linear_fwd_planes(xp: Planes, Wp: Planes, b, gelu: bool = False, save_grad: 
         epi = EPI_BIAS_GELU_GRAD if save_grad else EPI_BIAS_GELU
     if epi != EPI_BIAS:
         aux = torch.empty(shape, dtype=torch.float32, device=dev)
+    if xp.fmt:           # fp16 two-plane operands (the output planes, activations, at unit scale)
+        gemm_planes(xp, Wp, y.view(M, N) if y is not None else None, epi, bias=b, aux=aux.view(M, N) if aux is not None else None,
+                    act=code, Cp=yp)
+        return y, yp, aux
     tag = "gemm_p3_kernel<KC,KC,EPI_BIAS_GELU*> (fwd + activation)" if epi != EPI_BIAS else "gemm_p3_kernel<KC,KC,EPI_BIAS> (fwd)"
     with _gemm_timer(2.0 * M * N * K, tag):
         _l.check(_l.load().pxr_gemm_planes_f32(1, M, N, K, xp.ptr(), xp.ps, xp.pr, Wp.ptr(), Wp.ps, Wp.pr, _l.ptr(y), N, epi,
@@ -738,10 +742,12 @@ def input_ln_fwd(table, idx, idx_bstride, B, L, pos, gamma, beta, eps, p_drop=0.
     rstd = torch.empty(B * L, dtype=torch.float32, device=table.device) if save else None
     # algorithmic bytes: B*L table rows read once + y (+ xhat when saved) written; the [B,2,L+1,D] gather of the
     # reference never exists (SURVEY.md §8d "fused" rule)
-    yp = Planes.alloc(B * L, D, table.device) if planes else None
-    # (+ the three bf16 planes of y, 6 B per element, when the kernel also writes them for the QKV GEMM)
-    with _gemm_timer(B * L * D * (4.0 * (3 if save else 2) + (6.0 if planes else 0.0)), "ln_fwd_kernel<GATHER> (gather + pos + LN + dropout)"):
-        _l.check(Lb.pxr_input_ln_fwd_planes_f32(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
+    h2 = planes == "h2"
+    yp = Planes.alloc(B * L, D, table.device, fmt=int(h2)) if planes else None
+    fn = Lb.pxr_input_ln_fwd_h2_f32 if h2 else Lb.pxr_input_ln_fwd_planes_f32
+    # (+ the planes of y -- three bf16 ones, 6 B per element, or two fp16 ones -- when the kernel also writes them for the QKV GEMM)
+    with _gemm_timer(B * L * D * (4.0 * (3 if save else 2) + ((4.0 if h2 else 6.0) if planes else 0.0)), "ln_fwd_kernel<GATHER> (gather + pos + LN + dropout)"):
+        _l.check(fn(_l.ptr(table), N, _l.ptr(idx), idx_bstride, _l.ptr(pos), _l.ptr(gamma),
                                                 _l.ptr(beta), eps, B, L, D, _l.ptr(y), _l.ptr(xhat), _l.ptr(rstd), p_drop,
                                                 seed, stream_id, _l.ptr(step_dev), *_pl(yp), _l.stream_ptr()),
                  "pxr_input_ln_fwd_f32")
@@ -760,12 +766,12 @@ def ln_residual_fwd(x, res, gamma, beta, eps, p_drop=0.0, seed=0, stream_id=0, s
     y = torch.empty_like(x) if want_y else None
     xhat = torch.empty_like(x) if save else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
-    if planes == "h2":                # y as two fp16 planes (no dropout at these sites: the image tower)
-        assert p_drop == 0.0
+    if planes == "h2":                # y as two fp16 planes (the image tower, the sequence block of large batches)
         yp = Planes.alloc(rows, D, x.device, fmt=1)
         device_status(x.device)
         _l.check(Lb.pxr_ln_residual_fwd_h2_f32(_l.ptr(x), _l.ptr(res), _l.ptr(gamma), _l.ptr(beta), eps, rows, D, _l.ptr(y),
-                                               _l.ptr(xhat), _l.ptr(rstd), *_pl(yp), _l.stream_ptr()), "pxr_ln_residual_fwd_h2_f32")
+                                               _l.ptr(xhat), _l.ptr(rstd), p_drop, seed, stream_id, _l.ptr(step_dev), *_pl(yp),
+                                               _l.stream_ptr()), "pxr_ln_residual_fwd_h2_f32")
         return (y, xhat, rstd, yp)
     yp = Planes.alloc(rows, D, x.device) if planes else None
     _l.check(Lb.pxr_ln_residual_fwd_planes_f32(_l.ptr(x), _l.ptr(res), _l.ptr(gamma), _l.ptr(beta), eps, rows, D, _l.ptr(y),
@@ -889,12 +895,14 @@ def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id
         ctx, saved = _attn_long_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop, seed, stream_id, step_dev)
         return (split_planes(ctx.view(B * L, D)) if planes else ctx), (saved if save else None)
     fused_p = planes and attn_planes_supported(L, d)
+    h2 = planes == "h2"
+    assert fused_p or not h2, "h2 context planes come from the fused kernel only (attn_planes_supported)"
     ctx = None if fused_p else torch.empty(B, L, D, dtype=torch.float32, device=qkv.device)
-    cp_ = Planes.alloc(B * L, D, qkv.device) if fused_p else None
+    cp_ = Planes.alloc(B * L, D, qkv.device, fmt=int(h2)) if fused_p else None
     probs = torch.empty(B, H, L, L, dtype=torch.float32, device=qkv.device) if save else None
     base = qkv.data_ptr()
     q, k, v = _l.c_void_p(base), _l.c_void_p(base + 4 * D), _l.c_void_p(base + 8 * D)
-    _l.check(Lb.pxr_attn_fwd_planes_f32(q, k, v, 3 * D, _l.ptr(keymask), km_bstride, B, H, L, d, _l.ptr(ctx), D,
+    _l.check((Lb.pxr_attn_fwd_h2_f32 if h2 else Lb.pxr_attn_fwd_planes_f32)(q, k, v, 3 * D, _l.ptr(keymask), km_bstride, B, H, L, d, _l.ptr(ctx), D,
                                         _l.ptr(probs), p_drop, seed, stream_id, _l.ptr(step_dev), *_pl(cp_), _l.stream_ptr()),
              "pxr_attn_fwd_f32")
     if planes and not fused_p:

@@ -34,9 +34,11 @@ def pytest_collection_modifyitems(config, items):
 # csrc/gemm_p3.cuh), "bf16x3" (the same split inside the GEMM main loop, csrc/gemm_b3.cuh; PXR_PLANES=0) and "f32" (the
 # f32-input MFMA kernels; PXR_GEMM_MODE=f32).  The model-level parity suites below run in ALL of them inside one
 # `pytest -m gpu`, so the driver's GPU run covers the fallbacks too (only the default mode was exercised).
-MODE_MODULES = {"test_gpu_sasrec": ("planes", "bf16x3", "f32"), "test_gpu_eval": ("planes", "bf16x3", "f32"),
-                "test_gpu_vit": ("planes", "f32"), "test_gpu_mosasrec": ("planes", "bf16x3", "f32"),
-                "test_gpu_fullsize": ("planes", "f32"), "test_gpu_lazy_adamw": ("planes", "bf16x3")}
+# "h2" = planes with the sequence block FORCED onto the fp16 two-plane operands (PXR_SEQ_H2=1; by default only batches of
+# >= 16384 tokens take them, csrc/planes.cuh "h2" / model/seqcore.py::_h2_on): the same parity bars at the test shapes.
+MODE_MODULES = {"test_gpu_sasrec": ("planes", "bf16x3", "f32", "h2"), "test_gpu_eval": ("planes", "bf16x3", "f32"),
+                "test_gpu_vit": ("planes", "f32"), "test_gpu_mosasrec": ("planes", "bf16x3", "f32", "h2"),
+                "test_gpu_fullsize": ("planes", "f32", "h2"), "test_gpu_lazy_adamw": ("planes", "bf16x3")}
 
 
 @pytest.fixture(autouse=True)
@@ -47,17 +49,19 @@ def pxr_mode(request):
         return
     from pixelrec_amd import ops
 
-    prev_env = os.environ.get("PXR_PLANES")
+    prev_env = {k: os.environ.get(k) for k in ("PXR_PLANES", "PXR_SEQ_H2")}
     prev = ops.set_gemm_mode("f32" if mode == "f32" else "bf16x3")
-    os.environ["PXR_PLANES"] = "1" if mode == "planes" else "0"
+    os.environ["PXR_PLANES"] = "1" if mode in ("planes", "h2") else "0"
+    os.environ["PXR_SEQ_H2"] = "1" if mode == "h2" else "auto"
     try:
         yield mode
     finally:
         ops.set_gemm_mode(prev)
-        if prev_env is None:
-            os.environ.pop("PXR_PLANES", None)
-        else:
-            os.environ["PXR_PLANES"] = prev_env
+        for k, v in prev_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def pytest_generate_tests(metafunc):

@@ -280,3 +280,29 @@ def test_five_layers_planes_mode_steps():
                   "position_embedding.weight"):
             # (an element whose gradient is ~1e-8 moves by a fraction of lr that depends on the gradient's last bits)
             assert (sd[k] - ref[k]).abs().max().item() <= 3e-5, (step, k)
+
+
+def test_forced_h2_mode_really_runs_on_fp16_planes(pxr_mode):
+    """Mode "h2" of this module (conftest.py: PXR_SEQ_H2=1) must put the sequence block on the fp16 two-plane GEMMs -- not fall
+    back silently -- and by default only batches of >= 16384 tokens take them."""
+    from pixelrec_amd import ops
+
+    meta, z = load_case(CASES[-1])
+    m, _ = _model(meta)
+    m.train()
+    items, mask = torch.from_numpy(z["items"]).cuda(), torch.from_numpy(z["masked_index"]).cuda()
+    tags = []
+    ops.GEMM_TIMING = tags
+    try:
+        m((items, mask)).backward()
+    finally:
+        ops.GEMM_TIMING = None
+    on_h2 = [t[3] for t in tags if "HALF" in t[3]]
+    supported = ops.attn_planes_supported(meta["L"], meta["D"] // meta["H"]) and meta["D"] % 32 == 0
+    if pxr_mode == "h2" and supported:
+        # per layer: 4 forward GEMMs, 4 input-gradient GEMMs; one grouped weight-gradient launch for the step
+        assert len(on_h2) == 8 * meta["n_layers"] + 1, (len(on_h2), len(tags))
+        assert not [t[3] for t in tags if t[3].startswith("gemm_p3_kernel<KC")]     # no six-product GEMM left in the block
+    else:
+        assert not on_h2
+    assert m._h2_on(16384 // meta["L"] + 1) == (pxr_mode in ("planes", "h2") and supported)
