@@ -27,7 +27,9 @@ __device__ __forceinline__ int h2_exp_for(float max_abs, int top) {
   return e < -60 ? -60 : (e > 60 ? 60 : e);
 }
 
-// stat[0] = max |x|   (four independent 16-byte loads in flight per thread: the tensors are hundreds of MB)
+// stat[0] = max |x|   (four independent 16-byte loads in flight per thread: the tensors are hundreds of MB).  FLAT: contiguous rows --
+// no 64-bit division per load (a select between the two address forms made the compiler evaluate both: 1 TB/s instead of 4)
+template <bool FLAT>
 __global__ void __launch_bounds__(256) h2_max_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols4, float* stat) {
   const int64_t n = rows * cols4, stride = (int64_t)gridDim.x * 256;
   float m = 0.f;
@@ -36,8 +38,10 @@ __global__ void __launch_bounds__(256) h2_max_kernel(const float* __restrict__ x
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
   };
-  const bool flat = (ldx == (int64_t)cols4 * 4);      // contiguous rows: no 64-bit division per load
-  auto at = [&](int64_t i) { return *reinterpret_cast<const float4*>(flat ? x + i * 4 : x + (i / cols4) * ldx + (i % cols4) * 4); };
+  auto at = [&](int64_t i) {
+    if constexpr (FLAT) return *reinterpret_cast<const float4*>(x + i * 4);
+    else return *reinterpret_cast<const float4*>(x + (i / cols4) * ldx + (i % cols4) * 4);
+  };
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   for (; i + 3 * stride < n; i += 4 * stride) {
     const float4 a = at(i), b = at(i + stride), c = at(i + 2 * stride), d = at(i + 3 * stride);
@@ -45,8 +49,16 @@ __global__ void __launch_bounds__(256) h2_max_kernel(const float* __restrict__ x
   }
   for (; i < n; i += stride) take(at(i));
   if (bad) m = __int_as_float(0x7f800000);       // NaN -> inf
+  // one atomic per WORKGROUP, and only when it can raise the maximum: 16 384 same-address atomics (one per wave) serialise in one L2
+  // channel -- ~200 us on top of a 50 us read (measured)
+  __shared__ float wm[4];
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) h2_atomic_max(stat, m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (m > __hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) h2_atomic_max(stat, m);
+  }
 }
 // stat[0] = max |w|, stat[1] = max over columns j of sum_k |w[k][j]|   (w [rows][cols]).  A workgroup owns 32 columns: 8 row lanes x
 // 32 columns of threads walk the rows (128-byte coalesced segments), the 8 partial sums of a column are added in a fixed order
@@ -151,8 +163,9 @@ extern "C" int pxr_h2_split_auto_multi_f32(int n, const float* const* x, const i
     } else {
       const int64_t work = rows[i] * (cols[i] / 4);
       const int64_t blocks = (work + 255) / 256;
-      hipLaunchKernelGGL(h2_max_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, x[i], ldx[i], rows[i], (int)(cols[i] / 4),
-                         stats + 2 * i);
+      const dim3 grid((unsigned)(blocks > 4096 ? 4096 : blocks));
+      if (ldx[i] == cols[i]) hipLaunchKernelGGL(h2_max_kernel<true>, grid, dim3(256), 0, st, x[i], ldx[i], rows[i], (int)(cols[i] / 4), stats + 2 * i);
+      else hipLaunchKernelGGL(h2_max_kernel<false>, grid, dim3(256), 0, st, x[i], ldx[i], rows[i], (int)(cols[i] / 4), stats + 2 * i);
     }
   }
   hipLaunchKernelGGL(h2_split_auto_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, m);
