@@ -610,6 +610,8 @@ def main():
     g_union = g_union or float("nan")
     g_sum = sum(s_.elapsed_time(e_) for s_, e_, _, _ in gemm_events) * 1e-3 or float("nan")
     g_fl = sum(f for _, _, f, _ in gemm_events)
+    g_ex = sum(f * executed_products(t) for _, _, f, t in gemm_events)
+    g_h2 = any("HALF" in t for _, _, _, t in gemm_events)
     n_launch = len(gemm_events)
 
     def per_tag(events, unit_scale, unit_name):
@@ -639,7 +641,7 @@ def main():
                        if b3 else
                        "gemm_kernel / grouped_dw_kernel (v_mfma_f32_32x32x2_f32; every nn.Linear fwd/bwd of the step)"),
             "gemm_mode": ("planes" if planes_on else ops.gemm_mode()),
-            **mfma_roof(g_fl, g_union, b3), "traffic": traffic,
+            **mfma_roof(g_fl, g_union, b3, g_ex if g_h2 else None), "traffic": traffic,
             "traffic_source": ("profiles/r04/pmc/gemm_traffic_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                "this command on the same kernels (read from the committed file, NOT measured in this run)"
                                if traffic is not None else None),
@@ -745,11 +747,15 @@ def main():
                        "table optimizer rows (adamw_rows)" if t.startswith("adamw_rows") else "other instrumented (loss, sort, segsum, flat optimizer)")
                 fam[key] = fam.get(key, 0.0) + s_.elapsed_time(e_) * 1e3 / 2
             gfl = sum(w for _, _, w, t in evs if t.startswith("gemm") or t.startswith("grouped_dw")) / 2
+            gex = sum(w * executed_products(t) for _, _, w, t in evs if t.startswith("gemm") or t.startswith("grouped_dw")) / 2
+            on_h2 = any("HALF" in t for _, _, _, t in evs)
             gus = sum(v for k, v in fam.items() if k.startswith("gemm") or k.startswith("grouped"))
             fam["everything not bracketed with events (attention, the other LayerNorm sites, loss, id sort, segment sums, "
                 "flat optimizer, launch gaps) = step time - the rows above"] = tb * 1e6 - sum(fam.values())
             out["throughput_batches"][-1]["kernel_families_us_per_step"] = fam
-            out["throughput_batches"][-1]["gemm_family"] = {**mfma_roof(gfl, gus * 1e-6, b3), "us_per_step": gus}
+            out["throughput_batches"][-1]["gemm_family"] = {**mfma_roof(gfl, gus * 1e-6, b3, gex if on_h2 else None), "us_per_step": gus,
+                                                            "operands": ("two fp16 planes, 3 products per multiply (PXR_SEQ_H2: batches of "
+                                                                         ">= 16384 tokens)" if on_h2 else "three bf16 planes, 6 products")}
             gl = [(s_.elapsed_time(e_) * 1e-3, w) for s_, e_, w, t in evs if t.startswith("ln_fwd_kernel<GATHER>")]
             if gl and "roofline_gather_fused" in out:
                 sec = sum(x for x, _ in gl) / len(gl)
