@@ -224,13 +224,24 @@ int pxr_grouped_dw_h2_f32(int n, const void* const* dy, const int64_t* dy_plane_
                           const int64_t* x_panel_rows, const int* x_exp, const int* const* x_exp_dev, float* const* dW,
                           float* const* db, const int* T, const int* N, const int* K, int tile_hint, void* stream);
 /* h2 split with the scale chosen ON THE DEVICE (tensors that change every step): per matrix max |x| -> stats[2 i] (col_stats: also
- * the largest column sum of |x| -> stats[2 i + 1]) and e = 14 - ceil(log2 max) -> exps[i]; no host synchronisation.
+ * the largest column sum of |x| -> stats[2 i + 1]; col_stats 0: rows * max instead, an upper bound; col_stats 2: stats[2 i] was
+ * gathered by the producers, no statistics pass) and e = 14 - ceil(log2 max) -> exps[i]; no host synchronisation.
  * pxr_h2_bound_exp: *exp_out = 15 - ceil(log2(a_max[0] * b_colsum[0] * factor)) -- the exponent of an input gradient that leaves
  * a GEMM epilogue as planes before its maximum can be known (|dy W| <= max |dy| * max column sum of |W|). */
 int pxr_h2_split_auto_multi_f32(int n, const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ldx,
                                 void* const* planes, const int64_t* plane_stride, const int64_t* panel_rows, int col_stats,
                                 float* stats, int* exps, void* stream);
 int pxr_h2_bound_exp(const float* a_max, const float* b_colsum, float factor, int* exp_out, void* stream);
+/* Producers that gather the statistics themselves (col_stats = 2 of pxr_h2_split_auto_multi_f32 then skips its own pass): the
+ * LayerNorm backward of a residual site / the fused attention backward, as pxr_ln_bwd_f32(gather_mode 0) / pxr_attn_bwd_f32, plus
+ * *stat = max |gradient the next GEMMs read| (dx when given, else dz) / max(|dq|, |dk|, |dv|) by atomic maxima into a slot the
+ * caller zeroed. */
+int pxr_ln_bwd_stat_f32(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int D, float* dz,
+                        float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
+                        const int64_t* step_dev, void* ws, int64_t ws_bytes, float* stat, void* stream);
+int pxr_attn_bwd_stat_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
+                          const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d,
+                          float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, float* stat, void* stream);
 int pxr_ln_residual_fwd_h2_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps, int rows,
                                int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed, uint32_t stream_id,
                                const int64_t* step_dev, void* y_planes, int64_t y_plane_stride, int64_t y_panel_rows,

@@ -48,6 +48,7 @@ struct AttnArgs {
   int pcol[3];
   int op_fmt;               // PXR_PLANES_BF16X3 | PXR_PLANES_H2 (the forward's ctx planes; planes.cuh)
   int32_t* status;          // status word for the fp16 range check of h2 planes, or null
+  float* stat;              // backward (attn_bwd_mfma1_kernel): atomic max of |dq|, |dk|, |dv| into a zeroed slot, or null
 };
 
 // stage tile[row][0..w) <- src[(row)*ld + 0..w) for row < L; all threads of the block, float4 accesses
@@ -669,7 +670,20 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   const bool mine = n_base < d;
   f32x16 acc[TN];
   zero_acc<TN>(acc);
+  float gmax = 0.f;         // max |dq|, |dk|, |dv| over this thread's entries INSIDE the [L, d] block (the tiles' padding holds
+  auto take = [&]() {       // whatever the LDS held: store_acc masks it, so must the statistics)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bool col_ok = n_base + j * 32 + (lane & 31) < d;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (col_ok && row < L) gmax = fmaxf(gmax, fabsf(acc[j][e]));
+      }
+    }
+  };
   if (mine) lds_mma<false, false, TN>(acc, sS, ATT_SLD, sO, ATT_KLD, wm * 32, n_base, 64, lane);   // dV = Pd^T dctx
+  if (a.stat && mine) take();
   if (a.dv) store_acc<TN>(acc, a.dv + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
   // (sV was last read by the dPd product, two barriers ago: free for the plane staging)
   if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[2] + h * d);
@@ -682,12 +696,19 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   __syncthreads();
   zero_acc<TN>(acc);
   if (mine) lds_mma<true, false, TN>(acc, sS, ATT_SLD, sK, ATT_KLD, wm * 32, n_base, 64, lane);    // dQ = dS K
+  if (a.stat && mine) take();
   if (a.dq) store_acc<TN>(acc, a.dq + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
   if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[0] + h * d);
   zero_acc<TN>(acc);
   if (mine) lds_mma<false, false, TN>(acc, sS, ATT_SLD, sQ, ATT_KLD, wm * 32, n_base, 64, lane);   // dK = dS^T Q
+  if (a.stat && mine) take();
   if (a.dk) store_acc<TN>(acc, a.dk + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
   if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[1] + h * d);
+  if (a.stat) {
+    gmax = wave_max(gmax);
+    if (lane == 0 && gmax > __hip_atomic_load(a.stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<int*>(a.stat), __float_as_int(gmax));
+  }
 }
 
 // ---- sequences of 65..128 positions ------------------------------------------------------------------------------
@@ -1029,11 +1050,32 @@ extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* 
 }
 // the same with dq | dk | dv additionally -- or, all three NULL, only -- written as bf16x3 planes: column ranges starting at
 // col_q / col_k / col_v of one [B*L, g_cols] planes matrix (the gradient of the fused QKV projection's output).
+static int attn_bwd_impl(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
+                         const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d, float p_drop,
+                         uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* g_planes, int64_t g_plane_stride,
+                         int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v, float* stat, void* stream);
 extern "C" int pxr_attn_bwd_planes_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v,
                                        int64_t ld, const float* probs, int B, int H, int L, int d, float* dq, float* dk,
                                        float* dv, int64_t ld_d, float p_drop, uint64_t seed, uint32_t stream_id,
                                        const int64_t* step_dev, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows,
                                        int g_cols, int col_q, int col_k, int col_v, void* stream) {
+  return attn_bwd_impl(dctx, ld_ctx, q, k, v, ld, probs, B, H, L, d, dq, dk, dv, ld_d, p_drop, seed, stream_id, step_dev, g_planes,
+                       g_plane_stride, g_panel_rows, g_cols, col_q, col_k, col_v, nullptr, stream);
+}
+// pxr_attn_bwd_f32 that also leaves max(|dq|, |dk|, |dv|) in *stat by atomic maxima (the caller zeroes the slot): the statistics
+// pxr_h2_split_auto_multi_f32(col_stats = 2) needs.  Only the shapes the fused MFMA kernel serves (pxr_attn_planes_supported).
+extern "C" int pxr_attn_bwd_stat_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
+                                     const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d,
+                                     float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, float* stat,
+                                     void* stream) {
+  PXR_REQUIRE(stat && pxr_attn_planes_supported(L, d), "pxr_attn_bwd_stat_f32: no slot, or a shape the fused kernel does not serve (L=%d, d=%d)", L, d);
+  return attn_bwd_impl(dctx, ld_ctx, q, k, v, ld, probs, B, H, L, d, dq, dk, dv, ld_d, p_drop, seed, stream_id, step_dev, nullptr, 0, 0, 0,
+                       0, 0, 0, stat, stream);
+}
+static int attn_bwd_impl(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
+                         const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d, float p_drop,
+                         uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* g_planes, int64_t g_plane_stride,
+                         int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v, float* stat, void* stream) {
   PXR_REQUIRE(dctx && q && k && v && probs && ((dq && dk && dv) || (g_planes && !dq && !dk && !dv)), "pxr_attn_bwd_f32: null pointer");
   PXR_REQUIRE(!g_planes || (pxr_attn_planes_supported(L, d) && p3_mat_ok(g_planes, g_plane_stride, g_panel_rows, (int64_t)B * L, g_cols) &&
                             col_q % 8 == 0 && col_k % 8 == 0 && col_v % 8 == 0 && col_q >= 0 && col_k >= 0 && col_v >= 0 &&
@@ -1048,6 +1090,7 @@ extern "C" int pxr_attn_bwd_planes_f32(const float* dctx, int64_t ld_ctx, const 
   a.dctx = dctx; a.dq = dq; a.dk = dk; a.dv = dv; a.ld_d = ld_d; a.B = B; a.H = H; a.L = L; a.d = d;
   a.op = P3Mat{reinterpret_cast<__bf16*>(g_planes), g_plane_stride, g_panel_rows};
   a.pcol[0] = col_q; a.pcol[1] = col_k; a.pcol[2] = col_v;
+  a.stat = stat;
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;

@@ -36,19 +36,23 @@ namespace pxr {
 typedef __bf16 p3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 p3_bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_>
+// HALF_: the operands are TWO fp16 planes (planes.cuh "h2"), three products per multiply on v_mfma_f32_32x32x16_f16, hi*hi in one
+// accumulator set and the two cross terms in a second (gemm_p4.cuh has the big-tile version)
+template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_, bool HALF_ = false>
 struct P3Cfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, STAGES = STAGES_;
+  static constexpr bool HALF = HALF_;
+  static constexpr int NPL = HALF ? 2 : 3;                            // planes per operand
   static constexpr int G = WGM * WGN, NT = 64 * G, BK = 32;
   static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
   static constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;          // bytes per plane per stage
-  static constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
-  static constexpr int LDS_BYTES = STAGES * STAGE;
-  static constexpr int A_PIECES = 3 * BM / 16, B_PIECES = 3 * BN / 16;   // 1 KiB DMA pieces per K tile
-  static constexpr int A_PPW = A_PIECES / G, B_PPW = B_PIECES / G, PPW = A_PPW + B_PPW;
+  static constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
   static constexpr int EPI_LD = BN + 4;                               // floats per row of the epilogue's LDS tile
+  static constexpr int EPI_BYTES = BM * EPI_LD * 4;
+  static constexpr int LDS_BYTES = STAGES * STAGE > EPI_BYTES ? STAGES * STAGE : EPI_BYTES;
+  static constexpr int A_PIECES = NPL * BM / 16, B_PIECES = NPL * BN / 16;   // 1 KiB DMA pieces per K tile
+  static constexpr int A_PPW = A_PIECES / G, B_PPW = B_PIECES / G, PPW = A_PPW + B_PPW;
   static constexpr bool PINGPONG = false;
-  static constexpr bool HALF = false;      // (gemm_p4.cuh: operands as two fp16 planes)                             // (gemm_p4.cuh's configurations say true)
   static_assert(A_PIECES % G == 0 && B_PIECES % G == 0, "DMA pieces must divide evenly among the waves");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile = 32x32 blocks");
   static_assert(STAGES >= 2 && STAGES <= 6, "2..6 LDS stages");
@@ -98,7 +102,7 @@ __device__ __forceinline__ void p3_wait_tiles(int tiles) {
 // One operand's DMA plan.  BX = tile extent along the operand's x (BM or BN), PPWX = pieces this wave issues per K tile,
 // KC = flavour.  A piece's source = lane * 16 (the only per-lane part: ONE VGPR) + a wave-uniform byte offset (plane,
 // 1 KiB run, tile origin: SGPRs, added to the K-tile offset in the instruction's scalar offset).
-template <int BX, int PPWX, bool KC>
+template <int BX, int PPWX, bool KC, int NPL = 3>
 struct P3Operand {
   bufrsrc rs;
   unsigned scal[PPWX];     // wave-uniform byte offset of each piece (loop-invariant)
@@ -106,7 +110,7 @@ struct P3Operand {
   unsigned soff, sstep;    // byte offset of the next K tile to issue / its step
   // m: the matrix; x0: tile origin along x; area: byte offset of this operand's planes inside a stage
   __device__ __forceinline__ void init(const P3Mat& m, int x0, int wave, int lane, unsigned area) {
-    rs = make_rsrc(reinterpret_cast<const float*>(m.p), m.ps * 3 * 2);
+    rs = make_rsrc(reinterpret_cast<const float*>(m.p), m.ps * NPL * 2);
     // piece id q = wave * PPWX + j: plane-major, then 1 KiB run; its LDS offset inside the operand's area is q * 1024
     dst0 = __builtin_amdgcn_readfirstlane(area + (unsigned)(wave * PPWX * 1024));
 #pragma unroll
@@ -205,10 +209,11 @@ __device__ __forceinline__ void gemm_p3_mainloop(typename Cfg::Acc& accs, const 
   const int nk = K / 32;
   if (nk <= 0) return;
 
-  P3Operand<Cfg::BM, Cfg::A_PPW, A_KC> opA;
-  P3Operand<Cfg::BN, Cfg::B_PPW, B_KC> opB;
+  constexpr int NPL = Cfg::NPL;
+  P3Operand<Cfg::BM, Cfg::A_PPW, A_KC, NPL> opA;
+  P3Operand<Cfg::BN, Cfg::B_PPW, B_KC, NPL> opB;
   opA.init(A, m0, wave, lane, 0u);
-  opB.init(B, n0, wave, lane, (unsigned)(3 * Cfg::A_PLANE));
+  opB.init(B, n0, wave, lane, (unsigned)(NPL * Cfg::A_PLANE));
   const unsigned smem_base = (unsigned)(size_t)smem;
   unsigned i_stage = 0;                                       // stage of the next tile to issue
   auto issue = [&]() {
@@ -227,13 +232,13 @@ __device__ __forceinline__ void gemm_p3_mainloop(typename Cfg::Acc& accs, const 
 #pragma unroll
   for (int j = 0; j < TN; ++j) fb[j].init(wn * Cfg::WN + j * 32, lane);
   struct Frag {
-    p3_bf16x8 a[TM][3], b[TN][3];
+    p3_bf16x8 a[TM][NPL], b[TN][NPL];
   };
   auto read_frag = [&](Frag& f, int stage, int kb) {
     const char* sa = smem + stage * Cfg::STAGE;
-    const char* sb = sa + 3 * Cfg::A_PLANE;
+    const char* sb = sa + NPL * Cfg::A_PLANE;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NPL; ++p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) f.a[i][p] = fa[i].read(sa + p * Cfg::A_PLANE, kb);
 #pragma unroll
@@ -248,14 +253,34 @@ __device__ __forceinline__ void gemm_p3_mainloop(typename Cfg::Acc& accs, const 
 #define PXR_P3_PROD(ACC, PA, PB)                                                                                \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
       ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA], f.b[j][PB], ACC[i][j], 0, 0, 0);
-    PXR_P3_PROD(accl, 2, 0)        // lo  * hi
-    PXR_P3_PROD(accm, 1, 0)        // mid * hi
-    PXR_P3_PROD(accs.v, 0, 0)      // hi  * hi
-    PXR_P3_PROD(accl, 0, 2)        // hi  * lo
-    PXR_P3_PROD(accm, 0, 1)        // hi  * mid
-    PXR_P3_PROD(accl, 1, 1)        // mid * mid
+#define PXR_P3_PRODH(ACC, PA, PB)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(p3_f16x8, f.a[i][PA]),                \
+                                                         __builtin_bit_cast(p3_f16x8, f.b[j][PB]), ACC[i][j], 0, 0, 0);
+    if constexpr (Cfg::HALF) {
+      PXR_P3_PRODH(accm, 1, 0)       // lo * hi
+      PXR_P3_PRODH(accs.v, 0, 0)     // hi * hi
+      PXR_P3_PRODH(accm, 0, 1)       // hi * lo
+    } else {
+      PXR_P3_PROD(accl, 2, 0)        // lo  * hi
+      PXR_P3_PROD(accm, 1, 0)        // mid * hi
+      PXR_P3_PROD(accs.v, 0, 0)      // hi  * hi
+      PXR_P3_PROD(accl, 0, 2)        // hi  * lo
+      PXR_P3_PROD(accm, 0, 1)        // hi  * mid
+      PXR_P3_PROD(accl, 1, 1)        // mid * mid
+    }
 #undef PXR_P3_PROD
-    if constexpr (ONES) {
+#undef PXR_P3_PRODH
+    if constexpr (ONES && Cfg::HALF) {
+      p3_f16x8 ones_h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ones_h[e] = (_Float16)1.0f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          ones_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(p3_f16x8, f.a[i][p]), ones_h, ones_acc[i], 0, 0, 0);
+    } else if constexpr (ONES) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -326,6 +351,7 @@ __device__ __forceinline__ void p3_lds_barrier() {
 template <class Cfg, class TileFn>
 __device__ __forceinline__ void gemm_p3_stream(const P3Mat& A, const P3Mat& B, int K, int m_first, int n0, int n_tiles, char* smem,
                                                TileFn&& done) {
+  static_assert(!Cfg::HALF, "the scoring stream runs on the three bf16 planes");
   constexpr int TM = Cfg::TM, TN = Cfg::TN, S = Cfg::STAGES;
   const int tid = threadIdx.x;
   const int lane = tid & 63;

@@ -657,11 +657,19 @@ extern "C" int pxr_gemm_h2_f32(int b_kc, int M, int N, int K, const void* A, int
   // tiles: 2 | BM | BN | ring slots | accumulator sets.  256x256 (one set) when its rounds of 256 workgroups, each 1.75x as long as
   // a round of 256x128 tiles (two sets: hi*hi apart from the cross terms; measured: profiles/r04/lab/h2_lab_run1.log -- the square
   // tile reads half as many LDS bytes per MFMA), cost no more
+  // ... and, when 256-row tiles would not fill the chip twice (the reference's 3 200-token step), the lockstep tiles of the bf16x3
+  // kernels on two planes: 128x64 for wide outputs, 64x64 otherwise (lab, 3 200 tokens: 25.4 -> 16.6 us fc1, 36.3 -> 22.6 qkv,
+  // 14.8 -> 10.1 out-proj, 26.4 -> 17.0 fc2; profiles/r04/lab/h2_lab_run2_seq_tiles.log)
   if (tile_hint == 0) {
     const int64_t t128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128), t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     static const int env_sq = getenv("PXR_H2_SQUARE") ? atoi(getenv("PXR_H2_SQUARE")) : 1;
-    tile_hint = (env_sq && N >= 256 && 7 * ((t256 + 255) / 256) <= 4 * ((t128 + 255) / 256)) ? 225625641 : 225612842;
+    static const int env_small = getenv("PXR_H2_SMALL_TILES") ? atoi(getenv("PXR_H2_SMALL_TILES")) : 1;
+    if (env_small && t128 < 512) tile_hint = N >= 1024 ? 212806420 : 206406430;
+    else tile_hint = (env_sq && N >= 256 && 7 * ((t256 + 255) / 256) <= 4 * ((t128 + 255) / 256)) ? 225625641 : 225612842;
   }
+  if (tile_hint == 212806420) return epi_h2<P3Cfg<128, 64, 2, 2, 2, true>>(b_kc, epilogue, g, st);
+  if (tile_hint == 212806430) return epi_h2<P3Cfg<128, 64, 2, 2, 3, true>>(b_kc, epilogue, g, st);
+  if (tile_hint == 206406430) return epi_h2<P3Cfg<64, 64, 2, 2, 3, true>>(b_kc, epilogue, g, st);
   if (tile_hint == 225625641) return epi_h2<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>>(b_kc, epilogue, g, st);
   if (tile_hint == 225612842) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>>(b_kc, epilogue, g, st);
   if (tile_hint == 225612841) return epi_h2<P4Cfg<256, 128, 4, 2, 4, 1, 0, 2, true>>(b_kc, epilogue, g, st);

@@ -93,6 +93,37 @@ __global__ void __launch_bounds__(256) h2_colstat_kernel(const float* __restrict
   }
 }
 
+// max |x| of up to 16 CONTIGUOUS matrices in one launch (the weights of the sequence block: 8 small matrices, where one launch per
+// matrix costs more than the reads): H2_BPM workgroups per matrix, one atomic each
+constexpr int H2_BPM = 16;
+struct H2MaxMulti {
+  const float* x[16];
+  int64_t n4[16];          // float4 elements
+  int n;
+  float* stats;            // [n][2]
+};
+__global__ void __launch_bounds__(256) h2_max_multi_kernel(const H2MaxMulti m) {
+  const int mat = blockIdx.x / H2_BPM, part = blockIdx.x % H2_BPM;
+  const float4* x = reinterpret_cast<const float4*>(m.x[mat]);
+  const int64_t n = m.n4[mat];
+  float mx = 0.f;
+  bool bad = false;
+  for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < n; i += (int64_t)H2_BPM * 256) {
+    const float4 v = x[i];
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+  }
+  if (bad) mx = __int_as_float(0x7f800000);
+  __shared__ float wm[4];
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (mx > 0.f) h2_atomic_max(m.stats + 2 * mat, mx);
+  }
+}
+
 // (a kernel, not hipMemsetAsync: inside a captured step the memset node was seen to run out of order with the atomic maxima that
 // follow it -- intermittently zeroing finished statistics; a kernel node is ordered like every other launch of the stream)
 __global__ void h2_zero_kernel(float* p, int n) {
@@ -103,12 +134,16 @@ struct H2SplitAuto {
   const float* x[16]; int64_t ldx[16]; int rows[16], cols8[16]; P3Mat out[16];
   int64_t begin[17];
   int n;
-  const float* stats;      // [n][2]
+  float* stats;            // [n][2]
   int* exps;               // [n]
   int32_t* status;
+  int fill_colsum;         // no column statistics were gathered: stats[2 i + 1] = rows * max |x| (>= every column sum of |x|)
 };
 __global__ void __launch_bounds__(256) h2_split_auto_kernel(const H2SplitAuto m) {
-  if (blockIdx.x == 0 && threadIdx.x < m.n) m.exps[threadIdx.x] = h2_exp_for(m.stats[2 * threadIdx.x], 14);
+  if (blockIdx.x == 0 && threadIdx.x < m.n) {
+    m.exps[threadIdx.x] = h2_exp_for(m.stats[2 * threadIdx.x], 14);
+    if (m.fill_colsum) m.stats[2 * threadIdx.x + 1] = (float)m.rows[threadIdx.x] * m.stats[2 * threadIdx.x];
+  }
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= m.begin[m.n]) return;
   int pi = 0;
@@ -155,17 +190,31 @@ extern "C" int pxr_h2_split_auto_multi_f32(int n, const float* const* x, const i
   }
   m.begin[n] = total;
   PXR_REQUIRE((total + 255) / 256 < (1ll << 31), "pxr_h2_split_auto_multi_f32: too large");
-  hipLaunchKernelGGL(h2_zero_kernel, dim3(1), dim3(64), 0, st, stats, 2 * n);
-  for (int i = 0; i < n; ++i) {
-    if (col_stats) {
-      hipLaunchKernelGGL(h2_colstat_kernel, dim3((unsigned)((cols[i] + 31) / 32)), dim3(256), 0, st, x[i], ldx[i], (int)rows[i], (int)cols[i],
-                         stats + 2 * i);
+  // col_stats: 0 = max |x| only (stats[2 i + 1] is then filled with rows * max, a bound on every column sum), 1 = max and the largest
+  // column sum of |x|, 2 = the caller's producers already gathered stats[2 i] (atomic maxima into a zeroed slot): no statistics pass
+  m.fill_colsum = (col_stats != 1);
+  if (col_stats != 2) {
+    hipLaunchKernelGGL(h2_zero_kernel, dim3(1), dim3(64), 0, st, stats, 2 * n);
+    bool contiguous = true;
+    for (int i = 0; i < n; ++i) contiguous = contiguous && (ldx[i] == cols[i]);
+    if (col_stats == 0 && contiguous && n > 1) {
+      H2MaxMulti mm{};
+      mm.n = n; mm.stats = stats;
+      for (int i = 0; i < n; ++i) { mm.x[i] = x[i]; mm.n4[i] = rows[i] * (cols[i] / 4); }
+      hipLaunchKernelGGL(h2_max_multi_kernel, dim3((unsigned)(n * H2_BPM)), dim3(256), 0, st, mm);
     } else {
-      const int64_t work = rows[i] * (cols[i] / 4);
-      const int64_t blocks = (work + 255) / 256;
-      const dim3 grid((unsigned)(blocks > 4096 ? 4096 : blocks));
-      if (ldx[i] == cols[i]) hipLaunchKernelGGL(h2_max_kernel<true>, grid, dim3(256), 0, st, x[i], ldx[i], rows[i], (int)(cols[i] / 4), stats + 2 * i);
-      else hipLaunchKernelGGL(h2_max_kernel<false>, grid, dim3(256), 0, st, x[i], ldx[i], rows[i], (int)(cols[i] / 4), stats + 2 * i);
+      for (int i = 0; i < n; ++i) {
+        if (col_stats == 1) {
+          hipLaunchKernelGGL(h2_colstat_kernel, dim3((unsigned)((cols[i] + 31) / 32)), dim3(256), 0, st, x[i], ldx[i], (int)rows[i], (int)cols[i],
+                             stats + 2 * i);
+        } else {
+          const int64_t work = rows[i] * (cols[i] / 4);
+          const int64_t blocks = (work + 1023) / 1024;          // >= 4 loads per thread; few workgroups = few same-address atomics
+          const dim3 grid((unsigned)(blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks)));
+          if (ldx[i] == cols[i]) hipLaunchKernelGGL(h2_max_kernel<true>, grid, dim3(256), 0, st, x[i], ldx[i], rows[i], (int)(cols[i] / 4), stats + 2 * i);
+          else hipLaunchKernelGGL(h2_max_kernel<false>, grid, dim3(256), 0, st, x[i], ldx[i], rows[i], (int)(cols[i] / 4), stats + 2 * i);
+        }
+      }
     }
   }
   hipLaunchKernelGGL(h2_split_auto_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, m);

@@ -169,6 +169,7 @@ struct LnBwdArgs {
   uint64_t seed;
   const int64_t* step_dev;
   P3Mat gp;             // optional: planes of the gradient the next GEMMs read (dx when it is written, else dz)
+  float* stat;          // optional: atomic max of |that gradient| (a zeroed slot; the h2 split derives its scale from it)
 };
 
 template <int VEC, bool GATHER>
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
   const int blk = xcd_remap(blockIdx.x, gridDim.x);      // rows of one XCD are contiguous (pxr_common.h); partial index = blk
   const int r0 = blk * a.rows_per_block;
   const int r1 = min(a.rows, r0 + a.rows_per_block);
+  float gmax = 0.f;        // max |gradient the next GEMMs read| over this thread's elements (a.stat)
   for (int row = r0 + wave; row < r1; row += 4) {
     float4 g4[VEC], xh[VEC];
     float s1 = 0.f, s2 = 0.f;
@@ -233,6 +235,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
         z.z = rs * (g4[k].z - c1 - xh[k].z * c2); z.w = rs * (g4[k].w - c1 - xh[k].w * c2);
         *reinterpret_cast<float4*>(a.dz + (int64_t)row * D + c) = z;
         if constexpr (!GATHER) {
+          if (!a.dx) gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(z.x), fabsf(z.y)), fmaxf(fabsf(z.z), fabsf(z.w))));
           if (a.gp.p && !a.dx) p3_store4(a.gp, row, c, z);
           if (a.dx) {
             float4 o = z;
@@ -244,10 +247,18 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
               o.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? z.w * inv_keep : 0.f;
             }
             *reinterpret_cast<float4*>(a.dx + (int64_t)row * D + c) = o;
+            gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
             if (a.gp.p) p3_store4(a.gp, row, c, o);
           }
         }
       }
+    }
+  }
+  if constexpr (!GATHER) {
+    if (a.stat) {            // (NaN: fmaxf drops it -- a NaN gradient still reaches the planes and their range flag)
+      gmax = wave_max(gmax);
+      if (lane == 0 && gmax > __hip_atomic_load(a.stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<int*>(a.stat), __float_as_int(gmax));
     }
   }
   // cross-wave reduction of the per-lane partials in a fixed order (wave0 + wave1 + wave2 + wave3)
@@ -472,11 +483,31 @@ extern "C" int pxr_ln_bwd_f32(int gather_mode, const float* dy, const float* xha
                                step_dev, ws, ws_bytes, nullptr, 0, 0, stream);
 }
 // the same (gather_mode = 0), the gradient the next GEMMs read (dx when given, else dz) additionally written as planes
+static int ln_bwd_impl(int gather_mode, const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int D,
+                       float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
+                       const int64_t* step_dev, void* ws, int64_t ws_bytes, void* g_planes, int64_t g_plane_stride,
+                       int64_t g_panel_rows, float* stat, void* stream);
 extern "C" int pxr_ln_bwd_planes_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd,
                                      const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
                                      float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ws,
                                      int64_t ws_bytes, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows,
                                      void* stream) {
+  return ln_bwd_impl(gather_mode, dy, xhat, rstd, gamma, rows, D, dz, dx, dgamma, dbeta, p_drop, seed, stream_id, step_dev, ws, ws_bytes,
+                     g_planes, g_plane_stride, g_panel_rows, nullptr, stream);
+}
+// pxr_ln_bwd_f32 (residual sites) that also leaves max |gradient the next GEMMs read| (dx when given, else dz) in *stat by atomic
+// maxima -- the caller zeroes the slot; pxr_h2_split_auto_multi_f32(col_stats = 2) then needs no statistics pass of its own
+extern "C" int pxr_ln_bwd_stat_f32(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int D,
+                                   float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
+                                   const int64_t* step_dev, void* ws, int64_t ws_bytes, float* stat, void* stream) {
+  PXR_REQUIRE(stat, "pxr_ln_bwd_stat_f32: null statistics slot");
+  return ln_bwd_impl(0, dy, xhat, rstd, gamma, rows, D, dz, dx, dgamma, dbeta, p_drop, seed, stream_id, step_dev, ws, ws_bytes, nullptr, 0, 0,
+                     stat, stream);
+}
+static int ln_bwd_impl(int gather_mode, const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int D,
+                       float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
+                       const int64_t* step_dev, void* ws, int64_t ws_bytes, void* g_planes, int64_t g_plane_stride,
+                       int64_t g_panel_rows, float* stat, void* stream) {
   PXR_REQUIRE(dy && xhat && rstd && gamma && dz && ws, "pxr_ln_bwd_f32: null pointer");
   PXR_REQUIRE(p3_mat_ok(g_planes, g_plane_stride, g_panel_rows, rows, D) && !(g_planes && gather_mode),
               "pxr_ln_bwd_planes_f32: bad planes (residual sites only)");
@@ -493,6 +524,7 @@ extern "C" int pxr_ln_bwd_planes_f32(int gather_mode, const float* dy, const flo
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
   a.gp = P3Mat{reinterpret_cast<__bf16*>(g_planes), g_plane_stride, g_panel_rows};
+  a.stat = stat;
   hipStream_t st = (hipStream_t)stream;
   int rc = gather_mode ? launch_ln_bwd<true>(a, nblk, st) : launch_ln_bwd<false>(a, nblk, st);
   if (rc) return rc;

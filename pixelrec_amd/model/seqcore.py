@@ -265,10 +265,12 @@ class SeqRecCore(BaseModel):
         return [self._p(f"{i}.{n}", span=sp) for i in range(self.n_layers) for n, sp, _ in self._W_NAMES]
 
     def _weight_planes_h2(self):
-        """The weight matrices as h2 planes, scales (and the column statistics the input-gradient bound needs) found on the device."""
+        """The weight matrices as h2 planes, scales found on the device: ONE statistics launch for all of them (max |w| per matrix;
+        the input-gradient bound then uses rows x max |w| for the column sums: 2^2-2^3 looser than the true sums, one launch instead
+        of eight latency-bound ones -- 190 us per step at B = 64)."""
         mats = self._weight_mats()
         keys = [f"{i}.{k}" for i in range(self.n_layers) for _, _, k in self._W_NAMES]
-        return dict(zip(keys, ops.split_h2_auto(mats, col_stats=True)))
+        return dict(zip(keys, ops.split_h2_auto(mats, col_stats=False)))
 
     def _weight_planes(self, train: bool = False):
         """The block's weight matrices as planes.  Re-split from the flat parameter buffer (ONE launch) at the start of every
@@ -462,14 +464,19 @@ class SeqRecCore(BaseModel):
             pend = []
             h2m = bool(s.get("h2"))
 
+            # h2: every gradient that feeds GEMMs is written as fp32 by its producer, which also gathers max |.| into a slot of
+            # this zero-filled arena (ONE fill launch per step); the split then derives the power-of-two scale on the device
+            arena = torch.zeros(3 * self.n_layers, 1, 2, dtype=torch.float32, device=dh.device) if h2m else None
+            slot = iter(range(3 * self.n_layers))
+
             def ln_bwd_planes(*args, **kw):
-                """(dz, gradient the next GEMMs read as planes).  h2: the LayerNorm backward writes fp32, the split finds the
-                gradient's power-of-two scale on the device (ops.split_h2_auto)."""
+                """(dz, gradient the next GEMMs read as planes)."""
                 if not h2m:
                     dz, _, gp = ops.ln_bwd(*args, planes=True, **kw)
                     return dz, gp
-                dz, dx = ops.ln_bwd(*args, **kw)
-                return dz, ops.split_h2_auto([(dx if dx is not None else dz).view(T, D)])[0]
+                st = arena[next(slot)]
+                dz, dx = ops.ln_bwd(*args, stat=st, **kw)
+                return dz, ops.split_h2_auto([(dx if dx is not None else dz).view(T, D)], stats=st)[0]
 
             for i in reversed(range(self.n_layers)):
                 a = s["layers"][i]
@@ -486,8 +493,9 @@ class SeqRecCore(BaseModel):
                 pend.append((dxap, a["ctx"], g(f"{i}.o.w"), g(f"{i}.o.b")))
                 dctx, _ = ops.linear_bwd_input_planes(dxap, wp[f"{i}.o"], lead_shape=(B, L))
                 if h2m:
-                    dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv)
-                    dqkvp = ops.split_h2_auto([dqkv.view(T, 3 * D)])[0]
+                    st = arena[next(slot)]
+                    dqkv = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv, stat=st)
+                    dqkvp = ops.split_h2_auto([dqkv.view(T, 3 * D)], stats=st)[0]
                 else:
                     dqkvp = ops.attn_bwd(dctx, a["qkv"], a["probs"], B, H, L, d, pa, seed, 1 + 3 * i, step_dev=sdv, planes=True)
                 pend.append((dqkvp, a["h_in"], g(f"{i}.q.w", 3), g(f"{i}.q.b", 3)))

@@ -536,11 +536,15 @@ def h2_exponent(max_abs: float) -> int:
     return max(-60, min(60, 14 - math.frexp(max_abs)[1]))
 
 
-def split_h2_auto(mats, col_stats: bool = False):
+def split_h2_auto(mats, col_stats: bool = False, stats: torch.Tensor | None = None):
     """fp32 matrices -> h2 Planes whose power-of-two scales are chosen ON THE DEVICE (pxr_h2_split_auto_multi_f32): no host
     synchronisation -- gradients, weights that an optimizer step just moved.  Each result carries `exp_dev` (int32 [1]) and
-    `stats` (float32 [2]: max |x|; with col_stats also the largest column sum of |x|, what h2_bound_exp needs of a weight)."""
+    `stats` (float32 [2]: max |x|; then the largest column sum of |x| with col_stats, else rows * max |x| -- what h2_bound_exp needs
+    of a weight).  `stats` ([len(mats), 2] float32): the producers of the matrices already gathered max |x| into stats[:, 0]
+    (ln_bwd / attn_bwd with stat=...): no statistics pass at all."""
     outs = []
+    if stats is not None:
+        assert len(mats) <= MULTI_MAX and tuple(stats.shape) == (len(mats), 2) and stats.dtype == torch.float32 and stats.is_contiguous()
     for lo in range(0, len(mats), MULTI_MAX):
         ms = mats[lo:lo + MULTI_MAX]
         n = len(ms)
@@ -549,15 +553,15 @@ def split_h2_auto(mats, col_stats: bool = False):
         dev = ms[0].device
         device_status(dev)
         os_ = [Planes.alloc(m.shape[0], m.shape[1], dev, fmt=1) for m in ms]
-        stats = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        st = stats if stats is not None else torch.empty(n, 2, dtype=torch.float32, device=dev)
         exps = torch.empty(n, dtype=torch.int32, device=dev)
         P, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
         _l.check(_l.load().pxr_h2_split_auto_multi_f32(
             n, P(*[m.data_ptr() for m in ms]), I64(*[m.shape[0] for m in ms]), I64(*[m.shape[1] for m in ms]),
             I64(*[m.stride(0) for m in ms]), P(*[o.ptr().value for o in os_]), I64(*[o.ps for o in os_]), I64(*[o.pr for o in os_]),
-            int(col_stats), _l.ptr(stats), _l.ptr(exps), _l.stream_ptr()), "pxr_h2_split_auto_multi_f32")
+            2 if stats is not None else int(col_stats), _l.ptr(st), _l.ptr(exps), _l.stream_ptr()), "pxr_h2_split_auto_multi_f32")
         for i, o in enumerate(os_):
-            o.exp_dev, o.stats = exps[i:i + 1], stats[i]
+            o.exp_dev, o.stats = exps[i:i + 1], st[i]
         outs += os_
     return outs
 
@@ -813,7 +817,7 @@ class DeferredReductions:
 
 
 def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0, stream_id=0, need_dx=False,
-           step_dev=None, defer: DeferredReductions | None = None, planes: bool = False):
+           step_dev=None, defer: DeferredReductions | None = None, planes: bool = False, stat: torch.Tensor | None = None):
     """Backward of either LN site; dgamma/dbeta ([D] tensors) are overwritten (by `defer.flush()` when a
     DeferredReductions collector is given).  Returns (dz, dx|None) (+ with planes=True the Planes of dx when it exists,
     else of dz: what the following GEMMs read)."""
@@ -830,6 +834,12 @@ def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0
         dgamma = dbeta = None
     else:
         ws = _ws.get(ws_bytes, dy.device)
+    if stat is not None:        # also: max |gradient the next GEMMs read| by atomic maxima into the zeroed float32 slot `stat`
+        assert not planes and not gather_mode
+        _l.check(Lb.pxr_ln_bwd_stat_f32(_l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), rows, D, _l.ptr(dz), _l.ptr(dx),
+                                        _l.ptr(dgamma), _l.ptr(dbeta), p_drop, seed, stream_id, _l.ptr(step_dev), _l.ptr(ws), ws_bytes,
+                                        _l.ptr(stat), _l.stream_ptr()), "pxr_ln_bwd_stat_f32")
+        return dz, dx
     gp = Planes.alloc(rows, D, dy.device) if planes else None
     _l.check(Lb.pxr_ln_bwd_planes_f32(int(gather_mode), _l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), rows, D,
                                       _l.ptr(dz), _l.ptr(dx), _l.ptr(dgamma), _l.ptr(dbeta), p_drop, seed, stream_id,
@@ -910,10 +920,22 @@ def attn_fwd(qkv, keymask, km_bstride, B, H, L, d, p_drop=0.0, seed=0, stream_id
     return (cp_ if planes else ctx), probs
 
 
-def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, step_dev=None, planes: bool = False):
-    """-> dqkv [B,L,3*H*d] laid out like qkv; planes=True: as Planes [B*L, 3*H*d] INSTEAD of the fp32 tensor."""
+def attn_bwd(dctx, qkv, probs, B, H, L, d, p_drop=0.0, seed=0, stream_id=0, step_dev=None, planes: bool = False,
+             stat: torch.Tensor | None = None):
+    """-> dqkv [B,L,3*H*d] laid out like qkv; planes=True: as Planes [B*L, 3*H*d] INSTEAD of the fp32 tensor.  stat (a zeroed float32
+    slot; shapes of attn_planes_supported only): also max |dqkv| by atomic maxima."""
     Lb = _l.load()
     D = H * d
+    if stat is not None:
+        assert not planes and attn_planes_supported(L, d)
+        _req(dctx, torch.float32, "dctx"); _req(qkv, torch.float32, "qkv"); _req(probs, torch.float32, "probs")
+        dqkv = torch.empty_like(qkv)
+        cp = _l.c_void_p
+        base, g = qkv.data_ptr(), dqkv.data_ptr()
+        _l.check(Lb.pxr_attn_bwd_stat_f32(_l.ptr(dctx), D, cp(base), cp(base + 4 * D), cp(base + 8 * D), 3 * D, _l.ptr(probs), B, H, L, d,
+                                          cp(g), cp(g + 4 * D), cp(g + 8 * D), 3 * D, p_drop, seed, stream_id, _l.ptr(step_dev),
+                                          _l.ptr(stat), _l.stream_ptr()), "pxr_attn_bwd_stat_f32")
+        return dqkv
     if _attn_takes_gemm_path(L, d):
         dqkv = _attn_long_bwd(dctx, qkv, probs, B, H, L, d, p_drop, seed, stream_id, step_dev)
         return split_planes(dqkv.view(B * L, 3 * D)) if planes else dqkv

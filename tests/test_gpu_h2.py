@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = [0, 225625641, 225612842, 225612841]
+H2_TILES = [0, 225625641, 225612842, 225612841, 212806420, 212806430, 206406430]     # (the last three: 128x64 / 64x64 lockstep tiles)
 
 
 def _rel_rms(got, ref):
@@ -233,3 +233,37 @@ def test_device_chosen_scales_and_the_input_gradient_bound():
         assert (dW2.double() - rW).abs().max().item() <= 4e-6 * (T ** 0.5) * float(rW.abs().max())
         assert (db2.double() - rb).abs().max().item() <= 4e-6 * (T ** 0.5) * float(rb.abs().max()) + 1e-12
     ops.raise_on_bad_indices("cuda")
+
+
+def test_producers_gather_the_statistics_themselves():
+    """LayerNorm backward / fused attention backward leave max |gradient the GEMMs read| in a zeroed slot (atomic maxima); the split
+    that takes those statistics equals the one that makes its own pass."""
+    from pixelrec_amd import ops
+
+    torch.manual_seed(4)
+    B, L, D, H = 5, 20, 128, 4
+    rows = B * L
+    dy, xh = torch.randn(B, L, D).cuda() * 1e-4, torch.randn(B, L, D).cuda()
+    rstd, gam = (torch.rand(rows) + 0.5).cuda(), torch.randn(D).cuda()
+    for p_drop in (0.0, 0.2):
+        st = torch.zeros(1, 2, device="cuda")
+        dg, db = torch.empty(D, device="cuda"), torch.empty(D, device="cuda")
+        dz, dx = ops.ln_bwd(0, dy, xh, rstd, gam, dg, db, p_drop, 7, 3, need_dx=p_drop > 0, stat=st)
+        dz0, dx0 = ops.ln_bwd(0, dy, xh, rstd, gam, dg, db, p_drop, 7, 3, need_dx=p_drop > 0)
+        assert torch.equal(dz, dz0) and (dx is None or torch.equal(dx, dx0))
+        gr = dx if dx is not None else dz
+        assert float(st[0, 0]) == float(gr.abs().max())
+        a, = ops.split_h2_auto([gr.view(rows, D)], stats=st)
+        b, = ops.split_h2_auto([gr.view(rows, D)])
+        assert int(a.exp_dev.item()) == int(b.exp_dev.item()) and torch.equal(a.to_dense(), b.to_dense())
+    for Bq, Lq, Dq, Hq in ((5, 20, 128, 4), (5, 7, 96, 4), (3, 50, 512, 4)):       # (head sizes 32, 24 -- padded tile columns --, 128)
+        d = Dq // Hq
+        qkv = torch.randn(Bq, Lq, 3 * Dq).cuda()
+        mask = torch.ones(Bq, Lq, dtype=torch.int64).cuda()
+        _, probs = ops.attn_fwd(qkv, mask, Lq, Bq, Hq, Lq, d, 0.1, 5, 1, save=True)
+        dctx = torch.randn(Bq, Lq, Dq).cuda() * 1e-3
+        for _ in range(2):       # (twice: whatever the first launch left in the LDS must not enter the second one's statistics)
+            st = torch.zeros(1, 2, device="cuda")
+            g1 = ops.attn_bwd(dctx, qkv, probs, Bq, Hq, Lq, d, 0.1, 5, 1, stat=st)
+            g0 = ops.attn_bwd(dctx, qkv, probs, Bq, Hq, Lq, d, 0.1, 5, 1)
+            assert torch.equal(g1, g0) and float(st[0, 0]) == float(g0.abs().max()), (Lq, d)

@@ -289,6 +289,10 @@ int main(int argc, char** argv) {
     // the fp16 two-plane product against the six-product bf16 one: time, clock, error against fp64
     struct H2Shape { const char* name; int M, N, K; float sa, sb; int ea, eb; };
     const H2Shape hs[] = {
+        {"seq fc1 (B=64)", 3200, 1024, 512, 1.0f, 0.05f, 0, 8},
+        {"seq qkv (B=64)", 3200, 1536, 512, 1.0f, 0.05f, 0, 8},
+        {"seq out (B=64)", 3200, 512, 512, 1.0f, 0.05f, 0, 8},
+        {"seq fc2 (B=64)", 3200, 512, 1024, 1.0f, 0.05f, 0, 8},
         {"vit fc1", 69344, 3072, 768, 1.0f, 0.05f, 0, 8},
         {"vit fc2", 69344, 768, 3072, 1.0f, 0.05f, 0, 8},
         {"vit qkv", 69344, 2304, 768, 1.0f, 0.05f, 0, 8},
@@ -313,6 +317,11 @@ int main(int argc, char** argv) {
         g.A = Ap.m; g.B = Bp.m;
         run<P3Cfg<256, 128, 4, 2, 2>, true, true>("bf16x3 p3 256x128 lockstep", g, iters, nullptr, diffbuf);
         sample_err("bf16x3 six products (3 sets)", A, B, C, s.M, s.N, s.K, 1.0);
+        if (s.M <= 4096) {     // the product's lockstep tiles at 3 200 tokens
+          run<P3Cfg<128, 64, 2, 2, 2>, true, true>("bf16x3 p3 128x64 s2 (product, N >= 1024)", g, iters, nullptr, diffbuf);
+          run<P3Cfg<64, 64, 2, 2, 3>, true, true>("bf16x3 p3 64x64 s3 (product, N < 1024)", g, iters, nullptr, diffbuf);
+          sample_err("bf16x3 six products (64x64)", A, B, C, s.M, s.N, s.K, 1.0);
+        }
         run<P4Cfg<256, 128, 4, 2, 3, 3, 0>, true, true>("bf16x3 p4 256x128 acc3", g, iters, nullptr, diffbuf);
         if (s.N % 256 == 0) {
           run<P4Cfg<256, 256, 4, 2, 3, 1, 0, 3>, true, true, 64>("bf16x3 p4 256x256 acc1", g, iters, nullptr, diffbuf);
@@ -324,6 +333,15 @@ int main(int argc, char** argv) {
         Planes Ap = make_planes_h2(A, s.M, s.K, ldexpf(1.0f, s.ea)), Bp = make_planes_h2(B, s.N, s.K, ldexpf(1.0f, s.eb));
         g.A = Ap.m; g.B = Bp.m;
         const double cs = ldexp(1.0, -(s.ea + s.eb));
+        if (s.M <= 4096) {     // the same lockstep tiles on two fp16 planes (gemm_p3.cuh P3Cfg<..., HALF>)
+          run<P3Cfg<128, 64, 2, 2, 2, true>, true, true>("h2 p3 128x64 s2", g, iters, nullptr, diffbuf);
+          run<P3Cfg<128, 64, 2, 2, 3, true>, true, true>("h2 p3 128x64 s3", g, iters, nullptr, diffbuf);
+          run<P3Cfg<128, 64, 2, 2, 4, true>, true, true>("h2 p3 128x64 s4", g, iters, nullptr, diffbuf);
+          run<P3Cfg<64, 64, 2, 2, 3, true>, true, true>("h2 p3 64x64 s3", g, iters, nullptr, diffbuf);
+          run<P3Cfg<64, 64, 2, 2, 4, true>, true, true>("h2 p3 64x64 s4", g, iters, nullptr, diffbuf);
+          sample_err("h2 three products (64x64)", A, B, C, s.M, s.N, s.K, cs);
+          run<P3Cfg<128, 128, 2, 2, 3, true>, true, true>("h2 p3 128x128 s3", g, iters, nullptr, diffbuf);
+        }
         run<P4Cfg<256, 128, 4, 2, 4, 2, 0, 2, true>, true, true>("h2 p4 256x128 ns4 acc2", g, iters, nullptr, diffbuf);
         sample_err("h2 three products (2 sets)", A, B, C, s.M, s.N, s.K, cs);
         run<P4Cfg<256, 128, 4, 2, 4, 1, 0, 2, true>, true, true>("h2 p4 256x128 ns4 acc1", g, iters, nullptr, diffbuf);
