@@ -755,7 +755,7 @@ def main():
             out["throughput_batches"][-1]["kernel_families_us_per_step"] = fam
             out["throughput_batches"][-1]["gemm_family"] = {**mfma_roof(gfl, gus * 1e-6, b3, gex if on_h2 else None), "us_per_step": gus,
                                                             "operands": ("two fp16 planes, 3 products per multiply (PXR_SEQ_H2: batches of "
-                                                                         ">= 12288 tokens)" if on_h2 else "three bf16 planes, 6 products")}
+                                                                         ">= 6144 tokens)" if on_h2 else "three bf16 planes, 6 products")}
             gl = [(s_.elapsed_time(e_) * 1e-3, w) for s_, e_, w, t in evs if t.startswith("ln_fwd_kernel<GATHER>")]
             if gl and "roofline_gather_fused" in out:
                 sec = sum(x for x, _ in gl) / len(gl)

@@ -248,11 +248,11 @@ class SeqRecCore(BaseModel):
         multiply instead of six at the same 2^-22-grade accuracy).  The format has a finite range, so every operand that is not an
         O(1) activation gets a power-of-two scale found on the device -- extra passes over the weights and the gradients
         (ops.split_h2_auto) that only pay when the GEMMs are large, and the h2 GEMMs only have the 256-row ping-pong tiles:
-        PXR_SEQ_H2 = auto (default: from PXR_SEQ_H2_MIN_TOKENS = 12288 tokens per step, i.e. 246 sequences of 50 -- measured on MI355X: B = 128 1.65 -> 1.84 ms (slower), B = 256 2.98 -> 2.70 ms, B = 512 +21 %, B = 2048 +27 %) | 1 | 0."""
+        PXR_SEQ_H2 = auto (default: from PXR_SEQ_H2_MIN_TOKENS = 6144 tokens per step, i.e. 123 sequences of 50 -- measured on MI355X, h2 vs six products on one box: B = 64 0.953 vs 0.921 ms (slower: twelve extra launches for the scales), B = 128 1.466 vs 1.588 ms, B = 256 2.44 vs 2.98, B = 512 +21 %, B = 2048 +27 %) | 1 | 0."""
         mode = os.environ.get("PXR_SEQ_H2", "auto")
         if mode == "0" or not self._planes_on() or not ops.attn_planes_supported(self.max_seq_length, self.hidden_size // self.n_heads):
             return False
-        return mode == "1" or B * self.max_seq_length >= int(os.environ.get("PXR_SEQ_H2_MIN_TOKENS", "12288"))
+        return mode == "1" or B * self.max_seq_length >= int(os.environ.get("PXR_SEQ_H2_MIN_TOKENS", "6144"))
 
     _W_NAMES = (("q.w", 3, "qkv"), ("o.w", 1, "o"), ("f1.w", 1, "f1"), ("f2.w", 1, "f2"))
 

@@ -35,7 +35,7 @@ def pytest_collection_modifyitems(config, items):
 # f32-input MFMA kernels; PXR_GEMM_MODE=f32).  The model-level parity suites below run in ALL of them inside one
 # `pytest -m gpu`, so the driver's GPU run covers the fallbacks too (only the default mode was exercised).
 # "h2" = planes with the sequence block FORCED onto the fp16 two-plane operands (PXR_SEQ_H2=1; by default only batches of
-# >= 12288 tokens take them, csrc/planes.cuh "h2" / model/seqcore.py::_h2_on): the same parity bars at the test shapes.
+# >= 6144 tokens take them, csrc/planes.cuh "h2" / model/seqcore.py::_h2_on): the same parity bars at the test shapes.
 MODE_MODULES = {"test_gpu_sasrec": ("planes", "bf16x3", "f32", "h2"), "test_gpu_eval": ("planes", "bf16x3", "f32"),
                 "test_gpu_vit": ("planes", "f32"), "test_gpu_mosasrec": ("planes", "bf16x3", "f32", "h2"),
                 "test_gpu_fullsize": ("planes", "f32", "h2"), "test_gpu_lazy_adamw": ("planes", "bf16x3")}

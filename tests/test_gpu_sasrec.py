@@ -284,7 +284,7 @@ def test_five_layers_planes_mode_steps():
 
 def test_forced_h2_mode_really_runs_on_fp16_planes(pxr_mode):
     """Mode "h2" of this module (conftest.py: PXR_SEQ_H2=1) must put the sequence block on the fp16 two-plane GEMMs -- not fall
-    back silently -- and by default only batches of >= 12288 tokens take them."""
+    back silently -- and by default only batches of >= 6144 tokens take them."""
     from pixelrec_amd import ops
 
     meta, z = load_case(CASES[-1])
@@ -305,4 +305,4 @@ def test_forced_h2_mode_really_runs_on_fp16_planes(pxr_mode):
         assert not [t[3] for t in tags if t[3].startswith("gemm_p3_kernel<KC")]     # no six-product GEMM left in the block
     else:
         assert not on_h2
-    assert m._h2_on(12288 // meta["L"] + 1) == (pxr_mode in ("planes", "h2") and supported)
+    assert m._h2_on(6144 // meta["L"] + 1) == (pxr_mode in ("planes", "h2") and supported)
