@@ -246,9 +246,12 @@ class SeqRecCore(BaseModel):
     def _h2_on(self, B: int) -> bool:
         """Whether a forward over B sequences runs its GEMMs on TWO fp16 planes per operand (csrc/planes.cuh "h2": three MFMAs per
         multiply instead of six at the same 2^-22-grade accuracy).  The format has a finite range, so every operand that is not an
-        O(1) activation gets a power-of-two scale found on the device -- extra passes over the weights and the gradients
-        (ops.split_h2_auto) that only pay when the GEMMs are large, and the h2 GEMMs only have the 256-row ping-pong tiles:
-        PXR_SEQ_H2 = auto (default: from PXR_SEQ_H2_MIN_TOKENS = 6144 tokens per step, i.e. 123 sequences of 50 -- measured on MI355X, h2 vs six products on one box: B = 64 0.953 vs 0.921 ms (slower: twelve extra launches for the scales), B = 128 1.466 vs 1.588 ms, B = 256 2.44 vs 2.98, B = 512 +21 %, B = 2048 +27 %) | 1 | 0."""
+        O(1) activation gets a power-of-two scale found on the device: one statistics + one split launch for the weights, one split
+        launch per gradient tensor (its maximum comes from the kernel that produced it), a fill of the statistics arena -- about
+        twelve launches per step, which the cheaper GEMMs only pay back from ~6 000 tokens on.
+        PXR_SEQ_H2 = auto (default: from PXR_SEQ_H2_MIN_TOKENS = 6144 tokens per step, i.e. 123 sequences of 50; measured on one
+        MI355X, h2 vs six products: B = 64 0.953 vs 0.921 ms, B = 128 1.466 vs 1.588, B = 256 2.44 vs 2.98, B = 512 +21 %,
+        B = 2048 +27 %) | 1 | 0.  Read at every forward."""
         mode = os.environ.get("PXR_SEQ_H2", "auto")
         if mode == "0" or not self._planes_on() or not ops.attn_planes_supported(self.max_seq_length, self.hidden_size // self.n_heads):
             return False
