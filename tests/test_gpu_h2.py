@@ -267,3 +267,22 @@ def test_producers_gather_the_statistics_themselves():
             g1 = ops.attn_bwd(dctx, qkv, probs, Bq, Hq, Lq, d, 0.1, 5, 1, stat=st)
             g0 = ops.attn_bwd(dctx, qkv, probs, Bq, Hq, Lq, d, 0.1, 5, 1)
             assert torch.equal(g1, g0) and float(st[0, 0]) == float(g0.abs().max()), (Lq, d)
+
+
+def test_planes_equal_the_numpy_restatement_bit_for_bit():
+    """The split kernels against oracle/h2_oracle.py: same exponent rule, same fp16 roundings -> identical planes."""
+    import numpy as np
+
+    from oracle import h2_oracle as H
+    from pixelrec_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    for scale in (1.0, 0.03, 2e-6, 500.0):
+        x = (torch.randn(70, 96, generator=g) * scale)
+        xc = x.cuda()
+        (ph,) = ops.split_planes_multi([xc], h2=True)             # host-chosen scale
+        (pd,) = ops.split_h2_auto([xc])                           # device-chosen scale
+        e = H.exponent(float(x.abs().max()))
+        assert ph.exp == e and int(pd.exp_dev.item()) == e
+        want = torch.from_numpy(H.dense(*H.split(x.numpy(), e), e).astype(np.float32))
+        assert torch.equal(ph.to_dense().cpu(), want) and torch.equal(pd.to_dense().cpu(), want)
