@@ -217,12 +217,106 @@ def world_fields(world):
     return {"rccl_ranks": world, "dist_backend": (dist.get_backend() if dist.is_initialized() else None)}
 
 
+LINE_LIMIT = 4096          # the driver parses the LAST stdout line; round 5's 22.6 KB line came back unparsed
+
+
+def _num(x, digits=6):
+    """Shorter float text for the one-line record (the side file keeps full precision)."""
+    if isinstance(x, float) and x == x and abs(x) != float("inf"):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _pick(d, keys, digits=6):
+    return {k: _num(d[k], digits) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out):
+    """The ONE stdout line of the contract, cut from the full record: the contract's fields, `roofline` (dominant kernel family),
+    `cpu_baseline`, the six-product twin of the headline and where the north-star kernel targets stand -- nothing else.  Everything
+    bench.py measures beside that (throughput batches, PixelNet, scoring / gather / AdamW rooflines, spreads, notes) is written to
+    the side file named in `extras`.  Always < LINE_LIMIT bytes: optional members are dropped, in a fixed order, until it fits."""
+    keep = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "dist_backend", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "operands", "data", "final_loss", "host_enqueue_ms_per_step", "images_per_s")
+    line = {k: _num(out[k], 8) for k in keep if k in out}
+    cfg = dict(out.get("config", {}))
+    if isinstance(cfg.get("workload"), str) and len(cfg["workload"]) > 200:
+        cfg["workload"] = cfg["workload"][:197] + "..."
+    cfg.pop("hip_graph_error", None)
+    line["config"] = cfg
+    r = out.get("roofline") or {}
+    roof = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_kernel_us",
+                     "products_per_multiply", "algorithmic_tflops", "gemm_time_per_step_us", "gemm_mode"))
+    if "kernel" in r:
+        roof["kernel"] = r["kernel"].split(" (")[0][:120]
+    if isinstance(r.get("rocprofv3"), dict) and "frac" in r["rocprofv3"]:
+        roof["rocprofv3"] = _pick(r["rocprofv3"], ("avg_kernel_us", "achieved", "frac"))
+        roof["rocprofv3"]["source"] = r["rocprofv3"].get("source", "").split(" (")[0]
+    if r.get("traffic_source"):
+        roof["traffic_source"] = r["traffic_source"].split(":")[0]
+    line["roofline"] = roof
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["sample"] = str(cb.get("sample", ""))[:160]
+        if isinstance(cb.get("one_thread"), dict):
+            c["one_thread_value"] = _num(cb["one_thread"].get("value"))
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = cb
+    optional = []          # (key, value) in the order they are dropped LAST -> FIRST
+    if isinstance(out.get("six_products"), dict):
+        optional.append(("six_products", _pick(out["six_products"], ("value", "unit", "ms_per_step", "operands"))))
+    t = out.get("targets")
+    if isinstance(t, dict):
+        g, sc = t.get("gather_ge_0.70_of_hbm_peak", {}), t.get("scoring_ge_0.60_of_mfma_peak", {})
+        optional.append(("targets", {
+            "gather_frac_of_hbm_peak": {k: _num(v, 4) for k, v in g.items() if isinstance(v, float)}, "gather_met": g.get("met"),
+            "scoring_frac_of_mfma_peak": {k: _num(v, 4) for k, v in sc.items() if isinstance(v, float)}, "scoring_met": sc.get("met")}))
+    if isinstance(out.get("spread"), dict):
+        optional.append(("spread_ms_per_step", [_num(x, 5) for x in out["spread"].get("ms_per_step", [])]))
+    tb = [x for x in out.get("throughput_batches", []) if isinstance(x, dict)]
+    if tb:
+        optional.append(("throughput_batches", [{"batch_per_gpu": x.get("batch_per_gpu"), "value": _num(x.get("value"), 6),
+                                                 "operands": x.get("operands")} for x in tb]))
+    if isinstance(out.get("pixelnet"), dict) and "ms_per_step" in out["pixelnet"]:
+        optional.append(("pixelnet", _pick(out["pixelnet"], ("value", "unit", "ms_per_step", "images_per_s"))))
+    if out.get("extras"):
+        line["extras"] = out["extras"]
+    for k, v in optional:
+        line[k] = v
+    while len(json.dumps(line)) >= LINE_LIMIT and optional:
+        line.pop(optional.pop()[0], None)
+    while len(json.dumps(line)) >= LINE_LIMIT:       # pathological strings: cut the longest one
+        k = max((k for k in line if isinstance(line[k], str)), key=lambda k: len(line[k]))
+        line[k] = line[k][:len(line[k]) // 2]
+    return line
+
+
+def emit(out):
+    """Full record -> the side file (PXR_BENCH_EXTRAS, default gpurun_out/bench_extras.json under the repo); compact record -> the
+    last stdout line.  RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION is exported on the GPU boxes) and that
+    buffer is only flushed at exit: flush it first so the JSON line is the LAST line on stdout."""
+    path = os.environ.get("PXR_BENCH_EXTRAS") or os.path.join(ROOT, "gpurun_out", "bench_extras.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f)
+            f.write("\n")
+        out["extras"] = os.path.relpath(path, ROOT)
+    except OSError as e:
+        out["extras"] = f"not written ({type(e).__name__})"
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    text = json.dumps(compact_line(out))
+    assert len(text) < LINE_LIMIT and "\n" not in text
+    print(text, flush=True)
+
+
 def pixelnet_main(args):
     out = pixelnet_run(args, args.steps, max(args.warmup, 2))
     if out is not None:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -1161,11 +1255,7 @@ def main():
     elif world == 1:
         out["cpu_baseline"] = None
 
-    # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION is exported on the GPU boxes) and that buffer
-    # is only flushed at exit: flush it now so the JSON line is the LAST line on stdout
-    import ctypes
-    ctypes.CDLL(None).fflush(None)
-    print(json.dumps(out), flush=True)
+    emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 

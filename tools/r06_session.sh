@@ -1,0 +1,94 @@
+#!/bin/bash
+# Round-6 measurement stages (one MI355X through gpurun).  usage: bash tools/r06_session.sh <outdir-name> [stage ...]
+#   t:<pytest args>   a pytest selection (e.g. t:tests/test_gpu_bench_ranks.py)     tests   full GPU suite (-v log kept)
+#   bench             the default bench line                                         prof    rocprofv3 kernel stats + timeline of the B=64 step
+#   b2048             rocprofv3 kernel stats at B = 2048                             pmc64   FETCH_SIZE / WRITE_SIZE passes of the B=64 step
+#   pixel / pixelprof PixelNet line / its kernel stats                               quick   bench.py --no-extras --no-cpu-baseline (headline only)
+#   attn              tools/attn_bench.py                                            bq:<B>  short bench at batch B (headline fields only)
+#   flake:<n>         n more full-suite runs with faulthandler, one log per run      eval    tools/eval_bench.py
+#   fp64              tests/diag_fp64_trajectory.py (FP64_PERMS=<n> permuted repeats per arithmetic)
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+NAME=$1; shift
+OUT=$REPO/gpurun_out/$NAME
+mkdir -p "$OUT"
+export PYTHONUNBUFFERED=1
+cd "$REPO"
+for ST in "$@"; do
+case "$ST" in
+t:*)
+  SEL=${ST#t:}; TAG=$(echo "$SEL" | tr -c 'A-Za-z0-9\n' '_' | cut -c1-60)
+  ( time timeout 1500 python -m pytest $SEL -m gpu -q -x 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -25 ) > "$OUT/pytest_$TAG.log" 2>&1
+  tail -n 12 "$OUT/pytest_$TAG.log" ;;
+tests)
+  ( time timeout 2400 python -m pytest tests -m gpu -v 2>&1 | grep -v "amdgpu.ids\|socket.cpp" ) > "$OUT/pytest_gpu_full.log" 2>&1
+  grep -v "PASSED\|^$" "$OUT/pytest_gpu_full.log" | cut -c1-400 | tail -n 60 > "$OUT/pytest_gpu.log"
+  grep -c PASSED "$OUT/pytest_gpu_full.log"; tail -n 30 "$OUT/pytest_gpu.log" ;;
+flake:*)
+  NRUN=${ST#flake:}; mkdir -p "$OUT/flake"
+  ulimit -c 0
+  for i in $(seq 1 "$NRUN"); do
+    ( time PYTHONFAULTHANDLER=1 AMD_LOG_LEVEL=1 timeout 1500 python -X faulthandler -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 \
+        | grep -v "amdgpu.ids\|socket.cpp" | tail -n 40 ) > "$OUT/flake/run_$i.log" 2>&1
+    echo "run $i: $(grep -E 'passed|failed|error|Fatal|core dumped|Aborted|Segmentation' "$OUT/flake/run_$i.log" | tail -n 2 | tr '\n' ' ')"
+  done ;;
+quick)
+  timeout 300 python bench.py --no-extras --no-cpu-baseline > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
+  python - "$OUT/bench_quick.json" <<'P'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("quick:", round(d["value"]), "seq/s", round(d["ms_per_step"],4), "ms  gemm us", round(d["roofline"]["gemm_time_per_step_us"],1), "frac", round(d["roofline"]["frac"],3))
+P
+  ;;
+bench)
+  PXR_BENCH_EXTRAS="$OUT/bench_extras.json" timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+  tail -n 1 "$OUT/bench_default.json" | wc -c; tail -n 1 "$OUT/bench_default.json"; tail -3 "$OUT/bench_default.err" ;;
+driver)
+  # exactly the driver's command (its 22.6 KB line came back unparsed)
+  PXR_BENCH_EXTRAS="$OUT/bench_driver_extras.json" timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err"
+  tail -n 1 "$OUT/bench_driver.json" | wc -c; tail -n 1 "$OUT/bench_driver.json" ;;
+eval)
+  timeout 400 python tools/eval_bench.py > "$OUT/eval_bench.log" 2>&1; tail -20 "$OUT/eval_bench.log" ;;
+pixel)
+  timeout 400 python bench.py --model pixelnet --no-cpu-baseline > "$OUT/bench_pixelnet_b16.json" 2> "$OUT/bench_pixelnet_b16.err"; cut -c1-600 "$OUT/bench_pixelnet_b16.json"; tail -3 "$OUT/bench_pixelnet_b16.err" ;;
+prof)
+  P=$OUT/prof_bench; mkdir -p "$P"
+  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$P" -o bench -- python $REPO/bench.py --steps 50 --warmup 10 --age-steps 300 --no-cpu-baseline --no-extras --no-gemm-events > "$P/bench_stdout.log" 2>&1 )
+  python $REPO/tools/step_timeline.py "$P/bench_kernel_trace.csv" "$OUT/step_timeline.txt" > "$P/timeline.log" 2>&1
+  rm -f "$P/bench_kernel_trace.csv"; find "$P" -name "*.db" -delete
+  head -48 "$P/bench_kernel_stats.csv" | cut -c1-220 ;;
+b2048)
+  P=$OUT/prof_b2048; mkdir -p "$P"
+  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$P" -o b2048 -- python $REPO/bench.py --batch 2048 --steps 10 --warmup 3 --age-steps 20 --no-cpu-baseline --no-extras --no-gemm-events > "$P/stdout.log" 2>&1 )
+  rm -f "$P/b2048_kernel_trace.csv"; find "$P" -name "*.db" -delete
+  head -40 "$P/b2048_kernel_stats.csv" | cut -c1-220 ;;
+pixelprof)
+  P=$OUT/prof_pixelnet; mkdir -p "$P"
+  ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$P" -o pix -- python $REPO/bench.py --model pixelnet --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-gemm-events > "$P/stdout.log" 2>&1 )
+  rm -f "$P/pix_kernel_trace.csv"; find "$P" -name "*.db" -delete
+  head -25 "$P/pix_kernel_stats.csv" | cut -c1-220 ;;
+fp64)
+  timeout 600 python tests/diag_fp64_trajectory.py ${FP64_PERMS:-0} > "$OUT/fp64_trajectory.log" 2>&1; grep -v "amdgpu.ids" "$OUT/fp64_trajectory.log" | tail -24 ;;
+attn)
+  timeout 300 python tools/attn_bench.py > "$OUT/attn_bench.log" 2>&1; cat "$OUT/attn_bench.log" ;;
+bq:*)
+  BB=${ST#bq:}
+  timeout 400 python bench.py --batch $BB --steps 20 --warmup 5 --age-steps 40 --no-cpu-baseline --no-extras > "$OUT/bench_b$BB.json" 2> "$OUT/bench_b$BB.err"
+  python - "$OUT/bench_b$BB.json" <<'P'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("B", d["config"].get("batch_per_gpu"), round(d["value"]), "seq/s", round(d["ms_per_step"],4), "ms  gemm us", round(d["roofline"]["gemm_time_per_step_us"],1))
+P
+  ;;
+pmc64)
+  Q=$OUT/pmc64; mkdir -p "$Q"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$Q" -o $c -- python $REPO/bench.py --steps 10 --warmup 2 --age-steps 20 --no-cpu-baseline --no-extras --no-gemm-events --no-graph > "$Q/${c}_stdout.log" 2>&1 )
+  done
+  find "$Q" -name "*.db" -delete
+  python $REPO/tools/pmc_summarise.py "$Q/summary.json" $(ls "$Q"/*counter_collection.csv) > /dev/null 2>&1
+  python $REPO/tools/gemm_traffic.py "$Q/summary.json" "$OUT/gemm_traffic_summary.json" "round 5 code, default operands (fp16 two-plane), B=64" > "$OUT/gemm_traffic.log" 2>&1
+  rm -f "$Q"/*kernel_trace.csv "$Q"/*counter_collection.csv
+  cat "$OUT/gemm_traffic.log" ;;
+*) echo "unknown stage $ST" ;;
+esac
+done
