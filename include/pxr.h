@@ -32,7 +32,12 @@ extern "C" {
 #define PXR_ERR_LAUNCH (-2)
 #define PXR_ERR_WORKSPACE (-3)
 
-int pxr_version(void);                 /* major*10000 + minor*100 + patch */
+/* The ABI revision this header describes.  pxr_version() of the loaded library must EQUAL it: entries may change meaning between
+ * revisions while keeping their names (0.2.0 -> 0.3.0: the `stat` buffers of pxr_ln_bwd_stat_f32 / pxr_attn_bwd_stat_f32 became
+ * pxr_ln_bwd_partial_rows(rows) / 64 words instead of one caller-zeroed word, and pxr_ln_bwd_stat_f32 gained `zero`, `zero_n`),
+ * so a caller built against another revision must refuse to run instead of writing out of bounds (pixelrec_amd/lib.py does). */
+#define PXR_ABI_VERSION 300
+int pxr_version(void);                 /* major*10000 + minor*100 + patch; == PXR_ABI_VERSION of the header it was built from */
 const char* pxr_last_error(void);      /* message of the last failing call on this thread */
 const char* pxr_target_arch(void);     /* "gfx950" */
 

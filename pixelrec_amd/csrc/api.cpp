@@ -3,6 +3,7 @@
 #include <stdio.h>
 
 #include "pxr_common.h"
+#include "../../include/pxr.h"   // PXR_ABI_VERSION; also type-checks the entries defined in this file against their declarations
 
 static thread_local char g_err[512] = "";
 
@@ -37,7 +38,7 @@ int pxr_cu_count(void) {
   return cached[dev];
 }
 
-extern "C" int pxr_version(void) { return 200; }  // major*10000 + minor*100 + patch
+extern "C" int pxr_version(void) { return PXR_ABI_VERSION; }  // include/pxr.h
 extern "C" const char* pxr_last_error(void) { return g_err; }
 extern "C" const char* pxr_target_arch(void) { return "gfx950"; }
 

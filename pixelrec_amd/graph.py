@@ -155,4 +155,7 @@ class GraphedTrainStep:
             if hasattr(o, "_dirty"):
                 o._dirty = True
         self.model._step_counter += 1
+        if hasattr(self.model, "planes_housekeeping"):
+            self.model.planes_housekeeping()     # every PXR_H2_REFRESH_STEPS replays: exponents / statistics of the weight planes
+                                                 # re-derived from the values, status word polled (no stream stall)
         return self.loss

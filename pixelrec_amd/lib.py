@@ -148,6 +148,9 @@ _SIGNATURES = {
 }
 
 
+ABI_VERSION = 300      # include/pxr.h PXR_ABI_VERSION (tests/test_abi.py pins header == binding == library)
+
+
 def load():
     """Load libpxr.so (once) and bind every declared entry point.  Raises PxrError if anything is missing."""
     global _lib
@@ -173,6 +176,9 @@ def load():
             raise PxrError(f"{LIB_PATH} does not export `{name}` (stale build?)") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.pxr_version() != ABI_VERSION:
+        raise PxrError(f"{LIB_PATH} reports ABI revision {lib.pxr_version()}, this binding was written for {ABI_VERSION} "
+                       "(include/pxr.h PXR_ABI_VERSION): rebuild the library -- entries change meaning between revisions")
     _lib = lib
     return lib
 

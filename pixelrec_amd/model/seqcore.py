@@ -350,6 +350,32 @@ class SeqRecCore(BaseModel):
         else:
             self._wplanes_fresh = True
 
+    # ---- housekeeping of the planes the optimizer keeps current.  Under trust_optimizer_planes the flat AdamW launch
+    # rewrites the h2 weight planes with the exponents (and the consumers bound with the max |w| statistics) of the LAST split.  They
+    # are re-derived from the values every PXR_H2_REFRESH_STEPS optimizer steps (default 32: two light launches per 32 steps), so
+    # the 2^4 headroom of _W_TOP only has to cover 32 steps of AdamW -- |dw| <= 31.8 lr per step in the worst case, i.e. lr up
+    # to 15 max|w| / (32 * 31.8) ~ 1.2e-3 at max|w| = 0.08 -- instead of a whole epoch; and the status word is polled at the same
+    # interval without stalling the stream (ops.StatusPoll), so a value that does leave the range raises within two intervals.
+    _since_plane_refresh = 0
+    _status_poll = None
+
+    def planes_housekeeping(self):
+        """Call once per optimizer step from the host loop that trusts the optimizer's planes (GraphedTrainStep.__call__,
+        PxrAdamW.step when it is not being captured)."""
+        if not self.trust_optimizer_planes or self._flat is None or not self._flat.is_cuda:
+            return
+        self._since_plane_refresh += 1
+        if self._since_plane_refresh < int(os.environ.get("PXR_H2_REFRESH_STEPS", "32")):
+            return
+        self._since_plane_refresh = 0
+        if self._status_poll is None:
+            self._status_poll = ops.StatusPoll(self._flat.device)
+        self._status_poll.check()
+        if self._planes_fmt_active == 1 and self._wplanes_h2 is not None and self._planes_on():
+            ops.split_h2_auto(self._weight_mats(), col_stats=False, outs=self._wplanes_h2, top=self._W_TOP)
+            self._wplanes_h2_fresh = True
+        self._status_poll.start()
+
     def refresh_weight_planes(self):
         """Re-split now (after anything but the optimizer rewrote the weights: load_state_dict, a parameter broadcast, a
         restored snapshot), so that a captured step that trusts the optimizer's planes finds them valid."""

@@ -100,6 +100,30 @@ def clear_status_bits(device, bits: int):
     device_status(device).bitwise_and_(~int(bits))
 
 
+class StatusPoll:
+    """The status word watched WITHOUT stalling the stream: start() enqueues a 4-byte copy into pinned host memory behind the work
+    issued so far; check() looks at the copy of an EARLIER start() once its event has completed (a query, no wait) and raises through
+    raise_on_bad_indices when a bit is set.  A condition is therefore reported at most two polling intervals after the kernel that
+    flagged it (graph.GraphedTrainStep polls every PXR_H2_REFRESH_STEPS replays), not at the end of the epoch."""
+
+    def __init__(self, device=None):
+        self.device = device
+        self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._ev = None
+
+    def start(self):
+        self._host.copy_(device_status(self.device), non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record()
+
+    def check(self):
+        if self._ev is None or not self._ev.query():
+            return
+        self._ev = None
+        if int(self._host[0]):
+            raise_on_bad_indices(self.device)
+
+
 def raise_on_bad_indices(device=None):
     """Host check of the status word (synchronises): IndexError if a gather kernel met an item id outside the table
     since the last check -- what nn.Embedding raises in the reference (sasrec.py:68).  Called where the host
@@ -527,13 +551,19 @@ def grouped_linear_bwd_weight(problems):
         dy, x, dW, db = problems[0]
         M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
         S = _dw_token_parts(M, N, K)
-        if S > 1 and dy.is_contiguous() and x.is_contiguous() and dW.is_contiguous():
+        # (N % 4: part i starts i * (N K + N) floats into the workspace -- 16-byte aligned for the kernels' vector accesses only then)
+        if S > 1 and N % 4 == 0 and K % 4 == 0 and dy.is_contiguous() and x.is_contiguous() and dW.is_contiguous():
             step = (-(-M // S) + 63) // 64 * 64
             S = -(-M // step)
-            key = (dy.device, S, N, K)
+            # one workspace per (stream, shape): the side stream of fork_pending / overlap_weight_grads may run this route beside
+            # the main stream's
+            row = N * K + N
+            key = (dy.device, _l.raw_stream(), S, N, K)
             ws = _dw_split_ws.get(key)
             if ws is None:
-                ws = _dw_split_ws[key] = torch.empty(S, N * K + N, dtype=torch.float32, device=dy.device)
+                if len(_dw_split_ws) >= 8:       # a handful of (stream, shape) pairs exist in practice: never grow without bound
+                    _dw_split_ws.clear()
+                ws = _dw_split_ws[key] = torch.empty(S, row, dtype=torch.float32, device=dy.device)
             grouped_linear_bwd_weight([(dy[i * step:(i + 1) * step], x[i * step:(i + 1) * step], ws[i, :N * K].view(N, K), ws[i, N * K:])
                                        for i in range(S)])
             red = DeferredReductions()

@@ -292,6 +292,8 @@ class PxrAdamW:
                            close=(self._cumlog, self._cur_hyper, g["lr"], g["weight_decay"]) if fold else None)
         if segs:
             self.model.mark_weight_planes_fresh()
+        if hasattr(self.model, "planes_housekeeping") and flat.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self.model.planes_housekeeping()     # eager loops; a captured step is looked after by GraphedTrainStep.__call__
         if fold:
             self.step_count += 1
             return
@@ -455,8 +457,8 @@ class VisualAdamW:
         state = {}
         if self.step_count > 0:
             for i, (n, p) in enumerate(names):
-                if "post_layernorm" in n:
-                    continue
+                if n not in t.views:      # no gradient ever reaches it (post_layernorm under 'mean' / 'cls', where the reference
+                    continue              # has replaced it by Identity, load.py:112,116); under 'pool' it trains and is saved
                 off, cnt, shape = t.views[n]
                 state[i] = {"step": torch.tensor(float(self.step_count)),
                             "exp_avg": self._m[off - self._base:off - self._base + cnt].view(shape).clone(),
@@ -478,7 +480,7 @@ class VisualAdamW:
         steps = set()
         for pid, (n, p) in zip(ids, names):
             st = sd["state"].get(pid)
-            if st is None:
+            if st is None or n not in t.views:
                 continue
             off, cnt, shape = t.views[n]
             steps.add(int(float(st["step"])))

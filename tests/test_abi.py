@@ -16,7 +16,10 @@ def _header_symbols():
 
 def test_library_loads_and_reports_target():
     L = lib.load()
-    assert L.pxr_version() >= 100
+    # one ABI revision in three places: the header, the ctypes binding, the built library.  0.3.0 = the revision in which the
+    # `stat` buffers of pxr_ln_bwd_stat_f32 / pxr_attn_bwd_stat_f32 changed size under unchanged names
+    hdr = int(re.search(r"#define\s+PXR_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "pxr.h")).read()).group(1))
+    assert hdr == lib.ABI_VERSION == L.pxr_version() == 300
     assert L.pxr_target_arch() == b"gfx950"
 
 

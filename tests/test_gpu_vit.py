@@ -176,3 +176,17 @@ def test_native_encoder_matches_torch_tower(method, tune):
         ref_out = (torch.mean(ref.rec_fc(tower), dim=1) if method == "mean" else
                    ref.rec_fc(pooled) if method == "pool" else ref.rec_fc(tower[:, 0, :]))
         assert (enc(x.cuda()).cpu() - ref_out).abs().max().item() < 1e-4
+    # checkpoint layout: the saved state holds an entry for every parameter torch's AdamW holds one for -- under 'pool'
+    # that includes post_layernorm (reference load.py:119-120 keeps it trainable) -- with the same moments, and a load restores them
+    sd, tsd = opt.state_dict(), topt.state_dict()
+    assert set(sd["state"]) == set(tsd["state"]), (sorted(sd["state"]), sorted(tsd["state"]))
+    for i, st in tsd["state"].items():
+        assert (sd["state"][i]["exp_avg"].cpu() - st["exp_avg"]).abs().max().item() <= 3e-4 * max(st["exp_avg"].abs().max().item(), 1e-30) + 1e-9
+        assert float(sd["state"][i]["step"]) == float(st["step"]) == 3.0
+    opt2 = VisualAdamW(enc, lr=1e-2, weight_decay=0.05, eps=1e-2)
+    opt2.load_state_dict(sd)
+    sd2 = opt2.state_dict()
+    assert set(sd2["state"]) == set(sd["state"]) and opt2.step_count == 3
+    for i in sd["state"]:
+        assert torch.equal(sd2["state"][i]["exp_avg"], sd["state"][i]["exp_avg"])
+        assert torch.equal(sd2["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])

@@ -89,6 +89,21 @@ pmc64)
   python $REPO/tools/gemm_traffic.py "$Q/summary.json" "$OUT/gemm_traffic_summary.json" "round 5 code, default operands (fp16 two-plane), B=64" > "$OUT/gemm_traffic.log" 2>&1
   rm -f "$Q"/*kernel_trace.csv "$Q"/*counter_collection.csv
   cat "$OUT/gemm_traffic.log" ;;
+ab:*)
+  # ab:<label>:<ENV=VAL,ENV=VAL|->:<bench args with + for spaces>   short headline-only run under the given knobs
+  IFS=: read -r _ LAB ENVS ARGS <<< "$ST"
+  ARGS=$(echo "$ARGS" | tr '+' ' ')
+  ( [ "$ENVS" != "-" ] && export $(echo "$ENVS" | tr ',' ' ')
+    PXR_BENCH_EXTRAS="$OUT/ab_${LAB}_extras.json" timeout 400 python bench.py --no-cpu-baseline --no-extras $ARGS > "$OUT/ab_$LAB.json" 2> "$OUT/ab_$LAB.err" )
+  python - "$OUT/ab_$LAB.json" "$LAB" <<'P'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("ab", sys.argv[2], "B", d["config"].get("batch_per_gpu"), round(d["value"]), "seq/s", round(d["ms_per_step"],4), "ms  host", round(d.get("host_enqueue_ms_per_step",0),4), "gemm us", round(d["roofline"].get("gemm_time_per_step_us",0),1), "graph", d["config"].get("hip_graph"))
+except Exception as e:
+    print("ab", sys.argv[2], "FAILED", e)
+P
+  tail -n 2 "$OUT/ab_$LAB.err" | cut -c1-300 ;;
 *) echo "unknown stage $ST" ;;
 esac
 done
