@@ -371,10 +371,11 @@ def pixelnet_run(args, steps, warmup, init_dist=True, n_inst=3):
         eager_step(i)
     torch.cuda.synchronize()
     # the whole step -- image tower forward, backward of its trainable blocks, sequence block, both optimizer groups -- as ONE
-    # captured hipGraph (round 5: VisualAdamW keeps its step number on the device like PxrAdamW).  One rank only: replaying RCCL
-    # collectives from a graph stays opt-in (--graph-collectives) until it can be validated on more than one GPU
+    # captured hipGraph (round 5: VisualAdamW keeps its step number on the device like PxrAdamW); data parallel over RCCL: the
+    # collectives are captured with it (round 6; --no-graph-collectives issues eagerly)
     gstep, graph_err = None, None
-    if world == 1 and not getattr(args, "no_graph", False):
+    rccl = world > 1 and dist.is_initialized() and dist.get_backend() == "nccl" and not getattr(args, "no_graph_collectives", False)
+    if (world == 1 or rccl) and not getattr(args, "no_graph", False):
         try:
             from pixelrec_amd.graph import GraphedTrainStep
             gstep = GraphedTrainStep(dp, opt, *pool[0], warmup=1)
@@ -513,8 +514,9 @@ def main():
                     help="row-shard the item table over the ranks (pixelrec_amd/model/sharded.py) instead of replicating it")
     ap.add_argument("--force-collectives", action="store_true",
                     help="1-GPU validation knob: create a 1-rank RCCL group and run every gradient collective anyway")
-    ap.add_argument("--graph-collectives", action="store_true",
-                    help="capture the RCCL collectives inside the step hipGraph too (opt-in for world > 1)")
+    ap.add_argument("--graph-collectives", action="store_true", help="(default since round 6; kept for old command lines)")
+    ap.add_argument("--no-graph-collectives", action="store_true",
+                    help="data parallel: issue the step eagerly instead of replaying a hipGraph that contains the RCCL collectives")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="after the run, project the step of a W-rank data-parallel job on this ONE GPU: merge of W ranks' "
                          "sparse-gradient blocks + the merged row update are measured on a run fed W batches per step, the "
@@ -603,15 +605,31 @@ def main():
     pool = _Pool()
 
     gemm_events = []
-    # replaying RCCL collectives from a hipGraph is opt-in: it cannot be validated on the 1-GPU development box
-    use_graph = (not args.no_graph) and ((world == 1 and not args.force_collectives) or args.graph_collectives)
+    # data parallel: the captured step contains its RCCL collectives (round 6 default: the eager multi-rank step is host-bound --
+    # 1.47 ms against 0.85 ms replayed on a 1-rank RCCL group, profiles/r06).  Not over gloo (PXR_BENCH_SHARE_GPU: CPU staging).
+    collectives = world > 1 or args.force_collectives
+    use_graph = (not args.no_graph) and (not collectives or (not args.no_graph_collectives and dist.get_backend() == "nccl"))
     use_graph = use_graph and not args.table_sharding      # the sharded forward issues collectives: eager only
     use_graph = use_graph and args.table_update == "lazy"   # the dense sweep takes host-computed scalars
     gstep = None
+    graph_err = None
     if use_graph:
         from pixelrec_amd.graph import GraphedTrainStep
 
-        gstep = GraphedTrainStep(dp, opt, *pool[0], lookahead=not (not args.lookahead))
+        try:
+            gstep = GraphedTrainStep(dp, opt, *pool[0], lookahead=not (not args.lookahead))
+        except Exception as e:  # noqa: BLE001 -- a capture that fails is reported (stderr + `hip_graph_error`), the run goes on eagerly
+            if not collectives:
+                raise
+            graph_err = f"{type(e).__name__}: {e}"
+            print(f"bench.py: hipGraph capture of the data-parallel step failed ({graph_err}); issuing steps eagerly", file=sys.stderr)
+            gstep, use_graph = None, False
+            torch.cuda.synchronize()
+        if collectives:        # every rank replays or none does: a mixed world would deadlock in the first collective
+            ok = torch.tensor([1 if gstep is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and gstep is not None:
+                gstep, use_graph, graph_err = None, False, "another rank failed to capture"
 
     one = torch.ones((), dtype=torch.float32, device=dev)
     cursor = [0]          # position in the batch stream: every step of every phase consumes the NEXT batch
@@ -935,7 +953,7 @@ def main():
                                 "inner 2x, 2 layers, BPR loss vs 1 sampled negative, dropout 0.1, AdamW lr 1e-4 wd 0.1"),
                    "batch_per_gpu": B, "global_batch": world * B, "seq_len": L, "n_items": N, "embedding_size": D,
                    "parallelism": f"dp{world}" + ("+row-sharded-table" if args.table_sharding else ""),
-                   "hip_graph": bool(use_graph)},
+                   "hip_graph": bool(use_graph), **({"hip_graph_error": graph_err} if graph_err else {})},
         "final_loss": final_loss, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
         "spread": {"blocks": len(block_ms), "steps_per_block": args.steps, "ms_per_step": block_ms,
                    "median_ms_per_step": sorted(block_ms)[len(block_ms) // 2], "min_ms_per_step": min(block_ms),

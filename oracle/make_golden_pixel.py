@@ -27,7 +27,10 @@ D, L, H, NL, B, N_ITEMS = 64, 6, 2, 2, 3, 40
 TUNE = 5 + 16 * 2                    # freeze embeddings + blocks 0, 1; train block 2
 
 
-def main():
+def main(dnn_layers=(), out_name="mosasrec_tiny.npz", store_images=True):
+    """dnn_layers = () is the shipped head (one Linear + ReLU, overall/ViT.yaml:33); a non-empty list selects the reference's
+    MLPLayers head (layers.py:69-71, 239-294) -- that golden reuses the images of the first one (same generator seed) and does not
+    store them again."""
     # resolve transformers' lazy modules BEFORE the inert torchvision stub exists (its availability probe needs a real
     # module spec); these are the names REC/model/load.py:3,5 imports
     from transformers import BeitModel, CLIPVisionModel, SwinConfig, SwinModel, ViTMAEModel  # noqa: F401
@@ -46,13 +49,13 @@ def main():
             if index < config["fine_tune_arg"]["tune_scale"]:
                 p.requires_grad = False
         return MeanItemEncoder(item_encoder=model, input_dim=hidden, output_dim=config["embedding_size"],
-                               act_name="relu", dnn_layers=[])          # load.py:116-117
+                               act_name="relu", dnn_layers=list(dnn_layers))          # load.py:116-117
 
     ref_mod.load_model = load_model
     config = {"n_layers": NL, "n_heads": H, "embedding_size": D, "inner_size": 2, "hidden_dropout_prob": 0.1,
               "attn_dropout_prob": 0.1, "hidden_act": "gelu", "layer_norm_eps": 1e-12, "initializer_range": 0.02,
               "MAX_ITEM_LIST_LENGTH": L, "pretrain_path": None,
-              "fine_tune_arg": {"tune_scale": TUNE, "pre_trained": True, "activation": "relu", "dnn_layers": [],
+              "fine_tune_arg": {"tune_scale": TUNE, "pre_trained": True, "activation": "relu", "dnn_layers": list(dnn_layers),
                                 "method": "mean"}}
 
     class DL:
@@ -99,14 +102,19 @@ def main():
     item_seq[0, :2] = 0
     scores = model.predict(item_seq, feat)
     store["eval.item_images"] = item_imgs.numpy().astype(np.float16)
+    if not store_images:         # identical to the arrays of mosasrec_tiny.npz (checked by the test that reads both)
+        store.pop("images")
+        store.pop("eval.item_images")
+        store["dnn_layers"] = np.array(list(dnn_layers))
     store["eval.item_feature"] = feat.numpy()
     store["eval.item_seq"] = item_seq.numpy()
     store["eval.scores"] = scores.numpy()
 
-    out = os.path.join(ROOT, "tests", "golden", "mosasrec_tiny.npz")
+    out = os.path.join(ROOT, "tests", "golden", out_name)
     np.savez_compressed(out, **store)
     print(f"wrote {out}: {os.path.getsize(out) / 1e6:.2f} MB, {n_grads} gradients, loss {float(loss):.6f}")
 
 
 if __name__ == "__main__":
     main()
+    main(dnn_layers=(48,), out_name="mosasrec_dnn_tiny.npz", store_images=False)

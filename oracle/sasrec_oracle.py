@@ -251,15 +251,20 @@ class OracleTrainer:
     """zero_grad -> forward -> backward -> AdamW.step over ALL parameters incl. the whole table (dense
     weight-decay semantics, trainer.py:116-125, overall/ID.yaml:20-23).  Used as the CPU baseline in bench.py."""
 
-    def __init__(self, params: Params, cfg, lr=1e-4, weight_decay=0.1):
+    def __init__(self, params: Params, cfg, lr=1e-4, weight_decay=0.1, group_of=None):
+        """group_of (optional): parameter name -> (lr, weight_decay), the two-group optimizers of trainer.py:66-96 -- split by
+        'visual_encoder' in the name (:86-96) or by the `decay_check_name` fragment (:73-91; names there carry DDP's 'module.'
+        prefix, which the caller's function accounts for)."""
         self.p = {k: v.clone() for k, v in params.items()}
         self.m = {k: torch.zeros_like(v) for k, v in params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in params.items()}
         self.cfg, self.lr, self.wd, self.t = cfg, lr, weight_decay, 0
+        self.group_of = group_of
 
     def step(self, items, masked_index, drop=None):
         loss, grads = loss_and_grads(self.p, items, masked_index, self.cfg, drop)
         self.t += 1
         for k in self.p:
-            adamw_step(self.p[k], grads[k], self.m[k], self.v[k], self.t, self.lr, weight_decay=self.wd)
+            lr, wd = self.group_of(k) if self.group_of is not None else (self.lr, self.wd)
+            adamw_step(self.p[k], grads[k], self.m[k], self.v[k], self.t, lr, weight_decay=wd)
         return loss

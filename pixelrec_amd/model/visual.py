@@ -137,17 +137,43 @@ ENCODER_SHAPES = {
 }
 
 
+def _activation(act_name):
+    """activation_layer (layers.py:23-49) for the names the head supports; 'none' / None -> no module at all in an MLP head."""
+    key = act_name.lower() if isinstance(act_name, str) else act_name
+    table = {"relu": nn.ReLU, "sigmoid": nn.Sigmoid, "tanh": nn.Tanh, None: None, "none": None}
+    if key not in table:
+        raise NotImplementedError(f"activation {act_name!r}")
+    return table[key]() if table[key] is not None else None
+
+
+class MLPHead(nn.Module):
+    """The head `fine_tune_arg.dnn_layers: [h1, h2, ...]` selects (reference MLPLayers, layers.py:239-294, built by
+    PatchItemEncoder, layers.py:69-71, with dropout 0 and bn=False): for every consecutive pair of [input_dim, h1, ..., output_dim]
+    a Dropout(0), a Linear and -- unless the activation is 'none' -- the activation, ALSO after the last Linear.  The container
+    is `mlp_layers` and the modules keep their positions in it, so the parameter names are the reference's
+    (`rec_fc.mlp_layers.1.weight`, `rec_fc.mlp_layers.4.weight`, ...: checkpoints interchange)."""
+
+    def __init__(self, sizes, act_name):
+        super().__init__()
+        mods = []
+        for fan_in, fan_out in zip(sizes[:-1], sizes[1:]):
+            mods += [nn.Dropout(p=0.0), nn.Linear(fan_in, fan_out)]
+            a = _activation(act_name)
+            if a is not None:
+                mods.append(a)
+        self.mlp_layers = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.mlp_layers(x)
+
+
 class _ItemEncoderBase(nn.Module):
-    """PatchItemEncoder (layers.py:65-92): backbone + rec_fc = Linear(input_dim, output_dim) + activation,
-    xavier-normal weight / zero bias."""
+    """PatchItemEncoder (layers.py:65-92): backbone + rec_fc = Linear(input_dim, output_dim) + activation -- or, with
+    `dnn_layers`, the MLP head above -- xavier-normal weights / zero biases (layers.py:78-86)."""
 
     def __init__(self, item_encoder, input_dim, output_dim, act_name="relu", dnn_layers=None):
         super().__init__()
-        if dnn_layers:
-            raise NotImplementedError("dnn_layers != [] is not used by the shipped ViT config (overall/ViT.yaml:33)")
-        act = {"relu": nn.ReLU(), "sigmoid": nn.Sigmoid(), "tanh": nn.Tanh(), None: nn.Identity(), "none": nn.Identity()}
-        if (act_name.lower() if isinstance(act_name, str) else act_name) not in act:
-            raise NotImplementedError(f"activation {act_name!r}")
+        _activation(act_name)        # unsupported names raise here
         self.item_encoder = item_encoder
         # the MI355X-native forward/backward of the whole encoder (model/vit_native.py) used for every HIP tensor; the
         # torch modules below are parameter containers (reference names) and the CPU restatement used by CPU-only checks
@@ -157,9 +183,27 @@ class _ItemEncoderBase(nn.Module):
         self._anchor = None
         # weights rewritten behind the tower's back (load_state_dict; the trainable blocks never use cached planes)
         self.register_load_state_dict_post_hook(lambda mod, _keys: mod._native.drop_weight_planes())
-        self.rec_fc = nn.Sequential(nn.Linear(input_dim, output_dim), act[act_name.lower() if isinstance(act_name, str) else act_name])
-        nn.init.xavier_normal_(self.rec_fc[0].weight.data)
-        nn.init.constant_(self.rec_fc[0].bias.data, 0)
+        if dnn_layers:
+            self.rec_fc = MLPHead([input_dim] + [int(h) for h in dnn_layers] + [output_dim], act_name)
+        else:
+            self.rec_fc = nn.Sequential(nn.Linear(input_dim, output_dim), _activation(act_name) or nn.Identity())
+        for mod in self.rec_fc.modules():
+            if isinstance(mod, nn.Linear):
+                nn.init.xavier_normal_(mod.weight.data)
+                nn.init.constant_(mod.bias.data, 0)
+
+    def head_layers(self):
+        """[(weight name, bias name, activation module | None)] of the head's Linear layers in order (names relative to this module)."""
+        if isinstance(self.rec_fc, MLPHead):
+            mods = list(self.rec_fc.mlp_layers)
+            out = []
+            for i, mod in enumerate(mods):
+                if isinstance(mod, nn.Linear):
+                    nxt = mods[i + 1] if i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Linear, nn.Dropout)) else None
+                    out.append((f"rec_fc.mlp_layers.{i}.weight", f"rec_fc.mlp_layers.{i}.bias", nxt))
+            return out
+        a = self.rec_fc[1]
+        return [("rec_fc.0.weight", "rec_fc.0.bias", None if isinstance(a, nn.Identity) else a)]
 
 
 class MeanItemEncoder(_ItemEncoderBase):

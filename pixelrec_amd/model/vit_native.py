@@ -60,7 +60,8 @@ class NativeTower:
             order += [f"{vm}encoder.layers.{i}.{s}" for s in _BLOCK_ORDER]
         # post_layernorm is Identity in a load_model() encoder (load.py:112,116); a bare CLIPVisionEncoder still carries it
         order += [k for k in (vm + "post_layernorm.weight", vm + "post_layernorm.bias") if k in named]
-        order += ["rec_fc.0.weight", "rec_fc.0.bias"]
+        for wn, bn, _ in e.head_layers():       # one Linear, or the layers of the `dnn_layers` MLP head (layers.py:69-71)
+            order += [wn, bn]
         assert set(order) == set(named), sorted(set(named) ^ set(order))
         return [(k, named[k]) for k in order]
 
@@ -325,27 +326,37 @@ class NativeTower:
                                           1e-5, save=keep0)
         n_layers = len(e.item_encoder.vision_model.encoder.layers)
         blocks = []
-        act_relu = isinstance(e.rec_fc[1], torch.nn.ReLU)
+        head = e.head_layers()
+        for _, _, a_ in head:
+            if a_ is not None and not isinstance(a_, torch.nn.ReLU):
+                raise NotImplementedError("native image encoder: rec_fc activation must be relu or none (overall/ViT.yaml: relu)")
+        act_relu = isinstance(head[-1][2], torch.nn.ReLU)
         # opt-in (PXR_TOWER_H2_HEAD=1): the head's Linear over every token (method 'mean') on fp16 two-plane operands too -- the last
         # block writes its output as planes, the weight is split with a device-chosen scale.  Measured on MI355X (ViT-B/16, 69 344
         # tokens): 65.5 -> 66.2 ms per step -- the statistics pass over the head's gradient costs more than three products save on a
         # 768 x 512 weight; off by default.
-        head_h2 = (e.native_method == "mean" and act_relu and os.environ.get("PXR_TOWER_H2_HEAD", "0") == "1"
-                   and self.view("rec_fc.0.weight").shape[0] % 32 == 0)
+        head_h2 = (e.native_method == "mean" and act_relu and len(head) == 1 and os.environ.get("PXR_TOWER_H2_HEAD", "0") == "1"
+                   and self.view(head[0][0]).shape[0] % 32 == 0)
         for i in range(n_layers):
             x, s = self._block_fwd(i, x, keep=need_grad and i >= first, out_planes=head_h2 and i == n_layers - 1)
             blocks.append(s)
         xp_last = getattr(self, "_last_out_planes", None) if n_layers else None
         # head: rec_fc (Linear + activation) on every token then the token mean, or on the class token only
-        if not act_relu and not isinstance(e.rec_fc[1], torch.nn.Identity):
-            raise NotImplementedError("native image encoder: rec_fc activation must be relu or none (overall/ViT.yaml: relu)")
-        W, b = self.view("rec_fc.0.weight"), self.view("rec_fc.0.bias")
+        W, b = self.view(head[-1][0]), self.view(head[-1][1])
         head_in = x if e.native_method == "mean" else x[:, 0, :].contiguous()
         xh_p = rs_p = None
         if e.native_method == "pool":            # pooler_output: post_layernorm of the class token (HF CLIPVisionTransformer)
             y_p, xh_p, rs_p = ops.ln_residual_fwd(head_in.view(n, 1, -1), None, self.view(vm + "post_layernorm.weight"),
                                                   self.view(vm + "post_layernorm.bias"), 1e-5, save=need_grad)
             head_in = y_p.view(n, -1)
+        # an MLP head (fine_tune_arg.dnn_layers): the Linear + activation layers in front of the last one (same token set; the token
+        # mean of 'mean' comes after the LAST activation, layers.py:125-128)
+        hidden = []
+        for wn, bn, a_ in head[:-1]:
+            Wi, bi = self.view(wn), self.view(bn)
+            a_i = ops.linear_epi(head_in, Wi, bi, ops.EPI_BIAS_RELU) if a_ is not None else ops.linear_fwd(head_in, Wi, bi)
+            hidden.append((head_in, a_i, a_ is not None))
+            head_in = a_i
         Wp = None
         if xp_last is not None:
             Wp, = ops.split_h2_auto([W], col_stats=True)
@@ -357,6 +368,7 @@ class NativeTower:
         saved = None
         if need_grad:
             saved = dict(n=n, first=first, blocks=blocks, x_last=x, head_in=head_in, act=act, act_relu=act_relu, xh_p=xh_p, rs_p=rs_p,
+                         head=head, hidden=hidden,
                          patches=patches if keep0 else None, xh0=xh0, rs0=rs0, head_planes=(xp_last, Wp) if Wp is not None else None)
         return out, saved
 
@@ -415,22 +427,35 @@ class NativeTower:
             M = n
         D = dact.shape[-1]
         hp = saved.get("head_planes")
+        head = saved["head"]
+        wn_last, bn_last = head[-1][0], head[-1][1]
         dactp = None
         if hp is not None:       # the head ran on h2 operands: so do its weight and input gradients
             dactp, = ops.split_h2_auto([dact.view(M, D)])
-            ops.grouped_dw_planes([(dactp, hp[0], G("rec_fc.0.weight"), G("rec_fc.0.bias"))])
+            ops.grouped_dw_planes([(dactp, hp[0], G(wn_last), G(bn_last))])
         else:
-            ops.grouped_linear_bwd_weight([(dact.view(M, D), head_in.view(M, H), G("rec_fc.0.weight"), G("rec_fc.0.bias"))])
+            ops.grouped_linear_bwd_weight([(dact.view(M, D), head_in.reshape(M, -1), G(wn_last), G(bn_last))])
         n_layers = len(e.item_encoder.vision_model.encoder.layers)
         pool_ln = e.native_method == "pool" and saved["xh_p"] is not None and \
             e.item_encoder.vision_model.post_layernorm.weight.requires_grad
-        if first >= n_layers and not pool_ln:    # only rec_fc trains
+        only_head = first >= n_layers and not pool_ln     # nothing but rec_fc trains
+        if only_head and not saved["hidden"]:
             defer.flush()
             return
         if dactp is not None:
             dxl, _ = ops.linear_bwd_input_planes(dactp, hp[1], lead_shape=(n, T))
         else:
-            dxl = ops.linear_bwd_input(dact, self.view("rec_fc.0.weight"))
+            dxl = ops.linear_bwd_input(dact, self.view(wn_last))
+        # back through the hidden layers of an MLP head, last to first (their weight gradients are needed whatever else trains)
+        for k, ((h_in, a_i, relu_i), (wn, bn, _)) in enumerate(zip(reversed(saved["hidden"]), reversed(head[:-1]))):
+            da = torch.where(a_i > 0, dxl.view_as(a_i), torch.zeros_like(a_i)) if relu_i else dxl.view_as(a_i)
+            ops.grouped_linear_bwd_weight([(da.reshape(M, -1), h_in.reshape(M, -1), G(wn), G(bn))])
+            if only_head and k == len(saved["hidden"]) - 1:
+                break                             # the first layer's input gradient has no reader
+            dxl = ops.linear_bwd_input(da, self.view(wn))
+        if only_head:
+            defer.flush()
+            return
         if e.native_method == "pool":
             dxl, _ = ops.ln_bwd(0, dxl.view(n, 1, H), saved["xh_p"], saved["rs_p"], self.view(vm + "post_layernorm.weight"),
                                 G(vm + "post_layernorm.weight"), G(vm + "post_layernorm.bias"), defer=defer)

@@ -544,3 +544,114 @@ class OptimizerGroup:
             return
         for o, s in zip(self.opts, sd["group"]):
             o.load_state_dict(s)
+
+
+class FragmentAdamW:
+    """The reference's `decay_check_name` optimizer (code/REC/trainer/trainer.py:73-91): ONE torch.optim.AdamW whose two param
+    groups are split by a NAME FRAGMENT instead of by 'visual_encoder' -- group 0 = every trainable parameter whose name (as the
+    DDP-wrapped model yields it: 'module.' + the state_dict key) contains the fragment, updated with (modal_lr, modal_decay); group 1
+    = all the others with (rec_lr, rec_decay).  No shipped YAML sets it; it exists so that such a config runs instead of raising.
+
+    The fragment can cut through the flat parameter buffer anywhere ('LayerNorm', 'bias', 'item_embedding', ...), so this optimizer
+    works per parameter tensor: one `pxr_adamw_flat_f32` launch per tensor with its group's scalars computed on the host (torch's
+    single-tensor formulae: weight decay, moments, bias corrections -- the same kernel the flat launch of PxrAdamW runs), the item
+    table through the dense sweep `pxr_adamw_table_f32` (dense AdamW semantics on the sparse row gradient).  Eager only (host
+    scalars: not capturable) and nothing else keeps operand planes current: the model re-splits its weights every forward."""
+
+    def __init__(self, dp_model, fragment, in_lr, in_decay, out_lr, out_decay, betas=(0.9, 0.999), eps=1e-8):
+        self.dp = dp_model
+        self.model = dp_model.module if hasattr(dp_model, "module") else dp_model
+        self.fragment = str(fragment)
+        self.betas, self.eps = tuple(betas), float(eps)
+        self.param_groups = [{"lr": float(in_lr), "weight_decay": float(in_decay), "betas": self.betas, "eps": self.eps},
+                             {"lr": float(out_lr), "weight_decay": float(out_decay), "betas": self.betas, "eps": self.eps}]
+        self.step_count = 0
+        self._state = {}          # name -> (m, v)
+        self._slot = None
+        if hasattr(self.model, "trust_optimizer_planes"):
+            self.model.trust_optimizer_planes = False
+        self.has_table = has_item_table(self.model)
+
+    def _named(self):
+        """[(name as the reference's DDP-wrapped model yields it, parameter)] of the trainable parameters, named_parameters() order."""
+        pre = "module." if hasattr(self.dp, "module") else ""
+        return [(pre + n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+
+    def groups(self):
+        """-> (names of group 0, names of group 1), each in named_parameters() order (trainer.py:73-85)."""
+        named = self._named()
+        return [n for n, _ in named if self.fragment in n], [n for n, _ in named if self.fragment not in n]
+
+    def zero_grad(self, set_to_none: bool = False):
+        return None               # every backward overwrites the gradient buffers
+
+    def flush(self):
+        return None               # dense table semantics: nothing is ever owed
+
+    @torch.no_grad()
+    def step(self):
+        if hasattr(self.model, "wait_flat_grads"):
+            self.model.wait_flat_grads()
+        self.step_count += 1
+        b1, b2 = self.betas
+        for name, p in self._named():
+            g = self.param_groups[0 if self.fragment in name else 1]
+            st = self._state.get(name)
+            if st is None:
+                st = self._state[name] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+            if self.has_table and p is self.model.item_embedding.weight:
+                if self._slot is None or self._slot.numel() != p.shape[0] or self._slot.device != p.device:
+                    self._slot = torch.empty(p.shape[0], dtype=torch.int32, device=p.device)
+                    ops.slot_fill(self._slot, -1)
+                ops.adamw_table(p.data, st[0], st[1], self._slot, self.model.sparse_table_grad, g["lr"], b1, b2, self.eps,
+                                g["weight_decay"], self.step_count)
+                continue
+            if p.grad is None:
+                continue          # torch skips parameters without a gradient
+            if p.numel() % 4 != 0 or not p.data.is_contiguous() or not p.grad.is_contiguous():
+                raise NotImplementedError(f"FragmentAdamW: parameter {name} ({tuple(p.shape)}) is not a contiguous multiple of 4 floats")
+            ops.adamw_flat(p.data, p.grad, st[0], st[1], g["lr"], b1, b2, self.eps, g["weight_decay"], self.step_count)
+        enc = getattr(getattr(self.model, "visual_encoder", None), "_native", None)
+        if enc is not None and hasattr(enc, "drop_weight_planes"):
+            enc.drop_weight_planes(trainable_only=True)
+
+    def _order(self):
+        g0, g1 = self.groups()
+        return g0 + g1            # torch numbers the per-parameter state through the groups in order
+
+    def state_dict(self, layout: str = "torch"):
+        """The dict torch.optim.AdamW.state_dict() holds for the reference's two fragment groups (both layouts return it)."""
+        g0, g1 = self.groups()
+        state = {}
+        for i, n in enumerate(g0 + g1):
+            if n in self._state:
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self._state[n][0].clone(),
+                            "exp_avg_sq": self._state[n][1].clone()}
+        groups = []
+        for gi, (names, first) in enumerate(((g0, 0), (g1, len(g0)))):
+            g = self.param_groups[gi]
+            groups.append({"lr": g["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": g["weight_decay"],
+                           **_TORCH_GROUP_DEFAULTS, "params": list(range(first, first + len(names)))})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        order = self._order()
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != len(order):
+            raise ValueError(f"optimizer state has {len(ids)} parameters, this model trains {len(order)}")
+        named = dict(self._named())
+        steps = set()
+        self._state = {}
+        for pid, n in zip(ids, order):
+            st = sd["state"].get(pid)
+            if st is None:
+                continue
+            steps.add(int(float(st["step"])))
+            dev = named[n].device
+            self._state[n] = (st["exp_avg"].to(dev, torch.float32).clone().view_as(named[n]),
+                              st["exp_avg_sq"].to(dev, torch.float32).clone().view_as(named[n]))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)})")
+        self.step_count = steps.pop() if steps else 0
+        for gi, g in enumerate(sd["param_groups"][:2]):
+            self.param_groups[gi].update(lr=g["lr"], weight_decay=g["weight_decay"])

@@ -110,17 +110,26 @@ class Trainer:
         self.item_feature = None
         self.tot_item_num = None
         self.fused_topk = config["eval_fused_topk"] is None or bool(config["eval_fused_topk"])
-        # whole-step hipGraph replay for full-size batches (single rank, ID model): the host issues one graph launch
-        # per step instead of ~65 kernel launches.  `use_hip_graph: False` keeps the eager sequence.
+        # whole-step hipGraph replay for full-size batches (ID model): the host issues one graph launch per step instead of
+        # ~50 kernel launches.  Data parallel over RCCL too (round 6): the captured step CONTAINS its collectives (row all-gather,
+        # flat all-reduce) -- an eager multi-rank step is bound by the host (1.47 ms against 0.85 ms replayed, 1-rank RCCL group on
+        # one MI355X, profiles/r06) and the reference's DDP hides its exchange under the backward pass (run.py:40).  Not over gloo
+        # (CPU staging cannot be captured).  `use_hip_graph: False` keeps the eager sequence.
         g = config["use_hip_graph"]
         sharded = getattr(model.module, "_sharded", False)      # collectives inside forward: issued eagerly
-        self.use_graph = (g is None or bool(g)) and self.world == 1 and not self.use_modality and not sharded
+        import torch.distributed as _dist
+        rccl = self.world > 1 and _dist.is_initialized() and _dist.get_backend() == "nccl"
+        self.use_graph = (g is None or bool(g)) and (self.world == 1 or rccl) and not self.use_modality and not sharded
         self._gstep = None
         # every training step ends in optimizer.step(), which joins the weight-gradient side stream itself
         if hasattr(model.module, "defer_weight_grad_join"):
             model.module.defer_weight_grad_join = True
             if hasattr(model.module, "trust_optimizer_planes"):
                 model.module.trust_optimizer_planes = True   # only the optimizer / load_state_dict touch the weights here
+        if type(self.optimizer).__name__ == "FragmentAdamW":     # decay_check_name: host scalars per tensor, no plane upkeep
+            self.use_graph = False
+            if hasattr(model.module, "trust_optimizer_planes"):
+                model.module.trust_optimizer_planes = False
 
     # ---------------------------------------------------------------------------------------------- optimizer
     def _build_optimizer(self):
@@ -128,9 +137,13 @@ class Trainer:
         parameter is a 'rec' parameter, so both spellings resolve to one AdamW."""
         a = self.optim_args
         m = self.model.module
-        if self.config["decay_check_name"]:
-            # trainer.py:73-91: groups split by a name fragment instead of 'visual_encoder'; not used by any shipped YAML
-            raise NotImplementedError("decay_check_name is not built (the shipped configs leave it unset)")
+        if len(a) == 4 and self.config["decay_check_name"]:
+            # trainer.py:73-91: the two groups split by a name fragment instead of by 'visual_encoder' (no shipped YAML sets it):
+            # per-tensor launches with host scalars -- eager steps, planes re-split every forward
+            from ..optim import FragmentAdamW
+
+            return FragmentAdamW(self.model, self.config["decay_check_name"], a["modal_lr"], a["modal_decay"], a["rec_lr"],
+                                 a["rec_decay"])
         if len(a) == 4:
             rec = PxrAdamW(m, lr=a["rec_lr"], weight_decay=a["rec_decay"])
             modal = [p for n, p in m.named_parameters() if "visual_encoder" in n and p.requires_grad]

@@ -110,8 +110,12 @@ def test_vit_epilogues_and_small_kernels():
 
 # ("pool", 5 + 16 * 3): every block frozen, the pooled head's post_layernorm (named parameters 53, 54 of the 3-block tower --
 # 197, 198 of CLIP ViT-B, reference load.py:119-120) and rec_fc are all that train (advisor r4: its backward returned early)
-@pytest.mark.parametrize("method,tune", [("mean", 5 + 16 * 2), ("mean", 0), ("cls", 5 + 16), ("pool", 5 + 16), ("pool", 5 + 16 * 3)])
-def test_native_encoder_matches_torch_tower(method, tune):
+# dnn: fine_tune_arg.dnn_layers, the MLP head of reference layers.py:69-71, 239-294 (round 6) -- with a trainable block behind it, with
+# every block frozen (only the head's layers train: the backward stops at the first layer's weight gradient), and on the class token
+@pytest.mark.parametrize("method,tune,dnn", [("mean", 5 + 16 * 2, []), ("mean", 0, []), ("cls", 5 + 16, []), ("pool", 5 + 16, []),
+                                             ("pool", 5 + 16 * 3, []), ("mean", 5 + 16 * 2, [40]), ("mean", 5 + 16 * 3, [40, 32]),
+                                             ("cls", 5 + 16 * 2, [40])])
+def test_native_encoder_matches_torch_tower(method, tune, dnn):
     """Forward, every trainable gradient and three VisualAdamW steps of the native encoder against the torch restatement
     of the same tower under autograd + torch.optim.AdamW (tiny 3-block tower; full widths: tests/test_gpu_configs.py)."""
     import copy
@@ -121,7 +125,7 @@ def test_native_encoder_matches_torch_tower(method, tune):
 
     torch.manual_seed(5)
     cfg = {"encoder_name": "clip-vit-tiny-test", "encoder_source": "transformers", "embedding_size": 24, "pretrain_path": None,
-           "fine_tune_arg": {"tune_scale": tune, "pre_trained": False, "activation": "relu", "dnn_layers": [], "method": method}}
+           "fine_tune_arg": {"tune_scale": tune, "pre_trained": False, "activation": "relu", "dnn_layers": dnn, "method": method}}
     enc = visual.load_model(cfg)
     for p in enc.parameters():
         if p.dim() == 1:

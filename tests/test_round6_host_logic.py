@@ -1,0 +1,49 @@
+"""Round-6 host logic that needs no GPU: the decay_check_name optimizer is built (reference trainer.py:73-91), its group split and
+checkpoint layout follow torch.optim.AdamW's, the ops.StatusPoll / planes housekeeping bookkeeping."""
+import torch
+
+
+def test_trainer_builds_the_fragment_optimizer_instead_of_raising():
+    from pixelrec_amd.optim import FragmentAdamW
+    from pixelrec_amd.trainer.trainer import Trainer
+
+    class Cfg(dict):
+        def __getitem__(self, k):
+            return self.get(k)
+
+    t = Trainer.__new__(Trainer)
+    t.config = Cfg(decay_check_name="LayerNorm")
+    t.optim_args = {"modal_lr": 3e-3, "modal_decay": 0.02, "rec_lr": 1e-3, "rec_decay": 0.1}
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.module = torch.nn.Linear(4, 4)
+
+    t.model = M()
+    opt = t._build_optimizer()
+    assert isinstance(opt, FragmentAdamW) and opt.fragment == "LayerNorm"
+
+
+def test_fragment_groups_and_checkpoint_layout_follow_torch_adamw():
+    """Group membership and the numbering of the per-parameter state are torch.optim.AdamW's for the reference's two fragment groups."""
+    from pixelrec_amd.optim import FragmentAdamW
+
+    class Wrapped(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.module = torch.nn.Sequential()
+            self.module.add_module("dense", torch.nn.Linear(4, 4))
+            self.module.add_module("LayerNorm", torch.nn.LayerNorm(4))
+
+    dp = Wrapped()
+    opt = FragmentAdamW(dp, "LayerNorm", 3e-3, 0.02, 1e-3, 0.1)
+    named = [(n, p) for n, p in dp.named_parameters()]
+    g0 = [p for n, p in named if "LayerNorm" in n]
+    g1 = [p for n, p in named if "LayerNorm" not in n]
+    ref = torch.optim.AdamW([{"params": g0, "lr": 3e-3, "weight_decay": 0.02}, {"params": g1, "lr": 1e-3, "weight_decay": 0.1}])
+    mine, theirs = opt.state_dict(), ref.state_dict()
+    assert [g["params"] for g in mine["param_groups"]] == [g["params"] for g in theirs["param_groups"]]
+    for a, b in zip(mine["param_groups"], theirs["param_groups"]):
+        assert (a["lr"], a["weight_decay"], tuple(a["betas"]), a["eps"]) == (b["lr"], b["weight_decay"], tuple(b["betas"]), b["eps"])
+    assert opt.groups() == (["module.LayerNorm.weight", "module.LayerNorm.bias"], ["module.dense.weight", "module.dense.bias"])
