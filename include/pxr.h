@@ -312,10 +312,12 @@ int pxr_attn_bwd_planes_f32(const float* dctx, int64_t ld_ctx, const float* q, c
                             float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* g_planes,
                             int64_t g_plane_stride, int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v,
                             void* stream);
-/* Measurement helper of bench.py (no reference analogue): one wave samples the shader-clock counter and the constant 100 MHz
- * reference over `window_us` microseconds and writes their ratio -- the clock in GHz the device sustains over that window --
- * to *out_ghz.  Launched on a second stream beside the kernel being priced (the MFMA-bound scoring pass lowers the clock). */
-int pxr_clock_probe_f32(float* out_ghz, int64_t window_us, void* stream);
+/* Measurement hook of bench.py (no reference analogue): registers two uint64 in DEVICE memory (NULL unregisters).  Every later
+ * main-pass launch of the fused scoring adds the shader-clock cycles (s_memtime) and the constant 100 MHz reference ticks
+ * (s_memrealtime) that its workgroup 0 lived through: clk2[0] / clk2[1] * 0.1 = the clock in GHz the part sustained INSIDE those
+ * kernels (it lowers its clock under MFMA load; the nominal 2.4 GHz is what the 2.5 PFLOP/s peak assumes).  The caller zeroes the
+ * buffer.  Process-wide; replaces round 5's pxr_clock_probe_f32 (a one-wave probe on a second stream, which read the idle clock). */
+int pxr_score_topk_clock_out(uint64_t* clk2);
 /* Host-side recovery after PXR_STATUS_GEMM_TIMEOUT (a stream-K / split-K worker gave up waiting for a partial tile): waits for
  * the device and zeroes every stream's flag words, so that later launches start from the state they expect.  No reference
  * analogue: this build's own synchronisation (gemm_f32.hip stream-K, gemm_p3.hip split-K weight gradients). */

@@ -60,18 +60,28 @@ struct LnFwdArgs {
   P3Mat yp;                 // optional: y also as planes (the next GEMM's operand format, planes.cuh); p == null: none
   int yp_fmt;               // PXR_PLANES_BF16X3 | PXR_PLANES_H2 (two fp16 planes; a value beyond the fp16 range flags `status`)
   BprHead head;             // RESIDUAL only: the loss head's forward on the rows this launch writes (items == null: none)
+  int nt;                   // streaming-store policy, set by launch_ln_fwd: bit 0 y, bit 1 the planes of y, bit 2 xhat, bit 3 table-row loads
 };
 
 // RPW = rows per wave.  RPW = 2 (large batches): both rows' ids and table rows are requested before either is reduced,
 // so twice as many random 2 KB row fetches are in flight per CU (the kernel is a chain id -> row -> two wave
 // reductions -> stores; at B >= 512 it is HBM-latency bound with one row per wave), and xhat -- written once, read
 // only by the backward pass -- goes out with streaming stores so that it does not evict y, which the QKV GEMM reads next.
-template <int VEC, bool GATHER, int RPW = 1>
+// STAGE (RPW = 1 only, big launches): the planes of y leave through LDS.  A row-per-wave store of a plane touches, per instruction,
+// eight 64-byte row segments 64 * pr bytes apart -- HALF cache lines, and the memory side prices a half line like a whole one
+// (measured at 102 400 rows of D = 512: the two fp16 planes, 210 MB, cost 98 us, as much as y + xhat together, 420 MB).  The four
+// rows of a workgroup are adjacent in every panel, so the workgroup assembles the 256-byte run of each (plane, panel) in LDS
+// (the memory image, padded to 320 bytes per run against bank conflicts) and writes it with 16-byte stores: whole lines.  The
+// arithmetic and the bytes written are those of the unstaged kernel.
+constexpr int LN_STAGE_RUN = 320;
+template <int VEC, bool GATHER, int RPW = 1, bool STAGE = false>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
+  static_assert(!STAGE || RPW == 1, "staging assumes one row per wave, four adjacent rows per workgroup");
+  __shared__ __attribute__((aligned(16))) unsigned char stage_buf[STAGE ? 3 * VEC * 8 * LN_STAGE_RUN : 16];
   if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * RPW;   // rows of one XCD are contiguous (pxr_common.h)
-  if (row0 >= a.rows) return;
+  if (!STAGE && row0 >= a.rows) return;       // (a staging workgroup keeps its idle waves for the barrier)
   const int D = a.D;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
   const bool drop = a.drop_thr != 0u;
@@ -86,7 +96,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
     const float* src;
     const float* add;
     if constexpr (GATHER) {
-      const int rr = live[w] ? row : row0;
+      const int rr = live[w] ? row : (STAGE ? a.rows - 1 : row0);     // (an idle wave of a staging workgroup re-reads the last row)
       const int b = rr / a.L, t = rr - b * a.L;
       int64_t r = a.idx[(int64_t)b * a.idx_bstride + t];
       if (r < 0 || r >= a.n_table) {   // an error in the reference (nn.Embedding raises): flag it, then clamp
@@ -96,7 +106,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
       src = a.table + r * D;
       add = a.pos + (int64_t)t * D;
     } else {
-      const int rr = live[w] ? row : row0;
+      const int rr = live[w] ? row : (STAGE ? a.rows - 1 : row0);
       src = a.x + (int64_t)rr * D;
       add = a.res ? a.res + (int64_t)rr * D : nullptr;
     }
@@ -104,7 +114,9 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
     for (int k = 0; k < VEC; ++k) {
       const int c = (k * 64 + lane) * 4;
       if (c < D) {
-        float4 t4 = *reinterpret_cast<const float4*>(src + c);
+        float4 t4;
+        if (GATHER && (a.nt & 8)) t4 = pxr_ld_stream(src + c);
+        else t4 = *reinterpret_cast<const float4*>(src + c);
         if constexpr (!GATHER) {
           if (drop) {  // dropout on the sub-layer output BEFORE the residual add (layers.py:614, :670)
             const uint64_t e = (uint64_t)row * D + c;
@@ -163,7 +175,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
         xh.x = (v[w][k].x - mean) * rstd; xh.y = (v[w][k].y - mean) * rstd;
         xh.z = (v[w][k].z - mean) * rstd; xh.w = (v[w][k].w - mean) * rstd;
         if (a.xhat) {
-          if constexpr (RPW > 1) pxr_st_stream(a.xhat + (int64_t)row * D + c, xh);
+          if (RPW > 1 || (a.nt & 4)) pxr_st_stream(a.xhat + (int64_t)row * D + c, xh);
           else *reinterpret_cast<float4*>(a.xhat + (int64_t)row * D + c) = xh;
         }
         float4 y;
@@ -177,8 +189,34 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
             y.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? y.w * inv_keep : 0.f;
           }
         }
-        if (a.y) *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
-        if (a.yp.p) px_store4(a.yp, a.yp_fmt, a.status, row, c, y);
+        if (a.y) {
+          if (a.nt & 1) pxr_st_stream(a.y + (int64_t)row * D + c, y);
+          else *reinterpret_cast<float4*>(a.y + (int64_t)row * D + c) = y;
+        }
+        if constexpr (STAGE) {
+          // the run of (plane q, panel cb) starts at (q * NCB + cb) * LN_STAGE_RUN; inside it the global panel image of the 4 rows
+          const int cb = c >> 5;
+          unsigned char* dst = stage_buf + cb * LN_STAGE_RUN + wave * 64 + ((((c >> 3) & 3) ^ ((row >> 2) & 3)) << 4) + ((c & 4) << 1);
+          constexpr int PL = VEC * 8 * LN_STAGE_RUN;      // bytes of one plane's runs (NCB = D / 32 <= VEC * 8)
+          if (a.yp_fmt == PXR_PLANES_H2) {
+            const bool bad = !(fabsf(y.x) <= 65504.f) | !(fabsf(y.y) <= 65504.f) | !(fabsf(y.z) <= 65504.f) | !(fabsf(y.w) <= 65504.f);
+            if (bad && a.status) atomicOr(a.status, PXR_STATUS_H2_RANGE);
+            unsigned h0, l0, h1, l1;
+            h2_split2(y.x, y.y, h0, l0);
+            h2_split2(y.z, y.w, h1, l1);
+            *reinterpret_cast<p3_u32x2*>(dst) = p3_u32x2{h0, h1};
+            *reinterpret_cast<p3_u32x2*>(dst + PL) = p3_u32x2{l0, l1};
+          } else {
+            unsigned h0, m0, l0, h1, m1, l1;
+            p3_split2(y.x, y.y, h0, m0, l0);
+            p3_split2(y.z, y.w, h1, m1, l1);
+            *reinterpret_cast<p3_u32x2*>(dst) = p3_u32x2{h0, h1};
+            *reinterpret_cast<p3_u32x2*>(dst + PL) = p3_u32x2{m0, m1};
+            *reinterpret_cast<p3_u32x2*>(dst + 2 * PL) = p3_u32x2{l0, l1};
+          }
+        } else {
+          if (a.yp.p) px_store4s(a.yp, a.yp_fmt, a.status, row, c, y, (a.nt & 2) != 0);
+        }
         if constexpr (!GATHER) {
           if (ep) {   // (same association as bpr_fwd_kernel: per float4, then across a lane's chunks in column order)
             const float4 pv = *reinterpret_cast<const float4*>(ep + c);
@@ -201,6 +239,21 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs a) {
           a.head.lossrow[row] = -logf(sg + 1e-8f) * (float)a.head.mask[row];
         }
       }
+    }
+  }
+  if constexpr (STAGE) {
+    __syncthreads();
+    const int r_blk = xcd_remap(blockIdx.x, gridDim.x) * 4;                 // first row of this workgroup (a multiple of 4)
+    const int ncb = D >> 5, npl = a.yp_fmt == PXR_PLANES_H2 ? 2 : 3;
+    constexpr int PL = VEC * 8 * LN_STAGE_RUN;
+    unsigned char* base = reinterpret_cast<unsigned char*>(a.yp.p);
+    for (int i = threadIdx.x; i < npl * ncb * 16; i += 256) {                // 16-byte pieces: 16 per 256-byte run
+      const int piece = i & 15, run = i >> 4, q = run / ncb, cb = run - q * ncb;
+      if (r_blk + (piece >> 2) >= a.rows) continue;                          // rows past the end hold nothing
+      const p3_u32x4 v = *reinterpret_cast<const p3_u32x4*>(stage_buf + q * PL + cb * LN_STAGE_RUN + piece * 16);
+      unsigned char* dst = base + ((int64_t)q * a.yp.ps + ((int64_t)cb * a.yp.pr + r_blk) * 32) * 2 + piece * 16;
+      if (a.nt & 2) __builtin_nontemporal_store(v, reinterpret_cast<p3_u32x4*>(dst));
+      else *reinterpret_cast<p3_u32x4*>(dst) = v;
     }
   }
 }
@@ -384,8 +437,21 @@ static inline int ln_vec_for(int D) {
   return p;
 }
 
+// Store policy of a LayerNorm forward launch.  Its outputs are read by LATER launches (y and its planes by the next GEMM, xhat by
+// the backward pass): once they are far larger than the L2s (4 MB per XCD) nothing of them survives there, and write-back
+// allocation only evicts what the launch still needs (gamma / beta / pos, the ids).  From PXR_LN_NT_BYTES (default 48 MB) of fp32
+// output per tensor the stores stream (non-temporal).  PXR_LN_NT overrides the bits (measuring knob).
+static int ln_fwd_nt(const LnFwdArgs& a) {
+  static const int env_nt = getenv("PXR_LN_NT") ? atoi(getenv("PXR_LN_NT")) : -1;
+  static const int64_t nt_bytes = getenv("PXR_LN_NT_BYTES") ? atoll(getenv("PXR_LN_NT_BYTES")) : (48ll << 20);
+  if (env_nt >= 0) return env_nt;
+  return (int64_t)a.rows * a.D * 4 >= nt_bytes ? 7 : 0;
+}
+
 template <bool GATHER>
-static int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
+static int launch_ln_fwd(const LnFwdArgs& a_in, hipStream_t st) {
+  LnFwdArgs a = a_in;
+  a.nt = ln_fwd_nt(a);
   // large batches: two rows per wave (see ln_fwd_kernel); small ones keep one row per wave -- there the launch is a
   // few workgroups per CU and the shortest chain wins
   // (A/B knob, OFF by default: measured 3.75 vs 4.05 TB/s at B = 512 -- the row fetches are not what limits the kernel)
@@ -400,6 +466,20 @@ static int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
     return pxr_check_launch("pxr_ln_fwd");
   }
   const int blocks = (a.rows + 3) / 4;
+  // planes through LDS (whole-line stores) once the launch streams to HBM: from PXR_LN_STAGE_ROWS rows when set, else from 96 MB
+  // of fp32 y (measured at D = 512: 102 400 rows 234 -> 192 us with two fp16 planes, 281 -> 213 with three bf16 ones; at 25 600
+  // rows, where the outputs still fit the 256 MB MALL, half lines cost nothing and the extra barrier does: 42 -> 50 us);
+  // D a multiple of 32 in 256 .. 1024
+  static const int stage_rows = getenv("PXR_LN_STAGE_ROWS") ? atoi(getenv("PXR_LN_STAGE_ROWS")) : -1;
+  const bool stage = stage_rows >= 0 ? a.rows >= stage_rows : (int64_t)a.rows * a.D * 4 >= (96ll << 20);
+  if (a.yp.p && stage && a.D % 32 == 0 && a.D <= 1024 && a.D >= 256) {
+    switch (ln_vec_for(a.D)) {
+      case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, GATHER, 1, true>), dim3(blocks), dim3(256), 0, st, a); break;
+      case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, GATHER, 1, true>), dim3(blocks), dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((ln_fwd_kernel<4, GATHER, 1, true>), dim3(blocks), dim3(256), 0, st, a); break;
+    }
+    return pxr_check_launch("pxr_ln_fwd");
+  }
   switch (ln_vec_for(a.D)) {
     case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, GATHER>), dim3(blocks), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, GATHER>), dim3(blocks), dim3(256), 0, st, a); break;

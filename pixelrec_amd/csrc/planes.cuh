@@ -124,6 +124,28 @@ __device__ __forceinline__ void px_store4(const P3Mat& m, int fmt, int32_t* stat
     p3_store4(m, r, c, v);
   }
 }
+// px_store4 with streaming (non-temporal) stores on request: for planes far larger than the L2 that their reader -- a GEMM launched
+// after this kernel has ended -- streams from HBM / MALL anyway (stream: wave-uniform)
+__device__ __forceinline__ void px_store4s(const P3Mat& m, int fmt, int32_t* status, int64_t r, int c, const float4& v, bool stream) {
+  if (!stream) { px_store4(m, fmt, status, r, c, v); return; }
+  __bf16* dst = m.p + p3_chunk_index(m.pr, r, c & ~7) + (c & 4);
+  if (fmt == PXR_PLANES_H2) {
+    const bool bad = !(fabsf(v.x) <= 65504.f) | !(fabsf(v.y) <= 65504.f) | !(fabsf(v.z) <= 65504.f) | !(fabsf(v.w) <= 65504.f);
+    if (bad && status) atomicOr(status, PXR_STATUS_H2_RANGE);
+    unsigned h0, l0, h1, l1;
+    h2_split2(v.x, v.y, h0, l0);
+    h2_split2(v.z, v.w, h1, l1);
+    __builtin_nontemporal_store(p3_u32x2{h0, h1}, reinterpret_cast<p3_u32x2*>(dst));
+    __builtin_nontemporal_store(p3_u32x2{l0, l1}, reinterpret_cast<p3_u32x2*>(dst + m.ps));
+  } else {
+    unsigned h0, m0, l0, h1, m1, l1;
+    p3_split2(v.x, v.y, h0, m0, l0);
+    p3_split2(v.z, v.w, h1, m1, l1);
+    __builtin_nontemporal_store(p3_u32x2{h0, h1}, reinterpret_cast<p3_u32x2*>(dst));
+    __builtin_nontemporal_store(p3_u32x2{m0, m1}, reinterpret_cast<p3_u32x2*>(dst + m.ps));
+    __builtin_nontemporal_store(p3_u32x2{l0, l1}, reinterpret_cast<p3_u32x2*>(dst + 2 * m.ps));
+  }
+}
 static inline bool p3_mat_ok(const void* p, int64_t ps, int64_t pr, int64_t rows, int64_t cols) {
   return p == nullptr || (cols % 32 == 0 && pr % 32 == 0 && pr >= rows && ps >= pr * cols && ps % 8 == 0 && ((uintptr_t)p & 15) == 0);
 }

@@ -58,7 +58,29 @@ struct ScoreTopkArgs {
   int tile_stride;                        // 1 = every item tile; s > 1 = a SAMPLE (every s-th tile of each split's range)
   // threshold variant (score_thresh_kernel): per-user admission threshold and append buffers
   const float* tau; int* cand_cnt; float* cand_val; int* cand_idx; int cand_cap;
+  unsigned long long* clk;                // measurement hook (pxr_score_topk_clock_out; null: off): see score_clock_start
 };
+
+// The clock a main-pass kernel ACTUALLY runs at.  MI355X lowers its shader clock under sustained MFMA load (1.55-1.9 GHz instead of
+// 2.4 on the scoring passes: the part sits at its power limit), so a roofline fraction against the nominal peak mixes kernel
+// quality with power management.  When a buffer is registered, thread 0 of workgroup 0 samples the shader-clock counter (s_memtime)
+// and the constant 100 MHz reference (s_memrealtime) at its first and last instruction and ADDS both differences to clk[0] / clk[1]:
+// clock [GHz] = clk[0] / clk[1] * 0.1 over every main-pass launch since the buffer was zeroed.  Measured INSIDE the kernel it prices
+// (round 5's one-wave probe on a second stream read 2.4 GHz beside the same kernels: its wave evidently ran in the gaps).
+// (nothing is kept live across the kernel -- every register of the main passes is taken: the start samples are SUBTRACTED from the
+// sums at the first instruction, the end samples added at the last)
+__device__ __forceinline__ void score_clock_start(unsigned long long* clk) {
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicAdd(clk, 0ull - (unsigned long long)__builtin_readcyclecounter());
+    atomicAdd(clk + 1, 0ull - (unsigned long long)wall_clock64());
+  }
+}
+__device__ __forceinline__ void score_clock_stop(unsigned long long* clk) {
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicAdd(clk, (unsigned long long)__builtin_readcyclecounter());
+    atomicAdd(clk + 1, (unsigned long long)wall_clock64());
+  }
+}
 
 template <int KT>
 __global__ void __launch_bounds__(GEMM_THREADS) score_topk_kernel(ScoreTopkArgs a) {
@@ -478,6 +500,7 @@ __global__ void __launch_bounds__(Sp3Cfg::NT) score_thresh_p3_kernel(ScoreTopkAr
   int* hcount = reinterpret_cast<int*>(hlist + ST4_HIST_CAP);
   constexpr int NT = Sp3Cfg::NT;
   const int tid = threadIdx.x;
+  score_clock_start(a.clk);
   const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
   const int rb = t % a.row_blocks, sp = t / a.row_blocks;
   const int u0 = rb * SP3_BN;
@@ -574,6 +597,7 @@ __global__ void __launch_bounds__(Sp3Cfg::NT) score_thresh_p3_kernel(ScoreTopkAr
     }
     p3_lds_barrier();                                      // the bitmap is re-zeroed at the top of the next tile
   });
+  score_clock_stop(a.clk);
 }
 
 // ---- the same pass on the ping-pong main loop (gemm_p4.cuh; round 4): one k-block stream over all item tiles of the workgroup,
@@ -584,6 +608,7 @@ __global__ void __launch_bounds__(Sp3Cfg::NT) score_thresh_p3_kernel(ScoreTopkAr
 using Sp4Cfg = P4Cfg<SP3_BM, SP3_BN, 4, 2, 3, 3>;
 __global__ void __launch_bounds__(Sp4Cfg::NT) score_thresh_p4_kernel(ScoreTopkArgs a, P3Mat table_p, P3Mat users_p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  score_clock_start(a.clk);
   const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
   const int rb = t % a.row_blocks, sp = t / a.row_blocks;
   const int u0 = rb * SP3_BN;
@@ -627,6 +652,7 @@ __global__ void __launch_bounds__(Sp4Cfg::NT) score_thresh_p4_kernel(ScoreTopkAr
       }
     }
   });
+  score_clock_stop(a.clk);
 }
 
 // ---- "fewer products, exact results" (round 4): the threshold pass only has to DECIDE score >= tau, so it runs on a subset of
@@ -659,6 +685,7 @@ template <int NPL, int NS>
 __global__ void __launch_bounds__(512) score_thresh_fast_kernel(ScoreTopkArgs a, P3Mat table_p, P3Mat users_p) {
   using Cfg = SpfCfg<NPL, NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  score_clock_start(a.clk);
   const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
   const int rb = t % a.row_blocks, sp = t / a.row_blocks;
   const int u0 = rb * SPF_BN;
@@ -771,6 +798,7 @@ __global__ void __launch_bounds__(512) score_thresh_fast_kernel(ScoreTopkArgs a,
   });
   p3_wait_vm<0>();                                        // the last tile's reservations
   flush();
+  score_clock_stop(a.clk);
 }
 
 // tau'[u] = tau[u] - delta[u]: tau as topk_tau_kernel, delta[u] = c * ||users[u]||_2 * vmax[0]; cnt[u] = 0
@@ -1043,6 +1071,15 @@ static int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 static int sample_splits(int N, int kt) { return (((N + ST_BN - 1) / ST_BN) + st4_stride(kt) - 1) / st4_stride(kt); }
 static int64_t lists_bytes(int B, int N, int kt, int lists) { return a256((int64_t)B * sample_splits(N, kt) * lists * kt * 4) * 2; }
 
+static unsigned long long* g_score_clk = nullptr;
+// Measurement hook: register two uint64 in DEVICE memory (NULL unregisters).  Every later main-pass launch of the fused scoring
+// (score_thresh_p3 / _p4 / _fast kernels) adds the shader-clock cycles and the 100 MHz reference ticks its workgroup 0 lived through
+// (score_clock_start / _stop above): sustained clock [GHz] = clk[0] / clk[1] * 0.1.  The caller zeroes the buffer.  Process-wide, not stream-ordered.
+extern "C" int pxr_score_topk_clock_out(uint64_t* clk2) {
+  g_score_clk = reinterpret_cast<unsigned long long*>(clk2);
+  return PXR_OK;
+}
+
 extern "C" int64_t pxr_score_topk_ws_bytes(int B, int N, int K) {
   const int kt = pick_kt(K);
   if (kt == 0) return -1;
@@ -1232,6 +1269,7 @@ extern "C" int pxr_score_topk_fast_f32(const float* users, int64_t ld_users, int
   ScoreTopkArgs a{};
   a.users = users; a.ld_users = ld_users; a.table = table; a.hist_ptr = hist_ptr; a.hist_items = hist_items;
   a.B = B; a.N = N; a.D = D;
+  a.clk = g_score_clk;
   a.row_blocks = (B + ST_BM - 1) / ST_BM;
   a.tiles_n = (N + ST_BN - 1) / ST_BN;
   a.n_split = pick_split(B, N);

@@ -88,7 +88,7 @@ _SIGNATURES = {
     "pxr_adamw_hyper_append": (_I, [_P, _P, _I64, _I64, _P, _D, _D, _D, _D, _D, _I, _P]),
     "pxr_adamw_rows_f32": (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _D, _D, _D, _P]),
     "pxr_gemm_reset_flags": (_I, []),
-    "pxr_clock_probe_f32": (_I, [_P, _I64, _P]),
+    "pxr_score_topk_clock_out": (_I, [_P]),
     "pxr_adamw_rows_ids_f32": (_I, [_P, _P, _P, _P, _I64, _I, _P, _I64, _P, _P, _I64, _P, _D, _D, _D, _P]),
     "pxr_adamw_rows_ids2d_f32": (_I, [_P, _P, _P, _P, _I64, _I, _P, _I64, _I64, _I64, _P, _P, _I64, _P, _D, _D, _D, _P, _P]),
     "pxr_adamw_flat_tab_ex_f32": (_I, [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _P, _D, _D, _D, _D, _D, _I, _P, _P, _P, _P, _P, _P,

@@ -1577,13 +1577,26 @@ def adamw_flat_tab(p, g, m, v, hyper, step, beta1, beta2, eps, step_dev=None, pl
         split_planes_multi([p[o:o + r * c].view(r, c) for o, r, c, _ in late], [pl for _, _, _, pl in late])
 
 
-def clock_probe(window_us: int, stream=None) -> torch.Tensor:
-    """Launch the one-wave clock probe (pxr_clock_probe_f32) on `stream` (a torch stream; default: the current one); returns the
-    device float that will hold the sustained shader clock in GHz once the window has passed."""
-    out = torch.zeros(1, dtype=torch.float32, device="cuda")
-    st = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
-    _l.check(_l.load().pxr_clock_probe_f32(_l.ptr(out), int(window_us), ctypes.c_void_p(st)), "pxr_clock_probe_f32")
-    return out
+class ScoreClock:
+    """The shader clock the fused scoring's main-pass kernels sustain, measured inside them (pxr_score_topk_clock_out): a context
+    manager; `.ghz()` after the block has synchronised.  Measurement only (bench.py, tools/eval_bench.py)."""
+
+    def __init__(self, device="cuda"):
+        self.buf = torch.zeros(2, dtype=torch.int64, device=device)
+
+    def __enter__(self):
+        self.buf.zero_()
+        torch.cuda.synchronize()
+        _l.check(_l.load().pxr_score_topk_clock_out(_l.ptr(self.buf)), "pxr_score_topk_clock_out")
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        _l.check(_l.load().pxr_score_topk_clock_out(None), "pxr_score_topk_clock_out")
+
+    def ghz(self) -> float:
+        c, r = (int(x) for x in self.buf.tolist())
+        return c / r * 0.1 if r > 0 else float("nan")
 
 
 def counter_add(counter, delta=1):

@@ -117,7 +117,7 @@ SCRATCH_BUDGET = [
     (r"grouped_dw_p3_kernel<.*, 2>\(", 16),              # split-K weight gradients: 8 / 12 B in the store-then-add epilogue
     (r"tower_attn_bwd_dkv_kernel<[5-8]>", 84),           # ViT-B/16 tower attention backward (one 7-wave workgroup per CU)
     (r"tower_attn_bwd_dkv_kernel<9>", 432), (r"tower_attn_bwd_dq_kernel<9>", 236), (r"tower_attn_fwd_kernel<9, false>", 12),   # 257-token towers
-    (r"score_thresh_p3_kernel", 16),                     # six-product top-k pass
+    (r"score_thresh_p3_kernel", 20),                     # six-product top-k pass (round 6: +4 B, the clock hook's pointer)
     (r"score_topk2_kernel<", 600), (r"score_thresh_kernel<[01]>", 128),       # fallback top-k variants (PXR_TOPK_VARIANT / no planes)
 ]
 
@@ -136,7 +136,8 @@ def test_isa_gate_no_kernel_spills_outside_the_listed_budgets():
     # the kernels of the headline step (profiles/r05/bench_b64_step_timeline.txt) by name: present and scratch free
     for hot in (r"gemm_p3_kernel<pxr::P3Cfg<128, 64, 2, 2, 2, true>, true, 1, false>", r"gemm_p3_kernel<pxr::P3Cfg<128, 64, 2, 2, 2, true>, true, 5, false>",
                 r"gemm_p3_kernel<pxr::P3Cfg<64, 64, 2, 2, 3, true>, false, 4, false>", r"gemm_p3_kernel<pxr::P3Cfg<128, 64, 2, 2, 2, true>, false, 6, false>",
-                r"attn_fwd_mfma1_kernel<8>", r"attn_bwd_mfma1_kernel<8>", r"ln_fwd_kernel<2, true, 1>", r"ln_fwd_kernel<2, false, 1>",
+                r"attn_fwd_mfma1_kernel<8>", r"attn_bwd_mfma1_kernel<8>", r"ln_fwd_kernel<2, true, 1, false>", r"ln_fwd_kernel<2, false, 1, false>", r"ln_fwd_kernel<2, true, 1, true>",
+                r"ln_fwd_kernel<2, false, 1, true>", r"ln_fwd_kernel<4, false, 1, true>",
                 r"ln_bwd_kernel<2, false>", r"ln_bwd_kernel<2, true>", r"adamw_rows_kernel<256, 2>", r"adamw_flat_tab_kernel<true>",
                 r"segsum_kernel<1>", r"fused_pass_kernel<1>", r"h2_split_auto_kernel", r"score_thresh_fast_kernel<2, 4>", r"topk_rescore_kernel"):
         hits = [n for n in res if re.search(re.escape(hot), n)]

@@ -43,9 +43,10 @@ def test_fragment_groups_match_the_oracle(fragment):
         opt.step()
         ref = tr.step(torch.from_numpy(it), torch.from_numpy(mk))
         assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    tol = 2e-2 * max(IN[0] if g0 else 0.0, OUT[0] if g1 else 0.0)      # an AdamW step moves a weight by ~lr: 2 % of that (2e-5 at lr 1e-3)
     sd = model.state_dict()
     for k in params:
-        assert (sd[k].cpu() - tr.p[k]).abs().max().item() < 2e-5, k
+        assert (sd[k].cpu() - tr.p[k]).abs().max().item() < tol, k
     # the checkpoint has torch.optim.AdamW's shape: two groups, state numbered through them in order; a reload resumes it
     osd = opt.state_dict()
     assert [len(g["params"]) for g in osd["param_groups"]] == [len(g0), len(g1)]
@@ -64,4 +65,4 @@ def test_fragment_groups_match_the_oracle(fragment):
     tr.step(torch.from_numpy(it), torch.from_numpy(mk))
     sd = model.state_dict()
     for k in params:
-        assert (sd[k].cpu() - tr.p[k]).abs().max().item() < 2e-5, k
+        assert (sd[k].cpu() - tr.p[k]).abs().max().item() < tol, k

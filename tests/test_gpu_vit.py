@@ -184,8 +184,10 @@ def test_native_encoder_matches_torch_tower(method, tune, dnn):
     # that includes post_layernorm (reference load.py:119-120 keeps it trainable) -- with the same moments, and a load restores them
     sd, tsd = opt.state_dict(), topt.state_dict()
     assert set(sd["state"]) == set(tsd["state"]), (sorted(sd["state"]), sorted(tsd["state"]))
+    mtop = max(st["exp_avg"].abs().max().item() for st in tsd["state"].values())
     for i, st in tsd["state"].items():
-        assert (sd["state"][i]["exp_avg"].cpu() - st["exp_avg"]).abs().max().item() <= 3e-4 * max(st["exp_avg"].abs().max().item(), 1e-30) + 1e-9
+        # (the floor: the key-projection bias has a mathematically zero gradient, its moments are rounding noise of the backward pass)
+        assert (sd["state"][i]["exp_avg"].cpu() - st["exp_avg"]).abs().max().item() <= 3e-4 * max(st["exp_avg"].abs().max().item(), 1e-4 * mtop)
         assert float(sd["state"][i]["step"]) == float(st["step"]) == 3.0
     opt2 = VisualAdamW(enc, lr=1e-2, weight_decay=0.05, eps=1e-2)
     opt2.load_state_dict(sd)

@@ -7,9 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
-#include "../../pixelrec_amd/csrc/gemm_p4.cuh"
+#include "gemm_w4.cuh"
 
 void pxr_set_error(const char*, ...) {}
 int32_t* pxr_status_word(void) { return nullptr; }
@@ -100,6 +101,12 @@ __global__ void sample_err_kernel(const float* A, const float* B, const float* C
   atomicMax(reinterpret_cast<unsigned long long*>(out + 2), (unsigned long long)__double_as_longlong(e));
 }
 
+// Cfg::W4 exists only on the lab's own configurations (gemm_w4.cuh)
+template <class C, class = void>
+struct lab_is_w4 : std::false_type {};
+template <class C>
+struct lab_is_w4<C, std::void_t<decltype(C::W4)>> : std::true_type {};
+
 struct LabArgs {
   P3Mat A, B;
   float* C;
@@ -109,7 +116,8 @@ struct LabArgs {
 
 template <class Cfg, bool A_KC, bool B_KC, int DBG>
 __device__ __forceinline__ void lab_mainloop(typename Cfg::Acc& accs, const LabArgs& g, int m0, int n0, char* smem) {
-  if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, A_KC, B_KC, false, (DBG & 31)>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr);
+  if constexpr (lab_is_w4<Cfg>::value) gemm_w4_mainloop<Cfg, A_KC, B_KC>(accs, g.A, g.B, g.K, m0, n0, smem);
+  else if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, A_KC, B_KC, false, (DBG & 31)>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr);
   else gemm_p3_mainloop<Cfg, A_KC, B_KC, false>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, DBG & 31);
 }
 
@@ -124,7 +132,7 @@ __global__ void __launch_bounds__(Cfg::NT) lab_kernel(const LabArgs g) {
   typename Cfg::Acc accs;
   lab_mainloop<Cfg, A_KC, B_KC, DBG>(accs, g, m0, n0, smem);
   constexpr bool nostore = (DBG & 32) != 0;
-  if constexpr (Cfg::BM * Cfg::EPI_LD * 4 <= Cfg::LDS_BYTES && (!Cfg::PINGPONG || Cfg::BN <= 128)) {
+  if constexpr (!lab_is_w4<Cfg>::value && Cfg::BM * Cfg::EPI_LD * 4 <= Cfg::LDS_BYTES && (!Cfg::PINGPONG || Cfg::BN <= 128)) {
     p3_row_epilogue<Cfg>(accs, smem, g.M, g.N, m0, n0, [&](int, int row, int col, int nv, float (&v)[8]) {
       if (nostore && v[0] != 1.2345e38f) return;
       float* cp = g.C + (int64_t)row * g.N + col;
@@ -351,6 +359,13 @@ int main(int argc, char** argv) {
           run<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>, true, true, 64>("h2 p4 256x256 ns4 acc1", g, iters, nullptr, diffbuf);
           sample_err("h2 three products (1 set, 256x256)", A, B, C, s.M, s.N, s.K, cs);
           run<P4Cfg<256, 256, 4, 2, 3, 1, 0, 2, true>, true, true, 64>("h2 p4 256x256 ns3 acc1", g, iters, nullptr, diffbuf);
+          run<W4Cfg<4, 2, true>, true, true, 64>("h2 w4 256x256 ns4", g, iters, nullptr, diffbuf);
+          sample_err("h2 three products (w4)", A, B, C, s.M, s.N, s.K, cs);
+          run<W4Cfg<3, 2, true>, true, true, 64>("h2 w4 256x256 ns3", g, iters, nullptr, diffbuf);
+          run<W4Cfg<5, 2, true>, true, true, 64>("h2 w4 256x256 ns5", g, iters, nullptr, diffbuf);
+          run<W4Cfg<4, 2, true>, true, true, 32 + 64>("h2 w4 256x256 ns4 nostore", g, iters, nullptr, diffbuf);
+          run<W4Cfg<4, 2, true, 4, 2>, true, true, 64>("h2 f8 256x256 ns4", g, iters, nullptr, diffbuf);
+          run<W4Cfg<4, 2, true, 4, 2>, true, true, 32 + 64>("h2 f8 256x256 ns4 nostore", g, iters, nullptr, diffbuf);
           run<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>, true, true, 32 + 64>("h2 p4 256x256 ns4 acc1 nostore", g, iters, nullptr, diffbuf);
           run<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2, true>, true, true, 32 + 4>("h2 p4 256x256 ns4 acc1 nostore nomfma", g, iters, nullptr, diffbuf);
         }
@@ -388,6 +403,29 @@ int main(int argc, char** argv) {
     RUN("p4 256x128 ns3 acc3 nostore", 32, P4Cfg<256, 128, 4, 2, 3, 3, 0>);
     RUN("p4 256x256 ns3 acc1 npl3 nostore", 32, P4Cfg<256, 256, 4, 2, 3, 1, 0, 3>);
     RUN("p4 256x256 ns4 acc1 npl2 nostore", 32, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
+    if (n256) {
+      // gemm_w4.cuh: one wave per SIMD, 128 x 128 wave tiles; reference for bit-identity = the ping-pong one-set tile of the same planes
+      g.C = Cref;
+      run<P4Cfg<256, 256, 4, 2, 3, 1, 0, 3>, true, true, 64>("p4 256x256 ns3 acc1 npl3 (w4 reference)", g, iters, nullptr, diffbuf);
+      g.C = C;
+      RUN("w4 256x256 ns3 npl3", 64, W4Cfg<3, 3>);
+      RUN("w4 256x256 ns3 npl3 nostore", 32 + 64, W4Cfg<3, 3>);
+      g.C = Cref;
+      run<P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>, true, true, 64>("p4 256x256 ns4 acc1 npl2 (w4 reference)", g, iters, nullptr, diffbuf);
+      g.C = C;
+      RUN("w4 256x256 ns4 npl2", 64, W4Cfg<4, 2>);
+      RUN("w4 256x256 ns3 npl2", 64, W4Cfg<3, 2>);
+      RUN("w4 256x256 ns5 npl2", 64, W4Cfg<5, 2>);
+      RUN("w4 256x256 ns4 npl2 nostore", 32 + 64, W4Cfg<4, 2>);
+      RUN("f8 256x256 ns4 npl2 (8 waves free-running)", 64, W4Cfg<4, 2, false, 4, 2>);
+      RUN("f8 256x256 ns3 npl2", 64, W4Cfg<3, 2, false, 4, 2>);
+      RUN("f8 256x256 ns4 npl2 wg2x4", 64, W4Cfg<4, 2, false, 2, 4>);
+      RUN("f8 256x256 ns4 npl2 nostore", 32 + 64, W4Cfg<4, 2, false, 4, 2>);
+      RUN("f8 256x256 ns3 npl3", 64, W4Cfg<3, 3, false, 4, 2>);
+      g.C = Cref;
+      run<P3Cfg<256, 128, 4, 2, 2>, true, true>("p3 256x128 s2 (baseline again)", g, iters, nullptr, diffbuf);
+      g.C = C;
+    }
     RUN("p4 256x256 ns4 acc1 npl2 nostore nomfma", 36, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
     RUN("p4 256x256 ns4 acc1 npl2 nostore nodma", 34, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);
     RUN("p4 256x256 ns4 acc1 npl2 nostore noreads", 48, P4Cfg<256, 256, 4, 2, 4, 1, 0, 2>);

@@ -89,6 +89,16 @@ pmc64)
   python $REPO/tools/gemm_traffic.py "$Q/summary.json" "$OUT/gemm_traffic_summary.json" "round 5 code, default operands (fp16 two-plane), B=64" > "$OUT/gemm_traffic.log" 2>&1
   rm -f "$Q"/*kernel_trace.csv "$Q"/*counter_collection.csv
   cat "$OUT/gemm_traffic.log" ;;
+gln)
+  timeout 600 python tools/gather_ln_bench.py $GLN_NT 2>/dev/null | grep '^{' > "$OUT/gather_ln_bench.jsonl"
+  python - "$OUT/gather_ln_bench.jsonl" <<'P'
+import json,sys
+for l in open(sys.argv[1]):
+    d=json.loads(l); print("nt",d["nt"],"B",d["B"],d["ids"],d["planes"],"p",d.get("p_drop"),"xhat",d.get("xhat"),round(d["us"],1),"us",round(d["GBps"]),"GB/s",round(d["frac_of_8TBps"],3))
+P
+  ;;
+pmcp4)
+  timeout 1200 bash tools/pmc_p4.sh $NAME/pmc_p4 > "$OUT/pmc_p4.log" 2>&1; tail -n 30 "$OUT/pmc_p4.log" ;;
 ab:*)
   # ab:<label>:<ENV=VAL,ENV=VAL|->:<bench args with + for spaces>   short headline-only run under the given knobs
   IFS=: read -r _ LAB ENVS ARGS <<< "$ST"
