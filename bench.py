@@ -1105,12 +1105,6 @@ def main():
             os.environ["PXR_TOPK_PRODUCTS"] = "6"
             f6_i, f6_v = ops.score_topk(last2, D, 1024, table, 10, ptr, hitems, table_planes=tpl, table_norm_max=vmax)
             t_f6 = time_kernel(lambda: ops.score_topk(last2, D, 1024, table, 10, ptr, hitems, table_planes=tpl, table_norm_max=vmax), iters=10)
-            # the clock the part SUSTAINS inside this kernel (it is power-limited under MFMA load with random operands): the main-pass
-            # kernels record their own shader-clock cycles against the 100 MHz reference (ops.ScoreClock), 12 calls
-            with ops.ScoreClock(dev) as sc6:
-                for _ in range(12):
-                    ops.score_topk(last2, D, 1024, table, 10, ptr, hitems, table_planes=tpl, table_norm_max=vmax)
-            score_ghz = sc6.ghz()
             os.environ.pop("PXR_TOPK_PRODUCTS", None)
             f_i, f_v = ops.score_topk(last2, D, 1024, table, 10, ptr, hitems, table_planes=tpl, table_norm_max=vmax)
             same_ids = bool(torch.equal(f_i, lit_i))
@@ -1127,18 +1121,21 @@ def main():
                                        "note": "the WHOLE fused scoring + history / padding masks + top-10 call per 1024 users x 400 001 items "
                                                "(scores never reach HBM), timed end to end and priced as if all of it were the scoring product; "
                                                "the main-pass kernel alone: profiles/r04 eval kernel stats"}
-            # peak of the bf16 pipe at the sustained clock: 256 CUs x 4 SIMDs x 1024 flop/clk (v_mfma_f32_32x32x16_bf16: 32768 flop in
-            # 8 passes of 4 clk) -- 2.5 PFLOP/s is that at ~2.4 GHz
+            # the clock the part SUSTAINS inside the default threshold kernel (power-limited under MFMA load with random operands): the
+            # kernel records its own shader-clock cycles against the 100 MHz reference (ops.ScoreClock); peak of the bf16 / fp16 pipe at
+            # that clock: 256 CUs x 4 SIMDs x 1024 flop/clk (v_mfma_f32_32x32x16: 32768 flop in 8 passes of 4 clk) -- 2.5 PFLOP/s at ~2.4 GHz
+            score_ghz = sc3.ghz()
             peak_sus = 256 * 4 * 1024 * score_ghz * 1e9 / 1e12 if score_ghz > 0 else float("nan")
-            out["roofline_scoring"].update({"sustained_clock_ghz": score_ghz, "peak_at_sustained_clock": peak_sus,
-                                            "frac_of_sustained_peak": out["roofline_scoring"]["achieved"] / peak_sus,
-                                            "sustained_clock_note": "shader-clock cycles / 100 MHz reference ticks recorded by workgroup 0 of the "
-                                                                    "main-pass kernel itself over 12 calls (pxr_score_topk_clock_out)"})
+            ex3 = ops.topk_products() * fl / t_f / 1e12
             out["roofline_scoring_fused_topk"] = {
                 "ms_per_1024_users": t_f * 1e3, "identical_top10": same_ids, "products_in_threshold_pass": ops.topk_products(),
                 "identical_ids_and_values_to_six_product_schedule": same_bits, "six_product_schedule_ms": t_f6 * 1e3,
                 "row_norm_max_us_once_per_evaluation": t_nm * 1e6, "speedup_vs_literal_gemm_alone": t_s / t_f,
-                "sustained_clock_ghz": sc3.ghz(),
+                "sustained_clock_ghz": score_ghz, "peak_at_sustained_clock": peak_sus,
+                "executed_tflops_whole_call": ex3, "frac": ex3 / MFMA_BF16_PEAK_TF, "frac_of_sustained_peak": ex3 / peak_sus,
+                "sustained_clock_note": "shader-clock cycles / 100 MHz reference ticks recorded by workgroup 0 of score_thresh_fast_kernel "
+                                        "itself over 12 calls (pxr_score_topk_clock_out); the six-product pass runs at 1.70-1.79 GHz in the "
+                                        "lab (profiles/r06/lab)",
                 "note": "the product's default (trainer.evaluate): threshold pass on 3 of the 6 bf16 products (score_thresh_fast_kernel, "
                         "256 x 256 tiles, one accumulator set), threshold lowered by a rigorous per-user bound, survivors that can reach the "
                         "top 10 re-scored with all six products in the full pass's MFMA order (topk_rescore_kernel): bit-identical output at "
@@ -1237,8 +1234,9 @@ def main():
                                                    "the input LayerNorm, priced with everything that launch reads and writes)"},
             "scoring_ge_0.60_of_mfma_peak": {"literal_gemm": out.get("roofline_scoring_literal", {}).get("frac"),
                                              "fused_topk_six_products": sc_.get("frac"),
-                                             "sustained_clock_ghz": sc_.get("sustained_clock_ghz"),
-                                             "frac_of_peak_at_sustained_clock": sc_.get("frac_of_sustained_peak"),
+                                             "fused_topk_default_three_products": out.get("roofline_scoring_fused_topk", {}).get("frac"),
+                                             "sustained_clock_ghz": out.get("roofline_scoring_fused_topk", {}).get("sustained_clock_ghz"),
+                                             "frac_of_peak_at_sustained_clock": out.get("roofline_scoring_fused_topk", {}).get("frac_of_sustained_peak"),
                                              "met": bool((sc_.get("frac") or 0) >= 0.60),
                                              "note": "fractions of the dense bf16 MFMA peak on EXECUTED products (6 per fp32 multiply); not met.  "
                                                      "frac_of_peak_at_sustained_clock prices the same rate against 256 CUs x 4 SIMDs x 1024 "

@@ -313,7 +313,7 @@ int pxr_attn_bwd_planes_f32(const float* dctx, int64_t ld_ctx, const float* q, c
                             int64_t g_plane_stride, int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v,
                             void* stream);
 /* Measurement hook of bench.py (no reference analogue): registers two uint64 in DEVICE memory (NULL unregisters).  Every later
- * main-pass launch of the fused scoring adds the shader-clock cycles (s_memtime) and the constant 100 MHz reference ticks
+ * main-pass launch of the fused scoring's DEFAULT (reduced-product) threshold kernel adds the shader-clock cycles (s_memtime) and the constant 100 MHz reference ticks
  * (s_memrealtime) that its workgroup 0 lived through: clk2[0] / clk2[1] * 0.1 = the clock in GHz the part sustained INSIDE those
  * kernels (it lowers its clock under MFMA load; the nominal 2.4 GHz is what the 2.5 PFLOP/s peak assumes).  The caller zeroes the
  * buffer.  Process-wide; replaces round 5's pxr_clock_probe_f32 (a one-wave probe on a second stream, which read the idle clock). */

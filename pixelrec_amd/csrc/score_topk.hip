@@ -500,7 +500,6 @@ __global__ void __launch_bounds__(Sp3Cfg::NT) score_thresh_p3_kernel(ScoreTopkAr
   int* hcount = reinterpret_cast<int*>(hlist + ST4_HIST_CAP);
   constexpr int NT = Sp3Cfg::NT;
   const int tid = threadIdx.x;
-  score_clock_start(a.clk);
   const int t = xcd_remap(blockIdx.x, a.row_blocks * a.n_split);
   const int rb = t % a.row_blocks, sp = t / a.row_blocks;
   const int u0 = rb * SP3_BN;
@@ -597,7 +596,6 @@ __global__ void __launch_bounds__(Sp3Cfg::NT) score_thresh_p3_kernel(ScoreTopkAr
     }
     p3_lds_barrier();                                      // the bitmap is re-zeroed at the top of the next tile
   });
-  score_clock_stop(a.clk);
 }
 
 // ---- the same pass on the ping-pong main loop (gemm_p4.cuh; round 4): one k-block stream over all item tiles of the workgroup,
@@ -1073,7 +1071,7 @@ static int64_t lists_bytes(int B, int N, int kt, int lists) { return a256((int64
 
 static unsigned long long* g_score_clk = nullptr;
 // Measurement hook: register two uint64 in DEVICE memory (NULL unregisters).  Every later main-pass launch of the fused scoring
-// (score_thresh_p3 / _p4 / _fast kernels) adds the shader-clock cycles and the 100 MHz reference ticks its workgroup 0 lived through
+// (score_thresh_fast / score_thresh_p4 kernels; the six-product score_thresh_p3_kernel has no register to spare for the hook: it ran 18 % slower with it) adds the shader-clock cycles and the 100 MHz reference ticks its workgroup 0 lived through
 // (score_clock_start / _stop above): sustained clock [GHz] = clk[0] / clk[1] * 0.1.  The caller zeroes the buffer.  Process-wide, not stream-ordered.
 extern "C" int pxr_score_topk_clock_out(uint64_t* clk2) {
   g_score_clk = reinterpret_cast<unsigned long long*>(clk2);

@@ -117,7 +117,7 @@ SCRATCH_BUDGET = [
     (r"grouped_dw_p3_kernel<.*, 2>\(", 16),              # split-K weight gradients: 8 / 12 B in the store-then-add epilogue
     (r"tower_attn_bwd_dkv_kernel<[5-8]>", 84),           # ViT-B/16 tower attention backward (one 7-wave workgroup per CU)
     (r"tower_attn_bwd_dkv_kernel<9>", 432), (r"tower_attn_bwd_dq_kernel<9>", 236), (r"tower_attn_fwd_kernel<9, false>", 12),   # 257-token towers
-    (r"score_thresh_p3_kernel", 20),                     # six-product top-k pass (round 6: +4 B, the clock hook's pointer)
+    (r"score_thresh_p3_kernel", 16),                     # six-product top-k pass
     (r"score_topk2_kernel<", 600), (r"score_thresh_kernel<[01]>", 128),       # fallback top-k variants (PXR_TOPK_VARIANT / no planes)
 ]
 
