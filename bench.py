@@ -557,6 +557,7 @@ def main():
         model.weight_grad_mode = args.dw_mode
     model.defer_weight_grad_join = True      # every step below ends in opt.step(), which joins the side stream
     model.trust_optimizer_planes = True      # ... and nothing but the optimizer rewrites the weights between forwards
+    model.h2_stale_scales = True             # ... in a loop of similar steps (what GraphedTrainStep / the Trainer set)
     opt = None
 
     # synthetic batches, rank-distinct, resident in HBM before the timed region.  The stream does NOT repeat inside

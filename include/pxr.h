@@ -268,6 +268,35 @@ int pxr_h2_split_parts_f32(const float* x, int64_t rows, int64_t cols, int64_t l
 int pxr_attn_bwd_stat_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
                           const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d,
                           float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, float* stat, void* stream);
+/* ---- stale scales (round 6): the three h2 split launches per layer of a training step's backward pass removed.  The gradients a
+ * backward pass hands to its GEMMs change slowly from step to step, so their producers write the planes THEMSELVES under an exponent
+ * that exists before they run -- derived from the PREVIOUS step's maximum, `headroom` binades below the usual placement -- and leave
+ * this step's partial maxima for the next derivation.  A value that outgrows the headroom is SATURATED to +-65504 (never inf) and
+ * raises PXR_STATUS_H2_STALE (128) in the status word.
+ * pxr_ln_bwd_h2s_f32: a residual LayerNorm site's backward (reference layers.py:614-615 / :670-671 under autograd); dz as fp32, the
+ *   gradient the next GEMMs read (dropout applied when p_drop > 0; no fp32 copy) ONLY as two fp16 planes of gradient * 2^g_exp_dev[0];
+ *   stat[pxr_ln_bwd_partial_rows(rows)] partial maxima; zero / zero_n as pxr_ln_bwd_stat_f32.  pos_score != NULL: the loss head's
+ *   backward fused in as in pxr_bpr_ln_bwd_f32 (dy unused, rows == B * L); NULL: the eleven head arguments are ignored.
+ * pxr_attn_bwd_h2s_f32: dq | dk | dv ONLY as such planes (column ranges as in pxr_attn_bwd_planes_f32) + the 64 spread maxima.
+ * pxr_h2_sites_update: n <= 16 sites; per site m = max(maximum of its n_parts[s] partial maxima, run_max[s] * decay) (the maxima are
+ *   heavy-tailed: the scale follows a decaying maximum of the recent steps; run_max persistent, zero-initialised) -> exps[s] (m 2^e in
+ *   [2^(13-headroom), 2^(14-headroom))), stats[2 s ..] = (max 2^headroom, rows[s] max 2^headroom) and, where bound_b[s] (the largest
+ *   column sum of |W| of the weight behind the site) is given, bexp[s] = 15 - ceil(log2(max 2^headroom * bound_b[s][0] * bound_factor)):
+ *   the exponent of the planes a GEMM epilogue writes from site s (pxr_h2_bound_exp's rule).  A site without gradient keeps its entries.
+ *   Run it once per step after the LAST reader of the site exponents; seed it with one exact pass (pxr_ln_bwd_stat_f32 /
+ *   pxr_attn_bwd_stat_f32 + pxr_h2_split_parts_f32 leave the same partial maxima). */
+int pxr_ln_bwd_h2s_f32(const float* pos_score, const float* neg_score, const float* table, int64_t n_table, const int64_t* items,
+                       const int64_t* masked_index, int B, int L, float grad_scale, const float* grad_scale_dev, float* coef,
+                       const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int D, float* dz,
+                       float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                       void* ws, int64_t ws_bytes, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows,
+                       const int* g_exp_dev, float* stat, float* zero, int zero_n, void* stream);
+int pxr_attn_bwd_h2s_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
+                         const float* probs, int B, int H, int L, int d, float p_drop, uint64_t seed, uint32_t stream_id,
+                         const int64_t* step_dev, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows, int g_cols,
+                         int col_q, int col_k, int col_v, const int* g_exp_dev, float* stat, void* stream);
+int pxr_h2_sites_update(int n, const float* const* parts, const int* n_parts, const int* rows, const float* const* bound_b,
+                        float bound_factor, int headroom, float decay, float* run_max, int* exps, float* stats, int* bexp, void* stream);
 int pxr_ln_residual_fwd_h2_f32(const float* x, const float* res, const float* gamma, const float* beta, float eps, int rows,
                                int D, float* y, float* xhat, float* rstd, float p_drop, uint64_t seed, uint32_t stream_id,
                                const int64_t* step_dev, void* y_planes, int64_t y_plane_stride, int64_t y_panel_rows,

@@ -49,6 +49,8 @@ struct AttnArgs {
   int pcol[3];
   int op_fmt;               // PXR_PLANES_BF16X3 | PXR_PLANES_H2 (the forward's ctx planes; planes.cuh)
   int32_t* status;          // status word for the fp16 range check of h2 planes, or null
+  const int* gexp;          // backward: null = the gradient planes are three bf16 planes; else two fp16 planes of gradient *
+                            // 2^gexp[0], a DEVICE exponent chosen before the launch (previous step's statistics), saturating stores
   float* stat;              // backward (attn_bwd_mfma1_kernel): max of |dq|, |dk|, |dv| into PXR_ATTN_STAT_SLOTS zeroed words, or null
 };
 
@@ -332,7 +334,7 @@ __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TN], float* out, i
 template <int TN, int NT>
 __device__ __forceinline__ void store_acc_planes(const f32x16 (&acc)[TN], bool mine, float* tile, int m_base, int n_base, int L,
                                                  int w, int lane, const P3Mat& P, int64_t row0, int col0, int fmt = PXR_PLANES_BF16X3,
-                                                 int32_t* status = nullptr) {
+                                                 int32_t* status = nullptr, float stale_scale = 0.f) {
   const int h = lane >> 5, r = lane & 31;
   if (mine) {
 #pragma unroll
@@ -348,7 +350,8 @@ __device__ __forceinline__ void store_acc_planes(const f32x16 (&acc)[TN], bool m
     const float4 x0 = *reinterpret_cast<const float4*>(tile + row * ATT_KLD + c8);
     const float4 x1 = *reinterpret_cast<const float4*>(tile + row * ATT_KLD + c8 + 4);
     const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    px_store8(P, fmt, status, row0 + row, col0 + c8, v);
+    if (stale_scale != 0.f) px_store8_h2s(P, status, row0 + row, col0 + c8, v, stale_scale);
+    else px_store8(P, fmt, status, row0 + row, col0 + c8, v);
   }
   __syncthreads();
 }
@@ -671,6 +674,7 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   const bool mine = n_base < d;
   f32x16 acc[TN];
   zero_acc<TN>(acc);
+  const float gsc = a.gexp ? ldexpf(1.0f, a.gexp[0]) : 0.f;      // != 0: stale-scale fp16 planes (store_acc_planes)
   float gmax = 0.f;         // max |dq|, |dk|, |dv| over this thread's entries INSIDE the [L, d] block (the tiles' padding holds
   auto take = [&]() {       // whatever the LDS held: store_acc masks it, so must the statistics)
 #pragma unroll
@@ -687,7 +691,7 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   if (a.stat && mine) take();
   if (a.dv) store_acc<TN>(acc, a.dv + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
   // (sV was last read by the dPd product, two barriers ago: free for the plane staging)
-  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[2] + h * d);
+  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[2] + h * d, PXR_PLANES_BF16X3, a.status, gsc);
   __syncthreads();
 #pragma unroll
   for (int g = 0; g < ROWS; ++g) {
@@ -699,12 +703,12 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_mfma1_kernel(AttnArgs a) {
   if (mine) lds_mma<true, false, TN>(acc, sS, ATT_SLD, sK, ATT_KLD, wm * 32, n_base, 64, lane);    // dQ = dS K
   if (a.stat && mine) take();
   if (a.dq) store_acc<TN>(acc, a.dq + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
-  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[0] + h * d);
+  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[0] + h * d, PXR_PLANES_BF16X3, a.status, gsc);
   zero_acc<TN>(acc);
   if (mine) lds_mma<false, false, TN>(acc, sS, ATT_SLD, sQ, ATT_KLD, wm * 32, n_base, 64, lane);   // dK = dS^T Q
   if (a.stat && mine) take();
   if (a.dk) store_acc<TN>(acc, a.dk + dbase, a.ld_d, wm * 32, n_base, L, d, lane);
-  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[1] + h * d);
+  if (a.op.p) store_acc_planes<TN, NT>(acc, mine, sV, wm * 32, n_base, L, d, lane, a.op, (int64_t)b * L, a.pcol[1] + h * d, PXR_PLANES_BF16X3, a.status, gsc);
   if (a.stat) {
     // one atomic per WORKGROUP, spread over PXR_ATTN_STAT_SLOTS words (the caller -- or the LayerNorm backward launch in front of
     // this one -- zeroed them; pxr_h2_split_parts_f32 reduces them): round 4 raised ONE word once per wave, 2 048 same-address
@@ -809,14 +813,15 @@ __device__ __forceinline__ void acc_to_tile2(const f32x16& acc, bool mine, float
 }
 // ... and the second: rows < L of the tile as planes, 8 consecutive columns per thread and store
 __device__ __forceinline__ void tile2_to_planes(const float* tile, int L, int w, const P3Mat& P, int64_t row0, int col0, int fmt,
-                                                int32_t* status) {
+                                                int32_t* status, float stale_scale = 0.f) {
   const int cpr = w >> 3;
   for (int q = threadIdx.x; q < L * cpr; q += ATT2_NT) {
     const int row = q / cpr, c8 = (q - row * cpr) * 8;
     const float4 x0 = *reinterpret_cast<const float4*>(tile + row * ATT_KLD + c8);
     const float4 x1 = *reinterpret_cast<const float4*>(tile + row * ATT_KLD + c8 + 4);
     const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    px_store8(P, fmt, status, row0 + row, col0 + c8, v);
+    if (stale_scale != 0.f) px_store8_h2s(P, status, row0 + row, col0 + c8, v, stale_scale);
+    else px_store8(P, fmt, status, row0 + row, col0 + c8, v);
   }
 }
 
@@ -946,6 +951,7 @@ __global__ void __launch_bounds__(ATT2_NT, 4) attn_bwd_mfma2_kernel(AttnArgs a) 
   __syncthreads();
   const int wm = wave >> 2, n_base = (wave & 3) * 32;
   const bool mine = n_base < d;
+  const float gsc = a.gexp ? ldexpf(1.0f, a.gexp[0]) : 0.f;      // != 0: stale-scale fp16 planes (tile2_to_planes)
   float gmax = 0.f;
   auto take = [&](const f32x16& acc) {
     const bool col_ok = n_base + (lane & 31) < d;
@@ -969,7 +975,7 @@ __global__ void __launch_bounds__(ATT2_NT, 4) attn_bwd_mfma2_kernel(AttnArgs a) 
   if (a.op.p) {
     acc_to_tile2(acc[0], mine, T0, wm * 32, n_base, L, lane);
     __syncthreads();
-    tile2_to_planes(T0, L, d, a.op, (int64_t)b * L, a.pcol[2] + h * d, PXR_PLANES_BF16X3, nullptr);
+    tile2_to_planes(T0, L, d, a.op, (int64_t)b * L, a.pcol[2] + h * d, PXR_PLANES_BF16X3, a.status, gsc);
     __syncthreads();
   }
   tile2_store(T0, r0, L, d);                     // Q over dctx (rewrites the zero row the staging never touched)
@@ -988,8 +994,8 @@ __global__ void __launch_bounds__(ATT2_NT, 4) attn_bwd_mfma2_kernel(AttnArgs a) 
     acc_to_tile2(acc[0], mine, T1, wm * 32, n_base, L, lane);
     acc_to_tile2(acc2[0], mine, T0, wm * 32, n_base, L, lane);
     __syncthreads();
-    tile2_to_planes(T1, L, d, a.op, (int64_t)b * L, a.pcol[0] + h * d, PXR_PLANES_BF16X3, nullptr);
-    tile2_to_planes(T0, L, d, a.op, (int64_t)b * L, a.pcol[1] + h * d, PXR_PLANES_BF16X3, nullptr);
+    tile2_to_planes(T1, L, d, a.op, (int64_t)b * L, a.pcol[0] + h * d, PXR_PLANES_BF16X3, a.status, gsc);
+    tile2_to_planes(T0, L, d, a.op, (int64_t)b * L, a.pcol[1] + h * d, PXR_PLANES_BF16X3, a.status, gsc);
   }
   if (a.stat) {
     __shared__ float smax[NW];
@@ -1358,7 +1364,8 @@ extern "C" int pxr_attn_bwd_f32(const float* dctx, int64_t ld_ctx, const float* 
 static int attn_bwd_impl(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
                          const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d, float p_drop,
                          uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* g_planes, int64_t g_plane_stride,
-                         int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v, float* stat, void* stream);
+                         int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v, float* stat, void* stream,
+                         const int* g_exp = nullptr);
 extern "C" int pxr_attn_bwd_planes_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v,
                                        int64_t ld, const float* probs, int B, int H, int L, int d, float* dq, float* dk,
                                        float* dv, int64_t ld_d, float p_drop, uint64_t seed, uint32_t stream_id,
@@ -1377,11 +1384,25 @@ extern "C" int pxr_attn_bwd_stat_f32(const float* dctx, int64_t ld_ctx, const fl
   return attn_bwd_impl(dctx, ld_ctx, q, k, v, ld, probs, B, H, L, d, dq, dk, dv, ld_d, p_drop, seed, stream_id, step_dev, nullptr, 0, 0, 0,
                        0, 0, 0, stat, stream);
 }
+// dq | dk | dv ONLY as two fp16 planes of gradient * 2^g_exp_dev[0] (column ranges of one [B*L, g_cols] matrix as in
+// pxr_attn_bwd_planes_f32) under an exponent that exists before the launch (pxr_h2_sites_update: the previous step's maximum less the
+// headroom), range-checked and saturated (PXR_STATUS_H2_STALE), + this step's partial maxima in the PXR_ATTN_STAT_SLOTS words of
+// `stat` (zeroed by the caller / the LayerNorm launch in front).  Replaces pxr_attn_bwd_stat_f32 + pxr_h2_split_parts_f32.
+extern "C" int pxr_attn_bwd_h2s_f32(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
+                                    const float* probs, int B, int H, int L, int d, float p_drop, uint64_t seed, uint32_t stream_id,
+                                    const int64_t* step_dev, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows, int g_cols,
+                                    int col_q, int col_k, int col_v, const int* g_exp_dev, float* stat, void* stream) {
+  PXR_REQUIRE(g_planes && g_exp_dev && stat && pxr_attn_planes_supported(L, d),
+              "pxr_attn_bwd_h2s_f32: planes, exponent and slots are required; shapes of the fused kernel only (L=%d, d=%d)", L, d);
+  return attn_bwd_impl(dctx, ld_ctx, q, k, v, ld, probs, B, H, L, d, nullptr, nullptr, nullptr, 4, p_drop, seed, stream_id, step_dev, g_planes,
+                       g_plane_stride, g_panel_rows, g_cols, col_q, col_k, col_v, stat, stream, g_exp_dev);
+}
 static int attn_bwd_impl(const float* dctx, int64_t ld_ctx, const float* q, const float* k, const float* v, int64_t ld,
                          const float* probs, int B, int H, int L, int d, float* dq, float* dk, float* dv, int64_t ld_d, float p_drop,
                          uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* g_planes, int64_t g_plane_stride,
-                         int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v, float* stat, void* stream) {
+                         int64_t g_panel_rows, int g_cols, int col_q, int col_k, int col_v, float* stat, void* stream, const int* g_exp) {
   PXR_REQUIRE(dctx && q && k && v && probs && ((dq && dk && dv) || (g_planes && !dq && !dk && !dv)), "pxr_attn_bwd_f32: null pointer");
+  PXR_REQUIRE(!g_exp || (g_planes && stat), "pxr_attn_bwd_h2s_f32: the stale-scale form needs planes and the statistics slots");
   PXR_REQUIRE(!g_planes || (pxr_attn_planes_supported(L, d) && p3_mat_ok(g_planes, g_plane_stride, g_panel_rows, (int64_t)B * L, g_cols) &&
                             col_q % 8 == 0 && col_k % 8 == 0 && col_v % 8 == 0 && col_q >= 0 && col_k >= 0 && col_v >= 0 &&
                             (int64_t)H * d + (col_q > col_k ? (col_q > col_v ? col_q : col_v) : (col_k > col_v ? col_k : col_v)) <= g_cols),
@@ -1396,6 +1417,7 @@ static int attn_bwd_impl(const float* dctx, int64_t ld_ctx, const float* q, cons
   a.op = P3Mat{reinterpret_cast<__bf16*>(g_planes), g_plane_stride, g_panel_rows};
   a.pcol[0] = col_q; a.pcol[1] = col_k; a.pcol[2] = col_v;
   a.stat = stat;
+  a.gexp = g_exp; a.status = pxr_status_word();
   a.sqrt_d = sqrtf((float)d);
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;

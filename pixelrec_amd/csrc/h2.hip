@@ -186,6 +186,48 @@ __global__ void h2_bound_exp_kernel(const float* a_max, const float* b_colsum, f
   if (threadIdx.x == 0 && blockIdx.x == 0) *exp_out = h2_exp_for(a_max[0] * b_colsum[0] * factor, 15);
 }
 
+// ---- stale scales (round 6).  The gradients a backward pass hands to its GEMMs (LayerNorm backward outputs, dq | dk | dv) change
+// slowly from one training step to the next, and the h2 format tolerates a scale that is off by many binades (planes.cuh).  So their
+// producers write the planes THEMSELVES under the exponent this kernel derived from the PREVIOUS step's maximum, HEADROOM binades
+// below the usual placement (the recent maximum in [2^(13-H), 2^(14-H)): a value may exceed it 2^(H+2)-fold before it leaves the fp16
+// range -- and is then saturated and flagged, never inf), and leave this step's partial maxima for the next update: six split launches and six fp32
+// round trips per step disappear.  One workgroup per site: max over its partials -> exps[s], stats[2 s .. 2 s + 1] = (max 2^H, rows max
+// 2^H) (what a consumer may assume about the NEXT step's values) and, for a site whose planes feed a GEMM that writes its own output
+// as planes before knowing it (du), bexp[s] = 15 - ceil(log2(max 2^H * colsum |W| * factor)).  A site without gradient (max 0 or
+// non-finite) keeps its old entries.
+struct H2Sites {
+  const float* parts[16]; int n_parts[16]; int rows[16];
+  const float* bound_b[16];         // &W.stats[1] (largest column sum of |w|) or null
+  int n, headroom;
+  float bound_factor, decay;
+  int* exps; float* stats; int* bexp;
+  float* run_max;                   // [n] decaying maximum of the step maxima: run = max(step max, run * decay)
+};
+__global__ void __launch_bounds__(256) h2_sites_update_kernel(const H2Sites m) {
+  __shared__ float pmax[4];
+  const int s = blockIdx.x;
+  float mx = 0.f;
+  for (int q = threadIdx.x; q < m.n_parts[s]; q += 256) mx = fmaxf(mx, m.parts[s][q]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) pmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(pmax[0], pmax[1]), fmaxf(pmax[2], pmax[3]));
+    if (mx > 0.f && !isinf(mx)) {
+      // the maxima of these gradients are heavy-tailed (one sharp softmax row of one sequence sets max |dqkv|: 10 x from step to
+      // step is ordinary, 50 x was seen within 220 steps of the bench stream), so the scale follows a DECAYING maximum of the last
+      // steps' maxima (half-life ln 2 / (1 - decay) steps), not the last step alone
+      mx = fmaxf(mx, m.run_max[s] * m.decay);
+      m.run_max[s] = mx;
+      const float grown = ldexpf(mx, m.headroom);
+      m.exps[s] = h2_exp_for(mx, 14 - m.headroom);
+      m.stats[2 * s] = grown;
+      m.stats[2 * s + 1] = (float)m.rows[s] * grown;
+      if (m.bound_b[s]) m.bexp[s] = h2_exp_for(grown * m.bound_b[s][0] * m.bound_factor, 15);
+    }
+  }
+}
+
 // workgroups of the split: one 8-element chunk per thread (the kernel's loop is a grid-stride one, so any cap works; capping at
 // 8 192 workgroups -- three chunks per thread on 102 400-token tensors -- measured SLOWER: 162 vs 138 us per launch, profiles/r05)
 static inline int64_t h2_split_blocks(int64_t chunks) {
@@ -282,4 +324,26 @@ extern "C" int pxr_h2_bound_exp(const float* a_max, const float* b_colsum, float
   PXR_REQUIRE(a_max && b_colsum && exp_out && factor > 0.f, "pxr_h2_bound_exp: bad args");
   hipLaunchKernelGGL(h2_bound_exp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a_max, b_colsum, factor, exp_out);
   return pxr_check_launch("pxr_h2_bound_exp");
+}
+
+// exps / stats / bexp / run_max: persistent device arrays of n (<= 16) sites (run_max zero-initialised; decay: the per-step factor of the
+// decaying maximum the scales follow, 0 = the last step alone) (the caller seeds them once from an exact pass: pxr_h2_split_parts_f32
+// writes the same quantities; a site's exponent in use is exps[s], i.e. the headroom is already in it).  parts[s]: n_parts[s] partial
+// maxima of site s left by this step's producers; rows[s]: rows of the site's matrix; bound_b[s]: NULL or the address of the largest
+// column sum of |W| of the weight behind the site (Planes.stats + 1).
+extern "C" int pxr_h2_sites_update(int n, const float* const* parts, const int* n_parts, const int* rows, const float* const* bound_b,
+                                   float bound_factor, int headroom, float decay, float* run_max, int* exps, float* stats, int* bexp,
+                                   void* stream) {
+  PXR_REQUIRE(n >= 1 && n <= 16 && parts && n_parts && rows && bound_b && exps && stats && bexp && run_max && headroom >= 0 &&
+                  headroom <= 8 && bound_factor > 0.f && decay >= 0.f && decay <= 1.f,
+              "pxr_h2_sites_update: bad args (1..16 sites, headroom 0..8, decay in [0, 1])");
+  H2Sites m{};
+  m.n = n; m.headroom = headroom; m.bound_factor = bound_factor; m.exps = exps; m.stats = stats; m.bexp = bexp;
+  m.decay = decay; m.run_max = run_max;
+  for (int i = 0; i < n; ++i) {
+    PXR_REQUIRE(parts[i] && n_parts[i] >= 1 && n_parts[i] <= 1024 && rows[i] > 0, "pxr_h2_sites_update: site %d is bad", i);
+    m.parts[i] = parts[i]; m.n_parts[i] = n_parts[i]; m.rows[i] = rows[i]; m.bound_b[i] = bound_b[i];
+  }
+  hipLaunchKernelGGL(h2_sites_update_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, m);
+  return pxr_check_launch("pxr_h2_sites_update");
 }

@@ -273,6 +273,10 @@ struct LnBwdArgs {
   uint64_t seed;
   const int64_t* step_dev;
   P3Mat gp;             // optional: planes of the gradient the next GEMMs read (dx when it is written, else dz)
+  const int* gp_exp;    // null: three bf16 planes.  Else: two fp16 planes of gradient * 2^gp_exp[0] (a DEVICE exponent chosen before
+                        // this launch -- the previous step's statistics, pxr_h2_sites_update -- range-checked and saturated)
+  int dx_virtual;       // RESIDUAL with dropout, planes only: the site HAS a dx (the mask is applied) but its fp32 copy is not wanted
+  int32_t* status;
   float* stat;          // optional: stat[blk] = max of |that gradient| over workgroup blk's rows -- one plain store per workgroup
                         // (pxr_ln_bwd_partial_rows(rows) of them, nothing to zero); pxr_h2_split_parts_f32 reduces them.  (Round 4
                         // raised ONE word with an atomic per wave: 3 200 same-address atomics, 30 of the launch's 40 us at B = 64.)
@@ -281,7 +285,8 @@ struct LnBwdArgs {
   BprHead head;         // RESIDUAL only: dy is not read but formed from the loss head's backward (dy == null then)
 };
 
-template <int VEC, bool GATHER>
+// H2S: the planes are two fp16 planes under the device exponent a.gp_exp (stale scales), dx may be virtual (instantiated for D <= 1024)
+template <int VEC, bool GATHER, bool H2S = false>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
   if (a.step_dev) a.seed += (uint64_t)a.step_dev[0];
   __shared__ float red[3][2 * VEC * 256];  // waves 1..3 park their partial (dgamma | dbeta) here
@@ -301,6 +306,9 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
   const int r0 = blk * a.rows_per_block;
   const int r1 = min(a.rows, r0 + a.rows_per_block);
   float gmax = 0.f;        // max |gradient the next GEMMs read| over this thread's elements (a.stat)
+  const bool has_dx = a.dx != nullptr || (H2S && a.dx_virtual != 0);
+  float gsc = 1.0f;
+  if constexpr (H2S) gsc = ldexpf(1.0f, a.gp_exp[0]);
   for (int row = r0 + wave; row < r1; row += 4) {
     float4 g4[VEC], xh[VEC];
     float s1 = 0.f, s2 = 0.f;
@@ -370,9 +378,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
         z.z = rs * (g4[k].z - c1 - xh[k].z * c2); z.w = rs * (g4[k].w - c1 - xh[k].w * c2);
         *reinterpret_cast<float4*>(a.dz + (int64_t)row * D + c) = z;
         if constexpr (!GATHER) {
-          if (!a.dx) gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(z.x), fabsf(z.y)), fmaxf(fabsf(z.z), fabsf(z.w))));
-          if (a.gp.p && !a.dx) p3_store4(a.gp, row, c, z);
-          if (a.dx) {
+          if (!has_dx) gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(z.x), fabsf(z.y)), fmaxf(fabsf(z.z), fabsf(z.w))));
+          if (a.gp.p && !has_dx) {
+            if constexpr (H2S) px_store4_h2s(a.gp, a.status, row, c, z, gsc);
+            else p3_store4(a.gp, row, c, z);
+          }
+          if (has_dx) {
             float4 o = z;
             if (drop) {
               const uint64_t e = (uint64_t)row * D + c;
@@ -381,9 +392,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
               o.z = pxr_keep(a.seed, a.stream, e + 2, a.drop_thr) ? z.z * inv_keep : 0.f;
               o.w = pxr_keep(a.seed, a.stream, e + 3, a.drop_thr) ? z.w * inv_keep : 0.f;
             }
-            *reinterpret_cast<float4*>(a.dx + (int64_t)row * D + c) = o;
+            if (a.dx) *reinterpret_cast<float4*>(a.dx + (int64_t)row * D + c) = o;
             gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
-            if (a.gp.p) p3_store4(a.gp, row, c, o);
+            if (a.gp.p) {
+              if constexpr (H2S) px_store4_h2s(a.gp, a.status, row, c, o, gsc);
+              else p3_store4(a.gp, row, c, o);
+            }
           }
         }
       }
@@ -493,6 +507,20 @@ static int launch_ln_fwd(const LnFwdArgs& a_in, hipStream_t st) {
 
 template <bool GATHER>
 static int launch_ln_bwd(const LnBwdArgs& a, int nblk, hipStream_t st) {
+  if (a.gp_exp) {       // stale-scale fp16 planes: residual sites, D <= 1024
+    if constexpr (!GATHER) {
+      switch (ln_vec_for(a.D)) {
+        case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, false, true>), dim3(nblk), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, false, true>), dim3(nblk), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, false, true>), dim3(nblk), dim3(256), 0, st, a); break;
+        default: pxr_set_error("pxr_ln_bwd_h2s_f32: D=%d > 1024 unsupported", a.D); return PXR_ERR_BAD_ARG;
+      }
+      return pxr_check_launch("pxr_ln_bwd_h2s");
+    } else {
+      pxr_set_error("pxr_ln_bwd_h2s_f32: residual sites only");
+      return PXR_ERR_BAD_ARG;
+    }
+  }
   switch (ln_vec_for(a.D)) {
     case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, GATHER>), dim3(nblk), dim3(256), 0, st, a); break;
@@ -678,7 +706,7 @@ static int ln_bwd_impl(int gather_mode, const float* dy, const float* xhat, cons
                        float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
                        const int64_t* step_dev, void* ws, int64_t ws_bytes, void* g_planes, int64_t g_plane_stride,
                        int64_t g_panel_rows, float* stat, void* stream, const BprHead* head = nullptr, float* zero = nullptr,
-                       int zero_n = 0);
+                       int zero_n = 0, const int* g_exp = nullptr, int dx_virtual = 0);
 extern "C" int pxr_ln_bwd_planes_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd,
                                      const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
                                      float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ws,
@@ -714,11 +742,37 @@ extern "C" int pxr_bpr_ln_bwd_f32(const float* pos_score, const float* neg_score
   return ln_bwd_impl(0, nullptr, xhat, rstd, gamma, B * L, D, dz, dx, dgamma, dbeta, p_drop, seed, stream_id, step_dev, ws, ws_bytes,
                      g_planes, g_plane_stride, g_panel_rows, stat, stream, &h);
 }
+// A residual site's backward whose GEMM-facing gradient (dropout applied when p_drop > 0; no fp32 copy of it is written) leaves ONLY as
+// two fp16 planes of gradient * 2^g_exp_dev[0] -- an exponent that exists BEFORE the launch (the previous step's maximum of the same
+// gradient less PXR headroom binades: pxr_h2_sites_update) -- range-checked and saturated (PXR_STATUS_H2_STALE), together with this
+// step's partial maxima in stat[pxr_ln_bwd_partial_rows(rows)] for the next update.  pos_score != NULL: the loss head's backward is
+// fused in as in pxr_bpr_ln_bwd_f32 (dy unused).  Replaces pxr_ln_bwd_stat_f32 / pxr_bpr_ln_bwd_f32 + pxr_h2_split_parts_f32.
+extern "C" int pxr_ln_bwd_h2s_f32(const float* pos_score, const float* neg_score, const float* table, int64_t n_table, const int64_t* items,
+                                  const int64_t* masked_index, int B, int L, float grad_scale, const float* grad_scale_dev, float* coef,
+                                  const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int D, float* dz,
+                                  float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev,
+                                  void* ws, int64_t ws_bytes, void* g_planes, int64_t g_plane_stride, int64_t g_panel_rows,
+                                  const int* g_exp_dev, float* stat, float* zero, int zero_n, void* stream) {
+  PXR_REQUIRE(g_planes && g_exp_dev && stat, "pxr_ln_bwd_h2s_f32: planes, their device exponent and the statistics buffer are required");
+  BprHead h{};
+  if (pos_score) {
+    PXR_REQUIRE(neg_score && table && items && masked_index && coef && B > 0 && L > 0 && n_table > 0 && rows == B * L,
+                "pxr_ln_bwd_h2s_f32: null pointer / bad shape of the fused loss head");
+    h.table = table; h.items = items; h.mask = masked_index; h.pos = const_cast<float*>(pos_score); h.neg = const_cast<float*>(neg_score);
+    h.coef = coef; h.n_table = n_table; h.B = B; h.L = L; h.grad_scale = grad_scale; h.grad_scale_dev = grad_scale_dev;
+  }
+  return ln_bwd_impl(0, pos_score ? nullptr : dy, xhat, rstd, gamma, rows, D, dz, nullptr, dgamma, dbeta, p_drop, seed, stream_id, step_dev, ws,
+                     ws_bytes, g_planes, g_plane_stride, g_panel_rows, stat, stream, pos_score ? &h : nullptr, zero, zero_n, g_exp_dev,
+                     p_drop > 0.f ? 1 : 0);
+}
 static int ln_bwd_impl(int gather_mode, const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int D,
                        float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
                        const int64_t* step_dev, void* ws, int64_t ws_bytes, void* g_planes, int64_t g_plane_stride,
-                       int64_t g_panel_rows, float* stat, void* stream, const BprHead* head, float* zero, int zero_n) {
+                       int64_t g_panel_rows, float* stat, void* stream, const BprHead* head, float* zero, int zero_n, const int* g_exp,
+                       int dx_virtual) {
   PXR_REQUIRE((dy || head) && xhat && rstd && gamma && dz && ws, "pxr_ln_bwd_f32: null pointer");
+  PXR_REQUIRE(!g_exp || g_planes, "pxr_ln_bwd_h2s_f32: a plane exponent without planes");
+  PXR_REQUIRE(!dx_virtual || (g_planes && !dx && !gather_mode), "pxr_ln_bwd_h2s_f32: a planes-only dx needs planes (residual sites)");
   PXR_REQUIRE(zero_n >= 0 && zero_n <= 256 && (zero || zero_n == 0), "pxr_ln_bwd_f32: at most 256 floats to clear");
   PXR_REQUIRE(p3_mat_ok(g_planes, g_plane_stride, g_panel_rows, rows, D) && !(g_planes && gather_mode),
               "pxr_ln_bwd_planes_f32: bad planes (residual sites only)");
@@ -735,6 +789,7 @@ static int ln_bwd_impl(int gather_mode, const float* dy, const float* xhat, cons
   a.p_drop = p_drop; a.drop_thr = pxr_drop_threshold(p_drop); a.stream = stream_id; a.seed = seed;
   a.step_dev = step_dev;
   a.gp = P3Mat{reinterpret_cast<__bf16*>(g_planes), g_plane_stride, g_panel_rows};
+  a.gp_exp = g_exp; a.dx_virtual = dx_virtual; a.status = pxr_status_word();
   a.stat = stat;
   a.zero = zero; a.zero_n = zero_n;
   if (head) a.head = *head;

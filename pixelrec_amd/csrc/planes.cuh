@@ -124,6 +124,35 @@ __device__ __forceinline__ void px_store4(const P3Mat& m, int fmt, int32_t* stat
     p3_store4(m, r, c, v);
   }
 }
+// ---- h2 planes under a scale that was NOT derived from the values being stored (round 6: the previous step's maximum of the same
+// gradient with PXR_H2_STALE_HEADROOM binades of room, seqcore "stale scales"): v * scale is range-checked -- a value beyond the fp16
+// range raises PXR_STATUS_H2_STALE (a NaN PXR_STATUS_H2_RANGE as everywhere) -- and then SATURATED to +-65504, so that an outlier
+// step clips its largest gradient elements instead of writing inf into the planes (and NaN into the weights behind them).
+__device__ __forceinline__ float h2_sat(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+__device__ __forceinline__ void px_store4_h2s(const P3Mat& m, int32_t* status, int64_t r, int c, float4 v, float scale) {
+  v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+  const bool nan = (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+  const bool big = (fabsf(v.x) > 65504.f) | (fabsf(v.y) > 65504.f) | (fabsf(v.z) > 65504.f) | (fabsf(v.w) > 65504.f);
+  if ((nan | big) && status) atomicOr(status, nan ? PXR_STATUS_H2_RANGE : PXR_STATUS_H2_STALE);
+  if (big) v = make_float4(h2_sat(v.x), h2_sat(v.y), h2_sat(v.z), h2_sat(v.w));
+  h2_store4(m, r, c, v);
+}
+__device__ __forceinline__ void px_store8_h2s(const P3Mat& m, int32_t* status, int64_t r, int c, const float (&x)[8], float scale) {
+  float v[8];
+  bool nan = false, big = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] = x[e] * scale;
+    nan |= v[e] != v[e];
+    big |= fabsf(v[e]) > 65504.f;
+  }
+  if ((nan | big) && status) atomicOr(status, nan ? PXR_STATUS_H2_RANGE : PXR_STATUS_H2_STALE);
+  if (big) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = h2_sat(v[e]);
+  }
+  h2_store8(m, r, c, v);
+}
 // px_store4 with streaming (non-temporal) stores on request: for planes far larger than the L2 that their reader -- a GEMM launched
 // after this kernel has ended -- streams from HBM / MALL anyway (stream: wave-uniform)
 __device__ __forceinline__ void px_store4s(const P3Mat& m, int fmt, int32_t* status, int64_t r, int c, const float4& v, bool stream) {

@@ -33,6 +33,7 @@ int pxr_cu_count(void);          // api.cpp: compute units of the current device
 #define PXR_STATUS_ROWS_OVERFLOW 2   /* a rank's unique-row count exceeded the capacity of a reduced row exchange */
 #define PXR_STATUS_TOPK_UNDERFLOW 32 /* a user of the two-pass top-k ended with fewer than K candidates (non-finite scores / thresholds?) */
 #define PXR_STATUS_H2_RANGE 64       /* a producer of fp16 two-plane operands (planes.cuh "h2") met a value outside the fp16 range */
+#define PXR_STATUS_H2_STALE 128      /* h2 planes written under the previous step's scale: a value outgrew its headroom and was saturated */
 #define PXR_STATUS_SHARD_OVERFLOW 16 /* row-sharded table: more hit rows owned by ONE rank than the per-pair request capacity */
 
 static inline int pxr_check_launch(const char* what) {

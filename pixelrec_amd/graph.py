@@ -28,6 +28,8 @@ class GraphedTrainStep:
             self.model.split_catch_up = True             # sasrec.SASRec._forward_train: fork / join are graph edges here
         if hasattr(self.model, "trust_optimizer_planes"):
             self.model.trust_optimizer_planes = True     # the captured forward has no split launch (seqcore._weight_planes)
+        if hasattr(self.model, "h2_stale_scales"):
+            self.model.h2_stale_scales = True            # ... and its backward no gradient split launches (seqcore, ops.H2Sites)
         # the batch lives in ONE buffer (ids | mask): a caller that hands over two views of one packed tensor (bench.py,
         # the trainer's batcher) pays one copy per step instead of two
         n_i = items.numel()

@@ -129,6 +129,11 @@ _SIGNATURES = {
     "pxr_h2_bound_exp": (_I, [_P, _P, _F, _P, _P]),
     "pxr_ln_bwd_stat_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64, _P, _P, _I, _P]),
     "pxr_h2_split_parts_f32": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _P, _I, _P, _P, _P, _F, _P, _P]),
+    "pxr_ln_bwd_h2s_f32": (_I, [_P, _P, _P, _I64, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _F, _U64, _U32, _P, _P,
+                                _I64, _P, _I64, _I64, _P, _P, _P, _I, _P]),
+    "pxr_attn_bwd_h2s_f32": (_I, [_P, _I64, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _F, _U64, _U32, _P, _P, _I64, _I64, _I, _I, _I, _I, _P,
+                                  _P, _P]),
+    "pxr_h2_sites_update": (_I, [_I, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P]),
     "pxr_attn_bwd_stat_f32": (_I, [_P, _I64, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _P, _I64, _F, _U64, _U32, _P, _P, _P]),
     "pxr_ln_residual_fwd_h2_f32": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64, _I64, _P]),
     "pxr_input_ln_fwd_h2_f32": (_I, [_P, _I64, _P, _I64, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64, _I64, _P]),

@@ -151,6 +151,11 @@ def raise_on_bad_indices(device=None):
                            "tokens): an activation, a gradient or a scaled weight was NaN or left the fp16 range (|x| > 65504) "
                            "-- the affected outputs are inf / nan; set PXR_TOWER_H2=0 and / or PXR_SEQ_H2=0 (the six-product "
                            "bf16x3 GEMMs have fp32's range)")
+    if v & 128:
+        raise H2StaleOverflow("fp16 two-plane gradients under the recent steps' scale (PXR_SEQ_H2_STALE): a gradient exceeded the "
+                              f"decaying maximum of the last steps more than 2^{H2_STALE_HEADROOM + 2}-fold; its largest elements were "
+                              "saturated in that step (no inf / nan was written).  The Trainer goes on with per-step exact scales "
+                              "(PXR_SEQ_H2_STALE=0: six more launches per step)")
     if v & 16:
         raise RuntimeError("row-sharded table: one rank owned more of a batch's hit rows than the per-pair request capacity "
                            "(ShardedSASRec.pair_slack); rows were dropped -- raise the slack or use row_exchange='reduce_scatter'")
@@ -687,6 +692,101 @@ def split_h2_parts(x: torch.Tensor, parts: torch.Tensor, n_parts: int, bound_wit
     if bound_with is not None:
         o.pre_bound = (bound_with[0].stats.data_ptr(), float(factor), bexp)
     return o
+
+
+H2_STALE_HEADROOM = 3      # binades between the recent maximum and its placement in the planes (csrc/h2.hip "stale scales")
+H2_STALE_DECAY = 0.99      # per-step decay of the running maximum the scales follow (half-life 69 steps)
+
+
+class H2StaleOverflow(RuntimeError):
+    """PXR_STATUS_H2_STALE: a gradient outgrew the headroom of its stale scale and was saturated in one step."""
+
+
+class H2Sites:
+    """Persistent scale state of the gradients a backward pass hands to its GEMMs as h2 planes ("sites": per layer the LayerNorm-2
+    backward's output, the LayerNorm-1 backward's output, dqkv).  exps[s] is the exponent site s's producer uses in the NEXT step,
+    stats[s] = (max, rows * max) with the headroom applied, bexp[s] the exponent of the planes a GEMM epilogue writes from site s and
+    its weight (du).  `update()` -- one launch after the last consumer of a step -- derives all of it from the step's partial maxima
+    (pxr_h2_sites_update).  seeded_for: the batch geometry the state was derived from (a different one re-seeds through an exact pass)."""
+
+    def __init__(self, n: int, device):
+        assert 1 <= n <= 16
+        self.n = n
+        self.exps = torch.zeros(n, dtype=torch.int32, device=device)
+        self.stats = torch.zeros(n, 2, dtype=torch.float32, device=device)
+        self.bexp = torch.zeros(n, dtype=torch.int32, device=device)
+        self.run_max = torch.zeros(n, dtype=torch.float32, device=device)
+        self.seeded_for = None
+
+    def planes_like(self, s: int, rows: int, cols: int, bound_with=None) -> Planes:
+        """Fresh h2 Planes [rows, cols] whose exponent / statistics are site s's (views of the persistent arrays)."""
+        o = Planes.alloc(rows, cols, self.exps.device, fmt=1)
+        o.exp_dev, o.stats = self.exps[s:s + 1], self.stats[s]
+        if bound_with is not None:
+            o.pre_bound = (bound_with[0].stats.data_ptr(), float(bound_with[1]), self.bexp[s:s + 1])
+        return o
+
+    def update(self, parts, n_parts, rows, bound_b, bound_factor: float):
+        """parts[s]: tensor holding site s's partial maxima (first n_parts[s] words); bound_b[s]: None or the weight Planes whose
+        column-sum statistic bounds the GEMM output written from site s."""
+        n = self.n
+        assert len(parts) == len(n_parts) == len(rows) == len(bound_b) == n
+        P, I = ctypes.c_void_p * n, ctypes.c_int * n
+        bb = [(w.stats.data_ptr() + 4) if w is not None else None for w in bound_b]
+        _l.check(_l.load().pxr_h2_sites_update(n, P(*[t.data_ptr() for t in parts]), I(*[int(x) for x in n_parts]), I(*[int(r) for r in rows]),
+                                               P(*bb), float(bound_factor), H2_STALE_HEADROOM, H2_STALE_DECAY, _l.ptr(self.run_max),
+                                               _l.ptr(self.exps), _l.ptr(self.stats), _l.ptr(self.bexp), _l.stream_ptr()),
+                 "pxr_h2_sites_update")
+
+
+def ln_bwd_h2s(dy, xhat, rstd, gamma, dgamma, dbeta, sites: H2Sites, site: int, stat: torch.Tensor, p_drop=0.0, seed=0, stream_id=0,
+               step_dev=None, defer=None, zero: torch.Tensor | None = None, bound_with=None, head=None):
+    """A residual LayerNorm site's backward whose GEMM-facing gradient leaves ONLY as h2 planes under the site's stale scale
+    (pxr_ln_bwd_h2s_f32), + this step's partial maxima in `stat`.  head = (pos, neg, table, items, masked_index, grad_scale,
+    grad_scale_dev): the loss head's backward fused in (dy unused).  -> (dz, Planes, coef | None)."""
+    Lb = _l.load()
+    D = xhat.shape[-1]
+    rows = xhat.numel() // D
+    dz = torch.empty_like(xhat)
+    ws_bytes = int(Lb.pxr_ln_bwd_ws_bytes(rows, D))
+    if defer is not None:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xhat.device)   # must outlive this call
+        defer.add(ws, int(Lb.pxr_ln_bwd_partial_rows(rows)), 2 * D, dgamma, dbeta, D)
+        dgamma = dbeta = None
+    else:
+        ws = _ws.get(ws_bytes, xhat.device)
+    assert stat.numel() >= ln_bwd_stat_parts(rows) and (zero is None or zero.numel() <= 256)
+    device_status(xhat.device)
+    gp = sites.planes_like(site, rows, D, bound_with=bound_with)
+    coef = None
+    if head is not None:
+        pos, neg, table, items, masked_index, grad_scale, grad_scale_dev = head
+        B, L = pos.shape
+        coef = torch.empty(B, L, dtype=torch.float32, device=pos.device)
+        hargs = (_l.ptr(pos), _l.ptr(neg), _l.ptr(table), table.shape[0], _l.ptr(items), _l.ptr(masked_index), B, L, float(grad_scale),
+                 _l.ptr(grad_scale_dev), _l.ptr(coef))
+    else:
+        hargs = (None, None, None, 0, None, None, 0, 0, 1.0, None, None)
+    _l.check(Lb.pxr_ln_bwd_h2s_f32(*hargs, _l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), rows, D, _l.ptr(dz), _l.ptr(dgamma),
+                                   _l.ptr(dbeta), p_drop, seed, stream_id, _l.ptr(step_dev), _l.ptr(ws), ws_bytes, *_pl(gp),
+                                   _l.ptr(gp.exp_dev), _l.ptr(stat), _l.ptr(zero), zero.numel() if zero is not None else 0,
+                                   _l.stream_ptr()), "pxr_ln_bwd_h2s_f32")
+    return dz, gp, coef
+
+
+def attn_bwd_h2s(dctx, qkv, probs, B, H, L, d, sites: H2Sites, site: int, stat: torch.Tensor, p_drop=0.0, seed=0, stream_id=0,
+                 step_dev=None) -> Planes:
+    """dqkv ONLY as h2 Planes [B*L, 3*H*d] under the site's stale scale (pxr_attn_bwd_h2s_f32); `stat`: ATTN_STAT_SLOTS zeroed words."""
+    D = H * d
+    assert attn_planes_supported(L, d) and (3 * D) % 32 == 0 and stat.numel() >= ATTN_STAT_SLOTS
+    _req(dctx, torch.float32, "dctx"); _req(qkv, torch.float32, "qkv"); _req(probs, torch.float32, "probs")
+    device_status(qkv.device)
+    gp = sites.planes_like(site, B * L, 3 * D)
+    cp, base = _l.c_void_p, qkv.data_ptr()
+    _l.check(_l.load().pxr_attn_bwd_h2s_f32(_l.ptr(dctx), D, cp(base), cp(base + 4 * D), cp(base + 8 * D), 3 * D, _l.ptr(probs), B, H, L, d,
+                                            p_drop, seed, stream_id, _l.ptr(step_dev), *_pl(gp), 3 * D, 0, D, 2 * D, _l.ptr(gp.exp_dev),
+                                            _l.ptr(stat), _l.stream_ptr()), "pxr_attn_bwd_h2s_f32")
+    return gp
 
 
 def h2_bound_exp(dy: Planes, W: Planes, factor: float = 1.0) -> torch.Tensor:

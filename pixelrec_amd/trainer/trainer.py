@@ -126,6 +126,8 @@ class Trainer:
             model.module.defer_weight_grad_join = True
             if hasattr(model.module, "trust_optimizer_planes"):
                 model.module.trust_optimizer_planes = True   # only the optimizer / load_state_dict touch the weights here
+            if hasattr(model.module, "h2_stale_scales"):
+                model.module.h2_stale_scales = True          # consecutive training steps: gradient planes under the previous step's scales
         if type(self.optimizer).__name__ == "FragmentAdamW":     # decay_check_name: host scalars per tensor, no plane upkeep
             self.use_graph = False
             if hasattr(model.module, "trust_optimizer_planes"):
@@ -188,7 +190,10 @@ class Trainer:
                                                    lookahead=lookahead)
                 if self._gstep is not None and self._gstep.matches(data[0], data[1]):
                     # the replay adds its loss to self._graph_loss on the device
-                    self._gstep(data[0], data[1], next_items=next_items)
+                    try:
+                        self._gstep(data[0], data[1], next_items=next_items)
+                    except ops.H2StaleOverflow as e:      # raised by the status poll AFTER the replay: the step itself has run
+                        self._h2_stale_fallback(e)
                     continue
             self.optimizer.zero_grad()
             if self.use_modality:   # assemble the image batch on the device from the HBM-resident store
@@ -203,15 +208,30 @@ class Trainer:
                 self.model.sync_gradients(defer_flat=True)    # the consumers below wait for it
             if self.clip_grad_norm:                                   # trainer.py:123-124
                 clip_grad_norm_(self.model, **self.clip_grad_norm)
-            self.optimizer.step()
+            try:
+                self.optimizer.step()
+            except ops.H2StaleOverflow as e:              # (the optimizer's housekeeping polls the status word; the step has run)
+                self._h2_stale_fallback(e)
             total = total + losses.detach()
         if self._gstep is not None:
             total = total + self._graph_loss
             self._graph_loss.zero_()
         total_loss = float(total.item())          # the only host sync of the epoch
-        ops.raise_on_bad_indices(self.device)     # ... and where an out-of-catalogue item id surfaces (IndexError)
+        try:
+            ops.raise_on_bad_indices(self.device)     # ... and where an out-of-catalogue item id surfaces (IndexError)
+        except ops.H2StaleOverflow as e:
+            self._h2_stale_fallback(e)
         self._check_nan(total_loss)
         return total_loss
+
+    def _h2_stale_fallback(self, err):
+        """A gradient outgrew the headroom of its stale h2 scale in ONE step (its largest elements were saturated there, nothing
+        non-finite was written): say so and go on with per-step exact scales -- the captured step is dropped and re-captured."""
+        m = self.model.module
+        if getattr(m, "h2_stale_scales", False):
+            m.h2_stale_scales = False
+            self._gstep = None
+            self.logger.warning("%s -- continuing with exact per-step scales", err)
 
     def _check_nan(self, loss):
         if np.isnan(loss):

@@ -138,7 +138,7 @@ def test_isa_gate_no_kernel_spills_outside_the_listed_budgets():
                 r"gemm_p3_kernel<pxr::P3Cfg<64, 64, 2, 2, 3, true>, false, 4, false>", r"gemm_p3_kernel<pxr::P3Cfg<128, 64, 2, 2, 2, true>, false, 6, false>",
                 r"attn_fwd_mfma1_kernel<8>", r"attn_bwd_mfma1_kernel<8>", r"ln_fwd_kernel<2, true, 1, false>", r"ln_fwd_kernel<2, false, 1, false>", r"ln_fwd_kernel<2, true, 1, true>",
                 r"ln_fwd_kernel<2, false, 1, true>", r"ln_fwd_kernel<4, false, 1, true>",
-                r"ln_bwd_kernel<2, false>", r"ln_bwd_kernel<2, true>", r"adamw_rows_kernel<256, 2>", r"adamw_flat_tab_kernel<true>",
+                r"ln_bwd_kernel<2, false, false>", r"ln_bwd_kernel<2, true, false>", r"ln_bwd_kernel<2, false, true>", r"adamw_rows_kernel<256, 2>", r"adamw_flat_tab_kernel<true>",
                 r"segsum_kernel<1>", r"fused_pass_kernel<1>", r"h2_split_auto_kernel", r"score_thresh_fast_kernel<2, 4>", r"topk_rescore_kernel"):
         hits = [n for n in res if re.search(re.escape(hot), n)]
         assert hits, hot
