@@ -483,10 +483,12 @@ static int launch_ln_fwd(const LnFwdArgs& a_in, hipStream_t st) {
   // planes through LDS (whole-line stores) once the launch streams to HBM: from PXR_LN_STAGE_ROWS rows when set, else from 96 MB
   // of fp32 y (measured at D = 512: 102 400 rows 234 -> 192 us with two fp16 planes, 281 -> 213 with three bf16 ones; at 25 600
   // rows, where the outputs still fit the 256 MB MALL, half lines cost nothing and the extra barrier does: 42 -> 50 us);
-  // D a multiple of 32 in 256 .. 1024
+  // D a multiple of 32 in 256 .. 512 (PXR_LN_STAGE_ROWS set: up to 1024)
   static const int stage_rows = getenv("PXR_LN_STAGE_ROWS") ? atoi(getenv("PXR_LN_STAGE_ROWS")) : -1;
   const bool stage = stage_rows >= 0 ? a.rows >= stage_rows : (int64_t)a.rows * a.D * 4 >= (96ll << 20);
-  if (a.yp.p && stage && a.D % 32 == 0 && a.D <= 1024 && a.D >= 256) {
+  // (D <= 512: at D = 768 -- the image tower, 69 344 rows -- the staged launch measured 104 us against 99.5: 30 KB of LDS per
+  // workgroup there, and three quarters of a row's segments already share lines with their neighbours' in time)
+  if (a.yp.p && stage && a.D % 32 == 0 && a.D <= (stage_rows >= 0 ? 1024 : 512) && a.D >= 256) {
     switch (ln_vec_for(a.D)) {
       case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, GATHER, 1, true>), dim3(blocks), dim3(256), 0, st, a); break;
       case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, GATHER, 1, true>), dim3(blocks), dim3(256), 0, st, a); break;

@@ -48,6 +48,11 @@ driver)
   tail -n 1 "$OUT/bench_driver.json" | wc -c; tail -n 1 "$OUT/bench_driver.json" ;;
 eval)
   timeout 400 python tools/eval_bench.py > "$OUT/eval_bench.log" 2>&1; tail -20 "$OUT/eval_bench.log" ;;
+evalprof)
+  P=$OUT/prof_eval; mkdir -p "$P"
+  ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$P" -o eval -- python $REPO/tools/eval_bench.py > "$P/stdout.log" 2>&1 )
+  rm -f "$P/eval_kernel_trace.csv"; find "$P" -name "*.db" -delete
+  head -14 "$P/eval_kernel_stats.csv" | cut -c1-200 ;;
 pixel)
   timeout 400 python bench.py --model pixelnet --no-cpu-baseline > "$OUT/bench_pixelnet_b16.json" 2> "$OUT/bench_pixelnet_b16.err"; cut -c1-600 "$OUT/bench_pixelnet_b16.json"; tail -3 "$OUT/bench_pixelnet_b16.err" ;;
 prof)
@@ -95,6 +100,27 @@ gln)
 import json,sys
 for l in open(sys.argv[1]):
     d=json.loads(l); print("nt",d["nt"],"B",d["B"],d["ids"],d["planes"],"p",d.get("p_drop"),"xhat",d.get("xhat"),round(d["us"],1),"us",round(d["GBps"]),"GB/s",round(d["frac_of_8TBps"],3))
+P
+  ;;
+pmcsq)
+  # SQ / MFMA / LDS counters of the B = 64 step's kernels (the small h2 tiles that dominate it): three passes of 8 SQ counters
+  Q=$OUT/pmcsq; mkdir -p "$Q"
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
+             "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES" \
+             "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_UNALIGNED_STALL SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"; do
+    i=$((i+1))
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$Q" -o p$i -- python $REPO/bench.py --steps 10 --warmup 2 --age-steps 20 --no-cpu-baseline --no-extras --no-gemm-events --no-graph > "$Q/p${i}_stdout.log" 2>&1 )
+  done
+  find "$Q" -name "*.db" -delete
+  python $REPO/tools/pmc_summarise.py "$OUT/sq_counters_b64_summary.json" $(find "$Q" -name "*counter_collection.csv") > /dev/null 2>&1
+  rm -rf "$Q"
+  python - "$OUT/sq_counters_b64_summary.json" <<'P'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items(), key=lambda kv:-kv[1].get("avg_us_under_pmc",0)*kv[1].get("launches",0))[:14]:
+    cyc=v.get("GRBM_GUI_ACTIVE",0)/8; simd=cyc*1024
+    print(f"{k[:72]:72s} us {v['avg_us_under_pmc']:7.1f} n {v['launches']:4d} mfma_busy {v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/simd if simd else 0:5.3f} wait_any/wave {v.get('SQ_WAIT_ANY',0)/max(v.get('SQ_WAVE_CYCLES',1),1):5.3f} lds_conf/lds_active {v.get('SQ_LDS_BANK_CONFLICT',0)/max(v.get('SQ_LDS_IDX_ACTIVE',1),1):5.3f}")
 P
   ;;
 pmcp4)
