@@ -47,3 +47,38 @@ def test_fragment_groups_and_checkpoint_layout_follow_torch_adamw():
     for a, b in zip(mine["param_groups"], theirs["param_groups"]):
         assert (a["lr"], a["weight_decay"], tuple(a["betas"]), a["eps"]) == (b["lr"], b["weight_decay"], tuple(b["betas"]), b["eps"])
     assert opt.groups() == (["module.LayerNorm.weight", "module.LayerNorm.bias"], ["module.dense.weight", "module.dense.bias"])
+
+
+def test_trainer_falls_back_to_exact_scales_when_a_stale_scale_overflows():
+    """ops.H2StaleOverflow (status bit 128) is not fatal for a training run: the Trainer says so, turns the stale scales off and drops
+    its captured step (the next full batch re-captures on exact per-step scales)."""
+    import logging
+
+    from pixelrec_amd import ops
+    from pixelrec_amd.trainer.trainer import Trainer
+
+    class Inner(torch.nn.Module):
+        h2_stale_scales = True
+
+    class Wrapped(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.module = Inner()
+
+    t = Trainer.__new__(Trainer)
+    t.model, t._gstep = Wrapped(), object()
+    records = []
+
+    class H(logging.Handler):
+        def emit(self, r):
+            records.append(r.getMessage())
+
+    t.logger = logging.getLogger("pxr-test-stale")
+    t.logger.addHandler(H())
+    t._h2_stale_fallback(ops.H2StaleOverflow("a gradient exceeded its headroom"))
+    assert t.model.module.h2_stale_scales is False and t._gstep is None
+    assert records and "exact per-step scales" in records[0]
+    t._gstep = "kept"
+    t._h2_stale_fallback(ops.H2StaleOverflow("again"))          # already off: nothing to do, nothing dropped
+    assert t._gstep == "kept" and len(records) == 1
+    assert issubclass(ops.H2StaleOverflow, RuntimeError)
