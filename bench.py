@@ -237,7 +237,7 @@ def compact_line(out):
     bench.py measures beside that (throughput batches, PixelNet, scoring / gather / AdamW rooflines, spreads, notes) is written to
     the side file named in `extras`.  Always < LINE_LIMIT bytes: optional members are dropped, in a fixed order, until it fits."""
     keep = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "dist_backend", "steps", "warmup", "ms_per_step", "higher_is_better",
-            "scaling", "vs_baseline", "dtype", "operands", "data", "final_loss", "host_enqueue_ms_per_step", "images_per_s")
+            "scaling", "vs_baseline", "dtype", "operands", "data", "final_loss", "host_enqueue_ms_per_step", "h2_stale_overflows", "images_per_s")
     line = {k: _num(out[k], 8) for k in keep if k in out}
     cfg = dict(out.get("config", {}))
     if isinstance(cfg.get("workload"), str) and len(cfg["workload"]) > 200:
@@ -384,9 +384,12 @@ def pixelnet_run(args, steps, warmup, init_dist=True, n_inst=3):
             torch.cuda.synchronize()
 
     def step(i):
-        if gstep is not None:
-            return gstep(*pool[i % 2])
-        return eager_step(i)
+        try:
+            if gstep is not None:
+                return gstep(*pool[i % 2])
+            return eager_step(i)
+        except ops.H2StaleOverflow:        # (see main(): the step has run; a rank must not leave the others in a collective)
+            return gstep.loss if gstep is not None else torch.zeros((), device=dev)
 
     for i in range(2 if gstep is not None else 0):
         step(i)
@@ -657,11 +660,20 @@ def main():
         state.opt.step()
         return loss
 
+    stale_overflows = [0]
+
     def step(i=None, record=False):
         b = next_batch()
-        if gstep is not None:
-            return gstep(*b, next_items=peek_items())
-        return eager_step(b, peek_items())
+        try:
+            if gstep is not None:
+                return gstep(*b, next_items=peek_items())
+            return eager_step(b, peek_items())
+        except ops.H2StaleOverflow:
+            # raised by the status poll AFTER a step in which a gradient outgrew the headroom of its stale h2 scale (saturated there,
+            # nothing non-finite written; model/seqcore.py): counted and reported in the line (`h2_stale_overflows`), the run goes on --
+            # in a multi-rank job a rank that stopped here would leave the others hanging in the next collective
+            stale_overflows[0] += 1
+            return gstep.loss if gstep is not None else torch.zeros((), device=dev)
 
     def step_e():
         b = next_batch()
@@ -959,7 +971,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": world * B, "seq_len": L, "n_items": N, "embedding_size": D,
                    "parallelism": f"dp{world}" + ("+row-sharded-table" if args.table_sharding else ""),
                    "hip_graph": bool(use_graph), **({"hip_graph_error": graph_err} if graph_err else {})},
-        "final_loss": final_loss, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
+        "final_loss": final_loss, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3, "h2_stale_overflows": stale_overflows[0],
         "spread": {"blocks": len(block_ms), "steps_per_block": args.steps, "ms_per_step": block_ms,
                    "median_ms_per_step": sorted(block_ms)[len(block_ms) // 2], "min_ms_per_step": min(block_ms),
                    "max_ms_per_step": max(block_ms),

@@ -130,7 +130,7 @@ class SeqRecCore(BaseModel):
         # the feature sizes to be multiples of 32; PXR_PLANES=0 turns it off.
         self.use_planes = os.environ.get("PXR_PLANES", "1") != "0"
         self._wplanes = None
-        self.register_load_state_dict_post_hook(lambda mod, _keys: mod.refresh_weight_planes())
+        self.register_load_state_dict_post_hook(lambda mod, _keys: mod._after_weights_loaded())
 
     def _init_weights(self, module):
         """N(0, initializer_range) for every Linear/Embedding weight; LayerNorm (1, 0); biases 0 (sasrec.py:51-61)."""
@@ -392,6 +392,14 @@ class SeqRecCore(BaseModel):
                 return None
             self._h2_sites = ops.H2Sites(3 * self.n_layers, device)
         return self._h2_sites
+
+    def _after_weights_loaded(self):
+        """load_state_dict post hook: new weights mean new gradient magnitudes -- the stale gradient scales are re-seeded by an exact
+        pass (a captured step that baked them in must be re-captured by its owner, as after any load) -- and the planes are re-split."""
+        if self._h2_sites is not None:
+            self._h2_sites.seeded_for = None
+            self._h2_sites.run_max.zero_()
+        self.refresh_weight_planes()
 
     def refresh_weight_planes(self):
         """Re-split now (after anything but the optimizer rewrote the weights: load_state_dict, a parameter broadcast, a

@@ -16,7 +16,7 @@ with torch.device("cuda"):
     m = SASRec(bench.model_config(0.1), DL())
 m.train(); m.h2_stale_scales = True; m.trust_optimizer_planes = True
 opt = PxrAdamW(m, lr=1e-4, weight_decay=0.1)
-rng = np.random.default_rng(2020); zipf = synth.ZipfItems(N, seed=2020)
+rng = np.random.default_rng(int(os.environ.get("WATCH_SEED", "2020"))); zipf = synth.ZipfItems(N, seed=2020)
 orig = ops.H2Sites.update
 log = []
 def upd(self, parts, n_parts, rows, bound_b, f):
