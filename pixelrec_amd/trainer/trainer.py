@@ -231,6 +231,10 @@ class Trainer:
         if getattr(m, "h2_stale_scales", False):
             m.h2_stale_scales = False
             self._gstep = None
+            if self.world > 1:
+                # a re-capture runs a dry step WITH its collectives, which the other ranks would not match: this rank issues its steps
+                # eagerly from here on (the same collectives in the same order as a replaying rank's)
+                self.use_graph = False
             self.logger.warning("%s -- continuing with exact per-step scales", err)
 
     def _check_nan(self, loss):

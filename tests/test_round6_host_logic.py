@@ -66,7 +66,7 @@ def test_trainer_falls_back_to_exact_scales_when_a_stale_scale_overflows():
             self.module = Inner()
 
     t = Trainer.__new__(Trainer)
-    t.model, t._gstep = Wrapped(), object()
+    t.model, t._gstep, t.world, t.use_graph = Wrapped(), object(), 1, True
     records = []
 
     class H(logging.Handler):
@@ -76,7 +76,11 @@ def test_trainer_falls_back_to_exact_scales_when_a_stale_scale_overflows():
     t.logger = logging.getLogger("pxr-test-stale")
     t.logger.addHandler(H())
     t._h2_stale_fallback(ops.H2StaleOverflow("a gradient exceeded its headroom"))
-    assert t.model.module.h2_stale_scales is False and t._gstep is None
+    assert t.model.module.h2_stale_scales is False and t._gstep is None and t.use_graph is True
+    t.model.module.h2_stale_scales, t.world = True, 4        # data parallel: no re-capture (its dry step would issue unmatched collectives)
+    t._h2_stale_fallback(ops.H2StaleOverflow("on one rank of four"))
+    assert t.use_graph is False and len(records) == 2
+    records.pop()
     assert records and "exact per-step scales" in records[0]
     t._gstep = "kept"
     t._h2_stale_fallback(ops.H2StaleOverflow("again"))          # already off: nothing to do, nothing dropped
