@@ -124,8 +124,18 @@ def run(ctx, out):
                 by = Bt * L * D * (4.0 * 3 + 4.0)
                 alone.append({"batch_per_gpu": Bt, "avg_kernel_us": t_l * 1e6, "achieved": by / t_l / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": by / t_l / 1e9 / HBM_PEAK_GBS})
+            # HBM / fabric bytes per launch by FETCH_SIZE / WRITE_SIZE passes of the same launches (committed file, NOT measured here)
+            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06", "pmc", "gather_traffic_summary.json")
+            if os.path.exists(tf) and not custom:
+                import json as _json
+                tr = _json.load(open(tf))
+                for e_ in alone:
+                    grid = (e_["batch_per_gpu"] * L + 3) // 4 * 256
+                    hit = [v for k, v in tr.items() if "ln_fwd_kernel" in k and k.endswith(f"grid {grid}")]
+                    e_["traffic"] = hit[0]["hbm_bytes_per_launch"] if hit else None
+                    e_["algorithmic_bytes"] = e_["batch_per_gpu"] * L * D * 16.0
             out["roofline_gather_fused_alone"] = {"bound": "hbm", "kernel": "ln_fwd_kernel<GATHER> (h2 planes; Zipf ids of the bench stream)",
-                                                  "batches": alone,
+                                                  "batches": alone, "traffic_source": "profiles/r06/pmc/gather_traffic_summary.json",
                                                   "note": "bytes = B*L table rows read + y + xhat (fp32) + two fp16 planes of y written; at B = 512 "
                                                           "the 157 MB of outputs fit the 256 MB MALL, at B = 2048 (630 MB) they stream to HBM"}
         # (2) full-catalog scoring GEMM [1024,512] x [512,400001] on the fp32 MFMA

@@ -123,6 +123,47 @@ for k,v in sorted(d.items(), key=lambda kv:-kv[1].get("avg_us_under_pmc",0)*kv[1
     print(f"{k[:72]:72s} us {v['avg_us_under_pmc']:7.1f} n {v['launches']:4d} mfma_busy {v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/simd if simd else 0:5.3f} wait_any/wave {v.get('SQ_WAIT_ANY',0)/max(v.get('SQ_WAVE_CYCLES',1),1):5.3f} lds_conf/lds_active {v.get('SQ_LDS_BANK_CONFLICT',0)/max(v.get('SQ_LDS_IDX_ACTIVE',1),1):5.3f}")
 P
   ;;
+pmcgather)
+  # HBM / fabric traffic of the gather as the step runs it (ln_fwd_kernel<GATHER>) and of the standalone gather, by FETCH_SIZE / WRITE_SIZE
+  Q=$OUT/pmcgather; mkdir -p "$Q"
+  cat > /tmp/gather_one.py <<'PY'
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from pixelrec_amd import ops, synth
+dev = "cuda"; N, D, L = 400_001, 512, 50
+table = torch.randn(N, D, device=dev) * 0.02; pos = torch.randn(L, D, device=dev) * 0.02
+g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+zipf = synth.ZipfItems(N, seed=2020); rng = np.random.default_rng(0)
+for B in (512, 2048):
+    idx = torch.from_numpy(synth.train_batch(N, B, L, rng, zipf)[0][:, 0, :L].copy()).to(dev)
+    for _ in range(4): ops.input_ln_fwd(table, idx, L, B, L, pos, g, b, 1e-12, 0.1, 12345, 0, save=True, planes="h2")
+ids = torch.randint(1, N, (2048 * 102,), device=dev)
+for _ in range(4): ops.embed_gather(table, ids)
+torch.cuda.synchronize()
+PY
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$Q" -o $c -- python /tmp/gather_one.py > "$Q/${c}_stdout.log" 2>&1 )
+  done
+  find "$Q" -name "*.db" -delete
+  python - "$OUT/gather_traffic_summary.json" $(ls "$Q"/*counter_collection.csv) <<'P'
+import csv, json, sys
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for f in sys.argv[2:]:
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "ln_fwd_kernel" in k or "embed_gather" in k:
+            acc[(k.split("(")[0].replace("void ", ""), int(r["Grid_Size"]) if "Grid_Size" in r else 0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for (k, grid), cs in acc.items():
+    f, w = (sum(cs.get("FETCH_SIZE", [0])) / max(len(cs.get("FETCH_SIZE", [1])), 1)), (sum(cs.get("WRITE_SIZE", [0])) / max(len(cs.get("WRITE_SIZE", [1])), 1))
+    out[f"{k} grid {grid}"] = {"fetch_kb": f, "write_kb": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+                               "note": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)"}
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+for k, v in out.items(): print(k[:90], round(v["hbm_bytes_per_launch"] / 1e6, 1), "MB")
+P
+  rm -rf "$Q" ;;
 pmcp4)
   timeout 1200 bash tools/pmc_p4.sh $NAME/pmc_p4 > "$OUT/pmc_p4.log" 2>&1; tail -n 30 "$OUT/pmc_p4.log" ;;
 ab:*)
