@@ -174,6 +174,10 @@ struct RowsArgs {
   // step to step (see adamw_rows_kernel) -- 8 VALU issue slots per element-step instead of 14
   int fast; float sqrt_b2, log2_b2;
   int window;                // replayed steps per row before the closed form takes over (PXR_LAZY_EXACT; PXR_LAZY_WINDOW: a measuring knob)
+  // series replay (fast mode, round 6; see adamw_rows_kernel): a gap of >= series_min steps is summed in closed form -- the lanes of a
+  // wave share out the STEPS of the gap (six moments of the per-step scalars, wave-reduced), every element then takes one polynomial
+  int series, series_min; float log2_sb;
+  double log2_b1;            // log2 of the factor the exact step multiplies m by: 1 - float(1 - beta1), not float(beta1)
 };
 
 // One row is spread over LPR = ceil(D/EPL / 64) * 64 lanes (EPL = 2 or 4 elements per lane), so a row with a long gap is
@@ -183,16 +187,35 @@ struct RowsArgs {
 // workgroup (block = max(256, LPR) threads = RPB rows): last[row] is read by every wave of the row at the top and
 // written by one lane after a barrier.  The replayed step number is wave-uniform (readfirstlane), so the per-step
 // scalars come through the scalar cache, four steps per request.
-template <int EPL> struct RowVec;
-template <> struct RowVec<2> { typedef float2 T; };
-template <> struct RowVec<4> { typedef float4 T; };
+// EPL consecutive floats of a row (EPL = 2: one 8-byte access, 4 / 8: one / two 16-byte accesses; the offsets are multiples of EPL)
+template <int EPL>
+__device__ __forceinline__ void row_ld(const float* __restrict__ src, float (&d)[EPL]) {
+  if constexpr (EPL == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(src);
+    d[0] = t.x; d[1] = t.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < EPL / 4; ++q) {
+      const float4 t = reinterpret_cast<const float4*>(src)[q];
+      d[4 * q] = t.x; d[4 * q + 1] = t.y; d[4 * q + 2] = t.z; d[4 * q + 3] = t.w;
+    }
+  }
+}
+template <int EPL>
+__device__ __forceinline__ void row_st(float* __restrict__ dst, const float (&d)[EPL]) {
+  if constexpr (EPL == 2) {
+    *reinterpret_cast<float2*>(dst) = make_float2(d[0], d[1]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < EPL / 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+  }
+}
 
 template <int LPR, int EPL>
 __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(RowsArgs a,
                                                                                const float4* __restrict__ hyper) {
   constexpr int NT = LPR > 256 ? LPR : 256;
   constexpr int RPB = NT / LPR;
-  typedef typename RowVec<EPL>::T V;
   if (a.step_dev) {
     a.t_prev = (int)a.step_dev[0] + a.t_prev_bias;
     if (a.t_apply) a.t_apply = a.t_prev + 1;
@@ -218,9 +241,11 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
     // current -- few -- have read 6 KB for nothing)
     const bool in_table = work && (!a.claim || row < a.n_table);
     const int64_t o = row * a.D + c;
-    V p4 = {}, m4 = {}, v4 = {};
+    float pe[EPL], me[EPL], ve[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) pe[e] = me[e] = ve[e] = 0.f;
     if (in_table && col_ok) {
-      p4 = *reinterpret_cast<const V*>(a.p + o); m4 = *reinterpret_cast<const V*>(a.m + o); v4 = *reinterpret_cast<const V*>(a.v + o);
+      row_ld<EPL>(a.p + o, pe); row_ld<EPL>(a.m + o, me); row_ld<EPL>(a.v + o, ve);
     }
     if (a.claim) {
       if (work && row >= a.n_table) work = false;
@@ -237,13 +262,6 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
     work = __builtin_amdgcn_readfirstlane((int)work) != 0;
     k0 = __builtin_amdgcn_readfirstlane(k0);
     if (work) {
-      float pe[EPL], me[EPL], ve[EPL];
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) pe[e] = me[e] = ve[e] = 0.f;
-      if (col_ok) {
-        pe[0] = p4.x; pe[1] = p4.y; me[0] = m4.x; me[1] = m4.y; ve[0] = v4.x; ve[1] = v4.y;
-        if constexpr (EPL == 4) { pe[2] = p4.z; pe[3] = p4.w; me[2] = m4.z; me[3] = m4.w; ve[2] = v4.z; ve[3] = v4.w; }
-      }
       AdamHyper h;
       h.one_m_b1 = a.one_m_b1; h.b2 = a.b2; h.one_m_b2 = a.one_m_b2; h.eps = a.eps;
       int s = k0 + 1;
@@ -253,6 +271,68 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
 #pragma unroll
         for (int e = 0; e < EPL; ++e) adam_elem0(pe[e], me[e], ve[e], h);
       };
+      // (the series costs the same for any gap: it covers PXR_LAZY_EXACT steps, the exact mode's window, where the loop stops at 128)
+      const int series_end = min(a.t_prev, k0 + PXR_LAZY_EXACT);
+      if (a.series && series_end - s + 1 >= a.series_min) {
+        // SERIES replay.  With zero gradient, step j = 1..n of the gap (table entry s + j - 1) adds
+        //     - ss_j b1^j m_0 / (sqrt(v_0) c_j + eps),   c_j = sqrt(b2)^j / sqrt(bc2_j),
+        // to p, later shrunk by the weight decay of the steps behind it (P_j = prod_{i > j} decay_i).  The denominator moves slowly:
+        // D_j = D_1 (1 + w sig_j) with D_1 = sqrt(v_0) c_1 + eps, w = sqrt(v_0) c_1 / D_1 in [0, 1) (the ELEMENT's share) and
+        // sig_j = c_j / c_1 - 1 (the STEP's share: 0.05 % per step from sqrt(b2), plus what the bias correction still moves).  So
+        //     p_n = p_0 P_0 - (m_0 / D_1) sum_q (-w)^q T_q,      T_q = sum_j ss_j b1^j P_j sig_j^q,
+        // and the T_q depend on the row's gap only: lane l of every wave of the row computes the terms of steps l + 1, l + 65, ... and
+        // the wave sums them (DPP) -- ~150 VALU instructions per row instead of 8 per element-STEP (a mean of 80 steps per row on the
+        // aged bench stream: this loop was VALU-issue bound).  Truncated after q = 5; the remainder is BOUNDED per row
+        // (sum_j |a_j| |sig_j|^6 / (1 - |sig_j|), |w| < 1) and a row whose bound exceeds 2e-7 of T_0 -- the first ~200 optimizer
+        // steps, where the bias correction moves the denominator by percents per step -- takes the step-by-step loop below.
+        // Differences to the dense sweep: as the carried-product loop's (< 1e-6 relative on the sum of update terms; tests:
+        // tests/test_gpu_lazy_adamw.py fast_replay / series tests).
+        const int n = series_end - s + 1;
+        const int ln = threadIdx.x & 63;
+        const double cl_end = a.cumlog[series_end];
+        const float c1 = __builtin_amdgcn_exp2f(a.log2_sb) * hyper[s].z;
+        const float rc1 = __builtin_amdgcn_rcpf(c1);
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, rr = 0.f;
+        // b1^j with the exponent formed in double (its rounding in fp32 is a relative 1e-8 j, the same sign in every catch-up)
+        auto pow_b1 = [&](const int j) {
+          const double ad = (double)j * a.log2_b1;
+          const float ah = (float)ad, al = (float)(ad - (double)ah);
+          return __builtin_amdgcn_exp2f(ah) * fmaf(al, 0.69314718f, 1.0f);
+        };
+        for (int j0 = 0; j0 < n; j0 += 64) {
+          const int j = j0 + ln + 1;
+          if (j <= n) {
+            const float4 hs = hyper[s + j - 1];
+            const float pj = __expf((float)(cl_end - a.cumlog[s + j - 1]));
+            const float fj = (float)j;
+            const float aj = hs.y * pow_b1(j) * pj;
+            const float sg = fmaf(__builtin_amdgcn_exp2f(fj * a.log2_sb) * hs.z, rc1, -1.0f);
+            const float s2 = sg * sg, s3 = s2 * sg, s4 = s2 * s2, s5 = s4 * sg;
+            t0 += aj; t1 = fmaf(aj, sg, t1); t2 = fmaf(aj, s2, t2); t3 = fmaf(aj, s3, t3); t4 = fmaf(aj, s4, t4); t5 = fmaf(aj, s5, t5);
+            rr = fmaf(fabsf(aj), s4 * s2 * __builtin_amdgcn_rcpf(fmaxf(1.0f - fabsf(sg), 1e-3f)), rr);
+          }
+        }
+        t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2); t3 = wave_sum(t3); t4 = wave_sum(t4); t5 = wave_sum(t5);
+        rr = wave_sum(rr);
+        if (rr <= 2e-7f * fabsf(t0)) {                 // wave-uniform (wave_sum hands every lane lane 63's total)
+          const float p0f = __expf((float)(cl_end - a.cumlog[s - 1]));
+          const float fn = (float)n;
+          const float fm = pow_b1(n), fv = __builtin_amdgcn_exp2f(fn * a.log2_b2);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const float sq = __builtin_amdgcn_sqrtf(ve[e]);
+            const float d1 = fmaf(sq, c1, h.eps);
+            float r1 = __builtin_amdgcn_rcpf(d1);
+            r1 = r1 * fmaf(-d1, r1, 2.0f);
+            const float w = sq * c1 * r1;
+            const float poly = fmaf(-w, fmaf(-w, fmaf(-w, fmaf(-w, fmaf(-w, t5, t4), t3), t2), t1), t0);
+            pe[e] = fmaf(-(me[e] * r1), poly, pe[e] * p0f);
+            me[e] *= fm;
+            ve[e] = __fmul_rn(ve[e], fv);
+          }
+          s = series_end + 1;
+        }
+      }
       if (a.fast && s <= exact_end) {
         // The zero-gradient recurrence without its two quarter-rate instructions per element-step: sqrt(v_t) =
         // sqrt(v_0) sqrt(b2)^t is carried as a product, and 1/denom_t comes from 1/denom_{t-1} by Newton steps (the
@@ -336,21 +416,12 @@ __global__ void __launch_bounds__((LPR > 256 ? LPR : 256)) adamw_rows_kernel(Row
         float ge[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) ge[e] = 0.f;
-        if (a.grows && col_ok) {
-          const V g4 = *reinterpret_cast<const V*>(a.grows + i * a.D + c);
-          ge[0] = g4.x; ge[1] = g4.y;
-          if constexpr (EPL == 4) { ge[2] = g4.z; ge[3] = g4.w; }
-        }
+        if (a.grows && col_ok) row_ld<EPL>(a.grows + i * a.D + c, ge);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) adam_elem(pe[e], me[e], ve[e], ge[e], h);
       }
       if (col_ok) {
-        V p4, m4, v4;
-        p4.x = pe[0]; p4.y = pe[1]; m4.x = me[0]; m4.y = me[1]; v4.x = ve[0]; v4.y = ve[1];
-        if constexpr (EPL == 4) { p4.z = pe[2]; p4.w = pe[3]; m4.z = me[2]; m4.w = me[3]; v4.z = ve[2]; v4.w = ve[3]; }
-        *reinterpret_cast<V*>(a.p + o) = p4;
-        *reinterpret_cast<V*>(a.m + o) = m4;
-        *reinterpret_cast<V*>(a.v + o) = v4;
+        row_st<EPL>(a.p + o, pe); row_st<EPL>(a.m + o, me); row_st<EPL>(a.v + o, ve);
       }
     }
     if constexpr (LPR > 64) __syncthreads();   // every wave of the row has read last[row]
@@ -644,6 +715,17 @@ static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blo
   a.fast = lazy_replay_fast() ? 1 : 0;
   a.sqrt_b2 = sqrtf(a.b2);
   a.log2_b2 = log2f(a.b2);
+  a.log2_b1 = log2(1.0 - (double)a.one_m_b1);
+  a.log2_sb = (float)(0.5 * log2((double)a.b2));
+  // series replay (adamw_rows_kernel): fast mode only; its truncation bound is checked per row on the device, the moments need the
+  // update terms to die out inside the window (rho = b1 / sqrt(b2) <= 0.95: the defaults give 0.90045).  PXR_LAZY_SERIES=0: the
+  // carried-product loop for every gap (A/B; read per launch like PXR_LAZY_REPLAY)
+  {
+    const char* e = getenv("PXR_LAZY_SERIES");
+    a.series = (a.fast && !(e && atoi(e) == 0) && a.b1 > 0.f && a.b2 > 0.f && a.b1 / a.sqrt_b2 <= 0.95f) ? 1 : 0;
+    static const int env_min = getenv("PXR_LAZY_SERIES_MIN") ? atoi(getenv("PXR_LAZY_SERIES_MIN")) : 6;
+    a.series_min = env_min < 2 ? 2 : env_min;
+  }
   // Replayed steps per row before the closed form takes over.  Exact mode: 256 (the bit-identity window of the tests).  Fast
   // mode: 128 -- the Adam terms dropped beyond it sum to < 31.6 lr rho^128 / (1 - rho) = 4.7e-4 lr (rho = b1 / sqrt(b2) = 0.90045;
   // 4.7e-8 at lr 1e-4, against the 1e-5 parity budget), and the rows at the cap are the ones that set the kernel's duration.
@@ -653,10 +735,16 @@ static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blo
   if (a.window < 1) a.window = 1;
   if (a.window > PXR_LAZY_EXACT) a.window = PXR_LAZY_EXACT;
   hipStream_t st = (hipStream_t)stream;
-  // 2 elements per lane up to D = 2048 (a 512-wide row = 4 waves), 4 beyond (block size caps at 1024 threads)
+  // Elements per lane.  Step-by-step replays (exact mode, or betas that do not arm the series): 2 up to D = 2048 (a 512-wide row = 4
+  // waves: the loop is VALU-issue bound and its chain per lane is what a long gap costs), 4 beyond (block size caps at 1024 threads).
+  // Series replay: the kernel is a chain of memory round trips per row (id -> values | claim -> scalars -> stores); wider lanes mean
+  // fewer waves per row, more rows resident at once and the gap's moments computed by fewer waves -- measured at D = 512, B = 64:
+  // step 0.760 -> 0.752 ms from 2 to 4 (PXR_ROWS_EPL = 2 | 4 | 8: measuring knob)
   int epl = D <= 2048 ? 2 : 4;
-  static const int env_epl = getenv("PXR_ROWS_EPL") ? atoi(getenv("PXR_ROWS_EPL")) : 0;       // measuring knob
-  if (env_epl == 4 && D % 4 == 0) epl = 4;
+  if (a.series && D % 4 == 0) epl = 4;
+  static const int env_epl = getenv("PXR_ROWS_EPL") ? atoi(getenv("PXR_ROWS_EPL")) : 0;
+  if ((env_epl == 4 || env_epl == 8) && D % env_epl == 0 && (D / env_epl + 63) / 64 * 64 <= 1024) epl = env_epl;
+  if (env_epl == 2 && D <= 2048) epl = 2;
   const int lpr = ((D / epl + 63) / 64) * 64;          // lanes per row
   const int tl = lpr <= 64 ? 64 : (lpr <= 128 ? 128 : (lpr <= 256 ? 256 : (lpr <= 512 ? 512 : 1024)));
   const int rpb = tl >= 256 ? 1 : 256 / tl;          // == the kernel's RPB
@@ -674,13 +762,20 @@ static int adamw_rows_launch(const RowsArgs& a_in, int64_t work, int64_t max_blo
       case 512: PXR_ROWS_CASE(512, 2); break;
       default: PXR_ROWS_CASE(1024, 2); break;
     }
-  } else {
+  } else if (epl == 4) {
     switch (tl) {
       case 64: PXR_ROWS_CASE(64, 4); break;
       case 128: PXR_ROWS_CASE(128, 4); break;
       case 256: PXR_ROWS_CASE(256, 4); break;
       case 512: PXR_ROWS_CASE(512, 4); break;
       default: PXR_ROWS_CASE(1024, 4); break;
+    }
+  } else {
+    switch (tl) {
+      case 64: PXR_ROWS_CASE(64, 8); break;
+      case 128: PXR_ROWS_CASE(128, 8); break;
+      case 256: PXR_ROWS_CASE(256, 8); break;
+      default: PXR_ROWS_CASE(512, 8); break;
     }
   }
 #undef PXR_ROWS_CASE

@@ -349,7 +349,7 @@ def test_catch_up_from_a_raw_id_list_equals_the_unique_list():
     assert set(moved.tolist()) <= set(uniq.cpu().tolist()) and moved.numel() > 0
 
 
-def _optimizer_only_run(T=700, N=3000, D=64, seed=0, lr=1e-3):
+def _optimizer_only_run(T=700, N=3000, D=64, seed=0, lr=1e-3, truth=False):
     """Identical sparse gradient sequences into the dense sweep and the lazy replay (no model feedback)."""
     from pixelrec_amd import ops
     wd, b1, b2, eps = 0.1, 0.9, 0.999, 1e-8
@@ -362,6 +362,10 @@ def _optimizer_only_run(T=700, N=3000, D=64, seed=0, lr=1e-3):
     hyper = torch.zeros(T + 8, 4, device="cuda")
     cumlog = torch.zeros(T + 8, dtype=torch.float64, device="cuda")
     cap = 24
+    # the same recurrence in float64 (per-step scalars as the fp32 table holds them): what BOTH fp32 schedules approximate
+    p64, m64, v64 = p0.double(), torch.zeros_like(p0, dtype=torch.float64), torch.zeros_like(p0, dtype=torch.float64)
+    b1_64 = 1.0 - float(torch.tensor(1.0 - b1, dtype=torch.float32))     # the factor m - m * float(1 - b1) applies
+    b2_64, omb2_64 = float(torch.tensor(b2, dtype=torch.float32)), float(torch.tensor(1.0 - b2, dtype=torch.float32))
     for t in range(1, T + 1):
         hot = torch.randint(1, 60, (8,), generator=g)                       # short gaps
         warm = torch.randint(60, 600, (8,), generator=g)                    # gaps of tens .. ~200 steps: the replayed range
@@ -376,19 +380,44 @@ def _optimizer_only_run(T=700, N=3000, D=64, seed=0, lr=1e-3):
         ops.adamw_hyper_append(hyper, cumlog, t, lr, b1, b2, eps, wd)
         ops.adamw_rows(pl, ml, vl, last, hyper, cumlog, t - 1, t, b1, b2, eps, rows=sp.idx, n_rows=sp.n, max_rows=cap,
                        grows=sp.rows)
+        if truth:
+            g64 = torch.zeros_like(p64)
+            g64[idx.cuda()] = sp.rows[:len(idx)].double()
+            dec, ss, isb = (float(x) for x in hyper[t, :3].double().cpu())
+            p64 = p64 * dec
+            m64 = m64 + (g64 - m64) * (1.0 - b1_64)
+            v64 = v64 * b2_64 + omb2_64 * g64 * g64
+            p64 = p64 - ss * m64 / (v64.sqrt() * isb + eps)
     ops.adamw_rows(pl, ml, vl, last, hyper, cumlog, T, 0, b1, b2, eps)      # flush
+    if truth:
+        return (pd, md, vd), (pl, ml, vl), p64
     return (pd, md, vd), (pl, ml, vl)
 
 
 @pytest.mark.fast_replay
 def test_fast_replay_is_the_default_and_stays_inside_the_parity_budget():
-    """Default replay (sqrt(v) carried as a product, 1/denominator by one Newton step per replayed step) against the dense
-    sweep on identical gradient sequences: p within 1e-7 (the parity budget of the step is 1e-5), m / v to rounding."""
-    (pd, md, vd), (pl, ml, vl) = _optimizer_only_run()
+    """Default replay (round 6: gaps summed in closed form, csrc/adamw.hip "SERIES replay"; short gaps and the first ~200 optimizer
+    steps: sqrt(v) carried as a product, 1/denominator by Newton steps) against the dense sweep on identical gradient sequences, both
+    against the same recurrence in float64.  The closed form rounds ONCE per gap where the sweep rounds once per step, so it sits
+    CLOSER to the float64 recurrence than the sweep does, and the distance between the two fp32 schedules is the sweep's own
+    rounding walk: p within 5e-7 of the sweep (the parity budget of the step is 1e-5), m / v to rounding."""
+    (pd, md, vd), (pl, ml, vl), p64 = _optimizer_only_run(truth=True)
     assert not torch.equal(pd, pl)                                          # it IS the approximate path ...
-    assert (pd - pl).abs().max().item() < 1e-7                              # ... three decimal orders inside the budget
+    assert (pd - pl).abs().max().item() < 5e-7                              # ... well inside the budget
+    e_lazy, e_dense = (pl.double() - p64).abs(), (pd.double() - p64).abs()
+    assert e_lazy.max().item() < 2e-7 and e_lazy.max().item() <= e_dense.max().item(), (e_lazy.max(), e_dense.max())
+    assert e_lazy.mean().item() <= e_dense.mean().item(), (e_lazy.mean(), e_dense.mean())
     assert (md - ml).abs().max().item() <= 2e-6 * md.abs().max().item()
     assert ((vd - vl).abs() <= 4e-5 * vd.abs() + 1e-30).all()
+
+
+@pytest.mark.fast_replay
+def test_carried_product_replay_alone_stays_within_1e_7_of_the_sweep(monkeypatch):
+    """PXR_LAZY_SERIES=0 (every gap through the step-by-step loop, the default up to round 5): its roundings follow the sweep's."""
+    monkeypatch.setenv("PXR_LAZY_SERIES", "0")
+    (pd, md, vd), (pl, ml, vl) = _optimizer_only_run()
+    assert not torch.equal(pd, pl)
+    assert (pd - pl).abs().max().item() < 1e-7
 
 
 def test_exact_replay_mode_is_bit_identical_on_the_same_sequences():

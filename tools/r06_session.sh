@@ -57,7 +57,7 @@ pixel)
   timeout 400 python bench.py --model pixelnet --no-cpu-baseline > "$OUT/bench_pixelnet_b16.json" 2> "$OUT/bench_pixelnet_b16.err"; cut -c1-600 "$OUT/bench_pixelnet_b16.json"; tail -3 "$OUT/bench_pixelnet_b16.err" ;;
 prof)
   P=$OUT/prof_bench; mkdir -p "$P"
-  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$P" -o bench -- python $REPO/bench.py --steps 50 --warmup 10 --age-steps 300 --no-cpu-baseline --no-extras --no-gemm-events > "$P/bench_stdout.log" 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$P" -o bench -- python $REPO/bench.py --steps 50 --warmup 10 --age-steps ${PROF_AGE:-620} --no-cpu-baseline --no-extras --no-gemm-events > "$P/bench_stdout.log" 2>&1 )
   python $REPO/tools/step_timeline.py "$P/bench_kernel_trace.csv" "$OUT/step_timeline.txt" > "$P/timeline.log" 2>&1
   rm -f "$P/bench_kernel_trace.csv"; find "$P" -name "*.db" -delete
   head -48 "$P/bench_kernel_stats.csv" | cut -c1-220 ;;
