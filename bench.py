@@ -990,11 +990,31 @@ def main():
     if lazy_gaps is not None:
         # the lazy table AdamW as it runs in the timed steps: catch-up (before the forward reads the rows) + apply
         rows_us = sum(v["avg_kernel_us"] * v["launches_per_step"] for t, v in hbm_kernels.items() if t.startswith("adamw_rows"))
+        # round 6: a gap is summed in closed form (csrc/adamw.hip "SERIES replay"), so the launches are bound by the rows they move --
+        # every unique row of the batch is read and written once by a catch-up (p, m, v: 24 B per element) and once more by the apply
+        # (+ its gradient row: 28 B) -- not by the replayed steps any more
+        rows_bytes = float(lazy_gaps["unique_rows_per_step"]) * D * (24.0 + 28.0)
+        rp_rows = None
+        if rp_file and not custom and B == 64:
+            try:
+                import csv
+                rows_ = list(csv.DictReader(open(rp_file)))
+                steps_ = next(int(r_["Calls"]) for r_ in rows_ if "adamw_flat_tab" in r_["Name"])
+                us_ = sum(int(r_["TotalDurationNs"]) for r_ in rows_ if "adamw_rows_kernel" in r_["Name"]) / steps_ * 1e-3
+                rp_rows = {"source": rp_rel + " (read from the committed file, NOT measured in this run)", "us_per_step": us_,
+                           "achieved": rows_bytes / (us_ * 1e-6) / 1e9, "frac": rows_bytes / (us_ * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            except Exception as e_:  # noqa: BLE001
+                rp_rows = {"error": f"{type(e_).__name__}: {e_}"}
         out["roofline_adamw_rows"] = {
-            "bound": "valu/latency", "kernel": "adamw_rows_kernel (catch-up + apply)", "us_per_step": rows_us,
+            "bound": "hbm", "kernel": "adamw_rows_kernel (catch-up of the input rows | of the target / negative rows | apply)",
+            "us_per_step": rows_us, "algorithmic_bytes_per_step": rows_bytes, "achieved": rows_bytes / (rows_us * 1e-6) / 1e9 if rows_us else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rows_bytes / (rows_us * 1e-6) / 1e9 / HBM_PEAK_GBS if rows_us else None,
+            "rocprofv3": rp_rows,
             "kernels": {t: v for t, v in hbm_kernels.items() if t.startswith("adamw_rows")}, "gaps": lazy_gaps,
-            "note": "HIP events around both launches in the instrumented eager steps; work is data dependent (replayed "
-                    "steps per row), so time and the gap histogram are reported instead of GB/s"}
+            "note": "HIP events around the three launches in the instrumented EAGER steps (an event pair adds 4-5 us per launch; the "
+                    "captured step runs the second one beside the encoder); `rocprofv3`: the same launches inside the replayed graph.  "
+                    "bytes = unique rows of the batch x D x (24 B catch-up + 28 B apply); random 2 KB rows, three dependent round trips "
+                    "per row (id -> values | claim -> stores)"}
     gf = [v for t, v in hbm_kernels.items() if t.startswith("ln_fwd_kernel<GATHER>")]
     if gf:
         out["roofline_gather_fused"] = [{"bound": "hbm", "kernel": "ln_fwd_kernel<GATHER>", "batch_per_gpu": B,
