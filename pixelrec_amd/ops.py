@@ -937,6 +937,9 @@ def grouped_dw_planes(problems, tile_hint=0):
         _l.check(L.pxr_grouped_dw_planes_f32(n, *args, tile_hint, _l.stream_ptr()), "pxr_grouped_dw_planes_f32")
 
 
+COLSUM_DIRECT_ROWS = int(os.environ.get("PXR_COLSUM_DIRECT_ROWS", "128"))
+
+
 def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None, defer=None):
     """out[n] = sum_m x[m, n] (deterministic two-stage reduction; second stage deferred when `defer` is given)."""
     L = _l.load()
@@ -944,6 +947,11 @@ def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None, defer=None):
     M, N = x2d.shape
     o = out if out is not None else torch.empty(N, dtype=torch.float32, device=x2d.device)
     ws_bytes = int(L.pxr_colsum_ws_bytes(M, N))
+    if defer is not None and M <= COLSUM_DIRECT_ROWS and x2d.is_contiguous():
+        # few rows (the position-embedding gradient of a B = 64 step: 64 rows of L*D): the deferred launch sums the rows themselves --
+        # they ARE its partials -- and the first-stage launch is saved
+        defer.add(x2d, M, N, o)
+        return o
     if defer is not None:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2d.device)
         defer.add(ws, int(L.pxr_colsum_partial_rows(M)), N, o)
