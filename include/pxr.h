@@ -260,6 +260,11 @@ int pxr_h2_bound_exp(const float* a_max, const float* b_colsum, float factor, in
 int pxr_ln_bwd_stat_f32(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int D, float* dz,
                         float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
                         const int64_t* step_dev, void* ws, int64_t ws_bytes, float* stat, float* zero, int zero_n, void* stream);
+/* The same site in a PRE-LN block (the image tower; HF CLIPEncoderLayer, reached from the reference's REC/model/load.py:90-120):
+ * dz = res + LayerNorm-backward(dy), one launch instead of pxr_ln_bwd_f32 + pxr_add_f32 (the same bits); no dropout at these sites.
+ * stat optional (NULL: no statistics). */
+int pxr_ln_bwd_res_f32(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* res, int rows, int D,
+                       float* dz, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, float* stat, void* stream);
 int pxr_h2_split_parts_f32(const float* x, int64_t rows, int64_t cols, int64_t ldx, void* planes, int64_t plane_stride,
                            int64_t panel_rows, const float* parts, int n_parts, float* stats, int* exps,
                            const float* bound_b_colsum, float bound_factor, int* bound_exp_out, void* stream);

@@ -283,6 +283,8 @@ struct LnBwdArgs {
   float* zero;          // optional: zero_n floats this launch clears (the spread slots of the attention backward that follows it)
   int zero_n;
   BprHead head;         // RESIDUAL only: dy is not read but formed from the loss head's backward (dy == null then)
+  const float* res;     // RESIDUAL without dropout, optional: [rows, D] added to dz before it is stored / measured / split -- the
+                        // gradient that flows AROUND a pre-LN block's branch (dx = d_out + LN-backward(branch)): saves the add launch
 };
 
 // H2S: the planes are two fp16 planes under the device exponent a.gp_exp (stale scales), dx may be virtual (instantiated for D <= 1024)
@@ -376,6 +378,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
         float4 z;
         z.x = rs * (g4[k].x - c1 - xh[k].x * c2); z.y = rs * (g4[k].y - c1 - xh[k].y * c2);
         z.z = rs * (g4[k].z - c1 - xh[k].z * c2); z.w = rs * (g4[k].w - c1 - xh[k].w * c2);
+        if constexpr (!GATHER) {
+          if (a.res) {       // (res + z, the operand order of add_kernel(res, z): the same bits as the separate launch)
+            const float4 r = *reinterpret_cast<const float4*>(a.res + (int64_t)row * D + c);
+            z.x = r.x + z.x; z.y = r.y + z.y; z.z = r.z + z.z; z.w = r.w + z.w;
+          }
+        }
         *reinterpret_cast<float4*>(a.dz + (int64_t)row * D + c) = z;
         if constexpr (!GATHER) {
           if (!has_dx) gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(z.x), fabsf(z.y)), fmaxf(fabsf(z.z), fabsf(z.w))));
@@ -708,7 +716,7 @@ static int ln_bwd_impl(int gather_mode, const float* dy, const float* xhat, cons
                        float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
                        const int64_t* step_dev, void* ws, int64_t ws_bytes, void* g_planes, int64_t g_plane_stride,
                        int64_t g_panel_rows, float* stat, void* stream, const BprHead* head = nullptr, float* zero = nullptr,
-                       int zero_n = 0, const int* g_exp = nullptr, int dx_virtual = 0);
+                       int zero_n = 0, const int* g_exp = nullptr, int dx_virtual = 0, const float* res = nullptr);
 extern "C" int pxr_ln_bwd_planes_f32(int gather_mode, const float* dy, const float* xhat, const float* rstd,
                                      const float* gamma, int rows, int D, float* dz, float* dx, float* dgamma, float* dbeta,
                                      float p_drop, uint64_t seed, uint32_t stream_id, const int64_t* step_dev, void* ws,
@@ -726,6 +734,16 @@ extern "C" int pxr_ln_bwd_stat_f32(const float* dy, const float* xhat, const flo
   PXR_REQUIRE(stat, "pxr_ln_bwd_stat_f32: null statistics buffer");
   return ln_bwd_impl(0, dy, xhat, rstd, gamma, rows, D, dz, dx, dgamma, dbeta, p_drop, seed, stream_id, step_dev, ws, ws_bytes, nullptr, 0, 0,
                      stat, stream, nullptr, zero, zero_n);
+}
+// A residual site's backward in a PRE-LN block (the image tower): dz_out = res + LN-backward(dy) -- the gradient of the block's input
+// is the gradient of its output plus what comes back through the branch's LayerNorm -- in one launch instead of LayerNorm backward +
+// add; stat (optional): this launch's partial maxima of |dz_out| (pxr_ln_bwd_partial_rows(rows) words) for pxr_h2_split_parts_f32.
+// No dropout at these sites (CLIPEncoderLayer has none: HF modeling_clip.py, reached from the reference's load.py:90-120).
+extern "C" int pxr_ln_bwd_res_f32(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* res, int rows,
+                                  int D, float* dz, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, float* stat, void* stream) {
+  PXR_REQUIRE(res, "pxr_ln_bwd_res_f32: null residual gradient");
+  return ln_bwd_impl(0, dy, xhat, rstd, gamma, rows, D, dz, nullptr, dgamma, dbeta, 0.f, 0, 0, nullptr, ws, ws_bytes, nullptr, 0, 0, stat,
+                     stream, nullptr, nullptr, 0, nullptr, 0, res);
 }
 // The backward of the block's LAST LayerNorm with the loss head's backward fused in: dy is not read but formed per row from the
 // saved scores (bpr_loss.hip: coef * (E[pos] - E[neg])); coef [B*L] is written for the table-gradient segment sums.  Replaces
@@ -771,8 +789,9 @@ static int ln_bwd_impl(int gather_mode, const float* dy, const float* xhat, cons
                        float* dz, float* dx, float* dgamma, float* dbeta, float p_drop, uint64_t seed, uint32_t stream_id,
                        const int64_t* step_dev, void* ws, int64_t ws_bytes, void* g_planes, int64_t g_plane_stride,
                        int64_t g_panel_rows, float* stat, void* stream, const BprHead* head, float* zero, int zero_n, const int* g_exp,
-                       int dx_virtual) {
+                       int dx_virtual, const float* res) {
   PXR_REQUIRE((dy || head) && xhat && rstd && gamma && dz && ws, "pxr_ln_bwd_f32: null pointer");
+  PXR_REQUIRE(!res || (!gather_mode && !dx && !dx_virtual && p_drop == 0.f), "pxr_ln_bwd_res_f32: residual sites without dropout only");
   PXR_REQUIRE(!g_exp || g_planes, "pxr_ln_bwd_h2s_f32: a plane exponent without planes");
   PXR_REQUIRE(!dx_virtual || (g_planes && !dx && !gather_mode), "pxr_ln_bwd_h2s_f32: a planes-only dx needs planes (residual sites)");
   PXR_REQUIRE(zero_n >= 0 && zero_n <= 256 && (zero || zero_n == 0), "pxr_ln_bwd_f32: at most 256 floats to clear");
@@ -794,6 +813,7 @@ static int ln_bwd_impl(int gather_mode, const float* dy, const float* xhat, cons
   a.gp_exp = g_exp; a.dx_virtual = dx_virtual; a.status = pxr_status_word();
   a.stat = stat;
   a.zero = zero; a.zero_n = zero_n;
+  a.res = res;
   if (head) a.head = *head;
   hipStream_t st = (hipStream_t)stream;
   int rc = gather_mode ? launch_ln_bwd<true>(a, nblk, st) : launch_ln_bwd<false>(a, nblk, st);

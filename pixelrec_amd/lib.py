@@ -128,6 +128,7 @@ _SIGNATURES = {
     "pxr_h2_split_auto_multi_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "pxr_h2_bound_exp": (_I, [_P, _P, _F, _P, _P]),
     "pxr_ln_bwd_stat_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U32, _P, _P, _I64, _P, _P, _I, _P]),
+    "pxr_ln_bwd_res_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I64, _P, _P]),
     "pxr_h2_split_parts_f32": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _P, _I, _P, _P, _P, _F, _P, _P]),
     "pxr_ln_bwd_h2s_f32": (_I, [_P, _P, _P, _I64, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _F, _U64, _U32, _P, _P,
                                 _I64, _P, _I64, _I64, _P, _P, _P, _I, _P]),

@@ -233,7 +233,9 @@ class NativeTower:
                      h2p=h2p, gq=gq, fp=fp) if keep else None
         return x3, saved
 
-    def _block_bwd_planes(self, i, dx3, s, defer):
+    _dx_stat = None
+
+    def _block_bwd_planes(self, i, dx3, s, defer, dx3_stat=None):
         """Backward of a block whose forward ran on planes: every GEMM operand is a plane set (the saved activations, the
         gradients split once where they are produced in fp32), all four weight + bias gradients in one grouped launch."""
         vm = "item_encoder.vision_model."
@@ -248,16 +250,33 @@ class NativeTower:
         lead = (n, T)
         # fp16 two-plane operands (s["h2"]): each gradient is split with a scale found on the device; the one that leaves a GEMM
         # epilogue as planes (du) takes its scale from the bound |dx3 W2| * max |quick_gelu'| (= 1.0998)
-        split = (lambda t: ops.split_h2_auto([t])[0]) if s.get("h2") else ops.split_planes
-        dx3p = split(dx3.view(M, H))
+        h2m = bool(s.get("h2"))
+        split = (lambda t: ops.split_h2_auto([t])[0]) if h2m else ops.split_planes
+        # round 6: the residual adds of the pre-LN block ride in the LayerNorm backward launches (dx2 = dx3 + LN2-backward, dx = dx2 +
+        # LN1-backward: pxr_ln_bwd_res_f32, the same bits), and on fp16 two-plane operands those launches also leave the partial maxima
+        # of the sums, so their splits need no statistics pass (ops.split_h2_parts) -- two launches less per site.  dx3_stat: the
+        # maxima of dx3 when it came out of the next block's last launch.  PXR_TOWER_LN_RES=0: the separate launches (A/B)
+        fuse_res = os.environ.get("PXR_TOWER_LN_RES", "1") != "0"
+        n_parts = ops.ln_bwd_stat_parts(M) if (h2m and fuse_res) else 0
+        stat = (lambda: torch.empty(n_parts, dtype=torch.float32, device=dx3.device)) if n_parts else (lambda: None)
+        if n_parts and dx3_stat is not None:
+            dx3p = ops.split_h2_parts(dx3.view(M, H), dx3_stat, n_parts)
+        else:
+            dx3p = split(dx3.view(M, H))
         pend = [(dx3p, s["fp"], G("mlp.fc2.weight"), G("mlp.fc2.bias"))]
         _, dup = ops.linear_bwd_input_planes(dx3p, W2, mul=s["gq"], want_fp32=False, want_planes=True, mul_bound=1.1)   # x quick_gelu'
         pend.append((dup, s["h2p"], G("mlp.fc1.weight"), G("mlp.fc1.bias")))
         dh2, _ = ops.linear_bwd_input_planes(dup, W1, lead_shape=lead)
-        dz2, _ = ops.ln_bwd(0, dh2, s["xh2"], s["rs2"], P("layer_norm2.weight"), G("layer_norm2.weight"),
-                            G("layer_norm2.bias"), defer=defer)
-        dx2 = ops.add(dx3, dz2)
-        dx2p = split(dx2.view(M, H))
+        if fuse_res:
+            st2 = stat()
+            dx2, _ = ops.ln_bwd(0, dh2, s["xh2"], s["rs2"], P("layer_norm2.weight"), G("layer_norm2.weight"),
+                                G("layer_norm2.bias"), defer=defer, res=dx3, stat=st2)
+            dx2p = ops.split_h2_parts(dx2.view(M, H), st2, n_parts) if n_parts else split(dx2.view(M, H))
+        else:
+            dz2, _ = ops.ln_bwd(0, dh2, s["xh2"], s["rs2"], P("layer_norm2.weight"), G("layer_norm2.weight"),
+                                G("layer_norm2.bias"), defer=defer)
+            dx2 = ops.add(dx3, dz2)
+            dx2p = split(dx2.view(M, H))
         pend.append((dx2p, s["ctxp"], G("self_attn.out_proj.weight"), G("self_attn.out_proj.bias")))
         dctx, _ = ops.linear_bwd_input_planes(dx2p, Wo, lead_shape=lead)
         if s["P"] is None:          # the forward ran the fused attention: so does the backward
@@ -268,10 +287,17 @@ class NativeTower:
         dqkvp = split(dqkv.view(M, ld))
         pend.append((dqkvp, s["h1p"], G("self_attn.k_proj.weight", span=3), G("self_attn.k_proj.bias", span=3)))
         dh1, _ = ops.linear_bwd_input_planes(dqkvp, Wqkv, lead_shape=lead)
-        dz1, _ = ops.ln_bwd(0, dh1, s["xh1"], s["rs1"], P("layer_norm1.weight"), G("layer_norm1.weight"),
-                            G("layer_norm1.bias"), defer=defer)
-        dx = ops.add(dx2, dz1)
+        st1 = None
+        if fuse_res:
+            st1 = stat()
+            dx, _ = ops.ln_bwd(0, dh1, s["xh1"], s["rs1"], P("layer_norm1.weight"), G("layer_norm1.weight"),
+                               G("layer_norm1.bias"), defer=defer, res=dx2, stat=st1)
+        else:
+            dz1, _ = ops.ln_bwd(0, dh1, s["xh1"], s["rs1"], P("layer_norm1.weight"), G("layer_norm1.weight"),
+                                G("layer_norm1.bias"), defer=defer)
+            dx = ops.add(dx2, dz1)
         ops.grouped_dw_planes(pend)
+        self._dx_stat = st1        # partial maxima of the returned gradient (None: not gathered): the previous block's first split
         return dx
 
     def _attn_bwd(self, qkv, Pm, dctx, n, T, heads, d):
@@ -373,9 +399,9 @@ class NativeTower:
         return out, saved
 
     # ------------------------------------------------------------------------------------------ backward
-    def _block_bwd(self, i, dx3, s, defer):
+    def _block_bwd(self, i, dx3, s, defer, dx3_stat=None):
         if s.get("planes"):
-            return self._block_bwd_planes(i, dx3, s, defer)
+            return self._block_bwd_planes(i, dx3, s, defer, dx3_stat)
         vm = "item_encoder.vision_model."
         name = lambda t: f"{vm}encoder.layers.{i}.{t}"
         P = lambda t, **kw: self.view(name(t), **kw)
@@ -468,8 +494,11 @@ class NativeTower:
         else:
             dx = torch.zeros(n, T, H, dtype=torch.float32, device=dxl.device)
             dx[:, 0, :] = dxl
+        st = None                                # partial maxima of dx when the launch that produced it gathered them
         for i in reversed(range(max(first, 0), n_layers)):
-            dx = self._block_bwd(i, dx, saved["blocks"][i], defer)
+            self._dx_stat = None
+            dx = self._block_bwd(i, dx, saved["blocks"][i], defer, dx3_stat=st)
+            st = self._dx_stat
         if first < 0:                            # the embeddings train too (tune_scale < 5)
             dx0, _ = ops.ln_bwd(0, dx, saved["xh0"], saved["rs0"], self.view(vm + "pre_layrnorm.weight"),
                                 G(vm + "pre_layrnorm.weight"), G(vm + "pre_layrnorm.bias"), defer=defer)

@@ -1105,10 +1105,11 @@ class DeferredReductions:
 
 def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0, stream_id=0, need_dx=False,
            step_dev=None, defer: DeferredReductions | None = None, planes: bool = False, stat: torch.Tensor | None = None,
-           zero: torch.Tensor | None = None):
+           zero: torch.Tensor | None = None, res: torch.Tensor | None = None):
     """Backward of either LN site; dgamma/dbeta ([D] tensors) are overwritten (by `defer.flush()` when a
     DeferredReductions collector is given).  Returns (dz, dx|None) (+ with planes=True the Planes of dx when it exists,
-    else of dz: what the following GEMMs read)."""
+    else of dz: what the following GEMMs read).  res (a residual site without dropout -- a pre-LN block of the image tower): the
+    launch returns dz = res + LayerNorm-backward(dy), and `stat` then holds the partial maxima of that sum (pxr_ln_bwd_res_f32)."""
     Lb = _l.load()
     _req(dy, torch.float32, "dy")
     D = dy.shape[-1]
@@ -1122,6 +1123,14 @@ def ln_bwd(gather_mode, dy, xhat, rstd, gamma, dgamma, dbeta, p_drop=0.0, seed=0
         dgamma = dbeta = None
     else:
         ws = _ws.get(ws_bytes, dy.device)
+    if res is not None:
+        assert not gather_mode and not planes and not need_dx and p_drop == 0.0 and zero is None
+        _req(res, torch.float32, "res")
+        assert res.numel() == dy.numel() and (stat is None or stat.numel() >= ln_bwd_stat_parts(rows))
+        _l.check(Lb.pxr_ln_bwd_res_f32(_l.ptr(dy), _l.ptr(xhat), _l.ptr(rstd), _l.ptr(gamma), _l.ptr(res), rows, D, _l.ptr(dz),
+                                       _l.ptr(dgamma), _l.ptr(dbeta), _l.ptr(ws), ws_bytes, _l.ptr(stat), _l.stream_ptr()),
+                 "pxr_ln_bwd_res_f32")
+        return dz, None
     if stat is not None:        # also: per-workgroup partial maxima of |gradient the next GEMMs read| into stat[:ln_bwd_stat_parts(rows)];
         assert not planes and not gather_mode       # `zero` (<= 256 floats): cleared by the launch (attn_bwd's spread slots)
         assert stat.numel() >= ln_bwd_stat_parts(rows) and (zero is None or zero.numel() <= 256)

@@ -196,3 +196,28 @@ def test_native_encoder_matches_torch_tower(method, tune, dnn):
     for i in sd["state"]:
         assert torch.equal(sd2["state"][i]["exp_avg"], sd["state"][i]["exp_avg"])
         assert torch.equal(sd2["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+
+
+def test_tower_backward_residual_adds_inside_the_layernorm_launches_change_no_bit(monkeypatch):
+    """Round 6: a pre-LN block's residual adds ride in its LayerNorm backward launches (pxr_ln_bwd_res_f32), and on fp16 two-plane
+    operands those launches hand their partial maxima to the splits (no statistics pass).  Same additions, same maxima, same
+    exponents: every gradient of the two trainable ViT-B/16 blocks + head is bit-identical to the separate launches
+    (PXR_TOWER_LN_RES=0).  Surface: HF CLIPEncoderLayer backward, reached from the reference's REC/model/load.py:90-120."""
+    from pixelrec_amd.model import visual
+
+    cfg = {"encoder_name": "clip-vit-base-patch16", "encoder_source": "transformers", "embedding_size": 64, "pretrain_path": None,
+           "fine_tune_arg": {"tune_scale": 165, "pre_trained": False, "allow_random_backbone": True, "activation": "relu",
+                             "dnn_layers": [], "method": "mean"}}
+    torch.manual_seed(11)
+    enc = visual.load_model(cfg).cuda()
+    x = torch.randn(6, 3, 224, 224, device="cuda")
+    w = torch.randn(6, 64, device="cuda")
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PXR_TOWER_LN_RES", mode)
+        (enc(x) * w).sum().backward()             # (every backward overwrites the flat gradient buffer the .grad views live in)
+        torch.cuda.synchronize()
+        grads[mode] = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    assert len(grads["1"]) >= 34 and set(grads["0"]) == set(grads["1"])
+    for n in grads["0"]:
+        assert torch.equal(grads["0"][n], grads["1"][n]), n
