@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
   typename Cfg::Acc accs;
   if constexpr (Cfg::PINGPONG) gemm_p4_mainloop<Cfg, true, B_KC>(accs, g.A, g.B, g.K, m0, n0, smem);
   else gemm_p3_mainloop<Cfg, true, B_KC, EARLY>(accs, g.A, g.B, g.K, m0, n0, smem, nullptr, g.dbg);
+  if (g.dbg & 32) return;          // LAB: no epilogue at all
   // operands the epilogue reads (bias, residual / saved derivative): requested right AFTER the main loop, so that they arrive
   // under the accumulators' trip through LDS.  (Rounds 3-4 requested them BEFORE the main loop "to arrive under the MFMAs": with
   // every register an accumulator or a fragment the compiler parked them in scratch across the loop -- a store in the prologue and
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_p3_kernel(const P3Args g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       v[e] = p3_epi_elem<EPI>(v[e], EpiTraits<EPI>::HAS_BIAS ? bv[e] : 0.f, EpiTraits<EPI>::READS_AUX ? av[e] : 0.f, ao[e], g.act);
+    if (g.dbg & 16) return;        // LAB: the epilogue's arithmetic and LDS trip, none of its stores
     if constexpr (P3EpiTraits<EPI>::WRITES_AUX) {
       float* ap = g.aux + (int64_t)row * g.ldaux + col;
       if (vec) {
