@@ -39,7 +39,7 @@ for name, M, N, K in (("qkv", 3200, 1536, 512), ("out", 3200, 512, 512), ("fc1",
     xp, = ops.split_h2_auto([x])
     Wp, = ops.split_h2_auto([W])
     row = {}
-    for dbg in (0, 16, 32, 6, 6 + 16, 6 + 32):
+    for dbg in (0, 2, 4, 8, 6, 14, 16, 32, 6 + 16, 6 + 32):
         os.environ["PXR_P3_DBG"] = str(dbg)
         row[f"dbg{dbg}"] = round(graph_time(lambda: ops.gemm_planes(xp, Wp, y, ops.EPI_BIAS, bias=b)), 2)
     os.environ.pop("PXR_P3_DBG")
