@@ -39,9 +39,10 @@ for name, M, N, K in (("qkv", 3200, 1536, 512), ("out", 3200, 512, 512), ("fc1",
     xp, = ops.split_h2_auto([x])
     Wp, = ops.split_h2_auto([W])
     row = {}
+    hint = int(os.environ.get("PROBE_TILE", "0"))
     for dbg in (0, 2, 4, 8, 6, 14, 16, 32, 6 + 16, 6 + 32):
         os.environ["PXR_P3_DBG"] = str(dbg)
-        row[f"dbg{dbg}"] = round(graph_time(lambda: ops.gemm_planes(xp, Wp, y, ops.EPI_BIAS, bias=b)), 2)
+        row[f"dbg{dbg}"] = round(graph_time(lambda: ops.gemm_planes(xp, Wp, y, ops.EPI_BIAS, bias=b, tile_hint=hint)), 2)
     os.environ.pop("PXR_P3_DBG")
     res[name] = row
     print(name, json.dumps(row), flush=True)
