@@ -15,7 +15,7 @@ import torch
 
 class GraphedTrainStep:
     def __init__(self, dp_model, optimizer, items, masked_index, warmup=3, clip_grad_norm=None, loss_sum=None,
-                 lookahead=False):
+                 lookahead=False, h2_stale_scales=None):
         self.dp, self.opt = dp_model, optimizer
         self.loss_sum = loss_sum          # optional 0-dim device tensor: every replay adds its loss (epoch totals
                                           # without an eager add per step)
@@ -29,7 +29,9 @@ class GraphedTrainStep:
         if hasattr(self.model, "trust_optimizer_planes"):
             self.model.trust_optimizer_planes = True     # the captured forward has no split launch (seqcore._weight_planes)
         if hasattr(self.model, "h2_stale_scales"):
-            self.model.h2_stale_scales = True            # ... and its backward no gradient split launches (seqcore, ops.H2Sites)
+            # ... and its backward no gradient split launches (seqcore, ops.H2Sites).  An owner that manages the switch itself (the
+            # Trainer: exact scales for a while after an overflow) says which it wants; None: on
+            self.model.h2_stale_scales = True if h2_stale_scales is None else bool(h2_stale_scales)
         # the batch lives in ONE buffer (ids | mask): a caller that hands over two views of one packed tensor (bench.py,
         # the trainer's batcher) pays one copy per step instead of two
         n_i = items.numel()

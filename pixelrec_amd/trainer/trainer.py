@@ -180,14 +180,18 @@ class Trainer:
                 yield prev, None
 
         for data, next_items in with_next(_Prefetcher(train_data, self.device)):
+            self._steps_done = getattr(self, "_steps_done", 0) + 1
+            self._h2_stale_resume()
             if self.use_graph:
                 if self._gstep is None and data[0].shape[0] == self.config["train_batch_size"]:
                     from ..graph import GraphedTrainStep
 
-                    self._graph_loss = torch.zeros((), dtype=torch.float32, device=self.device)
+                    if getattr(self, "_graph_loss", None) is None:      # (kept across re-captures: a step captured in the middle
+                        self._graph_loss = torch.zeros((), dtype=torch.float32, device=self.device)   # of an epoch adds to the same sum)
                     self._gstep = GraphedTrainStep(self.model, self.optimizer, data[0], data[1], warmup=0,
                                                    clip_grad_norm=self.clip_grad_norm, loss_sum=self._graph_loss,
-                                                   lookahead=lookahead)
+                                                   lookahead=lookahead,
+                                                   h2_stale_scales=getattr(self.model.module, "h2_stale_scales", None))
                 if self._gstep is not None and self._gstep.matches(data[0], data[1]):
                     # the replay adds its loss to self._graph_loss on the device
                     try:
@@ -213,7 +217,7 @@ class Trainer:
             except ops.H2StaleOverflow as e:              # (the optimizer's housekeeping polls the status word; the step has run)
                 self._h2_stale_fallback(e)
             total = total + losses.detach()
-        if self._gstep is not None:
+        if getattr(self, "_graph_loss", None) is not None:     # (also when the captured step was dropped on the epoch's last steps)
             total = total + self._graph_loss
             self._graph_loss.zero_()
         total_loss = float(total.item())          # the only host sync of the epoch
@@ -224,9 +228,14 @@ class Trainer:
         self._check_nan(total_loss)
         return total_loss
 
+    H2_STALE_BACKOFF = (256, 1 << 16)      # steps on exact scales after the first overflow; the cap of the (x 4) back-off
+
     def _h2_stale_fallback(self, err):
         """A gradient outgrew the headroom of its stale h2 scale in ONE step (its largest elements were saturated there, nothing
-        non-finite was written): say so and go on with per-step exact scales -- the captured step is dropped and re-captured."""
+        non-finite was written): say so and go on with per-step exact scales -- the captured step is dropped and re-captured.
+        One rank: for a while -- gradient magnitudes move fastest in the first steps of a run and after a learning-rate change;
+        after H2_STALE_BACKOFF[0] steps (x 4 with every further overflow) the stale scales are re-seeded by an exact pass and
+        switched on again (_h2_stale_resume).  Data parallel: for good (see below)."""
         m = self.model.module
         if getattr(m, "h2_stale_scales", False):
             m.h2_stale_scales = False
@@ -235,7 +244,30 @@ class Trainer:
                 # a re-capture runs a dry step WITH its collectives, which the other ranks would not match: this rank issues its steps
                 # eagerly from here on (the same collectives in the same order as a replaying rank's)
                 self.use_graph = False
-            self.logger.warning("%s -- continuing with exact per-step scales", err)
+                self.logger.warning("%s -- continuing with exact per-step scales", err)
+                return
+            wait = getattr(self, "_stale_backoff", self.H2_STALE_BACKOFF[0])
+            self._stale_backoff = min(4 * wait, self.H2_STALE_BACKOFF[1])
+            self._stale_resume_at = getattr(self, "_steps_done", 0) + wait
+            self.logger.warning("%s -- continuing with exact per-step scales for the next %d steps", err, wait)
+
+    def _h2_stale_resume(self):
+        """Back to the stale scales once the back-off of _h2_stale_fallback has run out: their state is re-seeded by the next
+        step's exact pass (the dry step of the re-capture), the captured step is re-captured on them."""
+        at = getattr(self, "_stale_resume_at", None)
+        if at is None or getattr(self, "_steps_done", 0) < at:
+            return
+        self._stale_resume_at = None
+        m = self.model.module
+        if self.world > 1 or not hasattr(m, "h2_stale_scales") or m.h2_stale_scales:
+            return
+        m.h2_stale_scales = True
+        sites = getattr(m, "_h2_sites", None)
+        if sites is not None:
+            sites.seeded_for = None
+            sites.run_max.zero_()
+        self._gstep = None
+        self.logger.info("fp16 two-plane gradients back under the recent steps' scales (re-seeded)")
 
     def _check_nan(self, loss):
         if np.isnan(loss):

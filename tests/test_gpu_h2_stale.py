@@ -237,3 +237,36 @@ def test_captured_steps_on_stale_scales_track_the_eager_exact_steps(stale_env):
         if k.endswith("key.bias"):
             continue
         assert (out["graph"][1][k] - v).abs().max().item() <= 2e-5, k       # 12 steps at lr 1e-3: 2 % of one step's movement
+
+
+def test_trainer_epoch_loss_survives_a_mid_epoch_recapture(tmp_path, monkeypatch):
+    """A stale-scale overflow drops the captured step in the middle of an epoch and a new one is captured (twice: exact scales, then the
+    stale ones again): the epoch's loss is still the sum over ALL its steps -- equal, to rounding, to an eager run of the same epoch
+    (the reference's per-epoch total, trainer.py:105-128)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_eval import _harness
+    from pixelrec_amd import ops
+
+    def epoch(force_fallback_at, use_graph):
+        torch.manual_seed(3)                      # the same initial weights in both runs (the batcher is seeded by the config)
+        config, dataload, (train, valid, test), model, DataParallel, Trainer = _harness(tmp_path, 32, 6, 2, 2, 2, epochs=1, p_drop=0.0)
+        config["use_hip_graph"] = use_graph
+        trainer = Trainer(config, DataParallel(model.to(config["device"])))
+        trainer.H2_STALE_BACKOFF = (2, 64)
+        if force_fallback_at is not None:
+            orig = trainer._h2_stale_resume
+
+            def hook():
+                if trainer._steps_done == force_fallback_at:
+                    trainer._h2_stale_fallback(ops.H2StaleOverflow("forced by the test"))
+                orig()
+            trainer._h2_stale_resume = hook
+        return trainer._train_epoch(train, 0), len(train), trainer
+
+    base, n, _ = epoch(None, use_graph=False)
+    got, n2, tr = epoch(2, use_graph=True)
+    assert n == n2 and n >= 6
+    assert tr.model.module.h2_stale_scales is True and getattr(tr, "_stale_resume_at", None) is None      # fell back at step 2, resumed at step 4
+    assert abs(got - base) <= 2e-4 * abs(base), (got, base)

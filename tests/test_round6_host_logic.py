@@ -75,8 +75,21 @@ def test_trainer_falls_back_to_exact_scales_when_a_stale_scale_overflows():
 
     t.logger = logging.getLogger("pxr-test-stale")
     t.logger.addHandler(H())
+    t._steps_done = 1000
     t._h2_stale_fallback(ops.H2StaleOverflow("a gradient exceeded its headroom"))
     assert t.model.module.h2_stale_scales is False and t._gstep is None and t.use_graph is True
+    # one rank: exact scales for a while, then back (re-seeded, re-captured); the wait grows x 4 with every further overflow
+    assert t._stale_resume_at == 1000 + Trainer.H2_STALE_BACKOFF[0] and "for the next 256 steps" in records[0]
+    t._gstep, t._steps_done = "exact-scale graph", 1000 + Trainer.H2_STALE_BACKOFF[0] - 1
+    t._h2_stale_resume()
+    assert t.model.module.h2_stale_scales is False and t._gstep == "exact-scale graph"          # not yet
+    t._steps_done += 1
+    t._h2_stale_resume()
+    assert t.model.module.h2_stale_scales is True and t._gstep is None and t._stale_resume_at is None
+    t._h2_stale_fallback(ops.H2StaleOverflow("again, later"))
+    assert t._stale_resume_at == t._steps_done + 4 * Trainer.H2_STALE_BACKOFF[0]
+    del records[1:]
+    t._stale_resume_at = None
     t.model.module.h2_stale_scales, t.world = True, 4        # data parallel: no re-capture (its dry step would issue unmatched collectives)
     t._h2_stale_fallback(ops.H2StaleOverflow("on one rank of four"))
     assert t.use_graph is False and len(records) == 2
