@@ -48,6 +48,7 @@ class Collector:
         self.config = config
         self.data_struct = DataStruct()
         self.topk = config["topk"]
+        self._pending = []       # rec.topk blocks of eval_topk_collect, still on the device (one D2H copy per evaluation)
 
     def eval_batch_collect(self, scores_tensor, positive_u, positive_i, interaction=None):
         _, topk_idx = torch.topk(scores_tensor, max(self.topk), dim=-1)
@@ -61,9 +62,14 @@ class Collector:
         """topk_idx int64 [B, K] (already masked top-K item ids), positive_i int64 [B]."""
         pos_idx = (topk_idx == positive_i.to(topk_idx.device).view(-1, 1)).to(torch.int)
         pos_len = torch.ones(pos_idx.shape[0], 1, dtype=torch.int, device=pos_idx.device)
-        self.data_struct.update_tensor("rec.topk", torch.cat((pos_idx, pos_len), dim=1))
+        # kept on the device: a .cpu() per batch (DataStruct.update_tensor) is a host synchronisation per batch -- with the scores
+        # never leaving the GPU it was most of a 200 000-user evaluation's wall time (tools/diag/trainer_throughput.py)
+        self._pending.append(torch.cat((pos_idx, pos_len), dim=1))
 
     def get_data_struct(self):
+        if self._pending:
+            self.data_struct.update_tensor("rec.topk", torch.cat(self._pending, dim=0))
+            self._pending = []
         returned = copy.deepcopy(self.data_struct)
         for key in ["rec.topk"]:
             if key in self.data_struct:

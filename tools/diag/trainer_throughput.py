@@ -44,3 +44,14 @@ t0 = time.perf_counter()
 res = tr.evaluate(valid, load_best_model=False)
 torch.cuda.synchronize()
 print(f"full-sort evaluation of {len(valid.dataset) if hasattr(valid, 'dataset') else '?'} users: {time.perf_counter() - t0:.2f} s  {dict(res)}")
+
+# where the evaluation's time goes (host profile of one more pass)
+import cProfile  # noqa: E402
+import pstats  # noqa: E402
+
+pr = cProfile.Profile()
+pr.enable()
+tr.evaluate(valid, load_best_model=False)
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
