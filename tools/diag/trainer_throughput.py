@@ -55,3 +55,14 @@ tr.evaluate(valid, load_best_model=False)
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+
+# the whole fit loop: 3 epochs, validation after each, checkpoints when the metric improves
+config2, dataload2, (train2, valid2, test2), model2 = R.build(0, config_dict=cfg)
+tr2 = Trainer(config2, model2)
+t0 = time.perf_counter()
+best, best_res = tr2.fit(train2, valid2, saved=True)
+torch.cuda.synchronize()
+print(f"fit (3 epochs + 3 validations + checkpoints): {time.perf_counter() - t0:.1f} s; best {best}")
+t0 = time.perf_counter()
+res = tr2.evaluate(test2, load_best_model=True)
+print(f"test evaluation incl. loading the best checkpoint: {time.perf_counter() - t0:.1f} s {dict(res)}")
