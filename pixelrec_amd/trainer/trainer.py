@@ -527,6 +527,7 @@ class Trainer:
         self.model.eval()
         self.tot_item_num = eval_data.dataset.dataload.item_num
         self.compute_item_feature(self.config, eval_data.dataset.dataload, eval_data)
+        self.eval_collector._pending.clear()             # (blocks an aborted evaluation may have left behind)
         batches = eval_data
         if self.fused_topk and self.device.type == "cuda":
             batches = self._eval_prefetch(eval_data)      # batch construction + packing on a background thread
