@@ -36,6 +36,15 @@ from ..parallel import world_info
 from ..utils import calculate_valid_score, dict2str, early_stopping, ensure_dir, get_local_time
 
 
+def host_threads_for(config) -> int:
+    """Intra-op CPU threads the Trainer sets for the host side of its loop (0: leave torch's setting alone): `host_threads` of the
+    YAML if given; otherwise 1 unless the caller exported OMP_NUM_THREADS (see Trainer.__init__)."""
+    ht = config["host_threads"]
+    if ht is None:
+        ht = 0 if os.environ.get("OMP_NUM_THREADS") else 1
+    return int(ht)
+
+
 class _Prefetcher:
     """Builds host batches on a background thread (numpy releases the GIL) and stages them on the device."""
 
@@ -110,6 +119,18 @@ class Trainer:
         self.item_feature = None
         self.tot_item_num = None
         self.fused_topk = config["eval_fused_topk"] is None or bool(config["eval_fused_topk"])
+        # The host side of the loop is index arithmetic on small arrays (batcher, packing, pinned staging).  With the intra-op pool
+        # torch sizes by default -- one thread per core, 256 on the GPU hosts -- every torch.cat / copy above ATen's grain size wakes
+        # that whole team: measured on the Pixel200K-shaped run, B = 512 batches took 32 ms each to build instead of 3 (18 K instead
+        # of 141 K sequences/s; B = 64 stays below the grain size and never showed it).  The reference's launcher pins
+        # OMP_NUM_THREADS=1 for the same loop (main.py:5), and so does this build's main.py; a Trainer driven from a notebook or
+        # run.build() gets the same here unless the caller chose a thread count (OMP_NUM_THREADS set, or `host_threads` in the YAML;
+        # host_threads: 0 leaves torch's setting alone).
+        ht = host_threads_for(config)
+        if int(ht) > 0 and torch.get_num_threads() != int(ht):
+            self.logger.info("host threads of torch's intra-op pool: %d -> %d (host_threads / OMP_NUM_THREADS override)",
+                             torch.get_num_threads(), int(ht))
+            torch.set_num_threads(int(ht))
         # whole-step hipGraph replay for full-size batches (ID model): the host issues one graph launch per step instead of
         # ~50 kernel launches.  Data parallel over RCCL too (round 6): the captured step CONTAINS its collectives (row all-gather,
         # flat all-reduce) -- an eager multi-rank step is bound by the host (1.47 ms against 0.85 ms replayed, 1-rank RCCL group on

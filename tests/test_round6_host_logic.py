@@ -99,3 +99,19 @@ def test_trainer_falls_back_to_exact_scales_when_a_stale_scale_overflows():
     t._h2_stale_fallback(ops.H2StaleOverflow("again"))          # already off: nothing to do, nothing dropped
     assert t._gstep == "kept" and len(records) == 1
     assert issubclass(ops.H2StaleOverflow, RuntimeError)
+
+
+def test_trainer_pins_the_host_thread_pool_unless_the_caller_chose(monkeypatch):
+    """A Trainer built outside main.py (which exports OMP_NUM_THREADS=1 like the reference's launcher, main.py:5) limits torch's
+    intra-op pool to one thread: with one thread per core of a 256-core host every small torch.cat of the batcher woke the whole team
+    (B = 512 batches: 32 ms instead of 3).  OMP_NUM_THREADS or `host_threads` in the YAML override it."""
+    from pixelrec_amd.trainer.trainer import host_threads_for
+
+    class Cfg(dict):
+        def __getitem__(self, k):
+            return self.get(k)
+
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    assert host_threads_for(Cfg()) == 1 and host_threads_for(Cfg(host_threads=4)) == 4 and host_threads_for(Cfg(host_threads=0)) == 0
+    monkeypatch.setenv("OMP_NUM_THREADS", "8")
+    assert host_threads_for(Cfg()) == 0 and host_threads_for(Cfg(host_threads=2)) == 2

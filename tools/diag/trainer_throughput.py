@@ -23,7 +23,8 @@ print(f"dataset written in {time.perf_counter() - t0:.1f} s")
 cfg = dict(model="SASRec", n_layers=2, n_heads=4, embedding_size=512, inner_size=2, hidden_dropout_prob=0.1, attn_dropout_prob=0.1,
            hidden_act="gelu", layer_norm_eps=1e-12, initializer_range=0.02, seed=2020, state="INFO", use_modality=False,
            reproducibility=True, checkpoint_dir=os.path.join(tmp, "saved"), log_path=os.path.join(tmp, "log"), show_progress=False,
-           MAX_ITEM_LIST_LENGTH=50, data_path=os.path.join(tmp, "data") + "/", dataset="Pixel200K", epochs=3, train_batch_size=64,
+           MAX_ITEM_LIST_LENGTH=50, data_path=os.path.join(tmp, "data") + "/", dataset="Pixel200K", epochs=3,
+           train_batch_size=int(os.environ.get("TT_BATCH", "64")),
            optim_args={"learning_rate": 1e-4, "weight_decay": 0.1}, eval_batch_size=1024, topk=[5, 10], metrics=["Recall", "NDCG"],
            valid_metric="NDCG@10", metric_decimal_place=7, eval_step=1, stopping_step=30)
 t0 = time.perf_counter()
@@ -38,7 +39,7 @@ for ep in range(3):
     loss = tr._train_epoch(train, ep)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    n_seq = len(train) * 64
+    n_seq = len(train) * cfg["train_batch_size"]
     print(f"epoch {ep}: {dt:.2f} s, {len(train)} steps, {dt / len(train) * 1e3:.3f} ms/step, {n_seq / dt / 1e3:.1f} K sequences/s, loss {loss}")
 t0 = time.perf_counter()
 res = tr.evaluate(valid, load_best_model=False)
